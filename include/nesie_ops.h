@@ -1,0 +1,125 @@
+/*
+ * nesie_ops.h -- C ABI of libnesie_hip.so (MI355X / gfx950).
+ *
+ * These are the entry points the reference's pybind11 extension modules expose
+ * for the VoteNet/Nesie hot path.  Each one replaces a
+ * `*_wrapper` / `forward` / `backward` function of the reference; the cited
+ * file:line is the reference interface it stands in for.  Conventions follow
+ * the reference's: all buffers are device pointers to contiguous memory owned
+ * by the caller, outputs are pre-allocated by the caller and written in place,
+ * dimensions are passed redundantly as ints, and the launch is asynchronous on
+ * the HIP stream given as the last argument (`hipStream_t` passed as void*;
+ * NULL = the null stream).  Differences from the reference, all deliberate:
+ *   - no torch types anywhere in the signatures;
+ *   - every function returns 0 on success or a non-zero nesie_status, and
+ *     nesie_last_error() gives a message, instead of fprintf+exit(-1)
+ *     (e.g. reference group_points_cuda.cu:48-53);
+ *   - every launch goes to the caller's stream (the reference launches
+ *     sort_vertices and points_in_boxes on the legacy default stream).
+ */
+#ifndef NESIE_OPS_H_
+#define NESIE_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NESIE_OK = 0,
+  NESIE_ERR_INVALID_ARG = 1, /* null pointer / negative or inconsistent size  */
+  NESIE_ERR_UNSUPPORTED = 2, /* size outside what the kernels are built for   */
+  NESIE_ERR_LAUNCH = 3       /* HIP reported a launch error (see last_error)  */
+} nesie_status;
+
+/* Library identity and diagnostics. */
+int nesie_abi_version(void);
+const char *nesie_last_error(void); /* thread-local, never NULL */
+
+/* mmdet3d/ops/furthest_point_sample/src/furthest_point_sample.cpp:32-58
+ * furthest_point_sampling_wrapper(b, n, m, points[B,N,3], temp[B,N], idx[B,M]).
+ * temp must hold 1e10 on entry (furthest_point_sample.py:30) and holds the
+ * final running-min squared distances on return.  idx[:,0] = 0. */
+int nesie_furthest_point_sampling_wrapper(int b, int n, int m, const float *xyz,
+                                          float *temp, int *idx, void *stream);
+
+/* furthest_point_sample.cpp:59-65  furthest_point_sampling_with_dist_wrapper
+ * (b, n, m, dist[B,N,N], temp[B,N], idx[B,M]). */
+int nesie_furthest_point_sampling_with_dist_wrapper(int b, int n, int m,
+                                                    const float *dist,
+                                                    float *temp, int *idx,
+                                                    void *stream);
+
+/* mmdet3d/ops/ball_query/src/ball_query.cpp:30-47  ball_query_wrapper
+ * (b, n, m, min_radius, max_radius, nsample, new_xyz[B,M,3], xyz[B,N,3],
+ *  idx[B,M,nsample]).  idx must be zero on entry (ball_query.py:35). */
+int nesie_ball_query_wrapper(int b, int n, int m, float min_radius,
+                             float max_radius, int nsample,
+                             const float *new_xyz, const float *xyz, int *idx,
+                             void *stream);
+
+/* mmdet3d/ops/group_points/src/group_points.cpp:31-45  forward
+ * (b, c, n, npoints, nsample, points[B,C,N], idx[B,M,ns], out[B,C,M,ns]). */
+int nesie_group_points_forward(int b, int c, int n, int npoints, int nsample,
+                               const float *points, const int *idx, float *out,
+                               void *stream);
+
+/* group_points.cpp:47-62  backward
+ * (b, c, n, npoints, nsample, grad_out[B,C,M,ns], idx, grad_points[B,C,N]).
+ * grad_points must be zero on entry (group_points.py:218). */
+int nesie_group_points_backward(int b, int c, int n, int npoints, int nsample,
+                                const float *grad_out, const int *idx,
+                                float *grad_points, void *stream);
+
+/* mmdet3d/ops/gather_points/src/gather_points.cpp:28-42  gather_points_wrapper
+ * (b, c, n, npoints, points[B,C,N], idx[B,M], out[B,C,M]). */
+int nesie_gather_points_wrapper(int b, int c, int n, int npoints,
+                                const float *points, const int *idx, float *out,
+                                void *stream);
+
+/* gather_points.cpp:44-59  gather_points_grad_wrapper
+ * (b, c, n, npoints, grad_out[B,C,M], idx, grad_points[B,C,N] zeroed). */
+int nesie_gather_points_grad_wrapper(int b, int c, int n, int npoints,
+                                     const float *grad_out, const int *idx,
+                                     float *grad_points, void *stream);
+
+/* mmdet3d/ops/interpolate/src/interpolate.cpp:46-58  three_nn_wrapper
+ * (b, n, m, unknown[B,n,3], known[B,m,3], dist2[B,n,3], idx[B,n,3]).
+ * Also stands in for mmcv.ops.three_nn (side_pooling_module.py:204). */
+int nesie_three_nn_wrapper(int b, int n, int m, const float *unknown,
+                           const float *known, float *dist2, int *idx,
+                           void *stream);
+
+/* interpolate.cpp:60-75  three_interpolate_wrapper
+ * (b, c, m, n, points[B,C,M], idx[B,N,3], weight[B,N,3], out[B,C,N]). */
+int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
+                                    const float *points, const int *idx,
+                                    const float *weight, float *out,
+                                    void *stream);
+
+/* interpolate.cpp:77-93  three_interpolate_grad_wrapper
+ * (b, c, n, m, grad_out[B,C,N], idx, weight, grad_points[B,C,M] zeroed). */
+int nesie_three_interpolate_grad_wrapper(int b, int c, int n, int m,
+                                         const float *grad_out, const int *idx,
+                                         const float *weight,
+                                         float *grad_points, void *stream);
+
+/* mmdet3d/ops/rotated_iou/cuda_op/sort_vert.cpp:6-30  sort_vertices_forward
+ * (vertices[B,N,M,2] f32, mask[B,N,M] bool(1 byte), num_valid[B,N] i32)
+ * -> idx[B,N,9] i32.  The reference allocates idx; here the caller does. */
+int nesie_sort_vertices_forward(int b, int n, int m, const float *vertices,
+                                const uint8_t *mask, const int *num_valid,
+                                int *idx, void *stream);
+
+/* mmdet3d/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:46-48 /
+ * points_in_boxes_cuda.cu:153-181  points_in_boxes_batch
+ * (boxes[B,T,7] LiDAR frame bottom-centre, pts[B,M,3], out[B,M,T] i32 zeroed). */
+int nesie_points_in_boxes_batch(int b, int boxes_num, int pts_num,
+                                const float *boxes, const float *pts, int *out,
+                                void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESIE_OPS_H_ */

@@ -1,0 +1,66 @@
+"""ctypes binding of ``include/nesie_ops.h`` (libnesie_hip.so).
+
+This is the binding a maintainer of the reference would write in place of its
+pybind11 shims: plain pointers, ints and a stream handle.
+The library is looked up in-tree only (``nesie_amd/libnesie_hip.so``) and a
+missing or unloadable library is an ImportError -- never a silent fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnesie_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes, in the order of include/nesie_ops.h (stream last)
+SIGNATURES = {
+    "nesie_furthest_point_sampling_wrapper": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_furthest_point_sampling_with_dist_wrapper": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_ball_query_wrapper": [_I, _I, _I, _F, _F, _I, _P, _P, _P, _P],
+    "nesie_group_points_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "nesie_group_points_backward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "nesie_gather_points_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "nesie_gather_points_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "nesie_three_nn_wrapper": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_three_interpolate_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_three_interpolate_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load libnesie_hip.so once and attach argtypes.  Raises ImportError."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C nesie_amd/csrc`). nesie_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.nesie_abi_version.restype = _I
+    lib.nesie_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an entry point; non-zero status becomes a RuntimeError."""
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        msg = lib.nesie_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (status {status}): {msg}")

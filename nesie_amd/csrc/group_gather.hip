@@ -1,0 +1,115 @@
+// group_points / gather_points forward + backward for gfx950.
+//
+// Replaces group_points_kernel / group_points_grad_kernel
+// (reference mmdet3d/ops/group_points/src/group_points_cuda.cu:56-80, :10-31) and
+// gather_points_kernel / gather_points_grad_kernel
+// (reference mmdet3d/ops/gather_points/src/gather_points_cuda.cu:8-26, :51-70).
+// gather is group with nsample == 1, so one kernel pair serves both.
+//
+// Forward is pure data movement (HBM/L2 bound): a thread owns one output
+// column e = (p, s), reads idx[e] ONCE and walks CH_PER_THREAD channel rows, so
+// the index traffic is amortised over the channels and every store is a dense
+// 256-byte row segment per wave.  Backward is the same walk with a float
+// atomic add (the reference does the same; sum order is not deterministic).
+#include "common.h"
+
+namespace nesie {
+
+constexpr int GG_BLOCK = 256;
+constexpr int GG_CH = 8;  // channels walked per thread
+
+// points (B,C,N), idx (B,E) -> out (B,C,E)        E = npoints * nsample
+__global__ __launch_bounds__(GG_BLOCK) void group_fwd_kernel(
+    int c, int n, int e_total, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out) {
+  const int e = blockIdx.x * GG_BLOCK + threadIdx.x;
+  const int c0 = blockIdx.y * GG_CH;
+  const int bi = blockIdx.z;
+  if (e >= e_total) return;
+  int src = idx[(size_t)bi * e_total + e];
+  src = src < 0 ? 0 : (src >= n ? n - 1 : src);  // never fault on a bad index
+  const float *p = points + ((size_t)bi * c + c0) * n + src;
+  float *o = out + ((size_t)bi * c + c0) * e_total + e;
+  const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
+  float v[GG_CH];
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i)
+    if (i < cend) v[i] = p[(size_t)i * n];
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i)
+    if (i < cend) o[(size_t)i * e_total] = v[i];
+}
+
+// grad_out (B,C,E), idx (B,E) -> grad_points (B,C,N) += ...
+__global__ __launch_bounds__(GG_BLOCK) void group_bwd_kernel(
+    int c, int n, int e_total, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int e = blockIdx.x * GG_BLOCK + threadIdx.x;
+  const int c0 = blockIdx.y * GG_CH;
+  const int bi = blockIdx.z;
+  if (e >= e_total) return;
+  int dst = idx[(size_t)bi * e_total + e];
+  dst = dst < 0 ? 0 : (dst >= n ? n - 1 : dst);  // never fault on a bad index
+  const float *g = grad_out + ((size_t)bi * c + c0) * e_total + e;
+  float *gp = grad_points + ((size_t)bi * c + c0) * n + dst;
+  const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
+  float v[GG_CH];
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i)
+    if (i < cend) v[i] = g[(size_t)i * e_total];
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i)
+    if (i < cend) atomicAdd(gp + (size_t)i * n, v[i]);
+}
+
+static int launch_group(bool fwd, const char *W, int b, int c, int n, long long e_total,
+                        const float *a, const int *idx, float *o, void *stream) {
+  NESIE_REQUIRE(b >= 0 && c >= 0 && n >= 0 && e_total >= 0, W);
+  if (b == 0 || c == 0 || e_total == 0) return NESIE_OK;
+  NESIE_REQUIRE(n >= 1 && a && idx && o, W);
+  NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  dim3 grid(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b);
+  if (fwd)
+    hipLaunchKernelGGL(group_fwd_kernel, grid, dim3(GG_BLOCK), 0, (hipStream_t)stream, c,
+                       n, (int)e_total, a, idx, o);
+  else
+    hipLaunchKernelGGL(group_bwd_kernel, grid, dim3(GG_BLOCK), 0, (hipStream_t)stream, c,
+                       n, (int)e_total, a, idx, o);
+  return check_launch(W);
+}
+
+}  // namespace nesie
+
+using namespace nesie;
+
+extern "C" int nesie_group_points_forward(int b, int c, int n, int npoints, int nsample,
+                                          const float *points, const int *idx,
+                                          float *out, void *stream) {
+  NESIE_REQUIRE(npoints >= 0 && nsample >= 0, "group_points_forward");
+  return launch_group(true, "group_points_forward", b, c, n,
+                      (long long)npoints * nsample, points, idx, out, stream);
+}
+
+extern "C" int nesie_group_points_backward(int b, int c, int n, int npoints, int nsample,
+                                           const float *grad_out, const int *idx,
+                                           float *grad_points, void *stream) {
+  NESIE_REQUIRE(npoints >= 0 && nsample >= 0, "group_points_backward");
+  return launch_group(false, "group_points_backward", b, c, n,
+                      (long long)npoints * nsample, grad_out, idx, grad_points, stream);
+}
+
+extern "C" int nesie_gather_points_wrapper(int b, int c, int n, int npoints,
+                                           const float *points, const int *idx,
+                                           float *out, void *stream) {
+  NESIE_REQUIRE(npoints >= 0, "gather_points_wrapper");
+  return launch_group(true, "gather_points_wrapper", b, c, n, npoints, points, idx, out,
+                      stream);
+}
+
+extern "C" int nesie_gather_points_grad_wrapper(int b, int c, int n, int npoints,
+                                                const float *grad_out, const int *idx,
+                                                float *grad_points, void *stream) {
+  NESIE_REQUIRE(npoints >= 0, "gather_points_grad_wrapper");
+  return launch_group(false, "gather_points_grad_wrapper", b, c, n, npoints, grad_out,
+                      idx, grad_points, stream);
+}

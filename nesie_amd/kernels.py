@@ -1,0 +1,188 @@
+"""Kernel back end used by ``nesie_amd.mmdet3d_ops``.
+
+The product back end is :class:`HipKernels` (libnesie_hip.so on the current HIP
+stream).  ``use_backend`` lets TEST CODE and bench.py's cpu_baseline leg inject
+another object with the same methods (the CPU oracle lives outside this
+package, under ``oracle/``); nothing in nesie_amd ever installs one, and
+without an injected back end a non-HIP tensor is an error, not a fallback.
+
+Method names and argument order are those of the reference's extension
+modules; every tensor must be contiguous; outputs are
+pre-allocated by the caller and written in place.
+"""
+import contextlib
+
+import torch
+
+from . import _lib
+
+_injected = None
+
+
+def _ptr(t):
+    return t.data_ptr()
+
+
+def _check(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "nesie_amd kernels need HIP device tensors (got device "
+                f"{t.device}); there is no CPU path in the product")
+        if not t.is_contiguous():
+            raise RuntimeError("nesie_amd kernels need contiguous tensors")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+def _i32(*ts):
+    for t in ts:
+        if t.dtype != torch.int32:
+            raise TypeError(f"expected int32, got {t.dtype}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class HipKernels:
+    """libnesie_hip.so, asynchronous on torch's current HIP stream."""
+
+    name = "hip"
+
+    def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
+        _check(xyz, temp, idx); _f32(xyz, temp); _i32(idx)
+        assert xyz.numel() == b * n * 3 and temp.numel() == b * n and idx.numel() == b * m
+        with torch.cuda.device(xyz.device):
+            _lib.call("nesie_furthest_point_sampling_wrapper", b, n, m, _ptr(xyz),
+                      _ptr(temp), _ptr(idx), _stream(xyz))
+
+    def furthest_point_sampling_with_dist_wrapper(self, b, n, m, dist, temp, idx):
+        _check(dist, temp, idx); _f32(dist, temp); _i32(idx)
+        assert dist.numel() == b * n * n and temp.numel() == b * n and idx.numel() == b * m
+        with torch.cuda.device(dist.device):
+            _lib.call("nesie_furthest_point_sampling_with_dist_wrapper", b, n, m,
+                      _ptr(dist), _ptr(temp), _ptr(idx), _stream(dist))
+
+    def ball_query_wrapper(self, b, n, m, min_radius, max_radius, nsample, new_xyz, xyz,
+                           idx):
+        _check(new_xyz, xyz, idx); _f32(new_xyz, xyz); _i32(idx)
+        assert new_xyz.numel() == b * m * 3 and xyz.numel() == b * n * 3
+        assert idx.numel() == b * m * nsample
+        with torch.cuda.device(xyz.device):
+            _lib.call("nesie_ball_query_wrapper", b, n, m, float(min_radius),
+                      float(max_radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
+                      _stream(xyz))
+
+    def group_points_forward(self, b, c, n, npoints, nsample, points, idx, out):
+        _check(points, idx, out); _f32(points, out); _i32(idx)
+        assert points.numel() == b * c * n and idx.numel() == b * npoints * nsample
+        assert out.numel() == b * c * npoints * nsample
+        with torch.cuda.device(points.device):
+            _lib.call("nesie_group_points_forward", b, c, n, npoints, nsample,
+                      _ptr(points), _ptr(idx), _ptr(out), _stream(points))
+
+    def group_points_backward(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        _check(grad_out, idx, grad_points); _f32(grad_out, grad_points); _i32(idx)
+        assert grad_out.numel() == b * c * npoints * nsample
+        assert idx.numel() == b * npoints * nsample and grad_points.numel() == b * c * n
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_group_points_backward", b, c, n, npoints, nsample,
+                      _ptr(grad_out), _ptr(idx), _ptr(grad_points), _stream(grad_out))
+
+    def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
+        _check(points, idx, out); _f32(points, out); _i32(idx)
+        assert points.numel() == b * c * n and idx.numel() == b * npoints
+        assert out.numel() == b * c * npoints
+        with torch.cuda.device(points.device):
+            _lib.call("nesie_gather_points_wrapper", b, c, n, npoints, _ptr(points),
+                      _ptr(idx), _ptr(out), _stream(points))
+
+    def gather_points_grad_wrapper(self, b, c, n, npoints, grad_out, idx, grad_points):
+        _check(grad_out, idx, grad_points); _f32(grad_out, grad_points); _i32(idx)
+        assert grad_out.numel() == b * c * npoints and idx.numel() == b * npoints
+        assert grad_points.numel() == b * c * n
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_gather_points_grad_wrapper", b, c, n, npoints,
+                      _ptr(grad_out), _ptr(idx), _ptr(grad_points), _stream(grad_out))
+
+    def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
+        _check(unknown, known, dist2, idx); _f32(unknown, known, dist2); _i32(idx)
+        assert unknown.numel() == b * n * 3 and known.numel() == b * m * 3
+        assert dist2.numel() == b * n * 3 and idx.numel() == b * n * 3
+        with torch.cuda.device(unknown.device):
+            _lib.call("nesie_three_nn_wrapper", b, n, m, _ptr(unknown), _ptr(known),
+                      _ptr(dist2), _ptr(idx), _stream(unknown))
+
+    def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
+        _check(points, idx, weight, out); _f32(points, weight, out); _i32(idx)
+        assert points.numel() == b * c * m and idx.numel() == b * n * 3
+        assert weight.numel() == b * n * 3 and out.numel() == b * c * n
+        with torch.cuda.device(points.device):
+            _lib.call("nesie_three_interpolate_wrapper", b, c, m, n, _ptr(points),
+                      _ptr(idx), _ptr(weight), _ptr(out), _stream(points))
+
+    def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
+                                       grad_points):
+        _check(grad_out, idx, weight, grad_points); _f32(grad_out, weight, grad_points)
+        _i32(idx)
+        assert grad_out.numel() == b * c * n and idx.numel() == b * n * 3
+        assert weight.numel() == b * n * 3 and grad_points.numel() == b * c * m
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_three_interpolate_grad_wrapper", b, c, n, m, _ptr(grad_out),
+                      _ptr(idx), _ptr(weight), _ptr(grad_points), _stream(grad_out))
+
+    def sort_vertices_forward(self, vertices, mask, num_valid, idx):
+        _check(vertices, mask, num_valid, idx); _f32(vertices); _i32(num_valid, idx)
+        if mask.dtype != torch.bool:
+            raise TypeError("mask must be bool")
+        b, n, m, two = vertices.shape
+        assert two == 2 and tuple(mask.shape) == (b, n, m)
+        assert tuple(num_valid.shape) == (b, n) and tuple(idx.shape) == (b, n, 9)
+        with torch.cuda.device(vertices.device):
+            _lib.call("nesie_sort_vertices_forward", b, n, m, _ptr(vertices), _ptr(mask),
+                      _ptr(num_valid), _ptr(idx), _stream(vertices))
+
+    def points_in_boxes_batch(self, boxes, pts, out):
+        _check(boxes, pts, out); _f32(boxes, pts); _i32(out)
+        b, t, seven = boxes.shape
+        assert seven == 7 and pts.shape[0] == b and pts.shape[2] == 3
+        m = pts.shape[1]
+        assert tuple(out.shape) == (b, m, t)
+        with torch.cuda.device(boxes.device):
+            _lib.call("nesie_points_in_boxes_batch", b, t, m, _ptr(boxes), _ptr(pts),
+                      _ptr(out), _stream(boxes))
+
+
+_hip = None
+
+
+def backend_for(tensor):
+    """The back end that serves ``tensor``: injected one, else HIP (or raise)."""
+    global _hip
+    if _injected is not None:
+        return _injected
+    if not tensor.is_cuda:
+        raise RuntimeError(
+            f"nesie_amd op called on a {tensor.device} tensor: the product path is "
+            "HIP-only (libnesie_hip.so); there is no CPU fallback")
+    if _hip is None:
+        _lib.load()
+        _hip = HipKernels()
+    return _hip
+
+
+@contextlib.contextmanager
+def use_backend(backend):
+    """Test/bench hook: run the enclosed code with ``backend`` serving every op."""
+    global _injected
+    prev = _injected
+    _injected = backend
+    try:
+        yield backend
+    finally:
+        _injected = prev

@@ -1,0 +1,46 @@
+"""Host-side mirror of ``mmdet3d.ops`` for the VoteNet/Nesie hot path
+(reference mmdet3d/ops/__init__.py:5-41).  Hot-path names are real; the rest of
+the reference's ``__all__`` (voxel / spconv / paconv / knn / iou3d / roi-aware
+pooling ...) resolves to stubs that raise on use, so ``from mmdet3d.ops import X``
+style code keeps importing ("import-time requirement").
+"""
+from .ball_query import ball_query
+from .furthest_point_sample import (Points_Sampler, furthest_point_sample,
+                                    furthest_point_sample_with_dist)
+from .gather_points import gather_points
+from .group_points import GroupAll, QueryAndGroup, group_points, grouping_operation
+from .interpolate import three_interpolate, three_nn
+from .pointnet_modules import (ConvModule, PointFPModule, PointSAModule, PointSAModuleMSG,
+                               build_sa_module)
+from .roiaware_pool3d import points_in_boxes_batch
+from .rotated_iou import cal_iou_3d, sort_v
+
+_HOT = [
+    'ball_query', 'furthest_point_sample', 'furthest_point_sample_with_dist',
+    'three_interpolate', 'three_nn', 'gather_points', 'grouping_operation', 'group_points',
+    'GroupAll', 'QueryAndGroup', 'PointSAModule', 'PointSAModuleMSG', 'PointFPModule',
+    'points_in_boxes_batch', 'Points_Sampler', 'build_sa_module', 'cal_iou_3d', 'sort_v',
+    'ConvModule',
+]
+_OUT_OF_SCOPE = [
+    'nms', 'soft_nms', 'RoIAlign', 'roi_align', 'get_compiler_version',
+    'get_compiling_cuda_version', 'NaiveSyncBatchNorm1d', 'NaiveSyncBatchNorm2d',
+    'batched_nms', 'Voxelization', 'voxelization', 'dynamic_scatter', 'DynamicScatter',
+    'sigmoid_focal_loss', 'SigmoidFocalLoss', 'SparseBasicBlock', 'SparseBottleneck',
+    'RoIAwarePool3d', 'points_in_boxes_gpu', 'points_in_boxes_cpu',
+    'make_sparse_convmodule', 'knn', 'assign_score_withk', 'PAConv', 'PAConvCUDA',
+    'PAConvSAModuleMSG', 'PAConvSAModule', 'PAConvCUDASAModule', 'PAConvCUDASAModuleMSG',
+    'cal_giou_3d',
+]
+__all__ = _HOT + _OUT_OF_SCOPE
+
+
+def __getattr__(name):
+    if name in _OUT_OF_SCOPE:
+        def _stub(*args, **kwargs):
+            raise NotImplementedError(
+                f'mmdet3d.ops.{name} is outside the VoteNet/Nesie hot path this build '
+                'covers (SURVEY.md section 2a/2b)')
+        _stub.__name__ = name
+        return _stub
+    raise AttributeError(name)

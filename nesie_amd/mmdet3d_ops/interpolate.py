@@ -1,0 +1,62 @@
+"""Mirror of ``mmdet3d/ops/interpolate`` (three_nn.py:8-45, three_interpolate.py:8-63).
+``three_nn`` also stands in for ``mmcv.ops.three_nn`` (side_pooling_module.py:8,204)."""
+from typing import Tuple
+
+import torch
+from torch.autograd import Function
+
+from ..kernels import backend_for
+
+
+class ThreeNN(Function):
+    """target (B,N,3), source (B,M,3) -> (sqrt(dist2) (B,N,3), idx (B,N,3) int32)."""
+
+    @staticmethod
+    def forward(ctx, target: torch.Tensor, source: torch.Tensor):
+        assert target.is_contiguous()
+        assert source.is_contiguous()
+        B, N, _ = target.size()
+        m = source.size(1)
+        dist2 = target.new_empty((B, N, 3))
+        idx = target.new_empty((B, N, 3), dtype=torch.int32)
+        backend_for(target).three_nn_wrapper(B, N, m, target, source, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """features (B,C,M), indices (B,n,3), weight (B,n,3) -> (B,C,n)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, indices: torch.Tensor,
+                weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert indices.is_contiguous()
+        assert weight.is_contiguous()
+        B, c, m = features.size()
+        n = indices.size(1)
+        ctx.three_interpolate_for_backward = (indices, weight, m)
+        output = features.new_empty((B, c, n))
+        backend_for(features).three_interpolate_wrapper(B, c, m, n, features, indices,
+                                                        weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = grad_out.new_zeros((B, c, m))
+        grad_out_data = grad_out.data.contiguous()
+        backend_for(grad_out_data).three_interpolate_grad_wrapper(
+            B, c, n, m, grad_out_data, idx, weight, grad_features.data)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply

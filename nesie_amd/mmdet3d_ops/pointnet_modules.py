@@ -1,0 +1,237 @@
+"""Mirror of ``mmdet3d/ops/pointnet_modules``: ``PointSAModuleMSG`` / ``PointSAModule``
+(point_sa_module.py:12-341), ``PointFPModule`` (point_fp_module.py:10-78),
+``build_sa_module`` (builder.py:6-38), plus ``ConvModule`` restated from mmcv 1.3.17
+(the source is not in the reference tree): conv -> norm -> act,
+``bias='auto'`` means "bias iff no norm", sub-module names ``conv`` / ``bn`` /
+``activate`` so reference checkpoints' keys line up, Kaiming-normal(fan_out, relu)
+conv weights, unit norm weight, zero biases.
+"""
+from typing import List
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .furthest_point_sample import Points_Sampler
+from .gather_points import gather_points
+from .group_points import GroupAll, QueryAndGroup
+from .interpolate import three_interpolate, three_nn
+
+
+class ConvModule(nn.Module):
+    """1x1 Conv{1,2}d -> BN{1,2}d (or GN) -> ReLU, mmcv-style."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0,
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), bias='auto',
+                 inplace=True):
+        super().__init__()
+        conv_type = (conv_cfg or dict(type='Conv2d'))['type']
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        conv_cls = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[conv_type]
+        self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
+                             padding=padding, bias=bias)
+        self.norm_name = None
+        if self.with_norm:
+            ntype = norm_cfg['type']
+            if ntype in ('BN1d', 'BN'):
+                self.norm_name, norm = 'bn', nn.BatchNorm1d(out_channels)
+            elif ntype == 'BN2d':
+                self.norm_name, norm = 'bn', nn.BatchNorm2d(out_channels)
+            elif ntype == 'GN':
+                self.norm_name, norm = 'gn', nn.GroupNorm(norm_cfg['num_groups'],
+                                                          out_channels)
+            else:
+                raise KeyError(f'unsupported norm type {ntype}')
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=inplace)
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+    def init_weights(self):
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+        if self.conv.bias is not None:
+            nn.init.constant_(self.conv.bias, 0)
+        if self.with_norm:
+            nn.init.constant_(self.norm.weight, 1)
+            nn.init.constant_(self.norm.bias, 0)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.norm(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+class BasePointSAModule(nn.Module):
+    """sample -> group -> shared MLP -> pool (point_sa_module.py:12-211)."""
+
+    def __init__(self, num_point, radii, sample_nums, mlp_channels, fps_mod=['D-FPS'],
+                 fps_sample_range_list=[-1], dilated_group=False, use_xyz=True,
+                 pool_mod='max', normalize_xyz=False, grouper_return_grouped_xyz=False,
+                 grouper_return_grouped_idx=False):
+        super().__init__()
+        assert len(radii) == len(sample_nums) == len(mlp_channels)
+        assert pool_mod in ['max', 'avg']
+        assert isinstance(fps_mod, (list, tuple))
+        assert isinstance(fps_sample_range_list, (list, tuple))
+        assert len(fps_mod) == len(fps_sample_range_list)
+        if isinstance(mlp_channels, tuple):
+            mlp_channels = list(map(list, mlp_channels))
+        self.mlp_channels = mlp_channels
+        if isinstance(num_point, int):
+            self.num_point = [num_point]
+        elif isinstance(num_point, (list, tuple)):
+            self.num_point = num_point
+        else:
+            raise NotImplementedError('Error type of num_point!')
+        self.pool_mod = pool_mod
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        self.fps_mod_list = fps_mod
+        self.fps_sample_range_list = fps_sample_range_list
+        self.points_sampler = Points_Sampler(self.num_point, self.fps_mod_list,
+                                             self.fps_sample_range_list)
+        for i in range(len(radii)):
+            if num_point is not None:
+                min_radius = radii[i - 1] if (dilated_group and i != 0) else 0
+                grouper = QueryAndGroup(radii[i], sample_nums[i], min_radius=min_radius,
+                                        use_xyz=use_xyz, normalize_xyz=normalize_xyz,
+                                        return_grouped_xyz=grouper_return_grouped_xyz,
+                                        return_grouped_idx=grouper_return_grouped_idx)
+            else:
+                grouper = GroupAll(use_xyz)
+            self.groupers.append(grouper)
+
+    def _sample_points(self, points_xyz, features, indices, target_xyz):
+        xyz_flipped = points_xyz.transpose(1, 2).contiguous()
+        if indices is not None:
+            assert indices.shape[1] == self.num_point[0]
+            new_xyz = gather_points(xyz_flipped, indices).transpose(1, 2).contiguous() \
+                if self.num_point is not None else None
+        elif target_xyz is not None:
+            new_xyz = target_xyz.contiguous()
+        else:
+            indices = self.points_sampler(points_xyz, features)
+            new_xyz = gather_points(xyz_flipped, indices).transpose(1, 2).contiguous() \
+                if self.num_point is not None else None
+        return new_xyz, indices
+
+    def _pool_features(self, features):
+        if self.pool_mod == 'max':
+            new_features = F.max_pool2d(features, kernel_size=[1, features.size(3)])
+        elif self.pool_mod == 'avg':
+            new_features = F.avg_pool2d(features, kernel_size=[1, features.size(3)])
+        else:
+            raise NotImplementedError
+        return new_features.squeeze(-1).contiguous()
+
+    def forward(self, points_xyz, features=None, indices=None, target_xyz=None):
+        new_features_list = []
+        new_xyz, indices = self._sample_points(points_xyz, features, indices, target_xyz)
+        for i in range(len(self.groupers)):
+            grouped_results = self.groupers[i](points_xyz, new_xyz, features)
+            new_features = self.mlps[i](grouped_results)
+            new_features = self._pool_features(new_features)
+            new_features_list.append(new_features)
+        return new_xyz, torch.cat(new_features_list, dim=1), indices
+
+
+class PointSAModuleMSG(BasePointSAModule):
+    """Multi-scale grouping SA module (point_sa_module.py:214-290)."""
+
+    def __init__(self, num_point, radii, sample_nums, mlp_channels, fps_mod=['D-FPS'],
+                 fps_sample_range_list=[-1], dilated_group=False,
+                 norm_cfg=dict(type='BN2d'), use_xyz=True, pool_mod='max',
+                 normalize_xyz=False, bias='auto'):
+        super().__init__(num_point=num_point, radii=radii, sample_nums=sample_nums,
+                         mlp_channels=mlp_channels, fps_mod=fps_mod,
+                         fps_sample_range_list=fps_sample_range_list,
+                         dilated_group=dilated_group, use_xyz=use_xyz, pool_mod=pool_mod,
+                         normalize_xyz=normalize_xyz)
+        for i in range(len(self.mlp_channels)):
+            mlp_channel = self.mlp_channels[i]
+            if use_xyz:
+                mlp_channel[0] += 3
+            mlp = nn.Sequential()
+            for j in range(len(mlp_channel) - 1):
+                mlp.add_module(
+                    f'layer{j}',
+                    ConvModule(mlp_channel[j], mlp_channel[j + 1], kernel_size=(1, 1),
+                               stride=(1, 1), conv_cfg=dict(type='Conv2d'),
+                               norm_cfg=norm_cfg, bias=bias))
+            self.mlps.append(mlp)
+
+
+class PointSAModule(PointSAModuleMSG):
+    """Single-scale grouping SA module (point_sa_module.py:293-341)."""
+
+    def __init__(self, mlp_channels, num_point=None, radius=None, num_sample=None,
+                 norm_cfg=dict(type='BN2d'), use_xyz=True, pool_mod='max',
+                 fps_mod=['D-FPS'], fps_sample_range_list=[-1], normalize_xyz=False):
+        super().__init__(mlp_channels=[list(mlp_channels)], num_point=num_point,
+                         radii=[radius], sample_nums=[num_sample], norm_cfg=norm_cfg,
+                         use_xyz=use_xyz, pool_mod=pool_mod, fps_mod=fps_mod,
+                         fps_sample_range_list=fps_sample_range_list,
+                         normalize_xyz=normalize_xyz)
+
+
+class PointFPModule(nn.Module):
+    """Feature propagation: 3-NN inverse-distance interpolation + skip concat + MLP
+    (point_fp_module.py:10-78)."""
+
+    def __init__(self, mlp_channels: List[int], norm_cfg: dict = dict(type='BN2d')):
+        super().__init__()
+        self.fp16_enabled = False
+        self.mlps = nn.Sequential()
+        for i in range(len(mlp_channels) - 1):
+            self.mlps.add_module(
+                f'layer{i}',
+                ConvModule(mlp_channels[i], mlp_channels[i + 1], kernel_size=(1, 1),
+                           stride=(1, 1), conv_cfg=dict(type='Conv2d'), norm_cfg=norm_cfg))
+
+    def forward(self, target, source, target_feats, source_feats):
+        if source is not None:
+            dist, idx = three_nn(target, source)
+            dist_reciprocal = 1.0 / (dist + 1e-8)
+            norm = torch.sum(dist_reciprocal, dim=2, keepdim=True)
+            weight = dist_reciprocal / norm
+            interpolated_feats = three_interpolate(source_feats, idx, weight)
+        else:
+            interpolated_feats = source_feats.expand(*source_feats.size()[0:2],
+                                                     target.size(1))
+        if target_feats is not None:
+            new_features = torch.cat([interpolated_feats, target_feats], dim=1)
+        else:
+            new_features = interpolated_feats
+        new_features = new_features.unsqueeze(-1)
+        new_features = self.mlps(new_features)
+        return new_features.squeeze(-1)
+
+
+SA_MODULES = {'PointSAModule': PointSAModule, 'PointSAModuleMSG': PointSAModuleMSG}
+
+
+def build_sa_module(cfg, *args, **kwargs):
+    """Build an SA module from a ``dict(type=..., ...)`` (builder.py:6-38)."""
+    if cfg is None:
+        cfg_ = dict(type='PointSAModule')
+    else:
+        if not isinstance(cfg, dict):
+            raise TypeError('cfg must be a dict')
+        if 'type' not in cfg:
+            raise KeyError('the cfg dict must contain the key "type"')
+        cfg_ = cfg.copy()
+    module_type = cfg_.pop('type')
+    if module_type not in SA_MODULES:
+        raise KeyError(f'Unrecognized module type {module_type}')
+    return SA_MODULES[module_type](*args, **kwargs, **cfg_)

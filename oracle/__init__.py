@@ -1,0 +1,160 @@
+"""CPU oracle for the nesie_amd kernels -- TEST INFRASTRUCTURE ONLY.
+
+Loads ``oracle/liboracle.so`` (built from ``nesie_oracle.c`` by
+``oracle/Makefile``; see that file's header for what it restates and its pin
+status) and, when present, ``oracle/_ref/points_in_boxes_ref.so`` (the
+reference's own CPU source compiled where it lies).  Only tests/,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of bench.py may
+import this package; ``nesie_amd`` never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_PIB_PATH = os.path.join(_HERE, "_ref", "points_in_boxes_ref.so")
+
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_SIGS = {
+    "oracle_fps_block_size": [_I],
+    "oracle_furthest_point_sampling": [_I, _I, _I, _P, _P, _P],
+    "oracle_furthest_point_sampling_with_dist": [_I, _I, _I, _P, _P, _P],
+    "oracle_ball_query": [_I, _I, _I, _F, _F, _I, _P, _P, _P],
+    "oracle_group_points": [_I, _I, _I, _I, _I, _P, _P, _P],
+    "oracle_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P],
+    "oracle_gather_points": [_I, _I, _I, _I, _P, _P, _P],
+    "oracle_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P],
+    "oracle_three_nn": [_I, _I, _I, _P, _P, _P, _P],
+    "oracle_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "oracle_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "oracle_sort_vertices": [_I, _I, _I, _P, _P, _P, _P],
+    "oracle_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P],
+    "oracle_num_threads": [],
+}
+_lib = None
+_ref = None
+
+
+def build():
+    """(Re)build liboracle.so and, if the reference tree exists, oracle/_ref."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        for name, at in _SIGS.items():
+            f = getattr(L, name)
+            f.argtypes = at
+            f.restype = _I
+        _lib = L
+    return _lib
+
+
+def ref_points_in_boxes_available():
+    return os.path.exists(REF_PIB_PATH)
+
+
+def ref_points_in_boxes_cpu(boxes, pts):
+    """The REFERENCE's points_in_boxes_cpu (compiled from its own source).
+
+    boxes (T,7) LiDAR frame, pts (M,3) -> int32 (T, M).
+    """
+    global _ref
+    if _ref is None:
+        _ref = ctypes.CDLL(REF_PIB_PATH)
+        _ref.ref_points_in_boxes_cpu.argtypes = [_P, _I, _P, _I, _P]
+        _ref.ref_points_in_boxes_cpu.restype = _I
+    boxes = boxes.contiguous().float()
+    pts = pts.contiguous().float()
+    out = torch.zeros(boxes.shape[0], pts.shape[0], dtype=torch.int32)
+    _ref.ref_points_in_boxes_cpu(boxes.data_ptr(), boxes.shape[0], pts.data_ptr(),
+                                 pts.shape[0], out.data_ptr())
+    return out
+
+
+def _cpu(*ts):
+    for t in ts:
+        assert t.device.type == "cpu" and t.is_contiguous(), "oracle takes contiguous CPU tensors"
+
+
+class OracleKernels:
+    """Same method surface as nesie_amd.kernels.HipKernels, on CPU tensors."""
+
+    name = "oracle"
+
+    def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
+        _cpu(xyz, temp, idx)
+        lib().oracle_furthest_point_sampling(b, n, m, xyz.data_ptr(), temp.data_ptr(),
+                                             idx.data_ptr())
+
+    def furthest_point_sampling_with_dist_wrapper(self, b, n, m, dist, temp, idx):
+        _cpu(dist, temp, idx)
+        lib().oracle_furthest_point_sampling_with_dist(b, n, m, dist.data_ptr(),
+                                                       temp.data_ptr(), idx.data_ptr())
+
+    def ball_query_wrapper(self, b, n, m, min_radius, max_radius, nsample, new_xyz, xyz,
+                           idx):
+        _cpu(new_xyz, xyz, idx)
+        lib().oracle_ball_query(b, n, m, float(min_radius), float(max_radius), nsample,
+                                new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+
+    def group_points_forward(self, b, c, n, npoints, nsample, points, idx, out):
+        _cpu(points, idx, out)
+        lib().oracle_group_points(b, c, n, npoints, nsample, points.data_ptr(),
+                                  idx.data_ptr(), out.data_ptr())
+
+    def group_points_backward(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        _cpu(grad_out, idx, grad_points)
+        lib().oracle_group_points_grad(b, c, n, npoints, nsample, grad_out.data_ptr(),
+                                       idx.data_ptr(), grad_points.data_ptr())
+
+    def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
+        _cpu(points, idx, out)
+        lib().oracle_gather_points(b, c, n, npoints, points.data_ptr(), idx.data_ptr(),
+                                   out.data_ptr())
+
+    def gather_points_grad_wrapper(self, b, c, n, npoints, grad_out, idx, grad_points):
+        _cpu(grad_out, idx, grad_points)
+        lib().oracle_gather_points_grad(b, c, n, npoints, grad_out.data_ptr(),
+                                        idx.data_ptr(), grad_points.data_ptr())
+
+    def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
+        _cpu(unknown, known, dist2, idx)
+        lib().oracle_three_nn(b, n, m, unknown.data_ptr(), known.data_ptr(),
+                              dist2.data_ptr(), idx.data_ptr())
+
+    def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
+        _cpu(points, idx, weight, out)
+        lib().oracle_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
+                                       weight.data_ptr(), out.data_ptr())
+
+    def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
+                                       grad_points):
+        _cpu(grad_out, idx, weight, grad_points)
+        lib().oracle_three_interpolate_grad(b, c, n, m, grad_out.data_ptr(),
+                                            idx.data_ptr(), weight.data_ptr(),
+                                            grad_points.data_ptr())
+
+    def sort_vertices_forward(self, vertices, mask, num_valid, idx):
+        _cpu(vertices, mask, num_valid, idx)
+        b, n, m, _ = vertices.shape
+        assert mask.dtype == torch.bool
+        lib().oracle_sort_vertices(b, n, m, vertices.data_ptr(), mask.data_ptr(),
+                                   num_valid.data_ptr(), idx.data_ptr())
+
+    def points_in_boxes_batch(self, boxes, pts, out):
+        _cpu(boxes, pts, out)
+        b, t, _ = boxes.shape
+        lib().oracle_points_in_boxes_batch(b, t, pts.shape[1], boxes.data_ptr(),
+                                           pts.data_ptr(), out.data_ptr())
+
+
+def num_threads():
+    return lib().oracle_num_threads()

@@ -1,0 +1,472 @@
+/*
+ * nesie_oracle.c -- CPU restatement of the reference's point-cloud operators.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under nesie_amd/ may import, link or call
+ * this file.  It is used by tests/, by __graft_entry__.smoke() and by the
+ * cpu_baseline leg of bench.py, always as the checker / the timed CPU
+ * baseline, never as the product path.
+ *
+ * What it restates (reference = /root/reference, mmdetection3d-0.x fork):
+ *   mmdet3d/ops/furthest_point_sample/src/furthest_point_sample_cuda.cu
+ *   mmdet3d/ops/ball_query/src/ball_query_cuda.cu
+ *   mmdet3d/ops/group_points/src/group_points_cuda.cu
+ *   mmdet3d/ops/gather_points/src/gather_points_cuda.cu
+ *   mmdet3d/ops/interpolate/src/three_nn_cuda.cu, three_interpolate_cuda.cu
+ *   mmdet3d/ops/rotated_iou/cuda_op/sort_vert_kernel.cu
+ *   mmdet3d/ops/roiaware_pool3d/src/points_in_boxes_cuda.cu
+ *
+ * PIN STATUS.  The reference ships these operators as CUDA only, with no
+ * tests, fixtures or golden vectors, and it
+ * cannot run in this image.  So for fps / ball_query / group / gather /
+ * three_nn / three_interpolate / sort_vertices the parity is UNPINNED against
+ * reference outputs; the restatement is instead cross-checked in
+ * tests/test_oracle.py against (i) an independent numpy restatement and
+ * (ii) for FPS a literal thread-by-thread simulation of the reference's
+ * LDS tree reduction.  points_in_boxes is PINNED: it is checked against
+ * oracle/_ref/points_in_boxes_ref.so, compiled from the reference's own
+ * roiaware_pool3d/src/points_in_boxes_cpu.cpp by oracle/Makefile.
+ *
+ * Floating point discipline: every squared distance
+ * is ((dx*dx) + (dy*dy)) + (dz*dz) in fp32 with NO fma contraction; build
+ * with -ffp-contract=off (oracle/Makefile does).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* FPS                                                                 */
+/* ------------------------------------------------------------------ */
+
+/* furthest_point_sample_cuda.cu:11-15  opt_n_threads() */
+int oracle_fps_block_size(int n) {
+  int pow_2 = (int)(log((double)n) / log(2.0));
+  int bs = 1 << pow_2;
+  if (bs > 1024) bs = 1024;
+  if (bs < 1) bs = 1;
+  return bs;
+}
+
+/* furthest_point_sample_cuda.cu:17-23 (__update) and :76-136 (tree) */
+static int fps_tree_reduce(float *dists, int *dists_i, int bs) {
+  for (int stride = bs / 2; stride >= 1; stride >>= 1) {
+    for (int t = 0; t < stride; ++t) {
+      float v1 = dists[t], v2 = dists[t + stride];
+      int i1 = dists_i[t], i2 = dists_i[t + stride];
+      dists[t] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+      dists_i[t] = v2 > v1 ? i2 : i1;
+    }
+  }
+  return dists_i[0];
+}
+
+/* furthest_point_sample_cuda.cu:26-141  furthest_point_sampling_kernel.
+ * xyz (B,N,3) f32, temp (B,N) f32 (caller fills 1e10; updated in place),
+ * idx (B,M) i32.  Thread t of the reference owns k == t (mod bs) and keeps
+ * the first strict maximum; the tree then resolves ties between threads. */
+int oracle_furthest_point_sampling(int b, int n, int m, const float *xyz,
+                                   float *temp, int *idx) {
+  if (m <= 0) return 1; /* :34 */
+  const int bs = oracle_fps_block_size(n);
+#pragma omp parallel for schedule(static)
+  for (int bi = 0; bi < b; ++bi) {
+    const float *p = xyz + (size_t)bi * n * 3;
+    float *tp = temp + (size_t)bi * n;
+    int *out = idx + (size_t)bi * m;
+    float *d2buf = (float *)malloc(sizeof(float) * (size_t)n);
+    float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+    int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+    int old = 0;
+    out[0] = 0; /* :47 */
+    for (int j = 1; j < m; ++j) {
+      const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+      for (int k = 0; k < n; ++k) { /* :58-71, vectorisable part */
+        float dx = p[k * 3 + 0] - x1;
+        float dy = p[k * 3 + 1] - y1;
+        float dz = p[k * 3 + 2] - z1;
+        float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+        float t = tp[k];
+        float d2 = d < t ? d : t; /* min(d, temp[k]) */
+        tp[k] = d2;
+        d2buf[k] = d2;
+      }
+      for (int t = 0; t < bs; ++t) { /* :52-53 */
+        dists[t] = -1.0f;
+        dists_i[t] = 0;
+      }
+      for (int k = 0; k < n; ++k) { /* :69-70 per-thread first strict max */
+        int t = k & (bs - 1);
+        if (d2buf[k] > dists[t]) {
+          dists[t] = d2buf[k];
+          dists_i[t] = k;
+        }
+      }
+      old = fps_tree_reduce(dists, dists_i, bs);
+      out[j] = old; /* :138-139 */
+    }
+    free(d2buf);
+    free(dists);
+    free(dists_i);
+  }
+  return 1;
+}
+
+/* furthest_point_sample_cuda.cu:214-331  ..._with_dist_kernel (F-FPS).
+ * dist (B,N,N); same reduction, d = dist[old*n + k]. */
+int oracle_furthest_point_sampling_with_dist(int b, int n, int m,
+                                             const float *dist, float *temp,
+                                             int *idx) {
+  if (m <= 0) return 1;
+  const int bs = oracle_fps_block_size(n);
+#pragma omp parallel for schedule(static)
+  for (int bi = 0; bi < b; ++bi) {
+    const float *dm = dist + (size_t)bi * n * n;
+    float *tp = temp + (size_t)bi * n;
+    int *out = idx + (size_t)bi * m;
+    float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+    int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+    int old = 0;
+    out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+      for (int t = 0; t < bs; ++t) {
+        dists[t] = -1.0f;
+        dists_i[t] = 0;
+      }
+      for (int k = 0; k < n; ++k) {
+        float d = dm[(size_t)old * n + k];
+        float t0 = tp[k];
+        float d2 = d < t0 ? d : t0;
+        tp[k] = d2;
+        int t = k & (bs - 1);
+        if (d2 > dists[t]) {
+          dists[t] = d2;
+          dists_i[t] = k;
+        }
+      }
+      old = fps_tree_reduce(dists, dists_i, bs);
+      out[j] = old;
+    }
+    free(dists);
+    free(dists_i);
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* ball query                                                          */
+/* ------------------------------------------------------------------ */
+
+/* ball_query_cuda.cu:11-54.  new_xyz (B,M,3), xyz (B,N,3), idx (B,M,ns) i32
+ * zero-initialised by the caller (ball_query.py:35). */
+int oracle_ball_query(int b, int n, int m, float min_radius, float max_radius,
+                      int nsample, const float *new_xyz, const float *xyz,
+                      int *idx) {
+  const float max_radius2 = max_radius * max_radius; /* :27 */
+  const float min_radius2 = min_radius * min_radius; /* :28 */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi) {
+    for (int pi = 0; pi < m; ++pi) {
+      const float *c = new_xyz + ((size_t)bi * m + pi) * 3;
+      const float *p = xyz + (size_t)bi * n * 3;
+      int *o = idx + ((size_t)bi * m + pi) * nsample;
+      const float new_x = c[0], new_y = c[1], new_z = c[2];
+      int cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        float dx = new_x - p[k * 3 + 0];
+        float dy = new_y - p[k * 3 + 1];
+        float dz = new_z - p[k * 3 + 2];
+        float d2 = ((dx * dx) + (dy * dy)) + (dz * dz); /* :41-42 */
+        if (d2 == 0 || (d2 >= min_radius2 && d2 < max_radius2)) { /* :43 */
+          if (cnt == 0) {
+            for (int l = 0; l < nsample; ++l) o[l] = k; /* :44-48 */
+          }
+          o[cnt] = k;
+          ++cnt;
+          if (cnt >= nsample) break;
+        }
+      }
+    }
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* group / gather                                                      */
+/* ------------------------------------------------------------------ */
+
+/* group_points_cuda.cu:56-80.  points (B,C,N), idx (B,M,ns) -> out (B,C,M,ns) */
+int oracle_group_points(int b, int c, int n, int npoints, int nsample,
+                        const float *points, const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      const float *src = points + ((size_t)bi * c + ci) * n;
+      const int *ix = idx + (size_t)bi * npoints * nsample;
+      float *dst = out + ((size_t)bi * c + ci) * npoints * nsample;
+      for (int e = 0; e < npoints * nsample; ++e) dst[e] = src[ix[e]];
+    }
+  return 1;
+}
+
+/* group_points_cuda.cu:10-31 (atomicAdd scatter).  grad_points must be
+ * zeroed by the caller.  Summation order here: ascending (p, s). */
+int oracle_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                             const float *grad_out, const int *idx,
+                             float *grad_points) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      float *dst = grad_points + ((size_t)bi * c + ci) * n;
+      const int *ix = idx + (size_t)bi * npoints * nsample;
+      const float *g = grad_out + ((size_t)bi * c + ci) * npoints * nsample;
+      for (int e = 0; e < npoints * nsample; ++e) dst[ix[e]] += g[e];
+    }
+  return 1;
+}
+
+/* gather_points_cuda.cu:8-26.  points (B,C,N), idx (B,M) -> out (B,C,M) */
+int oracle_gather_points(int b, int c, int n, int npoints, const float *points,
+                         const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      const float *src = points + ((size_t)bi * c + ci) * n;
+      const int *ix = idx + (size_t)bi * npoints;
+      float *dst = out + ((size_t)bi * c + ci) * npoints;
+      for (int e = 0; e < npoints; ++e) dst[e] = src[ix[e]];
+    }
+  return 1;
+}
+
+/* gather_points_cuda.cu:51-70 (atomicAdd scatter), ascending m order. */
+int oracle_gather_points_grad(int b, int c, int n, int npoints,
+                              const float *grad_out, const int *idx,
+                              float *grad_points) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      float *dst = grad_points + ((size_t)bi * c + ci) * n;
+      const int *ix = idx + (size_t)bi * npoints;
+      const float *g = grad_out + ((size_t)bi * c + ci) * npoints;
+      for (int e = 0; e < npoints; ++e) dst[ix[e]] += g[e];
+    }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* three_nn / three_interpolate                                        */
+/* ------------------------------------------------------------------ */
+
+/* three_nn_cuda.cu:11-65.  unknown (B,n,3), known (B,m,3) ->
+ * dist2 (B,n,3) f32, idx (B,n,3) i32.  bests are double, d is float. */
+int oracle_three_nn(int b, int n, int m, const float *unknown,
+                    const float *known, float *dist2, int *idx) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int pi = 0; pi < n; ++pi) {
+      const float *u = unknown + ((size_t)bi * n + pi) * 3;
+      const float *kn = known + (size_t)bi * m * 3;
+      const float ux = u[0], uy = u[1], uz = u[2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40; /* :35 */
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float dx = ux - kn[k * 3 + 0];
+        float dy = uy - kn[k * 3 + 1];
+        float dz = uz - kn[k * 3 + 2];
+        float d = ((dx * dx) + (dy * dy)) + (dz * dz); /* :41 */
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float *od = dist2 + ((size_t)bi * n + pi) * 3;
+      int *oi = idx + ((size_t)bi * n + pi) * 3;
+      od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+      oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+  return 1;
+}
+
+/* three_interpolate_cuda.cu:11-35.  points (B,C,M), idx/weight (B,N,3) ->
+ * out (B,C,N); products rounded individually, summed left to right. */
+int oracle_three_interpolate(int b, int c, int m, int n, const float *points,
+                             const int *idx, const float *weight, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      const float *src = points + ((size_t)bi * c + ci) * m;
+      const int *ix = idx + (size_t)bi * n * 3;
+      const float *w = weight + (size_t)bi * n * 3;
+      float *dst = out + ((size_t)bi * c + ci) * n;
+      for (int p = 0; p < n; ++p) {
+        float a0 = w[p * 3 + 0] * src[ix[p * 3 + 0]];
+        float a1 = w[p * 3 + 1] * src[ix[p * 3 + 1]];
+        float a2 = w[p * 3 + 2] * src[ix[p * 3 + 2]];
+        dst[p] = (a0 + a1) + a2;
+      }
+    }
+  return 1;
+}
+
+/* three_interpolate_cuda.cu:61-84 (3 atomicAdds per element).
+ * grad_out (B,C,N) -> grad_points (B,C,M) zeroed by the caller. */
+int oracle_three_interpolate_grad(int b, int c, int n, int m,
+                                  const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci) {
+      float *dst = grad_points + ((size_t)bi * c + ci) * m;
+      const int *ix = idx + (size_t)bi * n * 3;
+      const float *w = weight + (size_t)bi * n * 3;
+      const float *g = grad_out + ((size_t)bi * c + ci) * n;
+      for (int p = 0; p < n; ++p) {
+        dst[ix[p * 3 + 0]] += g[p] * w[p * 3 + 0];
+        dst[ix[p * 3 + 1]] += g[p] * w[p * 3 + 1];
+        dst[ix[p * 3 + 2]] += g[p] * w[p * 3 + 2];
+      }
+    }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* sort_vertices                                                       */
+/* ------------------------------------------------------------------ */
+
+#define SV_MAX_IDX 9
+#define SV_INTER_OFFSET 8
+#define SV_EPS 1e-8 /* a double constant, as in the reference */
+
+/* sort_vert_kernel.cu:15-40.  The reference falls off the end of this
+ * function (undefined behaviour) when exactly one of y1, y2 is 0 or both are;
+ * this restatement returns false there, and tests avoid such inputs. */
+static int sv_compare(float x1, float y1, float x2, float y2) {
+  /* fabs on a float is the float overload in the reference's C++ */
+  if (fabsf(x1 - x2) < SV_EPS && fabsf(y2 - y1) < SV_EPS) return 0;
+  if (y1 > 0 && y2 < 0) return 1;
+  if (y1 < 0 && y2 > 0) return 0;
+  float n1 = x1 * x1 + y1 * y1 + SV_EPS;
+  float n2 = x2 * x2 + y2 * y2 + SV_EPS;
+  if (y1 > 0 && y2 > 0) {
+    return (fabsf(x1) * x1 / n1 - fabsf(x2) * x2 / n2 > SV_EPS) ? 1 : 0;
+  }
+  if (y1 < 0 && y2 < 0) {
+    return (fabsf(x1) * x1 / n1 - fabsf(x2) * x2 / n2 < SV_EPS) ? 1 : 0;
+  }
+  return 0;
+}
+
+/* sort_vert_kernel.cu:42-134.  vertices (B,N,M,2) f32, mask (B,N,M) u8,
+ * num_valid (B,N) i32 -> idx (B,N,9) i32.  `pad` is uninitialised in the
+ * reference when no invalid intersection exists; here it starts at M-1. */
+int oracle_sort_vertices(int b, int n, int m, const float *vertices,
+                         const uint8_t *mask, const int *num_valid, int *idx) {
+#pragma omp parallel for schedule(static)
+  for (long long bn = 0; bn < (long long)b * n; ++bn) {
+    const float *v = vertices + (size_t)bn * m * 2;
+    const uint8_t *mk = mask + (size_t)bn * m;
+    const int nv = num_valid[bn];
+    int *o = idx + (size_t)bn * SV_MAX_IDX;
+    int pad = m - 1;
+    for (int j = SV_INTER_OFFSET; j < m; ++j) {
+      if (!mk[j]) { pad = j; break; }
+    }
+    if (nv < 3) {
+      for (int j = 0; j < SV_MAX_IDX; ++j) o[j] = pad;
+      continue;
+    }
+    for (int j = 0; j < nv; ++j) {
+      float x_min = 1;
+      float y_min = -SV_EPS;
+      int i_take = 0;
+      for (int k = 0; k < m; ++k) {
+        float x = v[k * 2 + 0], y = v[k * 2 + 1];
+        if (j == 0) {
+          if (mk[k] && sv_compare(x, y, x_min, y_min)) {
+            x_min = x; y_min = y; i_take = k;
+          }
+        } else {
+          int i2 = o[j - 1];
+          float x2 = v[i2 * 2 + 0], y2 = v[i2 * 2 + 1];
+          if (mk[k] && sv_compare(x, y, x_min, y_min) &&
+              sv_compare(x2, y2, x, y)) {
+            x_min = x; y_min = y; i_take = k;
+          }
+        }
+        o[j] = i_take;
+      }
+    }
+    o[nv] = o[0];
+    for (int j = nv + 1; j < SV_MAX_IDX; ++j) o[j] = pad;
+    if (nv == 8) { /* :114-129 identical boxes */
+      int counter = 0;
+      for (int j = 0; j < 4; ++j) {
+        int check = o[j];
+        for (int k = 4; k < SV_INTER_OFFSET; ++k)
+          if (o[k] == check) counter++;
+      }
+      if (counter == 4) {
+        o[4] = o[0];
+        for (int j = 5; j < SV_MAX_IDX; ++j) o[j] = pad;
+      }
+    }
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* points_in_boxes_batch                                               */
+/* ------------------------------------------------------------------ */
+
+/* points_in_boxes_cuda.cu:24-49.  cos/sin are taken in double and rounded to
+ * float (the canonical form shared with the HIP kernel; the reference's
+ * device cosf/sinf differ from it by at most their own 2-ulp error). */
+static int pib_check(const float *pt, const float *box3d) {
+  float x = pt[0], y = pt[1], z = pt[2];
+  float cx = box3d[0], cy = box3d[1], cz = box3d[2];
+  float w = box3d[3], l = box3d[4], h = box3d[5], rz = box3d[6];
+  cz += h / 2.0; /* double division, rounded to float on the += */
+  if (fabsf(z - cz) > h / 2.0) return 0;
+  float rot_angle = rz + M_PI / 2;
+  float cosa = (float)cos((double)rot_angle), sina = (float)sin((double)rot_angle);
+  float shift_x = x - cx, shift_y = y - cy;
+  float local_x = shift_x * cosa + shift_y * (-sina);
+  float local_y = shift_x * sina + shift_y * cosa;
+  return (local_x > -l / 2.0) & (local_x < l / 2.0) & (local_y > -w / 2.0) &
+         (local_y < w / 2.0);
+}
+
+/* points_in_boxes_cuda.cu:79-105.  boxes (B,T,7) LiDAR frame bottom-centre,
+ * pts (B,M,3) -> out (B,M,T) i32 zeroed by the caller; writes 1 where inside. */
+int oracle_points_in_boxes_batch(int b, int boxes_num, int pts_num,
+                                 const float *boxes, const float *pts, int *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int pi = 0; pi < pts_num; ++pi) {
+      const float *pt = pts + ((size_t)bi * pts_num + pi) * 3;
+      const float *bx = boxes + (size_t)bi * boxes_num * 7;
+      int *o = out + ((size_t)bi * pts_num + pi) * boxes_num;
+      for (int k = 0; k < boxes_num; ++k)
+        if (pib_check(pt, bx + k * 7)) o[k] = 1;
+    }
+  return 1;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,204 @@
+"""HIP kernels (through the C ABI) against the CPU oracle on identical seeded inputs.
+Index outputs must be bit-exact; fp32 outputs of deterministic kernels too; the
+atomic scatter-adds are compared at 1e-5 (sum order differs, as in the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from nesie_amd import kernels
+from nesie_amd import mmdet3d_ops as ops
+from tests import _cases
+
+pytestmark = pytest.mark.gpu
+
+
+def both(fn, oracle_kernels, dev, *cpu_args):
+    """Run fn on HIP tensors with the product back end and on CPU tensors with the oracle."""
+    gpu_args = [a.to(dev) if torch.is_tensor(a) else a for a in cpu_args]
+    got = fn(*gpu_args)
+    torch.cuda.synchronize()
+    with kernels.use_backend(oracle_kernels):
+        want = fn(*cpu_args)
+    return got, want
+
+
+def eq(got, want):
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert torch.equal(got.cpu(), want), f"max abs diff {(got.cpu().double() - want.double()).abs().max()}"
+
+
+FPS_CASES = [
+    # n, m, batch, kwargs                       kernel variant exercised
+    (4096, 1024, 2, {}),                        # BASELINE config 1 (reg kernel, PPT 16)
+    (4096, 1024, 2, dict(dup_frac=0.25)),
+    (40000, 2048, 2, {}),                       # SA1 full size (stream kernel, PPT 40)
+    (40000, 2048, 2, dict(dup_frac=0.3)),       # under-sampled scene => duplicates
+    (2048, 1024, 3, {}), (1024, 512, 3, {}), (512, 256, 3, {}), (1024, 256, 3, {}),
+    (1000, 300, 2, dict(grid=True)),            # lattice ties
+    (37, 37, 2, {}), (64, 80, 2, dict(dup_frac=0.5)), (1, 3, 1, {}), (2, 2, 1, {}),
+    (1500, 64, 2, dict(dup_frac=0.3)), (5000, 100, 2, {}), (9000, 64, 1, {}),
+    (20000, 64, 1, {}), (30000, 33, 1, dict(dup_frac=0.2)), (45000, 40, 1, {}),
+    (60000, 40, 1, {}), (70000, 20, 1, {}),     # > 65536: generic kernel
+]
+
+
+@pytest.mark.parametrize("n,m,b,kw", FPS_CASES)
+def test_fps_bit_exact(oracle_kernels, hip_device, n, m, b, kw):
+    xyz = _cases.cloud(100 + n + m, b, n, **kw)
+    got, want = both(ops.furthest_point_sample, oracle_kernels, hip_device, xyz, m)
+    eq(got, want)
+
+
+def test_fps_temp_buffer_matches(oracle_kernels, hip_device):
+    for n, m in [(40000, 64), (3000, 200), (70000, 8)]:
+        xyz = _cases.cloud(n, 2, n, dup_frac=0.1)
+        t_cpu = torch.full((2, n), 1e10); i_cpu = torch.zeros((2, m), dtype=torch.int32)
+        oracle_kernels.furthest_point_sampling_wrapper(2, n, m, xyz, t_cpu, i_cpu)
+        t_gpu = torch.full((2, n), 1e10, device=hip_device)
+        i_gpu = torch.zeros((2, m), dtype=torch.int32, device=hip_device)
+        kernels.backend_for(t_gpu).furthest_point_sampling_wrapper(
+            2, n, m, xyz.to(hip_device), t_gpu, i_gpu)
+        eq(i_gpu, i_cpu); eq(t_gpu, t_cpu)
+
+
+def test_fps_with_dist_bit_exact(oracle_kernels, hip_device):
+    xyz = _cases.cloud(5, 2, 300, dup_frac=0.2)
+    d = ops.furthest_point_sample.__self__  # noqa: F841 (keep Function import alive)
+    from nesie_amd.mmdet3d_ops.furthest_point_sample import calc_square_dist
+    dist = calc_square_dist(xyz, xyz, norm=False).contiguous()
+    got, want = both(ops.furthest_point_sample_with_dist, oracle_kernels, hip_device, dist, 77)
+    eq(got, want)
+
+
+BQ_CASES = [
+    # n, m, radius, nsample, min_radius, batch, kwargs
+    (4096, 1024, 0.2, 32, 0.0, 2, {}),                 # BASELINE config 1
+    (40000, 2048, 0.2, 64, 0.0, 2, {}),                # SA1 full size
+    (40000, 2048, 0.2, 64, 0.0, 1, dict(dup_frac=0.3)),
+    (2048, 1024, 0.4, 32, 0.0, 3, {}), (1024, 512, 0.8, 16, 0.0, 3, {}),
+    (512, 256, 1.2, 16, 0.0, 3, {}), (1024, 256, 0.3, 16, 0.0, 3, {}),
+    (512, 64, 0.05, 16, 0.0, 2, {}),                   # empty / single-hit balls
+    (512, 61, 0.8, 16, 0.3, 2, {}),                    # min_radius > 0, ragged m
+    (100, 10, 10.0, 128, 0.0, 2, {}),                  # nsample > n
+    (1000, 7, 0.5, 1, 0.0, 1, {}), (65, 3, 5.0, 70, 0.0, 1, {}),
+]
+
+
+@pytest.mark.parametrize("n,m,r,ns,min_r,b,kw", BQ_CASES)
+def test_ball_query_bit_exact(oracle_kernels, hip_device, n, m, r, ns, min_r, b, kw):
+    xyz = _cases.cloud(7 + n + m, b, n, **kw)
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:m]
+    centres = xyz[:, pick].contiguous()
+    centres[:, -1] += 100.0  # an empty ball
+    got, want = both(ops.ball_query, oracle_kernels, hip_device, min_r, r, ns, xyz, centres)
+    eq(got, want)
+    assert (got[:, -1] == 0).all()
+
+
+@pytest.mark.parametrize("n,m,b", [(512, 256, 3), (1024, 512, 3), (49152, 1024, 2),
+                                   (32768, 1024, 1), (300, 0, 1), (300, 1, 2), (300, 2, 2),
+                                   (300, 3, 2), (64, 1500, 2), (1000, 2500, 1)])
+def test_three_nn_bit_exact(oracle_kernels, hip_device, n, m, b):
+    unknown = _cases.cloud(n, b, n, dup_frac=0.1)
+    known = _cases.cloud(m + 1, b, max(m, 1), dup_frac=0.2)[:, :m].contiguous()
+    if m >= 3:
+        unknown[:, :3] = known[:, :3]
+    (gd, gi), (wd, wi) = both(ops.three_nn, oracle_kernels, hip_device, unknown, known)
+    eq(gi, wi); eq(gd, wd)
+
+
+def test_group_gather_interpolate_forward_exact_and_grads_close(oracle_kernels, hip_device):
+    g = torch.Generator().manual_seed(0)
+    for (b, c, n, m, ns) in [(2, 3, 4096, 1024, 32), (2, 131, 2048, 256, 16), (1, 1, 40000, 2048, 64),
+                             (3, 9, 50, 7, 4)]:
+        pts = torch.randn(b, c, n, generator=g)
+        idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32)
+        got, want = both(ops.grouping_operation, oracle_kernels, hip_device, pts, idx)
+        eq(got, want)
+        go = torch.randn(b, c, m, ns, generator=g)
+
+        def grad(p, i, gout):
+            p = p.clone().requires_grad_(True)
+            ops.grouping_operation(p, i).backward(gout)
+            return p.grad
+        got, want = both(grad, oracle_kernels, hip_device, pts, idx, go)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+
+        gi = torch.randint(0, n, (b, m), generator=g, dtype=torch.int32)
+        got, want = both(ops.gather_points, oracle_kernels, hip_device, pts, gi)
+        eq(got, want)
+
+        def ggrad(p, i, gout):
+            p = p.clone().requires_grad_(True)
+            ops.gather_points(p, i).backward(gout)
+            return p.grad
+        got, want = both(ggrad, oracle_kernels, hip_device, pts, gi, go[..., 0].contiguous())
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+
+        q = 3 * m + 1
+        ti = torch.randint(0, n, (b, q, 3), generator=g, dtype=torch.int32)
+        w = torch.rand(b, q, 3, generator=g)
+        got, want = both(ops.three_interpolate, oracle_kernels, hip_device, pts, ti, w)
+        eq(got, want)
+        go3 = torch.randn(b, c, q, generator=g)
+
+        def igrad(p, i, ww, gout):
+            p = p.clone().requires_grad_(True)
+            ops.three_interpolate(p, i, ww).backward(gout)
+            return p.grad
+        got, want = both(igrad, oracle_kernels, hip_device, pts, ti, w, go3)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])
+def test_sort_vertices_bit_exact(oracle_kernels, hip_device, mode):
+    from tests.test_oracle import _vertices_for
+    v, mask, nv, _, _ = _vertices_for(mode, 4096, 33)
+    v = torch.nan_to_num(v)
+    got, want = both(ops.sort_v, oracle_kernels, hip_device, v, mask, nv)
+    eq(got, want)
+
+
+@pytest.mark.parametrize("mode", ["random", "identical", "aligned"])
+def test_cal_iou_3d_matches_cpu_chain(oracle_kernels, hip_device, mode):
+    a, b = _cases.box_pairs(44, 2048, mode)
+    got, want = both(ops.cal_iou_3d, oracle_kernels, hip_device, a, b)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5)
+    if mode == "identical":
+        torch.testing.assert_close(got.cpu(), torch.ones_like(want), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("t,m,b,yaw", [(9, 40000, 2, False), (20, 40000, 1, True), (1, 100, 1, True),
+                                       (300, 1000, 2, True)])
+def test_points_in_boxes_bit_exact(oracle_kernels, hip_device, t, m, b, yaw):
+    boxes = _cases.boxes_lidar(t, b, t, yaw=yaw)
+    pts = _cases.cloud(m, b, m)
+    pts[:, :min(t, m)] = boxes[:, :min(t, m), :3]
+    got, want = both(ops.points_in_boxes_batch, oracle_kernels, hip_device, pts, boxes)
+    eq(got, want)
+    assert got.sum() > 0
+
+
+def test_full_size_properties(hip_device):
+    """Size-independent properties at BASELINE shapes, no oracle involved."""
+    xyz = _cases.cloud(1, 8, 40000, dup_frac=0.2).to(hip_device)
+    idx = ops.furthest_point_sample(xyz, 2048)
+    assert idx.shape == (8, 2048) and (idx[:, 0] == 0).all()
+    assert int(idx.min()) >= 0 and int(idx.max()) < 40000
+    # FPS never re-picks a location while unpicked distinct locations remain:
+    picked = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    for bi in range(8):
+        assert torch.unique(picked[bi], dim=0).shape[0] == 2048
+    # greedy property: min distance to earlier picks is non-increasing
+    p = picked[0].double()
+    d = torch.cdist(p, p)
+    mins = torch.stack([d[j, :j].min() for j in range(1, 2048)])
+    assert (mins[1:] <= mins[:-1] + 1e-9).all()
+    # ball query rows: ascending hits then first-hit padding, all within radius
+    bq = ops.ball_query(0.0, 0.2, 64, xyz, picked.contiguous())
+    nb = torch.gather(xyz, 1, bq.long().view(8, -1, 1).expand(-1, -1, 3)).view(8, 2048, 64, 3)
+    d2 = ((nb - picked.unsqueeze(2)) ** 2).sum(-1)
+    assert (d2 < 0.2 ** 2 + 1e-6).all()
+    inc = bq[..., 1:] > bq[..., :-1]
+    pad = bq[..., 1:] == bq[..., :1]
+    assert (inc | pad).all()
