@@ -42,6 +42,15 @@ __device__ __forceinline__ int k_of_key_lo(unsigned lo, int L) {
   return (int)((q << L) | t);
 }
 
+// Order-preserving map float -> u32 for ANY sign (the F-FPS distance matrix is
+// a^2 + b^2 - 2ab and goes slightly negative); -0 is folded onto +0 first
+// because the reference compares them equal.
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  f = f + 0.0f;
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // Block-wide max of one u64 per thread; NW waves; one barrier per call.
 // `red` is [2][NW]; callers alternate `parity` between consecutive calls.
 template <int NW>
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
       float d2 = fminf(d, temp[k]);
       temp[k] = d2;
       unsigned long long key =
-          ((unsigned long long)__float_as_uint(d2) << 32) | key_lo_of(k, L);
+          ((unsigned long long)ordered_bits(d2) << 32) | key_lo_of(k, L);
       best = key > best ? key : best;
     }
     best = block_max_u64<NW>(best, red, r & 1);
