@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: ScanNet-shaped scenes/sec of one Nesie-VoteNet training step
+(forward + backward + grad all-reduce + clip + AdamW; 40 000 points/scene, batch 8 per
+GPU, fp32), data-parallel over N MI355X -- BASELINE.json `metric`, workload configs[2].
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = scenes all ranks processed / max-over-ranks
+time of exactly K steps (inputs resident in HBM before the timed region).  `roofline`
+prices the dominant kernel from HIP-event timings taken inside the timed region;
+`cpu_baseline` times the same step on the host through the CPU oracle (bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+from nesie_amd import dp, kernels
+from nesie_amd.scenes import make_batch
+from nesie_amd.votenet import build_nesie_votenet, nesie_votenet_scannet_cfg
+from nesie_amd.votenet.nesie_head import GTBatch
+
+NUM_POINTS = 40000
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+
+
+class KernelTimer:
+    """HIP-event timing of one back-end method (same stream the kernel launches on:
+    libnesie_hip.so launches on torch's current stream, so torch.cuda.Event brackets it)."""
+
+    def __init__(self, backend, method, select):
+        self.events, self.enabled = [], False
+        inner = getattr(backend, method)
+
+        def wrapped(*args):
+            if self.enabled and select(*args):
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                inner(*args)
+                e.record()
+                self.events.append((s, e))
+            else:
+                inner(*args)
+        setattr(backend, method, wrapped)
+
+    def mean_ms(self):
+        ts = [s.elapsed_time(e) for s, e in self.events]
+        return sum(ts) / len(ts) if ts else None
+
+
+def build_step(device, batch, seed, lr, wd):
+    torch.manual_seed(0)
+    model = build_nesie_votenet().to(device)
+    model.train()
+    pts, boxes, labels = make_batch(seed, batch, NUM_POINTS)
+    pts = pts.to(device)
+    gt = GTBatch.collate(boxes, labels, device)
+    bucket = dp.FlatGradBucket(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+
+    def step():
+        bucket.zero_()
+        losses = model.forward_train(pts, None, gt, None)
+        total = model.parse_losses(losses)
+        total.backward()
+        bucket.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2)
+        opt.step()
+        return total
+    return model, step, bucket
+
+
+def cpu_baseline(sample_batch, steps):
+    """The same training step on the host cores: index ops through oracle/ (the CPU
+    restatement, OpenMP), dense ops through PyTorch-CPU.  kind = "port"."""
+    import oracle
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    cfg = nesie_votenet_scannet_cfg()
+    with kernels.use_backend(oracle.OracleKernels()):
+        model, step, _ = build_step(torch.device('cpu'), sample_batch, 1000,
+                                    cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'])
+        step()  # warm-up (allocator, oneDNN primitives)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = (time.perf_counter() - t0) / steps
+    return dict(value=sample_batch / dt, unit='scenes/s', cores=cores, kind='port',
+                sample=f'{steps} timed training step(s) (after 1 warm-up) of {sample_batch} '
+                       f'scene(s) x {NUM_POINTS} pts, fwd+bwd+AdamW, oracle index ops + '
+                       f'PyTorch-CPU dense ops, {dt:.2f} s/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
+    ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
+    ap.add_argument('--cpu-batch', type=int, default=1)
+    ap.add_argument('--cpu-steps', type=int, default=1)
+    args = ap.parse_args()
+
+    rank, world, local = dp.init_distributed()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    from nesie_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+
+    cfg = nesie_votenet_scannet_cfg()
+    model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
+                                     cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'])
+    hip = kernels.backend_for(torch.empty(1, device=device))
+    # dominant kernel (profiles/): D-FPS over the 40 000-point scene
+    fps_timer = KernelTimer(hip, 'furthest_point_sampling_wrapper',
+                            lambda b, n, m, *_: n == NUM_POINTS)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    fps_timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    fps_timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        # FPS 40000->2048: algorithmic HBM bytes per launch = read xyz + temp once, write
+        # temp + idx (DESIGN.md "FPS"): B * (N*12 + N*4 + N*4 + M*4)
+        fps_ms = fps_timer.mean_ms()
+        alg_bytes = args.batch * (NUM_POINTS * 20 + 2048 * 4)
+        achieved = alg_bytes / (fps_ms * 1e-3) / 1e9 if fps_ms else None
+        out = {
+            'metric': 'ScanNet scenes/sec (fwd+bwd, 40k pts, bs=8)',
+            'value': value, 'unit': 'scenes/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Nesie-VoteNet supervised pretrain step '
+                                   '(nesie-votenet-scannet-pretrain-10%): fwd+bwd+AdamW, '
+                                   '40000 pts/scene, fp32, random-init weights',
+                       'scenes_per_gpu': args.batch, 'global_batch': world * args.batch,
+                       'points_per_scene': NUM_POINTS,
+                       'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'grad_allreduce_bytes': bucket.nbytes()},
+            'roofline': {'kernel': 'fps_stream_kernel<40> (D-FPS 40000->2048)',
+                         'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS if achieved else None,
+                         'traffic': None, 'avg_launch_ms': fps_ms,
+                         'algorithmic_bytes_per_launch': alg_bytes},
+        }
+        if args.cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,70 @@
+"""Data-parallel step plumbing: one process per GPU, scenes sharded by rank, ONE
+exchange per iteration -- an all-reduce(mean) of the flat gradient vector
+(2 640 477 fp32 = 10.56 MB for Nesie-VoteNet) over RCCL/xGMI.
+
+BatchNorm stays per-rank (the configs use plain BN, not SyncBN) and the EMA teacher is
+a deterministic function of the post-all-reduce parameters, so nothing else crosses
+ranks.  The message is latency-bound (a ring moves ~18.5 MB per GPU per step), so the
+gradients travel as a single flat bucket rather than per-tensor collectives.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract).
+    Returns (rank, world_size, local_rank).  backend: 'nccl' (= RCCL on ROCm) on GPUs,
+    'gloo' for the CPU tests."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatGradBucket:
+    """All parameters' gradients as views into one contiguous buffer, so the per-step
+    exchange is a single all-reduce and the optimiser sees ordinary ``p.grad``s."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero_(self):
+        self.flat.zero_()
+        for p in self.params:  # autograd accumulates in place into the views
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr():
+                raise RuntimeError('a gradient left the flat bucket (set_to_none?)')
+
+    def all_reduce_mean(self, group=None):
+        """In-place mean over ranks; a no-op in a single process."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+        return self.flat
+
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+
+def shard_range(total, rank, world):
+    """Scenes [lo, hi) of a global batch owned by ``rank`` (contiguous blocks)."""
+    per = total // world
+    assert per * world == total, 'global batch must divide by the world size'
+    return rank * per, (rank + 1) * per

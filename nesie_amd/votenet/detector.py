@@ -1,0 +1,87 @@
+"""VoteNet detector step (``mmdet3d/models/detectors/votenet.py:27-60``) and the
+Nesie-VoteNet ScanNet hyper-parameters (``configs/Nesie/nesie-votenet-scannet-pretrain-010.py:2-111``
+restated as a plain dict; the file itself does not travel)."""
+import copy
+
+import torch
+from torch import nn
+
+from .backbone import PointNet2SASSG
+from .nesie_head import NesieHead
+
+
+def nesie_votenet_scannet_cfg():
+    return dict(
+        backbone=dict(
+            in_channels=4, num_points=(2048, 1024, 512, 256), radius=(0.2, 0.4, 0.8, 1.2),
+            num_samples=(64, 32, 16, 16),
+            sa_channels=((64, 64, 128), (128, 128, 256), (128, 128, 256), (128, 128, 256)),
+            fp_channels=((256, 256), (256, 256)), norm_cfg=dict(type='BN2d'),
+            sa_cfg=dict(type='PointSAModule', pool_mod='max', use_xyz=True,
+                        normalize_xyz=True)),
+        bbox_head=dict(
+            num_classes=18, reg_max=32, alpha=1.0,
+            vote_module_cfg=dict(
+                in_channels=256, vote_per_seed=1, gt_per_seed=3, conv_channels=(256, 256),
+                conv_cfg=dict(type='Conv1d'), norm_cfg=dict(type='BN1d'), norm_feats=True,
+                vote_loss=dict(type='ChamferDistance', mode='l1', reduction='none',
+                               loss_dst_weight=10.0)),
+            vote_aggregation_cfg=dict(
+                type='PointSAModule', num_point=256, radius=0.3, num_sample=16,
+                mlp_channels=[256, 128, 128, 128], use_xyz=True, normalize_xyz=True),
+            pred_layer_cfg=dict(in_channels=128, shared_conv_channels=(128, 128), bias=True),
+            objectness_loss=dict(type='CrossEntropyLoss', class_weight=[0.2, 0.8],
+                                 reduction='sum', loss_weight=5.0),
+            center_loss=dict(type='ChamferDistance', mode='l2', reduction='sum',
+                             loss_src_weight=10.0, loss_dst_weight=10.0),
+            iou_loss=dict(type='IoU3DLoss', reduction='sum', loss_weight=3.0),
+            semantic_loss=dict(type='CrossEntropyLoss', reduction='sum', loss_weight=1.0),
+            iou_pred_loss=dict(type='GeneralQualityFocalLoss', reduction='sum',
+                               use_sigmoid=False, beta=2.0, loss_weight=3.0),
+            surface_loss=dict(type='SurfaceLoss', func_type='MSELoss', beta=5.0,
+                              reduction='sum', loss_weight=10.0),
+            side_loss=dict(type='SidePredLoss', label_func_type='SmoothL1Loss',
+                           loss_func_type='MSELoss', beta=5.0, reduction='sum',
+                           loss_weight=1.0),
+            grid_conv_cfg=dict(num_class=18, num_heading_bin=1, num_size_cluster=18,
+                               mean_size_arr_path=None, num_proposal=256,
+                               sampling='seed_fps', query_feats='seed')),
+        train_cfg=dict(pos_distance_thr=0.3, neg_distance_thr=0.6, sample_mod='vote'),
+        test_cfg=dict(sample_mod='seed', nms_thr=0.25, score_thr=0.05,
+                      per_class_proposal=True, add_info=True),
+        optimizer=dict(type='AdamW', lr=0.008, weight_decay=0.01),
+        grad_clip=dict(max_norm=10, norm_type=2),
+    )
+
+
+class VoteNet(nn.Module):
+    """backbone -> bbox head -> losses dict; total loss = sum of every entry whose key
+    contains 'loss' (mmdet BaseDetector._parse_losses)."""
+
+    def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.backbone = PointNet2SASSG(**backbone)
+        self.bbox_head = NesieHead(**bbox_head, train_cfg=train_cfg, test_cfg=test_cfg)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+
+    def extract_feat(self, points):
+        return self.backbone(points)
+
+    def forward_train(self, points, img_metas, gt_bboxes_3d, gt_labels_3d,
+                      pts_semantic_mask=None, pts_instance_mask=None, gt_bboxes_ignore=None):
+        points_cat = torch.stack(points) if isinstance(points, (list, tuple)) else points
+        x = self.extract_feat(points_cat)
+        bbox_preds = self.bbox_head(x, self.train_cfg['sample_mod'])
+        return self.bbox_head.loss(bbox_preds, points_cat, gt_bboxes_3d, gt_labels_3d,
+                                   pts_semantic_mask, pts_instance_mask, img_metas,
+                                   gt_bboxes_ignore=gt_bboxes_ignore)
+
+    @staticmethod
+    def parse_losses(losses):
+        return sum(v for k, v in losses.items() if 'loss' in k)
+
+
+def build_nesie_votenet(cfg=None):
+    cfg = copy.deepcopy(cfg or nesie_votenet_scannet_cfg())
+    return VoteNet(cfg['backbone'], cfg['bbox_head'], cfg['train_cfg'], cfg['test_cfg'])

@@ -1,0 +1,164 @@
+"""Side-aware quality head (``mmdet3d/models/dense_heads/side_pooling_module.py:10-370``).
+
+Per proposal: a 4x4x4 grid in the box and 6 face grids (4x4 each) are rotated /
+translated into the scene, each grid point gets [relative xyz (3), inverse-distance
+3-NN blend of the detached seed features (256)], a MiniPointNet pools each grid to a
+128-vector, and small heads emit per-class side scores (6 faces) and IoU scores.
+
+The 3-NN search and the 3-tap feature blend run on the native kernels
+(``three_nn`` / ``three_interpolate``); the reference reaches the same numbers with
+mmcv's three_nn plus an ``index_select`` that materialises (B, K*G*3, 256) floats.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..mmdet3d_ops import three_interpolate, three_nn
+
+
+def rot_gpu(t):
+    """Rotation about the upright axis, (...,) -> (...,3,3)  (:326-340)."""
+    c, s = torch.cos(t), torch.sin(t)
+    z, o = torch.zeros_like(t), torch.ones_like(t)
+    return torch.stack([torch.stack([c, s, z], -1), torch.stack([-s, c, z], -1),
+                        torch.stack([z, z, o], -1)], -2)
+
+
+class MiniPointNet(nn.Module):
+    """(B,C,K,G) -> (B,feature_dim,K): conv-bn-relu-conv, max over G, concat
+    [global, local], conv-bn-relu-conv, max over G  (:343-370)."""
+
+    def __init__(self, channels: int, feature_dim: int, hide_dim=256):
+        super().__init__()
+        self.first_conv = nn.Sequential(
+            nn.Conv2d(channels, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
+            nn.ReLU(inplace=True), nn.Conv2d(hide_dim, hide_dim // 2, 1))
+        self.second_conv = nn.Sequential(
+            nn.Conv2d(hide_dim, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
+            nn.ReLU(inplace=True), nn.Conv2d(hide_dim, feature_dim, 1))
+
+    def forward(self, points):
+        feature = self.first_conv(points)
+        feature_global = torch.max(feature, dim=-1, keepdim=True).values
+        feature = torch.cat([feature_global.expand(-1, -1, -1, feature.shape[-1]), feature],
+                            dim=1)
+        feature = self.second_conv(feature)
+        return torch.max(feature, dim=-1).values
+
+
+def _score_head(in_ch, out_ch):
+    return nn.Sequential(nn.Conv1d(in_ch, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+                         nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+                         nn.Conv1d(128, out_ch, 1))
+
+
+class SidePooling(nn.Module):
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr_path,
+                 num_proposal, sampling, seed_feat_dim=256, query_feats='seed',
+                 iou_class_depend=True):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        # the reference loads scannet_means.npz here (:28) and never reads it again
+        self.mean_size_arr = None
+        self.num_proposal = num_proposal
+        self.sampling = sampling
+        self.seed_feat_dim = seed_feat_dim
+        self.query_feats = query_feats
+        self.iou_class_depend = iou_class_depend
+        self.reg_topk = 4
+        self.grid_size = g = 4
+        self.left_mask = [i // g * g * g + i % g for i in range(g * g)]
+        self.right_mask = [i // g * g * g + i % g + g * (g - 1) for i in range(g * g)]
+        self.iou_size = num_class if iou_class_depend else 1
+        before, head = [], []
+        for _ in range(6):
+            before.append(MiniPointNet(seed_feat_dim + 3, 128))
+            head.append(_score_head(128 + 33 + 4 + 1, self.iou_size))
+        before.append(MiniPointNet(seed_feat_dim + 3, 128))
+        head.append(_score_head(128, self.iou_size))
+        self.mlps_before = nn.ModuleList(before)
+        self.mlps_head = nn.ModuleList(head)
+
+    def extract_features(self, end_points):
+        return (end_points['seed_points'].detach().contiguous(),
+                end_points['seed_features'].detach().contiguous())
+
+    def generate_grid(self, size):
+        """(B,K,3) sizes -> (B,K,g^3,3) box-frame grid, x slowest, z fastest (:87-122)."""
+        B, K = size.shape[:2]
+        g = self.grid_size
+        step = torch.linspace(-1, 1, g, device=size.device)
+        gx = step.view(g, 1, 1).repeat(1, g, g).view(1, 1, -1).expand(B, K, -1)
+        gy = step.view(1, g, 1).repeat(g, 1, g).view(1, 1, -1).expand(B, K, -1)
+        gz = step.view(1, 1, g).repeat(g, g, 1).view(1, 1, -1).expand(B, K, -1)
+        x_grid = gx * size[:, :, 0:1] / 2
+        y_grid = gy * size[:, :, 1:2] / 2
+        z_grid = gz * size[:, :, 2:3] / 2
+        return torch.cat([x_grid.unsqueeze(-1), y_grid.unsqueeze(-1), z_grid.unsqueeze(-1)],
+                         dim=-1)
+
+    def _to_scene(self, grid, center, heading):
+        B, K = center.shape[:2]
+        rot_mat = rot_gpu(heading).view(-1, 3, 3)
+        grid = torch.bmm(grid.reshape(B * K, -1, 3), rot_mat.transpose(1, 2)).view(B, K, -1, 3)
+        return grid + center.unsqueeze(2)
+
+    def grid_for_side(self, whole_grid, center, heading):
+        """front/back/top/down/left/right face grids, rotated + translated (:124-157)."""
+        g = self.grid_size
+        side_grid = torch.cat([
+            whole_grid[:, :, 0:g * g, :], whole_grid[:, :, -g * g:, :],
+            whole_grid[:, :, g - 1::g, :], whole_grid[:, :, ::g, :],
+            whole_grid[:, :, self.left_mask, :], whole_grid[:, :, self.right_mask, :]], dim=-2)
+        return self._to_scene(side_grid, center, heading)
+
+    def grid_for_bbox(self, whole_grid, center, heading):
+        return self._to_scene(whole_grid, center, heading)
+
+    def grid_features(self, origin_xyz, origin_features, whole_grid, center):
+        """(B,N,3),(B,C,N),(B,K*G,3),(B,K,3) -> (B,3+C,K,G)  (:183-243)."""
+        B, K = center.shape[:2]
+        grid_size = whole_grid.shape[1] // K
+        _, idx = three_nn(whole_grid, origin_xyz)  # (B, K*G, 3) int32
+        interp_points = torch.gather(origin_xyz, 1, idx.view(B, -1, 1).expand(-1, -1, 3).long())
+        expanded = whole_grid.unsqueeze(2).expand(-1, -1, 3, -1).reshape(B, -1, 3)
+        dist = interp_points - expanded
+        dist = torch.sqrt(torch.sum(dist * dist, dim=2))
+        relative_grid = whole_grid - center.unsqueeze(2).expand(-1, -1, grid_size, -1) \
+            .reshape(B, -1, 3)
+        weight = (1 / (dist + 1e-8)).view(B, -1, 3)
+        weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
+        interpolated = three_interpolate(origin_features, idx, weight)  # (B, C, K*G)
+        interpolated = interpolated.view(B, -1, K, grid_size)
+        return torch.cat([relative_grid.transpose(1, 2).reshape(B, -1, K, grid_size),
+                          interpolated], dim=1)
+
+    def dist_feature(self, end_points, prefix=''):
+        """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
+        for the jittered half -> (6, B, 38, 2K)  (:245-264)."""
+        prob = end_points[f'{prefix}bbox_probs'].detach()
+        stat = torch.cat([prob, prob.topk(self.reg_topk, dim=2)[0],
+                          prob.var(dim=2, keepdim=True)], dim=2)
+        return stat.permute(1, 0, 2, 3).repeat(1, 1, 1, 2)
+
+    def forward(self, center, size, heading, end_points, prefix=''):
+        B, K = size.shape[:2]
+        origin_xyz, origin_features = self.extract_features(end_points)
+        whole_grid = self.generate_grid(size)
+        side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
+        bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
+        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center)
+        side_feats = torch.split(side_feats, self.grid_size * self.grid_size, dim=-1)
+        bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)
+        dist_feature = self.dist_feature(end_points, prefix)
+        side_scores = []
+        for i in range(6):
+            f = self.mlps_before[i](side_feats[i].contiguous())
+            f = torch.cat((f, dist_feature[i]), dim=1)
+            side_scores.append(self.mlps_head[i](f))
+        end_points[f'{prefix}side_scores'] = torch.stack(side_scores, 0)
+        bbox_feats = self.mlps_before[6](bbox_feats)
+        end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)
+        return end_points
