@@ -20,6 +20,7 @@
 #ifndef NESIE_OPS_H_
 #define NESIE_OPS_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -43,6 +44,17 @@ const char *nesie_last_error(void); /* thread-local, never NULL */
  * final running-min squared distances on return.  idx[:,0] = 0. */
 int nesie_furthest_point_sampling_wrapper(int b, int n, int m, const float *xyz,
                                           float *temp, int *idx, void *stream);
+
+/* Same operator with caller-provided scratch (no reference counterpart: the
+ * reference kernel needs none).  For 4096 < n <= 65536 the kernel spatially sorts
+ * the scene into `workspace` and prunes whole 64-point buckets each round (results
+ * bit-identical); nesie_fps_workspace_bytes() says how much it needs (0 = this
+ * size runs without scratch).  workspace must be 16-byte aligned.  With a NULL or
+ * short workspace this behaves exactly like nesie_furthest_point_sampling_wrapper. */
+size_t nesie_fps_workspace_bytes(int b, int n);
+int nesie_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float *temp,
+                                     int *idx, void *workspace, size_t workspace_bytes,
+                                     void *stream);
 
 /* furthest_point_sample.cpp:59-65  furthest_point_sampling_with_dist_wrapper
  * (b, n, m, dist[B,N,N], temp[B,N], idx[B,M]). */

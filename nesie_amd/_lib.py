@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnesie_hip.so")
+LIB_PATH = os.environ.get("NESIE_LIB") or os.path.join(_HERE, "libnesie_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -18,6 +18,7 @@ _F = ctypes.c_float
 # name -> argtypes, in the order of include/nesie_ops.h (stream last)
 SIGNATURES = {
     "nesie_furthest_point_sampling_wrapper": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_furthest_point_sampling_ws": [_I, _I, _I, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "nesie_furthest_point_sampling_with_dist_wrapper": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_ball_query_wrapper": [_I, _I, _I, _F, _F, _I, _P, _P, _P, _P],
     "nesie_group_points_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -51,6 +52,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _I
+    lib.nesie_fps_workspace_bytes.argtypes = [_I, _I]
+    lib.nesie_fps_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_abi_version.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib

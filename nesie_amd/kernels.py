@@ -57,9 +57,16 @@ class HipKernels:
     def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
         _check(xyz, temp, idx); _f32(xyz, temp); _i32(idx)
         assert xyz.numel() == b * n * 3 and temp.numel() == b * n and idx.numel() == b * m
+        need = _lib.load().nesie_fps_workspace_bytes(b, n)
         with torch.cuda.device(xyz.device):
-            _lib.call("nesie_furthest_point_sampling_wrapper", b, n, m, _ptr(xyz),
-                      _ptr(temp), _ptr(idx), _stream(xyz))
+            if need:
+                # scratch for the bucket-pruned kernel, from torch's caching allocator
+                ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+                _lib.call("nesie_furthest_point_sampling_ws", b, n, m, _ptr(xyz),
+                          _ptr(temp), _ptr(idx), _ptr(ws), need, _stream(xyz))
+            else:
+                _lib.call("nesie_furthest_point_sampling_wrapper", b, n, m, _ptr(xyz),
+                          _ptr(temp), _ptr(idx), _stream(xyz))
 
     def furthest_point_sampling_with_dist_wrapper(self, b, n, m, dist, temp, idx):
         _check(dist, temp, idx); _f32(dist, temp); _i32(idx)

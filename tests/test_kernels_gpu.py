@@ -49,6 +49,22 @@ def test_fps_bit_exact(oracle_kernels, hip_device, n, m, b, kw):
     eq(got, want)
 
 
+@pytest.mark.parametrize("n,m", [(40000, 300), (5000, 100), (65536, 50), (4097, 64)])
+def test_fps_without_workspace_uses_the_streaming_kernel(oracle_kernels, hip_device, n, m):
+    """nesie_furthest_point_sampling_wrapper (no scratch) must agree as well."""
+    from nesie_amd import _lib
+    xyz = _cases.cloud(n + 3, 2, n, dup_frac=0.2)
+    t_cpu = torch.full((2, n), 1e10); i_cpu = torch.zeros((2, m), dtype=torch.int32)
+    oracle_kernels.furthest_point_sampling_wrapper(2, n, m, xyz, t_cpu, i_cpu)
+    x = xyz.to(hip_device)
+    t_gpu = torch.full((2, n), 1e10, device=hip_device)
+    i_gpu = torch.zeros((2, m), dtype=torch.int32, device=hip_device)
+    _lib.call("nesie_furthest_point_sampling_wrapper", 2, n, m, x.data_ptr(), t_gpu.data_ptr(),
+              i_gpu.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    eq(i_gpu, i_cpu); eq(t_gpu, t_cpu)
+
+
 def test_fps_temp_buffer_matches(oracle_kernels, hip_device):
     for n, m in [(40000, 64), (3000, 200), (70000, 8)]:
         xyz = _cases.cloud(n, 2, n, dup_frac=0.1)

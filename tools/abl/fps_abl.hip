@@ -17,7 +17,7 @@
 // kernel (PPT values per lane); for n <= 4096 the coordinates do too, above
 // that they are re-streamed from L2 each round with dense 12-byte-per-lane
 // loads (480 KB per scene at n = 40000 does not fit one CU's registers + LDS).
-#include "common.h"
+#include "../../nesie_amd/csrc/common.h"
 #include <stdlib.h>
 
 namespace nesie {
@@ -71,62 +71,14 @@ __device__ __forceinline__ unsigned long long block_max_u64(
   return r;
 }
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-// max over the 64 lanes, returned wave-uniform
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-  unsigned o;
-  o = dpp_u32<0xB1>(v);  v = o > v ? o : v;   // quad_perm [1,0,3,2]
-  o = dpp_u32<0x4E>(v);  v = o > v ? o : v;   // quad_perm [2,3,0,1]
-  o = dpp_u32<0x141>(v); v = o > v ? o : v;   // row_half_mirror
-  o = dpp_u32<0x140>(v); v = o > v ? o : v;   // row_mirror
-  unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  a = a > b ? a : b; c = c > d ? c : d;
-  return a > c ? a : c;
-}
-__device__ __forceinline__ float unordered_bits(unsigned u) {  // inverse of ordered_bits
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
-}
-__device__ __forceinline__ float wave_fmax(float f) {  // any sign, wave-uniform
-  return unordered_bits(wave_umax(ordered_bits(f)));
-}
-__device__ __forceinline__ float wave_fmin(float f) {
-  return unordered_bits(~wave_umax(~ordered_bits(f)));
-}
-
-// (value, key) arg-max over the lanes of a wave, wave-uniform results.  Keys are unique
-// among lanes with a non-zero key, so the common case (one lane holds the maximum) needs
-// a single DPP reduction; ties take a second one over the low key words.
-__device__ __forceinline__ int wave_argmax(bool valid, unsigned val, unsigned lo,
-                                           unsigned &vmax, unsigned &lomax) {
-  vmax = wave_umax(valid ? val : 0u);
-  unsigned long long eq = __ballot(valid && val == vmax);
-  if (__popcll(eq) == 1) {
-    const int wl = __builtin_ctzll(eq);
-    lomax = (unsigned)__builtin_amdgcn_readlane((int)lo, wl);
-    return wl;
-  }
-  lomax = wave_umax((valid && val == vmax) ? lo : 0u);
-  eq = __ballot(valid && val == vmax && lo == lomax);
-  return eq ? __builtin_ctzll(eq) : 0;
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
 // ---- n <= BLOCK*PPT, everything in registers --------------------------------
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(
     int n, int m, int L, const float *__restrict__ xyz, float *__restrict__ temp,
     int *__restrict__ idx) {
   constexpr int NW = BLOCK / 64;
-  __shared__ unsigned red_v[2][NW], red_l[2][NW];
-  __shared__ float sx[BLOCK * PPT], sy[BLOCK * PPT], sz[BLOCK * PPT];  // <= 48 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ unsigned long long red[2][NW];
+  const int tid = threadIdx.x;
   xyz += (size_t)blockIdx.x * n * 3;
   temp += (size_t)blockIdx.x * n;
   idx += (size_t)blockIdx.x * m;
@@ -142,36 +94,25 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(
     pz[j] = ok ? xyz[k * 3 + 2] : 0.f;
     tp[j] = ok ? temp[k] : 0.f;
     klo[j] = ok ? key_lo_of(k, L) : 0u;  // key 0 never wins: a real k has lo > 0
-    sx[k] = px[j]; sy[k] = py[j]; sz[k] = pz[j];  // k < BLOCK*PPT always
   }
-  __syncthreads();
-  float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+  int old = 0;
   if (tid == 0) idx[0] = 0;
   for (int r = 1; r < m; ++r) {
-    // invalid slots hold tp = 0 / klo = 0: their key (0, 0) loses to every real key
+    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
     unsigned long long best = 0ull;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       float d = sqdist_nofma(px[j] - x1, py[j] - y1, pz[j] - z1);
       float d2 = fminf(d, tp[j]);
       tp[j] = d2;
-      const unsigned long long key =
+      unsigned long long key =
           ((unsigned long long)__float_as_uint(d2) << 32) | klo[j];
+      key = klo[j] ? key : 0ull;
       best = key > best ? key : best;
     }
-    const unsigned bv = (unsigned)(best >> 32), bl = (unsigned)best;
-    unsigned wv, wl_;
-    wave_argmax(bl != 0u, bv, bl, wv, wl_);
-    unsigned gl = wl_;
-    if (NW > 1) {
-      if (lane == 0) { red_v[r & 1][wave] = wv; red_l[r & 1][wave] = wl_; }
-      __syncthreads();
-      const unsigned cv = red_v[r & 1][lane & (NW - 1)], cl = red_l[r & 1][lane & (NW - 1)];
-      unsigned gv;
-      wave_argmax(cl != 0u, cv, cl, gv, gl);
-    }
-    const int old = k_of_key_lo(gl, L);
-    x1 = sx[old]; y1 = sy[old]; z1 = sz[old];  // LDS broadcast, no global read
+    best = block_max_u64<NW>(best, red, r & 1);
+    old = k_of_key_lo((unsigned)best, L);
+    old = __builtin_amdgcn_readfirstlane(old);
     if (tid == 0) idx[r] = old;
   }
 #pragma unroll
@@ -313,6 +254,32 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
 // per bucket) -> ballot -> the active buckets are re-evaluated 64 points at a time
 // -> per-wave best -> one LDS exchange + one barrier -> every wave derives the
 // winner and its coordinates (no global read on the critical path).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// max over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  unsigned o;
+  o = dpp_u32<0xB1>(v);  v = o > v ? o : v;   // quad_perm [1,0,3,2]
+  o = dpp_u32<0x4E>(v);  v = o > v ? o : v;   // quad_perm [2,3,0,1]
+  o = dpp_u32<0x141>(v); v = o > v ? o : v;   // row_half_mirror
+  o = dpp_u32<0x140>(v); v = o > v ? o : v;   // row_mirror
+  unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  a = a > b ? a : b; c = c > d ? c : d;
+  return a > c ? a : c;
+}
+__device__ __forceinline__ float unordered_bits(unsigned u) {  // inverse of ordered_bits
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ float wave_fmax(float f) {  // any sign, wave-uniform
+  return unordered_bits(wave_umax(ordered_bits(f)));
+}
+__device__ __forceinline__ float wave_fmin(float f) {
+  return unordered_bits(~wave_umax(~ordered_bits(f)));
+}
+
 __device__ __forceinline__ unsigned part1by2(unsigned x) {  // 3 bits -> bits 0,3,6
   return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4);
 }
@@ -323,6 +290,27 @@ __device__ __forceinline__ unsigned part1by1(unsigned x) {  // 2 bits -> bits 0,
 struct FpsCand { unsigned val, lo; float x, y, z; };
 
 constexpr int FPS_CELLS = 8192;
+
+// (value, key) arg-max over the lanes of a wave, wave-uniform results.  Keys are unique
+// among lanes with a non-zero key, so the common case (one lane holds the maximum) needs
+// a single DPP reduction; ties take a second one over the low key words.
+__device__ __forceinline__ int wave_argmax(bool valid, unsigned val, unsigned lo,
+                                           unsigned &vmax, unsigned &lomax) {
+  vmax = wave_umax(valid ? val : 0u);
+  unsigned long long eq = __ballot(valid && val == vmax);
+  if (__popcll(eq) == 1) {
+    const int wl = __builtin_ctzll(eq);
+    lomax = (unsigned)__builtin_amdgcn_readlane((int)lo, wl);
+    return wl;
+  }
+  lomax = wave_umax((valid && val == vmax) ? lo : 0u);
+  eq = __ballot(valid && val == vmax && lo == lomax);
+  return eq ? __builtin_ctzll(eq) : 0;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
 
 // NW waves per scene; lane j of wave w owns buckets (q*64 + j)*NW + w, q < BPL.
 template <int NW>
@@ -443,7 +431,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     if (!init) {
       float d = sqdist_nofma(l.p.x - cx, l.p.y - cy, l.p.z - cz);
       d2 = fminf(d, l.p.w);
+#if ABL != 1
       if (l.valid && d2 != l.p.w) ws_pts[l.ss].w = d2;
+#endif
     }
     const unsigned lo = l.valid ? key_lo_of((int)l.o, L) : 0u;
     unsigned vmax, lomax;
@@ -479,6 +469,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
       const float ez = fmaxf(fmaxf(bloz[q] - cz, cz - bhiz[q]), 0.f);
       const float d2box = sqdist_nofma(ex, ey, ez);
       unsigned long long mask = __ballot(have[q] && d2box < __uint_as_float(bmax[q]));
+#if ABL == 2
+      mask = 0;
+#endif
       while (mask) {  // two buckets per trip so their loads overlap
         const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -562,7 +555,7 @@ static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *i
     unsigned *wo = (unsigned *)((char *)workspace + (size_t)b * n * 16);
     static const int nw = [] {
       const char *e = getenv("NESIE_FPS_WAVES");
-      return e ? atoi(e) : 16;
+      return e ? atoi(e) : 4;
     }();
     if (nw == 16)
       hipLaunchKernelGGL(fps_pruned_kernel<16>, grid, dim3(1024), 0, s, n, m, xyz, temp, idx, wp, wo);
