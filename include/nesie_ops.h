@@ -131,6 +131,16 @@ int nesie_points_in_boxes_batch(int b, int boxes_num, int pts_num,
                                 const float *boxes, const float *pts, int *out,
                                 void *stream);
 
+/* Max over the neighbourhood axis of a grouped tensor: x[rows, nsample] -> out[rows],
+ * argmax[rows] (one byte, smallest index on ties).  No extension entry in the reference:
+ * it calls ATen's F.max_pool2d(kernel=[1, nsample]) (point_sa_module.py:149-150) and
+ * torch.max(dim=-1) (side_pooling_module.py:361,368); same values, same tie rule.
+ * nsample must be a power of two in 4..64; x / grad_x 16-byte aligned. */
+int nesie_group_max_pool_forward(long long rows, int nsample, const float *x, float *out,
+                                 uint8_t *argmax, void *stream);
+int nesie_group_max_pool_backward(long long rows, int nsample, const float *grad_out,
+                                  const uint8_t *argmax, float *grad_x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

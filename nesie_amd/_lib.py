@@ -30,6 +30,8 @@ SIGNATURES = {
     "nesie_three_interpolate_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_group_max_pool_forward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
+    "nesie_group_max_pool_backward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
 }
 
 _lib = None

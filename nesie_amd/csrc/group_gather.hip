@@ -9,8 +9,10 @@
 // Forward is pure data movement (HBM/L2 bound): a thread owns one output
 // column e = (p, s), reads idx[e] ONCE and walks CH_PER_THREAD channel rows, so
 // the index traffic is amortised over the channels and every store is a dense
-// 256-byte row segment per wave.  Backward is the same walk with a float
-// atomic add (the reference does the same; sum order is not deterministic).
+// 256-byte row segment per wave.  Backward: when a scene's n accumulators for a
+// few channel rows fit LDS (pool.hip: group_bwd_lds_kernel) the adds go to LDS and
+// each row is written once; otherwise the same walk with float atomics to HBM
+// (the reference does the latter; sum order is not deterministic either way).
 #include "common.h"
 
 namespace nesie {
@@ -62,12 +64,17 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_kernel(
     if (i < cend) atomicAdd(gp + (size_t)i * n, v[i]);
 }
 
+int launch_group_bwd_lds(int b, int c, int n, long long e_total, const float *grad_out,
+                         const int *idx, float *grad_points, hipStream_t s);
+
 static int launch_group(bool fwd, const char *W, int b, int c, int n, long long e_total,
                         const float *a, const int *idx, float *o, void *stream) {
   NESIE_REQUIRE(b >= 0 && c >= 0 && n >= 0 && e_total >= 0, W);
   if (b == 0 || c == 0 || e_total == 0) return NESIE_OK;
   NESIE_REQUIRE(n >= 1 && a && idx && o, W);
   NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  if (!fwd && n <= 16384 && e_total >= 4 * (long long)n)
+    return launch_group_bwd_lds(b, c, n, e_total, a, idx, o, (hipStream_t)stream);
   dim3 grid(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b);
   if (fwd)
     hipLaunchKernelGGL(group_fwd_kernel, grid, dim3(GG_BLOCK), 0, (hipStream_t)stream, c,

@@ -1,0 +1,159 @@
+// Max-pool over the neighbourhood axis of a grouped tensor, forward + backward.
+//
+// Stands in for F.max_pool2d(features, kernel_size=[1, nsample]) in
+// BasePointSAModule._pool_features (reference mmdet3d/ops/pointnet_modules/
+// point_sa_module.py:136-158) and for torch.max(feature, dim=-1) in MiniPointNet
+// (reference mmdet3d/models/dense_heads/side_pooling_module.py:361,368).
+// x (R, ns) row-major with ns in {4..64, power of two}: each lane loads one float4, the
+// ns/4 lanes of a row reduce with DPP row operations (no LDS, no cross-row traffic), so
+// every wave instruction is one dense 1 KiB read: pure HBM streaming.
+// Ties resolve to the smallest index, as ATen's max_pool2d / max do; the arg-max is kept
+// as one byte per row for the backward, which writes grad * [s == argmax].
+#include "common.h"
+
+namespace nesie {
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dppm(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// (value, index) max with smallest-index tie-break, exchanged with the lane given by CTRL
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float &v, int &i) {
+  const float ov = __uint_as_float(dppm<CTRL>(__float_as_uint(v)));
+  const int oi = (int)dppm<CTRL>((unsigned)i);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+
+// LPR = lanes per row = ns / 4
+template <int LPR>
+__global__ __launch_bounds__(256) void group_max_fwd_kernel(
+    long long rows, const float4 *__restrict__ x, float *__restrict__ out,
+    uint8_t *__restrict__ arg) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 each
+  const long long row = t / LPR;
+  const int part = (int)(t % LPR);
+  const bool live = row < rows;
+  const float4 q = live ? x[t] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  float v = q.x; int i = part * 4;
+  if (q.y > v) { v = q.y; i = part * 4 + 1; }
+  if (q.z > v) { v = q.z; i = part * 4 + 2; }
+  if (q.w > v) { v = q.w; i = part * 4 + 3; }
+  if (LPR >= 2) argmax_step<0xB1>(v, i);    // lane ^ 1
+  if (LPR >= 4) argmax_step<0x4E>(v, i);    // lane ^ 2
+  if (LPR >= 8) argmax_step<0x141>(v, i);   // row_half_mirror: 7 - lane (within 8)
+  if (LPR >= 16) argmax_step<0x140>(v, i);  // row_mirror: 15 - lane (within 16)
+  if (live && part == 0) { out[row] = v; arg[row] = (uint8_t)i; }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(
+    long long rows, const float *__restrict__ grad_out, const uint8_t *__restrict__ arg,
+    float4 *__restrict__ grad_x) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = t / LPR;
+  const int part = (int)(t % LPR);
+  if (row >= rows) return;
+  const float g = grad_out[row];
+  const int a = (int)arg[row] - part * 4;
+  grad_x[t] = make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f,
+                          a == 3 ? g : 0.f);
+}
+
+// ---- scatter-add of grouped gradients through LDS --------------------------------
+// grad_points[b, c, idx[b, e]] += grad_out[b, c, e].  A workgroup owns CH channel rows of
+// one scene: their n accumulators sit in LDS (n * CH * 4 <= 64 KB), the grouped gradient
+// streams through once with dense reads, float adds go to LDS (ds_add_f32) instead of HBM
+// atomics, and the rows are written back once, dense.  Sum order is not fixed (as in the
+// reference's atomicAdd kernel, group_points_cuda.cu:10-31).
+__global__ __launch_bounds__(512) void group_bwd_lds_kernel(
+    int c, int n, int e_total, int ch, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  extern __shared__ float acc[];  // [ch][n]
+  const int bi = blockIdx.y;
+  const int c0 = blockIdx.x * ch;
+  const int cend = c - c0 < ch ? c - c0 : ch;
+  for (int i = threadIdx.x; i < cend * n; i += 512) acc[i] = 0.f;
+  __syncthreads();
+  const int *ix = idx + (size_t)bi * e_total;
+  for (int e = threadIdx.x; e < e_total; e += 512) {
+    int dst = ix[e];
+    dst = dst < 0 ? 0 : (dst >= n ? n - 1 : dst);
+    for (int i = 0; i < cend; ++i)
+      atomicAdd(&acc[i * n + dst], grad_out[((size_t)bi * c + c0 + i) * e_total + e]);
+  }
+  __syncthreads();
+  float *dst_rows = grad_points + ((size_t)bi * c + c0) * n;
+  for (int i = threadIdx.x; i < cend * n; i += 512) dst_rows[i] += acc[i];
+}
+
+}  // namespace nesie
+
+using namespace nesie;
+
+static int pool_dims_ok(const char *W, long long rows, int ns) {
+  if (rows < 0 || ns <= 0) { set_error("%s: negative size", W); return NESIE_ERR_INVALID_ARG; }
+  if (ns < 4 || ns > 64 || (ns & (ns - 1))) {
+    set_error("%s: nsample %d (needs a power of two in 4..64)", W, ns);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  return NESIE_OK;
+}
+
+extern "C" int nesie_group_max_pool_forward(long long rows, int nsample, const float *x,
+                                            float *out, uint8_t *argmax, void *stream) {
+  const char *W = "group_max_pool_forward";
+  int st = pool_dims_ok(W, rows, nsample);
+  if (st) return st;
+  if (rows == 0) return NESIE_OK;
+  NESIE_REQUIRE(x && out && argmax && ((uintptr_t)x & 15) == 0, W);
+  const int lpr = nsample / 4;
+  const long long threads = rows * lpr;
+  NESIE_REQUIRE(threads / 256 + 1 < (1ll << 31), W);
+  dim3 grid((unsigned)cdiv(threads, 256));
+  hipStream_t s = (hipStream_t)stream;
+#define L(N) hipLaunchKernelGGL(group_max_fwd_kernel<N>, grid, dim3(256), 0, s, rows, \
+                                (const float4 *)x, out, argmax)
+  if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
+  else if (lpr == 8) L(8); else L(16);
+#undef L
+  return check_launch(W);
+}
+
+extern "C" int nesie_group_max_pool_backward(long long rows, int nsample,
+                                             const float *grad_out, const uint8_t *argmax,
+                                             float *grad_x, void *stream) {
+  const char *W = "group_max_pool_backward";
+  int st = pool_dims_ok(W, rows, nsample);
+  if (st) return st;
+  if (rows == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && argmax && grad_x && ((uintptr_t)grad_x & 15) == 0, W);
+  const int lpr = nsample / 4;
+  const long long threads = rows * lpr;
+  NESIE_REQUIRE(threads / 256 + 1 < (1ll << 31), W);
+  dim3 grid((unsigned)cdiv(threads, 256));
+  hipStream_t s = (hipStream_t)stream;
+#define L(N) hipLaunchKernelGGL(group_max_bwd_kernel<N>, grid, dim3(256), 0, s, rows, \
+                                grad_out, argmax, (float4 *)grad_x)
+  if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
+  else if (lpr == 8) L(8); else L(16);
+#undef L
+  return check_launch(W);
+}
+
+// Called by nesie_group_points_backward (group_gather.hip) when n is small enough.
+namespace nesie {
+int launch_group_bwd_lds(int b, int c, int n, long long e_total, const float *grad_out,
+                         const int *idx, float *grad_points, hipStream_t s) {
+  int ch = 16384 / n;  // n * ch * 4 bytes <= 64 KB
+  if (ch > 32) ch = 32;
+  if (ch > c) ch = c;
+  const size_t lds = (size_t)ch * n * sizeof(float);
+  hipLaunchKernelGGL(group_bwd_lds_kernel, dim3(cdiv(c, ch), b), dim3(512), lds, s, c, n,
+                     (int)e_total, ch, grad_out, idx, grad_points);
+  return check_launch("group_points_backward");
+}
+}  // namespace nesie

@@ -165,6 +165,26 @@ class HipKernels:
                       _ptr(out), _stream(boxes))
 
 
+    def group_max_pool_forward(self, x, out, argmax):
+        """x (..., ns) -> out (...), argmax (...) uint8."""
+        _check(x, out, argmax); _f32(x, out)
+        ns = x.shape[-1]
+        rows = x.numel() // ns
+        assert out.numel() == rows and argmax.numel() == rows and argmax.dtype == torch.uint8
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_group_max_pool_forward", rows, ns, _ptr(x), _ptr(out),
+                      _ptr(argmax), _stream(x))
+
+    def group_max_pool_backward(self, grad_out, argmax, grad_x):
+        _check(grad_out, argmax, grad_x); _f32(grad_out, grad_x)
+        ns = grad_x.shape[-1]
+        rows = grad_x.numel() // ns
+        assert grad_out.numel() == rows and argmax.numel() == rows
+        with torch.cuda.device(grad_x.device):
+            _lib.call("nesie_group_max_pool_backward", rows, ns, _ptr(grad_out),
+                      _ptr(argmax), _ptr(grad_x), _stream(grad_x))
+
+
 _hip = None
 
 

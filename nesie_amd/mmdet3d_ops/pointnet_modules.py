@@ -16,6 +16,7 @@ from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup
 from .interpolate import three_interpolate, three_nn
+from .pool import group_max_pool
 
 
 class ConvModule(nn.Module):
@@ -128,7 +129,7 @@ class BasePointSAModule(nn.Module):
 
     def _pool_features(self, features):
         if self.pool_mod == 'max':
-            new_features = F.max_pool2d(features, kernel_size=[1, features.size(3)])
+            return group_max_pool(features).contiguous()  # == F.max_pool2d([1, nsample])
         elif self.pool_mod == 'avg':
             new_features = F.avg_pool2d(features, kernel_size=[1, features.size(3)])
         else:

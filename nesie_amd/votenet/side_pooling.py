@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..mmdet3d_ops import three_interpolate, three_nn
+from ..mmdet3d_ops.pool import group_max_pool
 
 
 def rot_gpu(t):
@@ -39,11 +40,11 @@ class MiniPointNet(nn.Module):
 
     def forward(self, points):
         feature = self.first_conv(points)
-        feature_global = torch.max(feature, dim=-1, keepdim=True).values
+        feature_global = group_max_pool(feature).unsqueeze(-1)
         feature = torch.cat([feature_global.expand(-1, -1, -1, feature.shape[-1]), feature],
                             dim=1)
         feature = self.second_conv(feature)
-        return torch.max(feature, dim=-1).values
+        return group_max_pool(feature)
 
 
 def _score_head(in_ch, out_ch):

@@ -156,5 +156,20 @@ class OracleKernels:
                                            pts.data_ptr(), out.data_ptr())
 
 
+    # dense-op stand-ins of the CPU path (PyTorch-CPU, first-index tie rule like ATen)
+    def group_max_pool_forward(self, x, out, argmax):
+        _cpu(x, out, argmax)
+        v, i = torch.max(x, dim=-1)
+        # torch.max(dim) returns an arbitrary index on ties; recompute the first one
+        first = (x == v.unsqueeze(-1)).to(torch.uint8).argmax(dim=-1)
+        out.copy_(v)
+        argmax.copy_(first.to(torch.uint8))
+
+    def group_max_pool_backward(self, grad_out, argmax, grad_x):
+        _cpu(grad_out, argmax, grad_x)
+        grad_x.zero_()
+        grad_x.scatter_(-1, argmax.long().unsqueeze(-1), grad_out.unsqueeze(-1))
+
+
 def num_threads():
     return lib().oracle_num_threads()

@@ -227,3 +227,27 @@ def test_full_size_properties(hip_device):
     inc = bq[..., 1:] > bq[..., :-1]
     pad = bq[..., 1:] == bq[..., :1]
     assert (inc | pad).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 2048, 64), (2, 128, 1024, 32), (3, 256, 512, 16),
+                                   (1, 5, 7, 4), (2, 3, 5, 8), (1, 128, 512, 64)])
+def test_group_max_pool_matches_aten(oracle_kernels, hip_device, shape):
+    """values and arg-max routing identical to F.max_pool2d([1, ns]) incl. relu-style ties."""
+    from nesie_amd.mmdet3d_ops.pool import group_max_pool
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).clamp_min(0.0)  # many exact zeros => ties
+    x[..., 1] = x[..., 0]                                # duplicated neighbours => ties
+    go = torch.randn(shape[:-1], generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.max_pool2d(xr, kernel_size=[1, shape[-1]]).squeeze(-1)
+    ref.backward(go)
+    xg = x.to(hip_device).requires_grad_(True)
+    out = group_max_pool(xg)
+    out.backward(go.to(hip_device))
+    eq(out.detach(), ref.detach())
+    eq(xg.grad, xr.grad)
+    with kernels.use_backend(oracle_kernels):  # the CPU path's stand-in agrees too
+        xc = x.clone().requires_grad_(True)
+        oc = group_max_pool(xc)
+        oc.backward(go)
+    assert torch.equal(oc.detach(), ref.detach()) and torch.equal(xc.grad, xr.grad)
