@@ -58,7 +58,11 @@ class KernelTimer:
         return sum(ts) / len(ts) if ts else None
 
 
-def build_step(device, batch, seed, lr, wd):
+def build_step(device, batch, seed, lr, wd, graph=False):
+    """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
+    all-reduce (world > 1), clip, AdamW.  With graph=True the device work of a step is
+    captured once into hipGraphs and replayed (the step has no host synchronisation);
+    the RCCL all-reduce stays an ordinary stream operation between the two graphs."""
     torch.manual_seed(0)
     model = build_nesie_votenet().to(device)
     model.train()
@@ -66,18 +70,52 @@ def build_step(device, batch, seed, lr, wd):
     pts = pts.to(device)
     gt = GTBatch.collate(boxes, labels, device)
     bucket = dp.FlatGradBucket(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    on_gpu = device.type == 'cuda'
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd,
+                            capturable=graph and on_gpu, foreach=True)
+    loss_out = torch.zeros((), device=device)
 
-    def step():
+    def fwd_bwd():
         bucket.zero_()
         losses = model.forward_train(pts, None, gt, None)
         total = model.parse_losses(losses)
         total.backward()
-        bucket.all_reduce_mean()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2)
+        loss_out.copy_(total.detach())
+
+    def update():
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2,
+                                       foreach=True)
         opt.step()
-        return total
-    return model, step, bucket
+
+    def eager_step():
+        fwd_bwd()
+        bucket.all_reduce_mean()
+        update()
+        return loss_out
+
+    if not (graph and on_gpu):
+        return model, eager_step, bucket
+
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        for _ in range(2):  # warm allocator / library handles before capture
+            eager_step()
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        fwd_bwd()
+    with torch.cuda.graph(g2, pool=g1.pool()):
+        update()
+
+    def graph_step():
+        g1.replay()
+        bucket.all_reduce_mean()
+        g2.replay()
+        return loss_out
+    graph_step.eager = eager_step
+    return model, graph_step, bucket
 
 
 def cpu_baseline(sample_batch, steps):
@@ -107,6 +145,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
+    ap.add_argument('--graph', type=int, default=1, help='replay the step as hipGraphs')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--cpu-steps', type=int, default=1)
@@ -121,7 +160,8 @@ def main():
 
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
-                                     cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'])
+                                     cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
+                                     graph=bool(args.graph))
     hip = kernels.backend_for(torch.empty(1, device=device))
     # dominant kernel (profiles/): D-FPS over the 40 000-point scene
     fps_timer = KernelTimer(hip, 'furthest_point_sampling_wrapper',
@@ -135,12 +175,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    fps_timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    # Kernel-level timing for the roofline entry: HIP events cannot bracket a kernel inside
+    # a replayed graph, so the same K steps are run once more un-captured with the events
+    # on the launch stream (identical kernels, identical inputs).
+    fps_timer.enabled = True
+    eager = getattr(step, 'eager', step)
+    for _ in range(min(args.steps, 5)):
+        eager()
+    torch.cuda.synchronize()
     fps_timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -166,6 +213,7 @@ def main():
                        'scenes_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'points_per_scene': NUM_POINTS,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'hip_graph': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes()},
             'roofline': {'kernel': 'fps_stream_kernel<40> (D-FPS 40000->2048)',
                          'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

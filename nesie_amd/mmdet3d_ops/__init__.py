@@ -11,7 +11,8 @@ from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup, group_points, grouping_operation
 from .interpolate import three_interpolate, three_nn
 from .pointnet_modules import (ConvModule, PointFPModule, PointSAModule, PointSAModuleMSG,
-                               build_sa_module)
+                               PointwiseConv1d, PointwiseConv2d, build_sa_module,
+                               pointwise_conv)
 from .roiaware_pool3d import points_in_boxes_batch
 from .rotated_iou import cal_iou_3d, sort_v
 

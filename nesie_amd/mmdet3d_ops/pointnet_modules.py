@@ -19,6 +19,34 @@ from .interpolate import three_interpolate, three_nn
 from .pool import group_max_pool
 
 
+def pointwise_conv(x, weight, bias=None):
+    """1x1 Conv1d/Conv2d as ONE strided-batched GEMM  out[b] = W @ x[b].
+
+    x (B, Cin, *spatial) contiguous NCHW is already the row-major (Cin x P) operand and
+    W @ x[b] is already the row-major NCHW output, so no layout change is needed (the
+    vendor conv path transposes to NHWC and back around its implicit-GEMM kernels).
+    Same arithmetic as F.conv{1,2}d with a 1x1 kernel, fp32 in / fp32 accumulate.
+    """
+    B, cin = x.shape[:2]
+    w2 = weight.reshape(weight.shape[0], cin)
+    out = torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x.reshape(B, cin, -1))
+    if bias is not None:
+        out = out + bias.view(1, -1, 1)
+    return out.view(B, w2.shape[0], *x.shape[2:])
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) whose forward is pointwise_conv (same parameters/keys)."""
+
+    def forward(self, x):
+        return pointwise_conv(x, self.weight, self.bias)
+
+
+class PointwiseConv2d(nn.Conv2d):
+    def forward(self, x):
+        return pointwise_conv(x, self.weight, self.bias)
+
+
 class ConvModule(nn.Module):
     """1x1 Conv{1,2}d -> BN{1,2}d (or GN) -> ReLU, mmcv-style."""
 
@@ -31,7 +59,8 @@ class ConvModule(nn.Module):
         self.with_activation = act_cfg is not None
         if bias == 'auto':
             bias = not self.with_norm
-        conv_cls = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[conv_type]
+        conv_cls = {'Conv1d': PointwiseConv1d, 'Conv2d': PointwiseConv2d}[conv_type]
+        assert kernel_size in (1, (1, 1)) and stride in (1, (1, 1)) and padding == 0
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=bias)
         self.norm_name = None

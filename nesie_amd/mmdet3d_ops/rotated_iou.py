@@ -43,8 +43,10 @@ sort_v = SortVertices.apply
 def box_intersection_th(corners1, corners2):
     """Edge-edge intersections of two rectangles: (B,N,4,4,2) points + (B,N,4,4) mask
     (box_intersection_2d.py:13-54)."""
-    line1 = torch.cat([corners1, corners1[:, :, [1, 2, 3, 0], :]], dim=3)
-    line2 = torch.cat([corners2, corners2[:, :, [1, 2, 3, 0], :]], dim=3)
+    # edge i runs from corner i to corner i+1 (roll instead of a [1,2,3,0] index list: no
+    # host->device index copy, so the step stays hipGraph-capturable)
+    line1 = torch.cat([corners1, torch.roll(corners1, -1, dims=2)], dim=3)
+    line2 = torch.cat([corners2, torch.roll(corners2, -1, dims=2)], dim=3)
     line1_ext = line1.unsqueeze(3).repeat([1, 1, 1, 4, 1])
     line2_ext = line2.unsqueeze(2).repeat([1, 1, 4, 1, 1])
     x1, y1, x2, y2 = (line1_ext[..., i] for i in range(4))
@@ -125,8 +127,10 @@ def box2corners_th(box):
     """(B,N,5) x,y,w,h,alpha -> (B,N,4,2) corners (oriented_iou_loss.py:6-36)."""
     B = box.size()[0]
     x, y, w, h, alpha = (box[..., i:i + 1] for i in range(5))
-    x4 = box.new_tensor([0.5, -0.5, -0.5, 0.5]).unsqueeze(0).unsqueeze(0) * w
-    y4 = box.new_tensor([0.5, 0.5, -0.5, -0.5]).unsqueeze(0).unsqueeze(0) * h
+    # corner signs (+,+) (-,+) (-,-) (+,-) without a host->device constant (graph-safe)
+    hw, hh = 0.5 * w, 0.5 * h
+    x4 = torch.cat([hw, -hw, -hw, hw], dim=-1)
+    y4 = torch.cat([hh, hh, -hh, -hh], dim=-1)
     corners = torch.stack([x4, y4], dim=-1)
     sin = torch.sin(alpha)
     cos = torch.cos(alpha)
@@ -151,8 +155,8 @@ def cal_iou(box1, box2):
 
 def cal_iou_3d(box3d1, box3d2, verbose=False):
     """3-D IoU of (B,N,7) boxes rotated about z only (:86-109)."""
-    box1 = box3d1[..., [0, 1, 3, 4, 6]]
-    box2 = box3d2[..., [0, 1, 3, 4, 6]]
+    box1 = torch.cat([box3d1[..., 0:2], box3d1[..., 3:5], box3d1[..., 6:7]], dim=-1)  # x y w h a
+    box2 = torch.cat([box3d2[..., 0:2], box3d2[..., 3:5], box3d2[..., 6:7]], dim=-1)
     zmax1 = box3d1[..., 2] + box3d1[..., 5] * 0.5
     zmin1 = box3d1[..., 2] - box3d1[..., 5] * 0.5
     zmax2 = box3d2[..., 2] + box3d2[..., 5] * 0.5

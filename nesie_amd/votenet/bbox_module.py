@@ -3,7 +3,7 @@ shared Conv1d stack, then class / side-distribution / heading 1x1 convs."""
 import torch
 from torch import nn
 
-from ..mmdet3d_ops import ConvModule
+from ..mmdet3d_ops import ConvModule, PointwiseConv1d
 
 
 class ReliableConvBboxHead(nn.Module):
@@ -28,18 +28,18 @@ class ReliableConvBboxHead(nn.Module):
         if len(cls_conv_channels) > 0:
             self.cls_convs = self._add_conv_branch(prev, cls_conv_channels)
             prev = cls_conv_channels[-1]
-        self.conv_cls = nn.Conv1d(prev, num_cls_out_channels, 1)
+        self.conv_cls = PointwiseConv1d(prev, num_cls_out_channels, 1)
         prev = out_channels
         if len(bbox_conv_channels) > 0:
             self.bbox_convs = self._add_conv_branch(prev, bbox_conv_channels)
             prev = bbox_conv_channels[-1]
-        self.conv_bbox = nn.Conv1d(prev, num_bbox_out_channels, 1)
+        self.conv_bbox = PointwiseConv1d(prev, num_bbox_out_channels, 1)
         prev = out_channels
         if len(heading_conv_channels) > 0:
             self.heading_convs = self._add_conv_branch(
                 prev, heading_conv_channels, dict(type='GN', num_groups=reg_max))
             prev = heading_conv_channels[-1]
-        self.conv_heading = nn.Conv1d(prev, num_heading_out_channels, 1)
+        self.conv_heading = PointwiseConv1d(prev, num_heading_out_channels, 1)
 
     def _add_conv_branch(self, in_channels, conv_channels, norm_cfg=None):
         spec = [in_channels] + list(conv_channels)

@@ -74,11 +74,13 @@ class CrossEntropyLoss(nn.Module):
         self.class_weight = class_weight
         self.reduction = reduction
         self.loss_weight = loss_weight
+        self.register_buffer('_cw', None if class_weight is None else
+                             torch.tensor(class_weight, dtype=torch.float32), persistent=False)
 
     def forward(self, cls_score, label, weight=None, avg_factor=None,
                 reduction_override=None):
         reduction = reduction_override if reduction_override else self.reduction
-        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        cw = self._cw.to(cls_score.dtype) if self._cw is not None else None
         loss = F.cross_entropy(cls_score, label, weight=cw, reduction='none')
         if weight is not None:
             weight = weight.float()

@@ -107,6 +107,10 @@ class NesieHead(nn.Module):
         self.integral = Integral(self.reg_max)
         self.grid_conv = SidePooling(**grid_conv_cfg)
         self.jitter_noise = None  # optional (noise_center, noise_size), each (B,K,3)
+        # device-resident constants (no host->device copy inside the step: hipGraph-safe)
+        self.register_buffer('_side_scale', torch.tensor(self.sizes + self.sizes), persistent=False)
+        self.register_buffer('_side_sign', torch.tensor([-1., -1., -1., 1., 1., 1.]),
+                             persistent=False)
 
     @staticmethod
     def _extract_input(feat_dict):
@@ -116,8 +120,8 @@ class NesieHead(nn.Module):
     def side2box(self, aggregated_points, bbox_pred, results):
         B, proposal_num = bbox_pred.shape[:2]
         res = self.integral(bbox_pred[..., :self.n_reg_outs]).reshape(B, proposal_num, -1)
-        scale = bbox_pred.new_tensor(self.sizes + self.sizes)  # x y z x y z
-        sign = bbox_pred.new_tensor([-1., -1., -1., 1., 1., 1.])
+        scale = self._side_scale.to(bbox_pred.dtype)  # x y z x y z
+        sign = self._side_sign.to(bbox_pred.dtype)
         results['surface_scale'] = scale.expand(B, proposal_num, 6)
         surface = aggregated_points.repeat(1, 1, 2) + sign * (res * scale)
         results['surface_pred'] = surface
@@ -354,10 +358,12 @@ class NesieHead(nn.Module):
                                       depth_to_lidar_boxes(gt.boxes).contiguous())
         inbox = (inbox > 0) & is_col.unsqueeze(1)  # (B,N,T)
         cnt = inbox.sum(-1)
-        rank = torch.cumsum(inbox.int(), dim=-1)
-        first = torch.argmax(inbox.int(), dim=-1)
-        second = torch.argmax((inbox & (rank == 2)).int(), dim=-1)
-        last = (T - 1) - torch.argmax(inbox.flip(-1).int(), dim=-1)
+        ib = inbox.to(torch.uint8)
+        first = torch.argmax(ib, dim=-1)
+        # second = first column after `first` that holds the point (0 if none; unused then)
+        second = torch.argmax(ib * (col.unsqueeze(1) > first.unsqueeze(-1)).to(torch.uint8),
+                              dim=-1)
+        last = (T - 1) - torch.argmax(ib.flip(-1), dim=-1)
 
         def vote_of(box_idx):
             c = torch.gather(centres, 1, box_idx.unsqueeze(-1).expand(-1, -1, 3))

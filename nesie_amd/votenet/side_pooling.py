@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from ..mmdet3d_ops import three_interpolate, three_nn
 from ..mmdet3d_ops.pool import group_max_pool
+from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d
 
 
 def rot_gpu(t):
@@ -32,11 +33,11 @@ class MiniPointNet(nn.Module):
     def __init__(self, channels: int, feature_dim: int, hide_dim=256):
         super().__init__()
         self.first_conv = nn.Sequential(
-            nn.Conv2d(channels, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
-            nn.ReLU(inplace=True), nn.Conv2d(hide_dim, hide_dim // 2, 1))
+            PointwiseConv2d(channels, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
+            nn.ReLU(inplace=True), PointwiseConv2d(hide_dim, hide_dim // 2, 1))
         self.second_conv = nn.Sequential(
-            nn.Conv2d(hide_dim, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
-            nn.ReLU(inplace=True), nn.Conv2d(hide_dim, feature_dim, 1))
+            PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
+            nn.ReLU(inplace=True), PointwiseConv2d(hide_dim, feature_dim, 1))
 
     def forward(self, points):
         feature = self.first_conv(points)
@@ -48,9 +49,9 @@ class MiniPointNet(nn.Module):
 
 
 def _score_head(in_ch, out_ch):
-    return nn.Sequential(nn.Conv1d(in_ch, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
-                         nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
-                         nn.Conv1d(128, out_ch, 1))
+    return nn.Sequential(PointwiseConv1d(in_ch, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+                         PointwiseConv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+                         PointwiseConv1d(128, out_ch, 1))
 
 
 class SidePooling(nn.Module):
@@ -72,6 +73,12 @@ class SidePooling(nn.Module):
         self.grid_size = g = 4
         self.left_mask = [i // g * g * g + i % g for i in range(g * g)]
         self.right_mask = [i // g * g * g + i % g + g * (g - 1) for i in range(g * g)]
+        # the six face selections of grid_for_side as ONE device-resident index (graph-safe)
+        face_idx = (list(range(0, g * g)) + list(range(g ** 3 - g * g, g ** 3))
+                    + list(range(g - 1, g ** 3, g)) + list(range(0, g ** 3, g))
+                    + self.left_mask + self.right_mask)
+        self.register_buffer('_face_idx', torch.tensor(face_idx, dtype=torch.long),
+                             persistent=False)
         self.iou_size = num_class if iou_class_depend else 1
         before, head = [], []
         for _ in range(6):
@@ -108,11 +115,7 @@ class SidePooling(nn.Module):
 
     def grid_for_side(self, whole_grid, center, heading):
         """front/back/top/down/left/right face grids, rotated + translated (:124-157)."""
-        g = self.grid_size
-        side_grid = torch.cat([
-            whole_grid[:, :, 0:g * g, :], whole_grid[:, :, -g * g:, :],
-            whole_grid[:, :, g - 1::g, :], whole_grid[:, :, ::g, :],
-            whole_grid[:, :, self.left_mask, :], whole_grid[:, :, self.right_mask, :]], dim=-2)
+        side_grid = torch.index_select(whole_grid, 2, self._face_idx)
         return self._to_scene(side_grid, center, heading)
 
     def grid_for_bbox(self, whole_grid, center, heading):

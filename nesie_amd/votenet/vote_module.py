@@ -2,7 +2,7 @@
 import torch
 from torch import nn
 
-from ..mmdet3d_ops import ConvModule
+from ..mmdet3d_ops import ConvModule, PointwiseConv1d
 from .losses import build_loss
 
 
@@ -32,7 +32,7 @@ class VoteModule(nn.Module):
             prev_channels = conv_channels[k]
         self.vote_conv = nn.Sequential(*vote_conv_list)
         out_channel = ((3 + in_channels) if with_res_feat else 3) * self.vote_per_seed
-        self.conv_out = nn.Conv1d(prev_channels, out_channel, 1)
+        self.conv_out = PointwiseConv1d(prev_channels, out_channel, 1)
 
     def forward(self, seed_points, seed_feats):
         """(B,N,3),(B,C,N) -> vote_points (B,M,3), vote_feats (B,C,M), offset (B,3,M)."""

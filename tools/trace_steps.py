@@ -4,12 +4,10 @@ find/tuning kernels in the warm-up do not pollute the per-step breakdown."""
 import collections, csv, sys
 
 path, k = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3
-marker = sys.argv[3] if len(sys.argv) > 3 else 'fps'
+marker = sys.argv[3] if len(sys.argv) > 3 else 'fps_pruned'
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name'] and '40' in r['Kernel_Name']]
-if not marks:
-    marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 sel = rows[marks[-k]:]
 t0, t1 = int(sel[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in sel)
 agg = collections.defaultdict(lambda: [0, 0])
