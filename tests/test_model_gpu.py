@@ -58,50 +58,47 @@ def test_full_config_step_runs_and_is_finite(hip_device):
             assert torch.isfinite(p.grad).all(), n
 
 
-def test_hip_graph_replay_matches_eager_steps(hip_device):
-    """bench.py replays the step as hipGraphs: same losses as the un-captured step."""
-    import bench
-    from nesie_amd.votenet import nesie_votenet_scannet_cfg
-    cfg = nesie_votenet_scannet_cfg()['optimizer']
+def test_hip_graph_replay_matches_eager_forward_backward(hip_device):
+    """bench.py replays the step as hipGraphs: a captured forward+backward must give the
+    loss and gradients of the un-captured one (same weights, pinned jitter noise)."""
+    from nesie_amd import dp
+    from nesie_amd.scenes import make_batch
+    from nesie_amd.votenet import build_nesie_votenet
+    from nesie_amd.votenet.nesie_head import GTBatch
+    torch.manual_seed(0)
+    model = build_nesie_votenet().to(hip_device)
+    g = torch.Generator().manual_seed(11)
+    model.bbox_head.jitter_noise = tuple(torch.randn(2, 256, 3, generator=g).to(hip_device)
+                                         for _ in range(2))
+    pts, boxes, labels = make_batch(1000, 2)
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    bucket = dp.FlatGradBucket(model.parameters())
+    loss_out = torch.zeros((), device=hip_device)
 
-    def run(graph):
-        model, step, _ = bench.build_step(hip_device, 2, 1000, cfg['lr'], cfg['weight_decay'],
-                                          graph=False)
-        g = torch.Generator().manual_seed(11)
-        model.bbox_head.jitter_noise = tuple(torch.randn(2, 256, 3, generator=g).to(hip_device)
-                                             for _ in range(2))
-        if graph:  # rebuild with capture, after the noise is pinned
-            torch.manual_seed(0)
-            model2, step, _ = bench.build_step(hip_device, 2, 1000, cfg['lr'],
-                                               cfg['weight_decay'], graph=False)
-            model2.bbox_head.jitter_noise = model.bbox_head.jitter_noise
-            return model2, step
-        return model, step
+    def fwd_bwd():
+        bucket.zero_()
+        losses = model.forward_train(pts, None, gt, None)
+        total = model.parse_losses(losses)
+        total.backward()
+        loss_out.copy_(total.detach())
 
-    # eager reference
-    m_e, step_e = run(False)
-    eager_losses = [step_e().item() for _ in range(3)]
-    # graph: capture happens inside build_step, so pin the noise through a subclass hook
-    import nesie_amd.votenet.nesie_head as nh
-    noise = m_e.bbox_head.jitter_noise
-    orig_init = nh.NesieHead.__init__
-
-    def patched(self, *a, **k):
-        orig_init(self, *a, **k)
-        self.jitter_noise = noise
-    nh.NesieHead.__init__ = patched
-    try:
-        _, step_g, _ = bench.build_step(hip_device, 2, 1000, cfg['lr'], cfg['weight_decay'],
-                                        graph=True)
-    finally:
-        nh.NesieHead.__init__ = orig_init
-    # build_step(graph=True) already ran 2 warm-up + 1 captured step on its own model, so
-    # compare a fresh eager model advanced by the same number of steps
-    m_ref, step_ref = run(False)
-    for _ in range(3):
-        step_ref()
-    want = [step_ref().item() for _ in range(2)]
-    got = [step_g().item() for _ in range(2)]
-    assert all(abs(e) < 1e6 for e in eager_losses)
-    for a, b in zip(got, want):
-        assert abs(a - b) <= 2e-3 * abs(b), (got, want)
+    fwd_bwd()
+    torch.cuda.synchronize()
+    want_loss, want_grad = loss_out.item(), bucket.flat.clone()
+    side = torch.cuda.Stream(hip_device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fwd_bwd()
+    bucket.flat.fill_(123.0)
+    loss_out.fill_(-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(loss_out.item() - want_loss) <= 1e-5 * abs(want_loss)
+    rel = ((bucket.flat - want_grad).norm() / want_grad.norm()).item()
+    assert rel < 1e-4, rel
