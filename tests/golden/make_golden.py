@@ -1,0 +1,320 @@
+#!/usr/bin/env python
+"""Generate golden vectors from the REFERENCE's own Python for the detector-head path.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).
+The reference package cannot be imported as a whole (`import mmdet3d` ->
+ModuleNotFoundError: mmcv, an ordinary error), so its leaf files are loaded BY PATH under
+their real dotted names, with
+  * tiny stand-ins for the third-party pieces that are not in the reference tree
+    (mmcv ConvModule / BaseModule / registries, mmdet weighted_loss / MSE / L1 / SmoothL1 /
+    CrossEntropy, multi_apply) written here from their published semantics
+     -- deliberately NOT the nesie_amd implementations;
+  * the native ops (`mmdet3d.ops`, `mmcv.ops.three_nn`, `sort_vertices`) served by
+    nesie_amd.mmdet3d_ops on the CPU oracle back end (the reference has no CPU ops);
+  * `Tensor.cuda()` made a no-op (the reference hard-codes `.cuda()`).
+What runs from the reference, unmodified: nesie_head.py (forward, loss, get_targets*),
+side_pooling_module.py, reliable_conv_bbox_module.py, vote_module.py, the five loss files,
+oriented_iou_loss.py + box_intersection_2d.py + cuda_op/cuda_ext.py.
+
+Weights and inputs are regenerated from seeds at test time (nesie_amd's head is built
+under torch.manual_seed and its state_dict is loaded into the reference head), so the
+fixtures hold only OUTPUTS: tests/golden/nesie_head_golden.pt (< 100 KB).
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.environ.get("NESIE_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from nesie_amd import kernels  # noqa: E402
+from nesie_amd import mmdet3d_ops as my_ops  # noqa: E402
+from nesie_amd.votenet.boxes import DepthInstance3DBoxes  # noqa: E402
+from tests.golden import golden_inputs  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------
+# third-party stand-ins (mmcv 1.3.17 / mmdet 2.19 semantics)
+# --------------------------------------------------------------------------------------
+class Registry:
+    def __init__(self, name):
+        self.name, self.module_dict = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco
+
+    def get(self, key):
+        return self.module_dict.get(key)
+
+    def __contains__(self, key):
+        return key in self.module_dict
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.module_dict[cfg.pop('type')](**cfg)
+
+
+class StubConvModule(nn.Module):
+    """conv -> norm -> act; bias='auto' => bias iff no norm; plain F.conv (not the bmm path)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), bias='auto',
+                 inplace=True, **kw):
+        super().__init__()
+        ctype = (conv_cfg or dict(type='Conv2d'))['type']
+        if bias == 'auto':
+            bias = norm_cfg is None
+        self.conv = dict(Conv1d=nn.Conv1d, Conv2d=nn.Conv2d)[ctype](
+            in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.norm_name = None
+        if norm_cfg is not None:
+            t = norm_cfg['type']
+            if t in ('BN1d', 'BN'):
+                self.norm_name = 'bn'; self.add_module('bn', nn.BatchNorm1d(out_channels))
+            elif t == 'BN2d':
+                self.norm_name = 'bn'; self.add_module('bn', nn.BatchNorm2d(out_channels))
+            elif t == 'GN':
+                self.norm_name = 'gn'
+                self.add_module('gn', nn.GroupNorm(norm_cfg['num_groups'], out_channels))
+        self.activate = nn.ReLU(inplace=inplace) if act_cfg is not None else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm_name:
+            x = getattr(self, self.norm_name)(x)
+        if self.activate is not None:
+            x = self.activate(x)
+        return x
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    t = (cfg or dict(type='Conv2d'))['type']
+    return dict(Conv1d=nn.Conv1d, Conv2d=nn.Conv2d)[t](*args, **kwargs)
+
+
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None, *a, **k):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+
+def _identity_decorator_factory(*a, **k):
+    def deco(fn):
+        return fn
+    return deco
+
+
+def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return dict(none=lambda l: l, mean=lambda l: l.mean(), sum=lambda l: l.sum())[reduction](loss)
+    if reduction == 'mean':
+        return loss.sum() / avg_factor
+    if reduction == 'none':
+        return loss
+    raise ValueError
+
+
+def weighted_loss(loss_func):
+    def wrapper(pred, target, weight=None, reduction='mean', avg_factor=None, **kwargs):
+        loss = loss_func(pred, target, **kwargs)
+        return weight_reduce_loss(loss, weight, reduction, avg_factor)
+    return wrapper
+
+
+def _mk_elementwise(fn):
+    class L(nn.Module):
+        def __init__(self, *args, **kw):
+            super().__init__()
+            names = ['reduction', 'loss_weight'] if fn is not _smooth else ['beta', 'reduction', 'loss_weight']
+            d = dict(beta=1.0, reduction='mean', loss_weight=1.0)
+            d.update(dict(zip(names, args))); d.update(kw)
+            self.beta, self.reduction, self.loss_weight = d['beta'], d['reduction'], d['loss_weight']
+
+        def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kw):
+            red = reduction_override if reduction_override else self.reduction
+            l = fn(pred, target, self.beta)
+            return self.loss_weight * weight_reduce_loss(l, weight, red, avg_factor)
+    return L
+
+
+def _mse(p, t, b): return (p - t) ** 2
+def _l1(p, t, b): return (p - t).abs()
+def _smooth(p, t, b):
+    d = (p - t).abs()
+    return torch.where(d < b, 0.5 * d * d / b, d - 0.5 * b)
+
+
+class StubCrossEntropyLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None,
+                 loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.class_weight, self.loss_weight = reduction, class_weight, loss_weight
+
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kw):
+        red = reduction_override if reduction_override else self.reduction
+        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        loss = F.cross_entropy(cls_score, label, weight=cw, reduction='none')
+        if weight is not None:
+            weight = weight.float()
+        return self.loss_weight * weight_reduce_loss(loss, weight, red, avg_factor)
+
+
+def multi_apply(func, *args, **kwargs):
+    from functools import partial
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path, **attrs):
+    m = _mod(name, **attrs)
+    m.__path__ = [path]
+    return m
+
+
+def install_reference_sandbox():
+    torch.Tensor.cuda = lambda self, *a, **k: self  # the reference hard-codes .cuda()
+    LOSSES, HEADS = Registry('loss'), Registry('head')
+    MSELoss, L1Loss, SmoothL1Loss = _mk_elementwise(_mse), _mk_elementwise(_l1), _mk_elementwise(_smooth)
+    for n, c in dict(MSELoss=MSELoss, L1Loss=L1Loss, SmoothL1Loss=SmoothL1Loss,
+                     CrossEntropyLoss=StubCrossEntropyLoss).items():
+        LOSSES.module_dict[n] = c
+    # --- third party ---
+    _mod('mmcv', is_tuple_of=lambda seq, t: isinstance(seq, tuple) and all(isinstance(i, t) for i in seq))
+    _mod('mmcv.cnn', ConvModule=StubConvModule)
+    _mod('mmcv.cnn.bricks', build_conv_layer=build_conv_layer)
+    _mod('mmcv.runner', BaseModule=BaseModule, force_fp32=_identity_decorator_factory,
+         auto_fp16=_identity_decorator_factory)
+    _mod('mmcv.ops', three_nn=my_ops.three_nn)
+    _mod('mmcv.utils', Registry=Registry)
+    _mod('mmdet')
+    _mod('mmdet.core', multi_apply=multi_apply)
+    _mod('mmdet.models', HEADS=HEADS, LOSSES=LOSSES)
+    _mod('mmdet.models.builder', HEADS=HEADS, LOSSES=LOSSES)
+    _mod('mmdet.models.losses', MSELoss=MSELoss, L1Loss=L1Loss, SmoothL1Loss=SmoothL1Loss,
+         CrossEntropyLoss=StubCrossEntropyLoss, FocalLoss=None, binary_cross_entropy=None)
+    _mod('mmdet.models.losses.utils', weighted_loss=weighted_loss)
+
+    def sort_vertices_forward(vertices, mask, num_valid):
+        idx = torch.empty(vertices.shape[0], vertices.shape[1], 9, dtype=torch.int32)
+        oracle.OracleKernels().sort_vertices_forward(vertices.contiguous(), mask.contiguous(),
+                                                     num_valid.contiguous(), idx)
+        return idx
+    _mod('sort_vertices', sort_vertices_forward=sort_vertices_forward)
+    # --- reference packages as path-only shells (their __init__.py is NOT executed) ---
+    r = os.path.join(REF, 'mmdet3d')
+    _pkg('mmdet3d', r)
+    _pkg('mmdet3d.ops', os.path.join(r, 'ops'), build_sa_module=my_ops.build_sa_module,
+         furthest_point_sample=my_ops.furthest_point_sample)
+    _pkg('mmdet3d.ops.rotated_iou', os.path.join(r, 'ops', 'rotated_iou'))
+    _pkg('mmdet3d.ops.rotated_iou.cuda_op', os.path.join(r, 'ops', 'rotated_iou', 'cuda_op'))
+    # min_enclosing_box.py (GIoU only, off the hot path) uses np.int, removed in numpy 2
+    _mod('mmdet3d.ops.rotated_iou.min_enclosing_box', smallest_bounding_box=None)
+    oi = importlib.import_module('mmdet3d.ops.rotated_iou.oriented_iou_loss')
+    sys.modules['mmdet3d.ops.rotated_iou'].cal_iou_3d = oi.cal_iou_3d
+    sys.modules['mmdet3d.ops.rotated_iou'].cal_giou_3d = oi.cal_giou_3d
+    _mod('mmdet3d.core', DepthInstance3DBoxes=DepthInstance3DBoxes)
+    _mod('mmdet3d.core.bbox', AxisAlignedBboxOverlaps3D=object)
+    _mod('mmdet3d.core.post_processing', aligned_3d_nms=None)
+    _pkg('mmdet3d.models', os.path.join(r, 'models'))
+    _mod('mmdet3d.models.builder', build_loss=lambda cfg: LOSSES.build(cfg))
+    lp = _pkg('mmdet3d.models.losses', os.path.join(r, 'models', 'losses'))
+    for f in ['chamfer_distance', 'surface_loss', 'side_pred_loss', 'iou3d_loss', 'gfocal_loss']:
+        importlib.import_module(f'mmdet3d.models.losses.{f}')
+    lp.chamfer_distance = sys.modules['mmdet3d.models.losses.chamfer_distance'].chamfer_distance
+    mu = _pkg('mmdet3d.models.model_utils', os.path.join(r, 'models', 'model_utils'))
+    mu.VoteModule = importlib.import_module('mmdet3d.models.model_utils.vote_module').VoteModule
+    _pkg('mmdet3d.models.dense_heads', os.path.join(r, 'models', 'dense_heads'))
+    return importlib.import_module('mmdet3d.models.dense_heads.nesie_head')
+
+
+def main():
+    ref_head_mod = install_reference_sandbox()
+    out = {}
+    with kernels.use_backend(oracle.OracleKernels()):
+        # ---- (1) rotated IoU chain, reference torch code + oracle sort ------------------
+        ri = sys.modules['mmdet3d.ops.rotated_iou']
+        for mode in golden_inputs.IOU_MODES:
+            a, b = golden_inputs.iou_boxes(mode)
+            out[f'iou3d/{mode}'] = ri.cal_iou_3d(a, b).clone()
+        # ---- (2) loss leaf functions ----------------------------------------------------
+        L = sys.modules['mmdet3d.models.losses.gfocal_loss']
+        pred, label, score, w = golden_inputs.qfl_inputs()
+        out['qfl/none'] = L.quality_focal_loss(pred, (label, score), w, beta=2.0, use_sigmoid=False,
+                                               reduction='none')
+        cd = sys.modules['mmdet3d.models.losses.chamfer_distance']
+        s, d = golden_inputs.chamfer_inputs()
+        for mode in ('l1', 'l2', 'smooth_l1'):
+            r_ = cd.chamfer_distance(s, d, criterion_mode=mode, reduction='none')
+            out[f'chamfer/{mode}'] = [t.clone() for t in r_]
+        # ---- (3) the whole head: forward + loss, reference code, our weights -------------
+        cfg = golden_inputs.head_cfg()
+        cfg['bbox_head']['grid_conv_cfg']['mean_size_arr_path'] = os.path.join(
+            REF, 'data/scannet/meta_data/scannet_means.npz')
+        mine = golden_inputs.build_my_head()
+        ref = ref_head_mod.NesieHead(**cfg['bbox_head'], train_cfg=cfg['train_cfg'],
+                                     test_cfg=cfg['test_cfg'])
+        missing, unexpected = ref.load_state_dict(mine.state_dict(), strict=False)
+        assert not unexpected, unexpected
+        assert all(k.endswith('num_batches_tracked') or 'project' in k for k in missing), missing
+        ref.train()
+        feat, points, boxes, labels = golden_inputs.head_inputs()
+        noise = golden_inputs.jitter_noise()
+        draws = iter(noise)
+        real_randn = torch.randn
+        torch.randn = lambda *a, **k: next(draws)  # jitter_bbox_preds draws centre then size noise
+        try:
+            preds = ref(feat, 'vote')
+        finally:
+            torch.randn = real_randn
+        gt = [DepthInstance3DBoxes(b) for b in boxes]
+        losses = ref.loss(preds, [p for p in points], gt, [l.clone() for l in labels])
+        targets = ref.get_targets([p for p in points], [DepthInstance3DBoxes(b) for b in boxes],
+                                  [l.clone() for l in labels], bbox_preds=preds)
+        for k, v in losses.items():
+            out[f'head/loss/{k}'] = v.detach().clone()
+        for k in ['vote_points', 'aggregated_points', 'aggregated_indices', 'obj_scores',
+                  'sem_scores', 'surface_pred', 'bbox_preds', 'jitter_bbox_preds', 'iou_scores',
+                  'iou_scores_jitter', 'side_scores', 'side_scores_jitter']:
+            out[f'head/pred/{k}'] = preds[k].detach().clone()
+        names = ['vote_targets', 'vote_target_masks', 'center_targets', 'bbox_targets',
+                 'mask_targets', 'valid_gt_masks', 'objectness_targets', 'objectness_weights',
+                 'box_loss_weights', 'valid_gt_weights', 'assignment']
+        for n, t in zip(names, targets):
+            out[f'head/target/{n}'] = (torch.cat(t, 0) if isinstance(t, list) else t).detach().clone()
+        # vote targets are big (B,N,9): keep a checksum + the non-zero rows count instead
+        vt = out.pop('head/target/vote_targets')
+        out['head/target/vote_targets_sum'] = vt.double().sum()
+        out['head/target/vote_targets_abs_sum'] = vt.double().abs().sum()
+        out['head/target/vote_targets_rows'] = vt[:, ::16].clone()
+        vm = out.pop('head/target/vote_target_masks')
+        out['head/target/vote_target_masks_sum'] = vm.sum()
+    path = os.path.join(ROOT, 'tests', 'golden', 'nesie_head_golden.pt')
+    torch.save(out, path)
+    print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'entries')
+    for k in sorted(out):
+        if k.startswith('head/loss'):
+            print(k, float(out[k]))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,96 @@
+"""Our detector-head path against golden OUTPUTS of the reference's own Python
+(tests/golden/nesie_head_golden.pt, produced by tests/golden/make_golden.py from
+nesie_head.py / side_pooling_module.py / the loss files / oriented_iou_loss.py loaded by
+path).  Inputs and weights are regenerated from seeds.  No GPU, no reference tree."""
+import os
+
+import pytest
+import torch
+
+from nesie_amd import kernels
+from nesie_amd.mmdet3d_ops import cal_iou_3d
+from nesie_amd.votenet import losses as L
+from nesie_amd.votenet.boxes import DepthInstance3DBoxes
+from tests.golden import golden_inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "nesie_head_golden.pt")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(GOLD)
+
+
+@pytest.mark.parametrize("mode", golden_inputs.IOU_MODES)
+def test_rotated_iou_chain(gold, oracle_kernels, mode):
+    a, b = golden_inputs.iou_boxes(mode)
+    with kernels.use_backend(oracle_kernels):
+        got = cal_iou_3d(a, b)
+    torch.testing.assert_close(got, gold[f"iou3d/{mode}"], rtol=1e-5, atol=1e-6)
+
+
+def test_quality_focal_loss_dense_rewrite(gold):
+    pred, label, score, w = golden_inputs.qfl_inputs()
+    got = L.quality_focal_loss(pred, (label, score), beta=2.0, use_sigmoid=False) * w
+    torch.testing.assert_close(got, gold["qfl/none"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["l1", "l2", "smooth_l1"])
+def test_chamfer_distance(gold, mode):
+    s, d = golden_inputs.chamfer_inputs()
+    got = L.chamfer_distance(s, d, criterion_mode=mode, reduction="none")
+    for g, w in zip(got, gold[f"chamfer/{mode}"]):
+        if g.dtype.is_floating_point:
+            torch.testing.assert_close(g, w, rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(g, w)
+
+
+@pytest.fixture(scope="module")
+def head_run(oracle_kernels):
+    head = golden_inputs.build_my_head()
+    feat, points, boxes, labels = golden_inputs.head_inputs()
+    head.jitter_noise = golden_inputs.jitter_noise()
+    with kernels.use_backend(oracle_kernels):
+        preds = head(feat, "vote")
+        losses = head.loss(preds, points, [DepthInstance3DBoxes(b) for b in boxes],
+                           [l.clone() for l in labels])
+        targets = head.get_targets(points, [DepthInstance3DBoxes(b) for b in boxes],
+                                   [l.clone() for l in labels], bbox_preds=preds)
+    return preds, losses, targets
+
+
+def test_head_forward_matches_reference_code(gold, head_run):
+    preds, _, _ = head_run
+    for key in ["vote_points", "aggregated_points", "obj_scores", "sem_scores", "surface_pred",
+                "bbox_preds", "jitter_bbox_preds", "iou_scores", "iou_scores_jitter",
+                "side_scores", "side_scores_jitter"]:
+        torch.testing.assert_close(preds[key], gold[f"head/pred/{key}"], rtol=1e-4, atol=1e-5,
+                                   msg=key)
+    assert torch.equal(preds["aggregated_indices"], gold["head/pred/aggregated_indices"])
+
+
+def test_head_targets_match_reference_loops(gold, head_run):
+    _, _, t = head_run
+    (vt, vm, ct, bt, mt, vg, ot, ow, bw, vgw, asg) = t
+    g = lambda k: gold[f"head/target/{k}"]  # noqa: E731
+    assert torch.equal(asg, g("assignment")) and torch.equal(ot, g("objectness_targets"))
+    assert torch.equal(mt, g("mask_targets")) and torch.equal(vg.long(), g("valid_gt_masks").long())
+    torch.testing.assert_close(ct, g("center_targets"), rtol=0, atol=0)
+    torch.testing.assert_close(bt.reshape(-1, 7), g("bbox_targets"), rtol=0, atol=0)
+    torch.testing.assert_close(ow, g("objectness_weights"), rtol=1e-6, atol=0)
+    torch.testing.assert_close(bw, g("box_loss_weights"), rtol=1e-6, atol=0)
+    torch.testing.assert_close(vgw, g("valid_gt_weights"), rtol=1e-6, atol=0)
+    assert vm.sum() == g("vote_target_masks_sum")
+    torch.testing.assert_close(vt[:, ::16], g("vote_targets_rows"), rtol=0, atol=0)
+    assert abs(vt.double().sum() - g("vote_targets_sum")) < 1e-6
+    assert abs(vt.double().abs().sum() - g("vote_targets_abs_sum")) < 1e-6
+
+
+def test_head_losses_match_reference_code(gold, head_run):
+    _, losses, _ = head_run
+    assert set(losses) == {k.split("/")[-1] for k in gold if k.startswith("head/loss/")}
+    for k, v in losses.items():
+        want = gold[f"head/loss/{k}"]
+        assert want > 0, k
+        torch.testing.assert_close(v.detach(), want, rtol=1e-4, atol=1e-6, msg=k)
