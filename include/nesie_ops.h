@@ -141,6 +141,27 @@ int nesie_group_max_pool_forward(long long rows, int nsample, const float *x, fl
 int nesie_group_max_pool_backward(long long rows, int nsample, const float *grad_out,
                                   const uint8_t *argmax, float *grad_x, void *stream);
 
+/* Training-mode BatchNorm with an optional fused ReLU over x[B, C, P] (statistics per
+ * channel over B*P; biased variance for normalisation, unbiased for running_var, as
+ * torch.nn.BatchNorm{1,2}d).  No extension entry in the reference: it builds
+ * conv -> BN -> ReLU from mmcv ConvModule / nn.BatchNorm + nn.ReLU
+ * (point_sa_module.py:277-289, side_pooling_module.py:55-78,346-358).
+ * forward : y = relu?(gamma * (x - mean) * invstd + beta); writes save_mean/save_invstd
+ *           [C] and updates running_mean/var [C] in place (NULL = skip) with `momentum`.
+ * backward: dx, dgamma [C], dbeta [C] from dy, x, y (y only read when relu != 0).
+ * workspace: nesie_bn_workspace_bytes(b, c, p) bytes, 16-byte aligned tensors. */
+size_t nesie_bn_workspace_bytes(int b, int c, long long p);
+int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float *gamma,
+                          const float *beta, float *running_mean, float *running_var,
+                          float momentum, float eps, int relu, float *y, float *save_mean,
+                          float *save_invstd, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const float *x,
+                           const float *y, const float *gamma, const float *save_mean,
+                           const float *save_invstd, int relu, float *dx, float *dgamma,
+                           float *dbeta, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

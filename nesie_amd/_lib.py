@@ -32,6 +32,10 @@ SIGNATURES = {
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_group_max_pool_forward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_group_max_pool_backward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
+    "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
+                              _P, _P, ctypes.c_size_t, _P],
+    "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P,
+                               _P, ctypes.c_size_t, _P],
 }
 
 _lib = None
@@ -56,6 +60,8 @@ def load():
         fn.restype = _I
     lib.nesie_fps_workspace_bytes.argtypes = [_I, _I]
     lib.nesie_fps_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_bn_workspace_bytes.argtypes = [_I, _I, ctypes.c_longlong]
+    lib.nesie_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_abi_version.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib

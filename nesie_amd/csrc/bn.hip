@@ -1,0 +1,297 @@
+// Training-mode BatchNorm (+ fused ReLU) forward and backward for gfx950.
+//
+// Stands in for the ATen/MIOpen batch_norm + relu pairs the reference builds with
+// mmcv ConvModule (conv -> BN -> ReLU: reference mmdet3d/ops/pointnet_modules/
+// point_sa_module.py:277-289, point_fp_module.py:28-37, model_utils/vote_module.py:61-74)
+// and with nn.BatchNorm + nn.ReLU in side_pooling_module.py:55-78, 346-358.
+// x (B, C, P) fp32 contiguous, statistics per channel over the B*P positions.
+//
+// All kernels are pure HBM streaming (float4 per lane, no re-reads inside a kernel):
+//   forward : stats  (read x)            -> finalize (C threads) -> apply (read x, write y)
+//   backward: reduce (read dy, x, [y])   -> finalize             -> apply (read dy, x, [y]; write dx)
+// i.e. 3 tensor passes forward and 7 backward, ReLU and its mask included (the unfused
+// pair costs 5 and 10).  Sums are taken about a per-channel shift (the channel's first
+// element) so E[x^2]-E[x]^2 does not cancel; partials are combined in double.
+#include "common.h"
+
+namespace nesie {
+
+constexpr int BN_BLOCK = 256;
+constexpr int BN_SPAN = 8192;  // floats of one (b, c) row handled by a stats/reduce block
+
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int w = 0; w < BN_BLOCK / 64; ++w) r += sh[w];
+  return r;
+}
+
+// partial[(c * nslice + b * sp + s) * 2 + {0,1}] = sum(x - shift), sum((x - shift)^2)
+__global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
+    int c_total, long long p, int sp, const float *__restrict__ x,
+    float *__restrict__ partial) {
+  __shared__ float sh[BN_BLOCK / 64];
+  const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const float *row = x + ((size_t)b * c_total + c) * p;
+  const float shift = x[(size_t)c * p];  // first element of the channel (b = 0)
+  const long long lo = (long long)s * BN_SPAN;
+  const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  float a0 = 0.f, a1 = 0.f;
+  if ((p & 3) == 0) {
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
+      const float4 v = *(const float4 *)(row + i);
+      const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+      a0 += (d0 + d1) + (d2 + d3);
+      a1 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+      const float d = row[i] - shift;
+      a0 += d; a1 += d * d;
+    }
+  }
+  a0 = block_sum(a0, sh);
+  a1 = block_sum(a1, sh);
+  if (threadIdx.x == 0) {
+    const size_t o = ((size_t)c * (gridDim.z * sp) + (size_t)b * sp + s) * 2;
+    partial[o] = a0; partial[o + 1] = a1;
+  }
+}
+
+// coef[c*4 + {0,1,2,3}] = scale, bias, mean, invstd
+__global__ void bn_finalize_kernel(int c_total, int nslice, double n, const float *x, long long p,
+                                   const float *partial, const float *gamma,
+                                   const float *beta, float *running_mean,
+                                   float *running_var, float momentum, float eps,
+                                   float *save_mean, float *save_invstd, float *coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c_total) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nslice; ++i) {
+    s0 += (double)partial[((size_t)c * nslice + i) * 2];
+    s1 += (double)partial[((size_t)c * nslice + i) * 2 + 1];
+  }
+  const double shift = (double)x[(size_t)c * p];
+  const double m = s0 / n;
+  double var = s1 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const double mean = shift + m;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  if (running_mean) {
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)invstd;
+  const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  coef[c * 4 + 0] = (float)(g * invstd);
+  coef[c * 4 + 1] = (float)(bt - mean * g * invstd);
+  coef[c * 4 + 2] = (float)mean;
+  coef[c * 4 + 3] = (float)invstd;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
+    int c_total, long long p, const float *__restrict__ x, const float *__restrict__ coef,
+    float *__restrict__ y) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
+  const size_t base = ((size_t)b * c_total + c) * p;
+  const long long lo = (long long)blockIdx.x * BN_SPAN;
+  const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  if ((p & 3) == 0) {
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
+      const float4 v = *(const float4 *)(x + base + i);
+      float4 o = make_float4(v.x * sc + bi, v.y * sc + bi, v.z * sc + bi, v.w * sc + bi);
+      if (RELU) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      *(float4 *)(y + base + i) = o;
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+      float o = x[base + i] * sc + bi;
+      y[base + i] = RELU ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
+// backward partials: sum(g), sum(g * xhat), g = RELU ? dy * [y > 0] : dy
+template <bool RELU>
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
+    int c_total, long long p, int sp, const float *__restrict__ dy,
+    const float *__restrict__ x, const float *__restrict__ y,
+    const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+    float *__restrict__ partial) {
+  __shared__ float sh[BN_BLOCK / 64];
+  const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * c_total + c) * p;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const long long lo = (long long)s * BN_SPAN;
+  const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  float a0 = 0.f, a1 = 0.f;
+  if ((p & 3) == 0) {
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
+      float4 g = *(const float4 *)(dy + base + i);
+      const float4 v = *(const float4 *)(x + base + i);
+      if (RELU) {
+        const float4 o = *(const float4 *)(y + base + i);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      a0 += (g.x + g.y) + (g.z + g.w);
+      a1 += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) +
+            (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+      float g = dy[base + i];
+      if (RELU) g = y[base + i] > 0.f ? g : 0.f;
+      a0 += g; a1 += g * ((x[base + i] - mean) * invstd);
+    }
+  }
+  a0 = block_sum(a0, sh);
+  a1 = block_sum(a1, sh);
+  if (threadIdx.x == 0) {
+    const size_t o = ((size_t)c * (gridDim.z * sp) + (size_t)b * sp + s) * 2;
+    partial[o] = a0; partial[o + 1] = a1;
+  }
+}
+
+// coef[c*4 + {0,1,2}] = gamma*invstd, sum(g)/n, sum(g*xhat)/n ; dgamma, dbeta written
+__global__ void bn_bwd_finalize_kernel(int c_total, int nslice, double n, const float *partial,
+                                       const float *gamma, const float *save_invstd,
+                                       float *dgamma, float *dbeta, float *coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c_total) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nslice; ++i) {
+    s0 += (double)partial[((size_t)c * nslice + i) * 2];
+    s1 += (double)partial[((size_t)c * nslice + i) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)s0;
+  if (dgamma) dgamma[c] = (float)s1;
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  coef[c * 4 + 0] = (float)(g * (double)save_invstd[c]);
+  coef[c * 4 + 1] = (float)(s0 / n);
+  coef[c * 4 + 2] = (float)(s1 / n);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
+    int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
+    const float *__restrict__ y, const float *__restrict__ save_mean,
+    const float *__restrict__ save_invstd, const float *__restrict__ coef,
+    float *__restrict__ dx) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float a = coef[c * 4 + 0], k1 = coef[c * 4 + 1], k2 = coef[c * 4 + 2];
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const size_t base = ((size_t)b * c_total + c) * p;
+  const long long lo = (long long)blockIdx.x * BN_SPAN;
+  const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  if ((p & 3) == 0) {
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
+      float4 g = *(const float4 *)(dy + base + i);
+      const float4 v = *(const float4 *)(x + base + i);
+      if (RELU) {
+        const float4 o = *(const float4 *)(y + base + i);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      float4 r;
+      r.x = a * (g.x - k1 - (v.x - mean) * invstd * k2);
+      r.y = a * (g.y - k1 - (v.y - mean) * invstd * k2);
+      r.z = a * (g.z - k1 - (v.z - mean) * invstd * k2);
+      r.w = a * (g.w - k1 - (v.w - mean) * invstd * k2);
+      *(float4 *)(dx + base + i) = r;
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+      float g = dy[base + i];
+      if (RELU) g = y[base + i] > 0.f ? g : 0.f;
+      dx[base + i] = a * (g - k1 - (x[base + i] - mean) * invstd * k2);
+    }
+  }
+}
+
+static inline int bn_sp(long long p) { return (int)((p + BN_SPAN - 1) / BN_SPAN); }
+
+}  // namespace nesie
+
+using namespace nesie;
+
+extern "C" size_t nesie_bn_workspace_bytes(int b, int c, long long p) {
+  if (b <= 0 || c <= 0 || p <= 0) return 0;
+  const size_t nslice = (size_t)b * bn_sp(p);
+  return ((size_t)c * nslice * 2 + (size_t)c * 4) * sizeof(float);
+}
+
+static int bn_check(const char *W, int b, int c, long long p, const void *ws, size_t ws_bytes) {
+  NESIE_REQUIRE(b >= 0 && c >= 0 && p >= 0, W);
+  if (b == 0 || c == 0 || p == 0) return NESIE_OK;
+  NESIE_REQUIRE(ws && ws_bytes >= nesie_bn_workspace_bytes(b, c, p), W);
+  NESIE_REQUIRE(b <= 65535 && c <= 65535 && bn_sp(p) < (1 << 30), W);
+  return NESIE_OK;
+}
+
+extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
+                                     const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var,
+                                     float momentum, float eps, int relu, float *y,
+                                     float *save_mean, float *save_invstd, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+  const char *W = "bn_relu_forward";
+  int st = bn_check(W, b, c, p, workspace, workspace_bytes);
+  if (st || b == 0 || c == 0 || p == 0) return st;
+  NESIE_REQUIRE(x && y && save_mean && save_invstd, W);
+  NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  const int sp = bn_sp(p), nslice = b * sp;
+  float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
+  dim3 grid(sp, c, b);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
+                     (double)b * (double)p, x, p, partial, gamma, beta, running_mean,
+                     running_var, momentum, eps, save_mean, save_invstd, coef);
+  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, coef, y);
+  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, coef, y);
+  return check_launch(W);
+}
+
+extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy,
+                                      const float *x, const float *y, const float *gamma,
+                                      const float *save_mean, const float *save_invstd,
+                                      int relu, float *dx, float *dgamma, float *dbeta,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+  const char *W = "bn_relu_backward";
+  int st = bn_check(W, b, c, p, workspace, workspace_bytes);
+  if (st || b == 0 || c == 0 || p == 0) return st;
+  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && (!relu || y), W);
+  NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  const int sp = bn_sp(p), nslice = b * sp;
+  float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
+  dim3 grid(sp, c, b);
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x, y,
+                       save_mean, save_invstd, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x,
+                       y, save_mean, save_invstd, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
+                     (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, y,
+                       save_mean, save_invstd, coef, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, y,
+                       save_mean, save_invstd, coef, dx);
+  return check_launch(W);
+}

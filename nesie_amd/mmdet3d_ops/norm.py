@@ -1,0 +1,72 @@
+"""Training-mode BatchNorm with the following ReLU fused, on the native kernels.
+
+The reference builds conv -> BN -> ReLU from mmcv ``ConvModule`` and from
+``nn.BatchNorm{1,2}d`` + ``nn.ReLU`` (point_sa_module.py:277-289,
+side_pooling_module.py:55-78, 346-358); these classes ARE ``nn.BatchNorm{1,2}d`` (same
+parameters, buffers and state-dict keys) whose training forward runs
+``nesie_bn_relu_forward`` (3 streaming passes) instead of batch_norm + relu (5), and whose
+backward runs ``nesie_bn_relu_backward`` (7 passes instead of 10).  Evaluation mode and the
+injected CPU back end use the ATen path.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+
+from ..kernels import backend_for
+
+
+class BNReLUTrain(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        c = x.shape[1]
+        y = torch.empty_like(x)
+        save_mean = x.new_empty(c)
+        save_invstd = x.new_empty(c)
+        backend_for(x).bn_relu_forward(x, weight, bias, running_mean, running_var, momentum,
+                                       eps, relu, y, save_mean, save_invstd)
+        ctx.relu = relu
+        ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        c = x.shape[1]
+        dx = torch.empty_like(x)
+        dgamma, dbeta = x.new_empty(c), x.new_empty(c)
+        backend_for(dy).bn_relu_backward(dy, x, y, weight, save_mean, save_invstd, ctx.relu,
+                                         dx, dgamma, dbeta)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _FusedBNReLU:
+    """Mixin over nn.BatchNorm{1,2}d: ``relu=True`` folds the activation into the norm."""
+
+    def _init_fused(self, relu):
+        self.fuse_relu = bool(relu)
+
+    def forward(self, x):
+        backend = backend_for(x)  # raises for CPU tensors without an injected back end
+        native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
+                  and self.affine and self.track_running_stats and self.momentum is not None)
+        if native:
+            self.num_batches_tracked.add_(1)
+            return BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean,
+                                     self.running_var, self.momentum, self.eps, self.fuse_relu)
+        y = super().forward(x)
+        return F.relu(y) if self.fuse_relu else y
+
+
+class FusedBNReLU1d(_FusedBNReLU, nn.BatchNorm1d):
+    def __init__(self, num_features, relu=True, **kw):
+        nn.BatchNorm1d.__init__(self, num_features, **kw)
+        self._init_fused(relu)
+
+
+class FusedBNReLU2d(_FusedBNReLU, nn.BatchNorm2d):
+    def __init__(self, num_features, relu=True, **kw):
+        nn.BatchNorm2d.__init__(self, num_features, **kw)
+        self._init_fused(relu)

@@ -16,6 +16,7 @@ from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup
 from .interpolate import three_interpolate, three_nn
+from .norm import FusedBNReLU1d, FusedBNReLU2d
 from .pool import group_max_pool
 
 
@@ -64,12 +65,16 @@ class ConvModule(nn.Module):
         self.conv = conv_cls(in_channels, out_channels, kernel_size, stride=stride,
                              padding=padding, bias=bias)
         self.norm_name = None
+        self.act_fused = False  # True: the norm layer applies the ReLU itself
         if self.with_norm:
             ntype = norm_cfg['type']
+            relu_follows = act_cfg is not None
             if ntype in ('BN1d', 'BN'):
-                self.norm_name, norm = 'bn', nn.BatchNorm1d(out_channels)
+                self.norm_name, norm = 'bn', FusedBNReLU1d(out_channels, relu=relu_follows)
+                self.act_fused = relu_follows
             elif ntype == 'BN2d':
-                self.norm_name, norm = 'bn', nn.BatchNorm2d(out_channels)
+                self.norm_name, norm = 'bn', FusedBNReLU2d(out_channels, relu=relu_follows)
+                self.act_fused = relu_follows
             elif ntype == 'GN':
                 self.norm_name, norm = 'gn', nn.GroupNorm(norm_cfg['num_groups'],
                                                           out_channels)
@@ -97,7 +102,7 @@ class ConvModule(nn.Module):
         x = self.conv(x)
         if self.with_norm:
             x = self.norm(x)
-        if self.with_activation:
+        if self.with_activation and not self.act_fused:
             x = self.activate(x)
         return x
 

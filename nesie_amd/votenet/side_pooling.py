@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from ..mmdet3d_ops import three_interpolate, three_nn
 from ..mmdet3d_ops.pool import group_max_pool
+from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d
 
 
@@ -33,11 +34,11 @@ class MiniPointNet(nn.Module):
     def __init__(self, channels: int, feature_dim: int, hide_dim=256):
         super().__init__()
         self.first_conv = nn.Sequential(
-            PointwiseConv2d(channels, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
-            nn.ReLU(inplace=True), PointwiseConv2d(hide_dim, hide_dim // 2, 1))
+            PointwiseConv2d(channels, hide_dim, 1, bias=False), FusedBNReLU2d(hide_dim),
+            nn.Identity(), PointwiseConv2d(hide_dim, hide_dim // 2, 1))  # [2] was the ReLU
         self.second_conv = nn.Sequential(
-            PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), nn.BatchNorm2d(hide_dim),
-            nn.ReLU(inplace=True), PointwiseConv2d(hide_dim, feature_dim, 1))
+            PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), FusedBNReLU2d(hide_dim),
+            nn.Identity(), PointwiseConv2d(hide_dim, feature_dim, 1))
 
     def forward(self, points):
         feature = self.first_conv(points)
@@ -49,8 +50,10 @@ class MiniPointNet(nn.Module):
 
 
 def _score_head(in_ch, out_ch):
-    return nn.Sequential(PointwiseConv1d(in_ch, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
-                         PointwiseConv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+    # indices as in the reference Sequential (conv, bn, relu, conv, bn, relu, conv); the
+    # ReLUs are folded into the norm layers, Identity keeps the state-dict positions
+    return nn.Sequential(PointwiseConv1d(in_ch, 128, 1), FusedBNReLU1d(128), nn.Identity(),
+                         PointwiseConv1d(128, 128, 1), FusedBNReLU1d(128), nn.Identity(),
                          PointwiseConv1d(128, out_ch, 1))
 
 
