@@ -141,6 +141,14 @@ int nesie_group_max_pool_forward(long long rows, int nsample, const float *x, fl
 int nesie_group_max_pool_backward(long long rows, int nsample, const float *grad_out,
                                   const uint8_t *argmax, float *grad_x, void *stream);
 
+/* Rotated 3-D IoU of n box pairs (x, y, z, dx, dy, dz, yaw; rotation about z only) with the
+ * Jacobian w.r.t. the 7 parameters of box1 (jac may be NULL: value only).  One kernel for
+ * the reference's torch chain cal_iou_3d -> cal_iou -> oriented_box_intersection_2d ->
+ * sort_v (rotated_iou/oriented_iou_loss.py:86-109, box_intersection_2d.py:13-184), same
+ * formulas, masks and vertex order; box2 is treated as a constant. */
+int nesie_iou3d_forward(int n, const float *box1, const float *box2, float *iou, float *jac,
+                        void *stream);
+
 /* Training-mode BatchNorm with an optional fused ReLU over x[B, C, P] (statistics per
  * channel over B*P; biased variance for normalisation, unbiased for running_var, as
  * torch.nn.BatchNorm{1,2}d).  No extension entry in the reference: it builds

@@ -185,6 +185,18 @@ class HipKernels:
                       _ptr(argmax), _ptr(grad_x), _stream(grad_x))
 
 
+    def iou3d_forward(self, box1, box2, iou, jac):
+        """box1, box2 (n,7); iou (n,); jac (n,7) or None."""
+        _check(box1, box2, iou); _f32(box1, box2, iou)
+        n = iou.numel()
+        assert box1.numel() == n * 7 and box2.numel() == n * 7
+        if jac is not None:
+            _check(jac); _f32(jac)
+            assert jac.numel() == n * 7
+        with torch.cuda.device(box1.device):
+            _lib.call("nesie_iou3d_forward", n, _ptr(box1), _ptr(box2), _ptr(iou),
+                      0 if jac is None else _ptr(jac), _stream(box1))
+
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
                         y, save_mean, save_invstd):
         """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place."""

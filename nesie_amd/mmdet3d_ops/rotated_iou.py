@@ -153,8 +153,42 @@ def cal_iou(box1, box2):
     return inter_area / u, corners1, corners2, u
 
 
+class RotatedIoU3D(Function):
+    """cal_iou_3d as ONE native kernel: value + Jacobian w.r.t. the first box."""
+
+    @staticmethod
+    def forward(ctx, box3d1, box3d2):
+        shape = box3d1.shape[:-1]
+        b1 = box3d1.reshape(-1, 7).contiguous().float()
+        b2 = box3d2.reshape(-1, 7).contiguous().float()
+        iou = b1.new_empty(b1.shape[0])
+        need_grad = box3d1.requires_grad
+        jac = b1.new_empty(b1.shape[0], 7) if need_grad else None
+        backend_for(b1).iou3d_forward(b1, b2, iou, jac)
+        ctx.save_for_backward(jac)
+        ctx.in_shape = box3d1.shape
+        return iou.view(shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (jac,) = ctx.saved_tensors
+        if jac is None:
+            return None, None
+        return (grad.reshape(-1, 1) * jac).view(ctx.in_shape), None
+
+
 def cal_iou_3d(box3d1, box3d2, verbose=False):
-    """3-D IoU of (B,N,7) boxes rotated about z only (:86-109)."""
+    """3-D IoU of (B,N,7) boxes rotated about z only (:86-109).  On the HIP back end the
+    whole chain is one kernel (the second box must not require grad -- it never does on
+    this path); other back ends evaluate the torch chain below."""
+    if not verbose and getattr(backend_for(box3d1), 'name', '') == 'hip' \
+            and not box3d2.requires_grad:
+        return RotatedIoU3D.apply(box3d1, box3d2)
+    return cal_iou_3d_torch(box3d1, box3d2, verbose)
+
+
+def cal_iou_3d_torch(box3d1, box3d2, verbose=False):
+    """The reference's torch chain (:86-109) with the native sort_vertices inside."""
     box1 = torch.cat([box3d1[..., 0:2], box3d1[..., 3:5], box3d1[..., 6:7]], dim=-1)  # x y w h a
     box2 = torch.cat([box3d2[..., 0:2], box3d2[..., 3:5], box3d2[..., 6:7]], dim=-1)
     zmax1 = box3d1[..., 2] + box3d1[..., 5] * 0.5

@@ -304,3 +304,38 @@ def test_fused_bn_relu_matches_aten(hip_device, shape, relu):
     # and ATen agrees wherever the masks agree (sanity of the closed form itself)
     if not relu:
         torch.testing.assert_close(xr.grad.double(), dx, rtol=1e-3, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])
+def test_fused_iou3d_matches_torch_chain(oracle_kernels, hip_device, mode):
+    """nesie_iou3d_forward (value + Jacobian) vs the reference-shaped torch chain."""
+    from nesie_amd.mmdet3d_ops.rotated_iou import cal_iou_3d_torch
+    a, b = _cases.box_pairs(17, 4096, mode)
+    ag = a.to(hip_device).requires_grad_(True)
+    got = ops.cal_iou_3d(ag, b.to(hip_device))
+    w = torch.linspace(0.5, 1.5, 4096, device=hip_device).view(1, -1)
+    (got * w).sum().backward()
+    if mode == "identical":
+        # exactly coincident rectangles: every mask (t in (0,1), num == 0, corner-in-box with
+        # 1e-6 slack) is decided by the last bit of sin/cos, so the torch chain is evaluated
+        # on the same device; a handful of pairs may still take the other branch
+        ac = a.to(hip_device).requires_grad_(True)
+        want = cal_iou_3d_torch(ac, b.to(hip_device))
+        (want * w).sum().backward()
+        want, ac_grad = want.detach().cpu(), ac.grad.cpu()
+        bad = ((got.detach().cpu() - want).abs() > 1e-4).float().mean().item()
+        assert bad < 0.01, bad
+        assert (got.detach().cpu() > 0.999).float().mean() > 0.98
+        return
+    with kernels.use_backend(oracle_kernels):
+        ac = a.clone().requires_grad_(True)
+        want = cal_iou_3d_torch(ac, b)
+        (want * w.cpu()).sum().backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-5)
+    # gradients: compare where the pair is not within rounding of a topology change
+    # (a vertex entering/leaving the polygon flips masks that are piecewise constant)
+    gerr = (ag.grad.cpu() - ac.grad).abs().amax(-1)[0]
+    tol = 1e-3 * ac.grad.abs().amax(-1)[0].clamp_min(1e-2)
+    assert (gerr > tol).float().mean().item() < 0.01, (gerr > tol).float().mean().item()
+    if mode == "disjoint":
+        assert got.abs().max() == 0 and ag.grad.abs().max() == 0
