@@ -20,6 +20,25 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def host_cores():
+    """Host threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU
+    quota and by the GPU box's per-GPU CPU share (16), overridable with NESIE_CPU_CORES."""
+    if os.environ.get('NESIE_CPU_CORES'):
+        return int(os.environ['NESIE_CPU_CORES'])
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
+# both OpenMP runtimes in the process (torch's and the oracle's) read this at start-up
+os.environ.setdefault('OMP_NUM_THREADS', str(host_cores()))
+
 import torch
 import torch.distributed as dist
 
@@ -122,7 +141,7 @@ def cpu_baseline(sample_batch, steps):
     """The same training step on the host cores: index ops through oracle/ (the CPU
     restatement, OpenMP), dense ops through PyTorch-CPU.  kind = "port"."""
     import oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = nesie_votenet_scannet_cfg()
     with kernels.use_backend(oracle.OracleKernels()):
@@ -148,7 +167,7 @@ def main():
     ap.add_argument('--graph', type=int, default=1, help='replay the step as hipGraphs')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=10)
     args = ap.parse_args()
 
     rank, world, local = dp.init_distributed()
@@ -166,6 +185,11 @@ def main():
     # dominant hand-written kernel (profiles/): D-FPS over the 40 000-point scene
     fps_timer = KernelTimer(hip, 'furthest_point_sampling_wrapper',
                             lambda b, n, m, *_: n == NUM_POINTS)
+    # largest streaming launches: BatchNorm+ReLU over the SA1 output (B,128,2048,64)
+    big = args.batch * 128 * 2048 * 64
+    bn_fwd_timer = KernelTimer(hip, 'bn_relu_forward', lambda x, *_: x.numel() == big)
+    bn_bwd_timer = KernelTimer(hip, 'bn_relu_backward', lambda dy, *_: dy.numel() == big)
+    timers = (fps_timer, bn_fwd_timer, bn_bwd_timer)
 
     def sync():
         if world > 1:
@@ -183,12 +207,14 @@ def main():
     # Kernel-level timing for the roofline entry: HIP events cannot bracket a kernel inside
     # a replayed graph, so the same K steps are run once more un-captured with the events
     # on the launch stream (identical kernels, identical inputs).
-    fps_timer.enabled = True
+    for t in timers:
+        t.enabled = True
     eager = getattr(step, 'eager', step)
     for _ in range(min(args.steps, 5)):
         eager()
     torch.cuda.synchronize()
-    fps_timer.enabled = False
+    for t in timers:
+        t.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,6 +249,22 @@ def main():
                          'traffic': None, 'avg_launch_ms': fps_ms,
                          'algorithmic_bytes_per_launch': alg_bytes},
         }
+        # HBM-streaming kernels, priced on their largest launch (tensor = 537 MB at B = 8,
+        # far beyond the 256 MB Infinity Cache): forward = stats + apply = 3 tensor passes,
+        # backward = reduce + apply = 7 passes
+        tensor_bytes = big * 4
+        def _stream(name, ms, passes):
+            if not ms:
+                return None
+            a = passes * tensor_bytes / (ms * 1e-3) / 1e9
+            return {'kernel': name, 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'avg_launch_ms': ms,
+                    'algorithmic_bytes_per_launch': passes * tensor_bytes}
+        out['roofline_streaming'] = [
+            _stream('nesie::bn_stats_kernel + bn_apply_kernel<relu> (B,128,2048,64)',
+                    bn_fwd_timer.mean_ms(), 3),
+            _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,128,2048,64)',
+                    bn_bwd_timer.mean_ms(), 7)]
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
