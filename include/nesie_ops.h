@@ -141,6 +141,13 @@ int nesie_group_max_pool_forward(long long rows, int nsample, const float *x, fl
 int nesie_group_max_pool_backward(long long rows, int nsample, const float *grad_out,
                                   const uint8_t *argmax, float *grad_x, void *stream);
 
+/* Same-class LHS-NMS of the teacher's pseudo boxes, on the device: boxes[B,K,8] f32 =
+ * axis-aligned (x1,y1,z1,x2,y2,z2,score,class), K <= 64; keep[B,K] u8 = 1 for every box
+ * the reference's lhs_3d_faster_samecls returns in `pick`
+ * (models/detectors/votenet_nesie.py:733-779; the reference runs it in numpy on the host). */
+int nesie_lhs_nms_samecls(int b, int k, const float *boxes, float thr, uint8_t *keep,
+                          void *stream);
+
 /* Rotated 3-D IoU of n box pairs (x, y, z, dx, dy, dz, yaw; rotation about z only) with the
  * Jacobian w.r.t. the 7 parameters of box1 (jac may be NULL: value only).  One kernel for
  * the reference's torch chain cal_iou_3d -> cal_iou -> oriented_box_intersection_2d ->

@@ -185,6 +185,15 @@ class HipKernels:
                       _ptr(argmax), _ptr(grad_x), _stream(grad_x))
 
 
+    def lhs_nms_samecls(self, boxes, thr, keep):
+        """boxes (B,K,8) f32, keep (B,K) uint8."""
+        _check(boxes, keep); _f32(boxes)
+        b, k, eight = boxes.shape
+        assert eight == 8 and tuple(keep.shape) == (b, k) and keep.dtype == torch.uint8
+        with torch.cuda.device(boxes.device):
+            _lib.call("nesie_lhs_nms_samecls", b, k, _ptr(boxes), float(thr), _ptr(keep),
+                      _stream(boxes))
+
     def iou3d_forward(self, box1, box2, iou, jac):
         """box1, box2 (n,7); iou (n,); jac (n,7) or None."""
         _check(box1, box2, iou); _f32(box1, box2, iou)

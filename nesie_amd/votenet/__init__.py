@@ -5,9 +5,11 @@ from .backbone import PointNet2SASSG
 from .boxes import DepthInstance3DBoxes
 from .detector import VoteNet, build_nesie_votenet, nesie_votenet_scannet_cfg
 from .nesie_head import NesieHead
+from .semi import AugMeta, EMATeacher, VoteNetNesie, build_nesie_votenet_semi
 from .side_pooling import MiniPointNet, SidePooling
 from .vote_module import VoteModule
 
 __all__ = ['PointNet2SASSG', 'DepthInstance3DBoxes', 'VoteNet', 'build_nesie_votenet',
            'nesie_votenet_scannet_cfg', 'NesieHead', 'MiniPointNet', 'SidePooling',
-           'VoteModule']
+           'VoteModule', 'AugMeta', 'EMATeacher', 'VoteNetNesie',
+           'build_nesie_votenet_semi']

@@ -295,14 +295,19 @@ class NesieHead(nn.Module):
          valid_gt_weights, assignment) = targets
         B, num_proposal = assignment.shape
         bbox_targets_cat = bbox_targets.reshape(-1, 7)
-        quality = []
-        for i in range(B):
-            q = pseudo_quality_score[i]
-            if q.shape[0] != 0:
-                quality.append(q.to(assignment.device)[assignment[i]])
-            else:
-                quality.append(torch.zeros(num_proposal, 6, device=assignment.device))
-        pseudo_quality_side = torch.stack(quality)
+        if torch.is_tensor(pseudo_quality_score):
+            # padded (B, T, 6) form (zeros on padding / on the fake box of an empty scene)
+            pseudo_quality_side = torch.gather(
+                pseudo_quality_score, 1, assignment.unsqueeze(-1).expand(-1, -1, 6))
+        else:
+            quality = []
+            for i in range(B):
+                q = pseudo_quality_score[i]
+                if q.shape[0] != 0:
+                    quality.append(q.to(assignment.device)[assignment[i]])
+                else:
+                    quality.append(torch.zeros(num_proposal, 6, device=assignment.device))
+            pseudo_quality_side = torch.stack(quality)
         pseudo_quality_mean = pseudo_quality_side.mean(dim=-1)
 
         s2t, t2s = self.center_loss(bbox_preds['bbox_preds'][..., :3], center_targets,

@@ -32,6 +32,7 @@ _SIGS = {
     "oracle_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "oracle_sort_vertices": [_I, _I, _I, _P, _P, _P, _P],
     "oracle_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P],
+    "oracle_lhs_nms_samecls": [_I, _I, _P, _F, _P],
     "oracle_num_threads": [],
 }
 _lib = None
@@ -155,6 +156,11 @@ class OracleKernels:
         lib().oracle_points_in_boxes_batch(b, t, pts.shape[1], boxes.data_ptr(),
                                            pts.data_ptr(), out.data_ptr())
 
+
+    def lhs_nms_samecls(self, boxes, thr, keep):
+        _cpu(boxes, keep)
+        b, k, _ = boxes.shape
+        lib().oracle_lhs_nms_samecls(b, k, boxes.data_ptr(), float(thr), keep.data_ptr())
 
     # dense-op stand-ins of the CPU path (PyTorch-CPU, first-index tie rule like ATen)
     def group_max_pool_forward(self, x, out, argmax):

@@ -470,3 +470,61 @@ int oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ */
+/* LHS-NMS of pseudo labels                                            */
+/* ------------------------------------------------------------------ */
+
+/* lhs_3d_faster_samecls (mmdet3d/models/detectors/votenet_nesie.py:733-779), the
+ * numpy routine the teacher's pseudo boxes go through: greedy over descending score;
+ * the boxes that overlap the current pick (IoU > thr, same class) are removed, but the
+ * better-scored HALF of them is kept as well.  boxes (B,K,8) f32 = axis-aligned
+ * (x1,y1,z1,x2,y2,z2,score,class); keep (B,K) u8 = 1 for the reference's `pick`.
+ * Arithmetic in double like numpy's float64 arrays.  np.argsort leaves the order of
+ * equal scores unspecified; here (and in the HIP kernel) ties order by index. */
+int oracle_lhs_nms_samecls(int b, int k, const float *boxes, float thr, uint8_t *keep) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *bx = boxes + (size_t)bi * k * 8;
+    uint8_t *kp = keep + (size_t)bi * k;
+    int *order = (int *)malloc(sizeof(int) * (size_t)k); /* ascending (score, index) */
+    int n = k;
+    for (int i = 0; i < k; ++i) { order[i] = i; kp[i] = 0; }
+    for (int i = 1; i < k; ++i) { /* stable insertion sort */
+      int v = order[i], j = i - 1;
+      while (j >= 0 && bx[order[j] * 8 + 6] > bx[v * 8 + 6]) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = v;
+    }
+    int *ov = (int *)malloc(sizeof(int) * (size_t)k);
+    while (n > 0) {
+      const int i = order[n - 1];
+      kp[i] = 1;
+      const double ai = ((double)bx[i*8+3] - bx[i*8+0]) * ((double)bx[i*8+4] - bx[i*8+1]) *
+                        ((double)bx[i*8+5] - bx[i*8+2]) + 1e-8;
+      int nov = 0;
+      for (int p = 0; p < n - 1; ++p) {
+        const int j = order[p];
+        double xx1 = fmax(bx[i*8+0], bx[j*8+0]), yy1 = fmax(bx[i*8+1], bx[j*8+1]);
+        double zz1 = fmax(bx[i*8+2], bx[j*8+2]), xx2 = fmin(bx[i*8+3], bx[j*8+3]);
+        double yy2 = fmin(bx[i*8+4], bx[j*8+4]), zz2 = fmin(bx[i*8+5], bx[j*8+5]);
+        double l = fmax(0.0, xx2 - xx1), w = fmax(0.0, yy2 - yy1), h = fmax(0.0, zz2 - zz1);
+        double aj = ((double)bx[j*8+3] - bx[j*8+0]) * ((double)bx[j*8+4] - bx[j*8+1]) *
+                    ((double)bx[j*8+5] - bx[j*8+2]) + 1e-8;
+        double inter = l * w * h;
+        double o = inter / (ai + aj - inter);
+        o = o * (bx[i*8+7] == bx[j*8+7] ? 1.0 : 0.0);
+        if (o > (double)thr) ov[nov++] = p; /* positions in `order`, ascending */
+      }
+      for (int c = 0; c < nov / 2; ++c) kp[order[ov[nov - c - 1]]] = 1;
+      /* delete position n-1 and the overlapped positions */
+      int w_ = 0, q = 0;
+      for (int p = 0; p < n - 1; ++p) {
+        if (q < nov && ov[q] == p) { ++q; continue; }
+        order[w_++] = order[p];
+      }
+      n = w_;
+    }
+    free(order);
+    free(ov);
+  }
+  return 1;
+}

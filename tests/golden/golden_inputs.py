@@ -68,3 +68,63 @@ def head_inputs():
 def jitter_noise():
     g = torch.Generator().manual_seed(9)
     return torch.randn(2, 32, 3, generator=g), torch.randn(2, 32, 3, generator=g)
+
+
+# ---- semi-supervised path ----------------------------------------------------------------
+def nms_boxes():
+    """(3, 64, 8) axis-aligned boxes with clusters of same-class overlaps and score ties."""
+    g = torch.Generator().manual_seed(21)
+    c = torch.rand(3, 8, 3, generator=g) * 4
+    centre = c[:, torch.arange(64) % 8] + (torch.rand(3, 64, 3, generator=g) - 0.5) * 0.4
+    half = 0.3 + torch.rand(3, 64, 3, generator=g) * 0.4
+    score = torch.rand(3, 64, generator=g)
+    score[:, 40:] = 0.0                       # the masked-out tail of the top-64 list
+    score[:, 5] = score[:, 6]                 # an exact tie
+    cls = torch.randint(0, 3, (3, 64), generator=g).float()
+    return torch.cat([centre - half, centre + half, score.unsqueeze(-1), cls.unsqueeze(-1)], -1)
+
+
+def teacher_preds():
+    """A teacher output dict with enough confident proposals to survive the filters."""
+    g = torch.Generator().manual_seed(22)
+    B, K, C = 3, 256, 18
+    centres = torch.rand(B, 12, 3, generator=g) * torch.tensor([6.0, 6.0, 1.5])
+    which = torch.randint(0, 12, (B, K), generator=g)
+    centre = torch.gather(centres, 1, which.unsqueeze(-1).expand(-1, -1, 3)) \
+        + torch.randn(B, K, 3, generator=g) * 0.05
+    size = 0.5 + torch.rand(B, K, 3, generator=g)
+    heading = (torch.rand(B, K, 1, generator=g) - 0.5) * 0.2
+    sem = torch.randn(B, K, C, generator=g)
+    sem.scatter_(2, (which % C).unsqueeze(-1), 3.0 + torch.rand(B, K, 1, generator=g))
+    obj = torch.stack([torch.zeros(B, K), 1.5 + 3 * torch.rand(B, K, generator=g)], -1)
+    obj[:, ::3] = obj[:, ::3].flip(-1)        # a third are confident negatives
+    iou = torch.rand(B, K, C, generator=g) * 0.9
+    side = torch.rand(B, K, 6, C, generator=g)
+    vote = torch.rand(B, 1024, 3, generator=g)
+    return dict(bbox_preds=torch.cat([centre, size, heading], -1), sem_scores=sem, obj_scores=obj,
+                iou_scores=iou, side_scores=side, vote_points=vote)
+
+
+def ulb_statistics():
+    g = torch.Generator().manual_seed(23)
+    ulb_list = torch.randint(0, 4, (108, 18), generator=g).float()
+    ulb_list[60:] = 0
+    ulb_flag = torch.ones(108)
+    ulb_flag[:60] = 0
+    return ulb_list, ulb_flag, 12, 108
+
+
+def aug_metas():
+    """Teacher / student augmentation of 3 scenes, as AugMeta fields."""
+    g = torch.Generator().manual_seed(24)
+    out = []
+    for _ in range(2):
+        ang = (torch.rand(3, generator=g) - 0.5) * 0.3
+        c, s_, z, o = torch.cos(ang), torch.sin(ang), torch.zeros(3), torch.ones(3)
+        rot = torch.stack([torch.stack([c, -s_, z], -1), torch.stack([s_, c, z], -1),
+                           torch.stack([z, z, o], -1)], -2)
+        out.append(dict(flip_h=torch.tensor([True, False, True]) ^ (len(out) == 1),
+                        flip_v=torch.tensor([False, True, True]),
+                        rot_mat=rot, scale=0.9 + 0.2 * torch.rand(3, generator=g),
+                        trans=torch.randn(3, 3, generator=g) * 0.1))
+    return out  # [teacher, student]

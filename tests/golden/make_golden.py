@@ -247,6 +247,72 @@ def install_reference_sandbox():
     return importlib.import_module('mmdet3d.models.dense_heads.nesie_head')
 
 
+def semi_goldens():
+    """votenet_nesie.py by path: lhs_3d_faster_samecls, get_pseudo_labels,
+    transformation_bbox_preds -- with the reference's OWN DepthInstance3DBoxes
+    (core/bbox/structures/{utils,base_box3d,depth_box3d}.py loaded by path)."""
+    r = os.path.join(REF, 'mmdet3d')
+    core = sys.modules['mmdet3d.core']
+    _mod('mmdet3d.ops.iou3d', iou3d_cuda=None)
+    sys.modules['mmdet3d.ops'].points_in_boxes_batch = my_ops.points_in_boxes_batch
+    _mod('mmdet3d.core.points', BasePoints=type('BasePoints', (), {}))
+    _pkg('mmdet3d.core.bbox.structures', os.path.join(r, 'core', 'bbox', 'structures'))
+    sys.modules['mmdet3d.core.bbox'].__path__ = [os.path.join(r, 'core', 'bbox')]
+    dep = importlib.import_module('mmdet3d.core.bbox.structures.depth_box3d')
+    RefBoxes = dep.DepthInstance3DBoxes
+    core.DepthInstance3DBoxes = RefBoxes
+    core.bbox3d2result = None
+    core.merge_aug_bboxes_3d = None
+    DET = Registry('det')
+    sys.modules['mmdet.models'].DETECTORS = DET
+
+    class SingleStage3DDetector(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    _pkg('mmdet3d.models.detectors', os.path.join(r, 'models', 'detectors'))
+    _mod('mmdet3d.models.detectors.single_stage', SingleStage3DDetector=SingleStage3DDetector)
+    sys.modules['mmcv'].build_from_cfg = None
+    rn = sys.modules['mmcv.runner']
+    rn.HOOKS, rn.Hook, rn.Priority, rn.get_priority = Registry('hook'), object, None, None
+    vn = importlib.import_module('mmdet3d.models.detectors.votenet_nesie')
+    out = {}
+    # (a) LHS-NMS
+    nb = golden_inputs.nms_boxes()
+    picks = torch.zeros(nb.shape[0], nb.shape[1], dtype=torch.uint8)
+    for i in range(nb.shape[0]):
+        pick = vn.lhs_3d_faster_samecls(nb[i].numpy().astype(np.float64), 0.25, False)
+        picks[i, torch.as_tensor(np.array(pick, dtype=np.int64))] = 1
+    out['semi/nms_keep'] = picks
+    # (b) pseudo labels, (c) re-augmentation
+    det = vn.VoteNetNesie.__new__(vn.VoteNetNesie)
+    nn.Module.__init__(det)
+    ulb_list, ulb_flag, n_lb, n_ulb = golden_inputs.ulb_statistics()
+    det.ulb_list, det.ulb_flag = ulb_list, ulb_flag
+    det.lb_map, det.ulb_map = list(range(n_lb)), list(range(n_ulb))
+    det.CLASSES = list(range(18))
+    det.train_cfg = types.SimpleNamespace(thresh_warmup=True, use_cbl=True)
+    preds = {k: v.clone() for k, v in golden_inputs.teacher_preds().items()}
+    labels, boxes, quality = det.get_pseudo_labels(preds, 'ScanNet')
+    out['semi/pl_counts'] = torch.tensor([len(l) for l in labels])
+    for i in range(len(labels)):
+        out[f'semi/pl_labels/{i}'] = labels[i].clone()
+        out[f'semi/pl_boxes/{i}'] = boxes[i].clone()
+        out[f'semi/pl_quality/{i}'] = quality[i].clone()
+    mt, ms = golden_inputs.aug_metas()
+
+    def metas(m):
+        res = []
+        for i in range(3):
+            flow = (['HF'] if m['flip_h'][i] else []) + (['VF'] if m['flip_v'][i] else []) + ['R', 'S', 'T']
+            res.append(dict(transformation_3d_flow=flow, pcd_rotation=m['rot_mat'][i].clone(),
+                            pcd_scale_factor=float(m['scale'][i]), pcd_trans=m['trans'][i].clone()))
+        return res
+    moved = det.transformation_bbox_preds([b.clone() for b in boxes], metas(mt), metas(ms))
+    for i in range(3):
+        out[f'semi/pl_boxes_student/{i}'] = moved[i].tensor.clone()
+    return out
+
+
 def main():
     ref_head_mod = install_reference_sandbox()
     out = {}
@@ -308,6 +374,7 @@ def main():
         out['head/target/vote_targets_rows'] = vt[:, ::16].clone()
         vm = out.pop('head/target/vote_target_masks')
         out['head/target/vote_target_masks_sum'] = vm.sum()
+        out.update(semi_goldens())
     path = os.path.join(ROOT, 'tests', 'golden', 'nesie_head_golden.pt')
     torch.save(out, path)
     print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'entries')

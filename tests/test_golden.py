@@ -94,3 +94,60 @@ def test_head_losses_match_reference_code(gold, head_run):
         want = gold[f"head/loss/{k}"]
         assert want > 0, k
         torch.testing.assert_close(v.detach(), want, rtol=1e-4, atol=1e-6, msg=k)
+
+
+# ---- semi-supervised path (votenet_nesie.py + the reference's own DepthInstance3DBoxes) ---------
+def test_lhs_nms_matches_reference_numpy(gold, oracle_kernels):
+    boxes = golden_inputs.nms_boxes().contiguous()
+    keep = torch.zeros(3, 64, dtype=torch.uint8)
+    oracle_kernels.lhs_nms_samecls(boxes, 0.25, keep)
+    want = gold["semi/nms_keep"]
+    # np.argsort leaves the order of the equal (zero) scores unspecified, so only the boxes
+    # with a unique score are comparable one by one; the tail must agree in count
+    scores = boxes[..., 6]
+    for i in range(3):
+        uniq = torch.tensor([(scores[i] == s).sum() == 1 for s in scores[i]])
+        assert torch.equal(keep[i][uniq], want[i][uniq]), i
+    assert abs(int(keep.sum()) - int(want.sum())) <= 6
+
+
+@pytest.fixture(scope="module")
+def pseudo(oracle_kernels):
+    from nesie_amd.votenet import semi
+    cfg = golden_inputs.head_cfg()
+    det = semi.VoteNetNesie.__new__(semi.VoteNetNesie)
+    torch.nn.Module.__init__(det)
+    det.train_cfg = dict(cfg["train_cfg"], thresh_warmup=True, use_cbl=True)
+    ulb_list, ulb_flag, n_lb, n_ulb = golden_inputs.ulb_statistics()
+    det.state = semi.PseudoLabelState(n_lb, n_ulb, 18, "cpu")
+    det.state.ulb_list, det.state.ulb_flag = ulb_list.clone(), ulb_flag.clone()
+    preds = {k: v.clone() for k, v in golden_inputs.teacher_preds().items()}
+    with kernels.use_backend(oracle_kernels):
+        return det.get_pseudo_labels(preds, "ScanNet")
+
+
+def test_pseudo_labels_match_reference(gold, pseudo):
+    labels, boxes, quality, valid = pseudo
+    counts = gold["semi/pl_counts"]
+    assert counts.sum() > 10
+    assert torch.equal(valid.sum(1), counts)
+    for i in range(3):
+        n = int(counts[i])
+        assert valid[i, :n].all() and not valid[i, n:].any()
+        assert torch.equal(labels[i, :n], gold[f"semi/pl_labels/{i}"].long())
+        torch.testing.assert_close(boxes[i, :n], gold[f"semi/pl_boxes/{i}"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(quality[i, :n], gold[f"semi/pl_quality/{i}"], rtol=1e-6, atol=1e-6)
+
+
+def test_teacher_to_student_box_reaugmentation(gold, pseudo):
+    from nesie_amd.votenet import semi
+    _, boxes, _, valid = pseudo
+    mt, ms = golden_inputs.aug_metas()
+    meta_t, meta_s = semi.AugMeta(**mt), semi.AugMeta(**ms)
+    moved = semi.transform_boxes(semi.untransform_boxes(boxes, meta_t), meta_s)
+    for i in range(3):
+        n = int(valid[i].sum())
+        want = gold[f"semi/pl_boxes_student/{i}"]
+        torch.testing.assert_close(moved[i, :n, :6], want[:, :6], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(torch.sin(moved[i, :n, 6]), torch.sin(want[:, 6]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(torch.cos(moved[i, :n, 6]), torch.cos(want[:, 6]), rtol=1e-4, atol=1e-5)

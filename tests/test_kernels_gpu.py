@@ -339,3 +339,17 @@ def test_fused_iou3d_matches_torch_chain(oracle_kernels, hip_device, mode):
     assert (gerr > tol).float().mean().item() < 0.01, (gerr > tol).float().mean().item()
     if mode == "disjoint":
         assert got.abs().max() == 0 and ag.grad.abs().max() == 0
+
+
+@pytest.mark.parametrize("k", [64, 37, 1])
+def test_lhs_nms_bit_exact(oracle_kernels, hip_device, k):
+    from tests.golden import golden_inputs
+    boxes = golden_inputs.nms_boxes()[:, :k].contiguous()
+    g = torch.Generator().manual_seed(k)
+    more = torch.cat([boxes, boxes[:, torch.randperm(k, generator=g)]], 0)  # permuted copies
+    want = torch.zeros(more.shape[0], k, dtype=torch.uint8)
+    oracle_kernels.lhs_nms_samecls(more.contiguous(), 0.25, want)
+    got = torch.zeros(more.shape[0], k, dtype=torch.uint8, device=hip_device)
+    kernels.backend_for(got).lhs_nms_samecls(more.contiguous().to(hip_device), 0.25, got)
+    eq(got, want)
+    assert 0 < int(want.sum()) < want.numel() or k == 1

@@ -102,3 +102,33 @@ def test_hip_graph_replay_matches_eager_forward_backward(hip_device):
     assert abs(loss_out.item() - want_loss) <= 1e-5 * abs(want_loss)
     rel = ((bucket.flat - want_grad).norm() / want_grad.norm()).item()
     assert rel < 1e-4, rel
+
+
+def test_semi_supervised_step_on_gpu(hip_device):
+    """Student/teacher step (BASELINE config 4 shape per GPU, reduced batch) runs on the HIP
+    path: teacher pseudo labels, re-augmentation, supervised + unsupervised losses, EMA."""
+    from nesie_amd.scenes import make_batch
+    from nesie_amd.votenet import semi
+    from nesie_amd.votenet.nesie_head import GTBatch
+    torch.manual_seed(0)
+    model = semi.build_nesie_votenet_semi().to(hip_device)
+    model.teacher = semi.EMATeacher.__new__(semi.EMATeacher)
+    model.teacher.__dict__.update(momentum=0.001, interval=1, warm_up=10,
+                                  params=[p for _, p in model.named_parameters()],
+                                  emas=[b for n, b in model.named_buffers() if n.startswith('ema_')])
+    model.init_label_state(12, 108, hip_device)
+    pts, boxes, labels = make_batch(2000, 3)
+    g = torch.Generator().manual_seed(1)
+    meta_t = semi.AugMeta.random(3, hip_device, g, strong=False)
+    meta_s = semi.AugMeta.random(3, hip_device, g, strong=True)
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes[:1], labels[:1], hip_device)
+    rows = torch.tensor([5, 17], device=hip_device)
+    losses = model.forward_train(meta_s.apply_points(pts), meta_t.apply_points(pts), gt,
+                                 [True, False, False], meta_s, meta_t, rows)
+    total = model.parse_losses(losses)
+    total.backward()
+    model.teacher.update(0)
+    assert torch.isfinite(total)
+    assert len(losses) == 12
+    assert float(model.state.ulb_flag.sum()) == 106

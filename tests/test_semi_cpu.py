@@ -1,0 +1,89 @@
+"""Semi-supervised student/teacher step on the CPU oracle back end."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from nesie_amd import kernels
+from nesie_amd.votenet import semi
+from nesie_amd.votenet.nesie_head import GTBatch
+from tests import _small
+
+
+def _semi_model():
+    cfg = _small.small_cfg()
+    torch.manual_seed(0)
+    return semi.build_nesie_votenet_semi(cfg)
+
+
+def test_aug_roundtrip_and_consistency_with_points():
+    g = torch.Generator().manual_seed(3)
+    meta = semi.AugMeta.random(4, torch.device('cpu'), g)
+    meta.scale = 0.9 + 0.2 * torch.rand(4, generator=g)
+    meta.trans = torch.randn(4, 3, generator=g) * 0.1
+    boxes = torch.cat([torch.randn(4, 5, 3, generator=g), torch.rand(4, 5, 3, generator=g) + 0.5,
+                       (torch.rand(4, 5, 1, generator=g) - 0.5) * 3], -1)
+    back = semi.untransform_boxes(semi.transform_boxes(boxes, meta), meta)
+    torch.testing.assert_close(back[..., :6], boxes[..., :6], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(torch.cos(back[..., 6]), torch.cos(boxes[..., 6]), rtol=1e-4, atol=1e-5)
+    # box centres move exactly like points under the same augmentation
+    pts = torch.cat([boxes[..., :3], torch.zeros(4, 5, 1)], -1)
+    moved = meta.apply_points(pts)[..., :3]
+    torch.testing.assert_close(semi.transform_boxes(boxes, meta)[..., :3], moved, rtol=1e-5, atol=1e-5)
+
+
+def test_ema_update_swap_and_state_dict_names():
+    model = _semi_model()
+    names = [n for n, _ in model.named_buffers() if n.startswith('ema_')]
+    assert len(names) == len(list(model.parameters()))
+    assert 'ema_backbone_SA_modules_0_mlps_0_layer0_conv_weight' in names
+    p0 = model.backbone.SA_modules[0].mlps[0].layer0.conv.weight
+    e0 = model.ema_backbone_SA_modules_0_mlps_0_layer0_conv_weight
+    before = p0.detach().clone()
+    with torch.no_grad():
+        p0.add_(1.0)
+    model.teacher.update(0)  # momentum = min(0.001, 1/10)
+    torch.testing.assert_close(e0, before * 0.999 + (before + 1) * 0.001)
+    student, teacher = p0.detach().clone(), e0.clone()
+    model.teacher.swap()
+    assert torch.equal(p0, teacher) and torch.equal(e0, student)
+    model.teacher.swap()
+    assert torch.equal(p0, student) and torch.equal(e0, teacher)
+
+
+def test_classwise_thresholds_as_coded():
+    st = semi.PseudoLabelState(num_labeled=12, num_unlabeled=108, num_classes=4, device='cpu')
+    st.ulb_list[0] = torch.tensor([5., 0., 9., 2.])
+    st.ulb_flag[:100] = 0
+    acc = st.classwise_acc(True)
+    srt = torch.tensor([9., 5., 2., 0.])
+    a = srt / max(9.0, 10 * 8 * 12 / 108)
+    torch.testing.assert_close(acc, a / (2 - a))
+
+
+def test_student_teacher_step_runs_and_updates_state(oracle_kernels):
+    model = _semi_model()
+    model.init_label_state(12, 108, torch.device('cpu'))
+    pts, boxes, labels = _small.small_batch(batch=3, n=2048)
+    g = torch.Generator().manual_seed(1)
+    meta_t = semi.AugMeta.random(3, pts.device, g, strong=False)
+    meta_s = semi.AugMeta.random(3, pts.device, g, strong=True)
+    use_label = [True, False, False]
+    gt = GTBatch.collate(boxes[:1], labels[:1], pts.device)
+    rows = torch.tensor([5, 17])
+    # permissive teacher so some pseudo boxes survive at random init
+    with torch.no_grad():
+        model.bbox_head.conv_pred.conv_cls.bias[1] += 6.0
+        model.bbox_head.conv_pred.conv_cls.bias[2] += 3.0
+    model.teacher.resync()  # teacher = the (biased) student weights
+    with kernels.use_backend(oracle_kernels):
+        losses = model.forward_train(meta_s.apply_points(pts), meta_t.apply_points(pts), gt,
+                                     use_label, meta_s, meta_t, rows)
+        total = model.parse_losses(losses)
+        total.backward()
+    assert set(losses) >= {'vote_loss', 'surface_loss', 'unsup_center_loss', 'unsup_iou_loss',
+                           'unsup_semantic_loss', 'unsup_surface_loss'}
+    assert torch.isfinite(total)
+    assert model.state.ulb_flag[5] == 0 and model.state.ulb_flag[17] == 0
+    assert model.state.ulb_flag.sum() == 106
