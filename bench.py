@@ -46,6 +46,7 @@ from nesie_amd import dp, kernels
 from nesie_amd.scenes import make_batch
 from nesie_amd.votenet import build_nesie_votenet, nesie_votenet_scannet_cfg
 from nesie_amd.votenet.nesie_head import GTBatch
+from nesie_amd.votenet import semi
 
 NUM_POINTS = 40000
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -77,26 +78,57 @@ class KernelTimer:
         return sum(ts) / len(ts) if ts else None
 
 
-def build_step(device, batch, seed, lr, wd, graph=False):
+def transform_gt(boxes, meta, i):
+    """GT boxes (K,7) of scene i carried into the student view."""
+    one = semi.AugMeta(meta.flip_h[i:i + 1], meta.flip_v[i:i + 1], meta.rot_mat[i:i + 1],
+                       meta.scale[i:i + 1], meta.trans[i:i + 1], meta.flow)
+    return semi.transform_boxes(boxes.unsqueeze(0).to(meta.trans.device), one)[0].cpu()
+
+
+def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
     all-reduce (world > 1), clip, AdamW.  With graph=True the device work of a step is
     captured once into hipGraphs and replayed (the step has no host synchronisation);
     the RCCL all-reduce stays an ordinary stream operation between the two graphs."""
     torch.manual_seed(0)
-    model = build_nesie_votenet().to(device)
-    model.train()
+    on_gpu = device.type == 'cuda'
     pts, boxes, labels = make_batch(seed, batch, NUM_POINTS)
     pts = pts.to(device)
-    gt = GTBatch.collate(boxes, labels, device)
+    loss_out = torch.zeros((), device=device)
+    if workload == 'semi':
+        # BASELINE configs[3]: 1 labeled + 2 unlabeled scenes per item, student and teacher
+        # views of the same scenes (train-010.py:319-336); value counts STUDENT scenes
+        model = semi.build_nesie_votenet_semi().to(device)
+        model.teacher = semi.EMATeacher.__new__(semi.EMATeacher)
+        model.teacher.__dict__.update(
+            momentum=0.001, interval=1, warm_up=10,
+            params=[p for n, p in model.named_parameters()],
+            emas=[b for n, b in model.named_buffers() if n.startswith('ema_')])
+        model.init_label_state(120, 1081, device)
+        use_label = [i % 3 == 0 for i in range(batch)]
+        g = torch.Generator().manual_seed(seed)
+        meta_t = semi.AugMeta.random(batch, device, g, strong=False)
+        meta_s = semi.AugMeta.random(batch, device, g, strong=True)
+        pts_s, pts_t = meta_s.apply_points(pts), meta_t.apply_points(pts)
+        lab = [i for i, f in enumerate(use_label) if f]
+        gt_boxes = torch.stack  # noqa: F841
+        gt = GTBatch.collate([transform_gt(boxes[i], meta_s, i) for i in lab],
+                             [labels[i] for i in lab], device)
+        rows = torch.arange(sum(1 for f in use_label if not f), device=device)
+    else:
+        model = build_nesie_votenet().to(device)
+        gt = GTBatch.collate(boxes, labels, device)
+    model.train()
     bucket = dp.FlatGradBucket(model.parameters())
-    on_gpu = device.type == 'cuda'
     opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd,
                             capturable=graph and on_gpu, foreach=True)
-    loss_out = torch.zeros((), device=device)
 
     def fwd_bwd():
         bucket.zero_()
-        losses = model.forward_train(pts, None, gt, None)
+        if workload == 'semi':
+            losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows)
+        else:
+            losses = model.forward_train(pts, None, gt, None)
         total = model.parse_losses(losses)
         total.backward()
         loss_out.copy_(total.detach())
@@ -105,6 +137,8 @@ def build_step(device, batch, seed, lr, wd, graph=False):
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2,
                                        foreach=True)
         opt.step()
+        if workload == 'semi':
+            model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)
 
     def eager_step():
         fwd_bwd()
@@ -165,6 +199,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
     ap.add_argument('--graph', type=int, default=1, help='replay the step as hipGraphs')
+    ap.add_argument('--workload', default='pretrain', choices=['pretrain', 'semi'],
+                    help='pretrain = BASELINE configs[2] (the metric); semi = configs[3]')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=10)
@@ -180,7 +216,7 @@ def main():
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
                                      cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
-                                     graph=bool(args.graph))
+                                     graph=bool(args.graph), workload=args.workload)
     hip = kernels.backend_for(torch.empty(1, device=device))
     # dominant hand-written kernel (profiles/): D-FPS over the 40 000-point scene
     fps_timer = KernelTimer(hip, 'furthest_point_sampling_wrapper',
@@ -233,9 +269,13 @@ def main():
             'value': value, 'unit': 'scenes/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'Nesie-VoteNet supervised pretrain step '
-                                   '(nesie-votenet-scannet-pretrain-10%): fwd+bwd+AdamW, '
-                                   '40000 pts/scene, fp32, random-init weights',
+            'config': {'workload': ('Nesie-VoteNet supervised pretrain step '
+                                    '(nesie-votenet-scannet-pretrain-10%): fwd+bwd+AdamW, '
+                                    '40000 pts/scene, fp32, random-init weights')
+                       if args.workload == 'pretrain' else
+                       ('Nesie student/teacher semi-sup step (nesie-votenet-scannet-train-10%): '
+                        'student fwd+bwd on B scenes (1 labeled : 2 unlabeled) + EMA-teacher '
+                        'fwd on B + pseudo labels + AdamW + EMA; value = student scenes/s'),
                        'scenes_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'points_per_scene': NUM_POINTS,
                        'parallelism': f'dp{world}' if world > 1 else 'single',

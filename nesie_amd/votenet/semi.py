@@ -203,8 +203,8 @@ class PseudoLabelState:
         num_classes = self.ulb_list.shape[1]
         hist = torch.zeros(rows.shape[0], num_classes, device=labels.device)
         hist.scatter_add_(1, labels.clamp(0, num_classes - 1), valid.float())
-        self.ulb_flag[rows] = 0.0
-        self.ulb_list[rows] = hist
+        self.ulb_flag.index_fill_(0, rows, 0.0)   # no host scalar copy: hipGraph-safe
+        self.ulb_list.index_copy_(0, rows, hist)
 
 
 # ---- the detector -----------------------------------------------------------------------------
