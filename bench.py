@@ -95,10 +95,11 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     pts, boxes, labels = make_batch(seed, batch, NUM_POINTS)
     pts = pts.to(device)
     loss_out = torch.zeros((), device=device)
-    if workload == 'semi':
-        # BASELINE configs[3]: 1 labeled + 2 unlabeled scenes per item, student and teacher
+    if workload in ('semi', 'saqe'):
+        # BASELINE configs[3] (Nesie) / configs[4] (SAQE head, same step): 1 labeled + 2 unlabeled scenes per item, student and teacher
         # views of the same scenes (train-010.py:319-336); value counts STUDENT scenes
-        model = semi.build_nesie_votenet_semi().to(device)
+        model = (semi.build_saqe_votenet_semi() if workload == 'saqe'
+                 else semi.build_nesie_votenet_semi()).to(device)
         model.teacher = semi.EMATeacher.__new__(semi.EMATeacher)
         model.teacher.__dict__.update(
             momentum=0.001, interval=1, warm_up=10,
@@ -125,7 +126,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
 
     def fwd_bwd():
         bucket.zero_()
-        if workload == 'semi':
+        if workload in ('semi', 'saqe'):
             losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows)
         else:
             losses = model.forward_train(pts, None, gt, None)
@@ -137,7 +138,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2,
                                        foreach=True)
         opt.step()
-        if workload == 'semi':
+        if workload in ('semi', 'saqe'):
             model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)
 
     def eager_step():
@@ -199,8 +200,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU')
     ap.add_argument('--graph', type=int, default=1, help='replay the step as hipGraphs')
-    ap.add_argument('--workload', default='pretrain', choices=['pretrain', 'semi'],
-                    help='pretrain = BASELINE configs[2] (the metric); semi = configs[3]')
+    ap.add_argument('--workload', default='pretrain', choices=['pretrain', 'semi', 'saqe'],
+                    help='pretrain = BASELINE configs[2] (the metric); semi = configs[3]; '
+                         'saqe = configs[4] (use --batch 16)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=10)
@@ -273,7 +275,8 @@ def main():
                                     '(nesie-votenet-scannet-pretrain-10%): fwd+bwd+AdamW, '
                                     '40000 pts/scene, fp32, random-init weights')
                        if args.workload == 'pretrain' else
-                       ('Nesie student/teacher semi-sup step (nesie-votenet-scannet-train-10%): '
+                       ('%s student/teacher semi-sup step (%s-votenet-scannet-train-10%%): '
+                        % (('SAQE', 'saqe') if args.workload == 'saqe' else ('Nesie', 'nesie')) +
                         'student fwd+bwd on B scenes (1 labeled : 2 unlabeled) + EMA-teacher '
                         'fwd on B + pseudo labels + AdamW + EMA; value = student scenes/s'),
                        'scenes_per_gpu': args.batch, 'global_batch': world * args.batch,

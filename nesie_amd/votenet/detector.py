@@ -54,14 +54,29 @@ def nesie_votenet_scannet_cfg():
     )
 
 
+def saqe_votenet_scannet_cfg():
+    """``configs/SAQE/saqe-votenet-scannet-pretrain-010.py``: the Nesie config with the SAQE
+    head's two extra losses (``:78-81``)."""
+    cfg = nesie_votenet_scannet_cfg()
+    cfg['bbox_head'].update(
+        angle_loss=dict(type='SmoothL1Loss', reduction='sum', loss_weight=10.0),
+        angle_pred_loss=dict(type='MSELoss', reduction='sum', loss_weight=1.0))
+    cfg['head_type'] = 'SAQEHead'
+    return cfg
+
+
 class VoteNet(nn.Module):
     """backbone -> bbox head -> losses dict; total loss = sum of every entry whose key
     contains 'loss' (mmdet BaseDetector._parse_losses)."""
 
-    def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None):
+    def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None, head_type='NesieHead'):
         super().__init__()
         self.backbone = PointNet2SASSG(**backbone)
-        self.bbox_head = NesieHead(**bbox_head, train_cfg=train_cfg, test_cfg=test_cfg)
+        if head_type == 'SAQEHead':
+            from .saqe_head import SAQEHead as head_cls
+        else:
+            head_cls = NesieHead
+        self.bbox_head = head_cls(**bbox_head, train_cfg=train_cfg, test_cfg=test_cfg)
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
 
@@ -84,4 +99,9 @@ class VoteNet(nn.Module):
 
 def build_nesie_votenet(cfg=None):
     cfg = copy.deepcopy(cfg or nesie_votenet_scannet_cfg())
-    return VoteNet(cfg['backbone'], cfg['bbox_head'], cfg['train_cfg'], cfg['test_cfg'])
+    return VoteNet(cfg['backbone'], cfg['bbox_head'], cfg['train_cfg'], cfg['test_cfg'],
+                   head_type=cfg.get('head_type', 'NesieHead'))
+
+
+def build_saqe_votenet(cfg=None):
+    return build_nesie_votenet(cfg or saqe_votenet_scannet_cfg())

@@ -142,7 +142,7 @@ class NesieHead(nn.Module):
         else:
             n_c, n_s = torch.randn_like(size), torch.randn_like(size)
         center_jitter = center + size * n_c * 0.3
-        size_jitter = torch.clamp(size + size * n_s * 0.3, min=1e-8)
+        size_jitter = torch.clamp(size + size * n_s * 0.3, min=1e-8)  # SAQEHead overrides
         heading_jitter = heading
         center_all = torch.cat([center, center_jitter], dim=1)
         size_all = torch.cat([size, size_jitter], dim=1)

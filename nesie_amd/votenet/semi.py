@@ -213,9 +213,14 @@ class VoteNetNesie(VoteNet):
     labeled ones, unsupervised terms against the teacher's filtered pseudo boxes on the
     unlabeled ones), teacher = EMA weights, forward only."""
 
+    # the three places VoteNetSAQE differs (votenet_saqe.py:121,170,201)
+    objectness_key = 'obj_scores'
+    quality_coef = (5 / 3, 8 / 3)
+    sup_loss_name = 'loss'
+
     def __init__(self, backbone, bbox_head, train_cfg=None, test_cfg=None, ema=None,
-                 num_classes=18):
-        super().__init__(backbone, bbox_head, train_cfg, test_cfg)
+                 num_classes=18, head_type='NesieHead'):
+        super().__init__(backbone, bbox_head, train_cfg, test_cfg, head_type=head_type)
         self.num_classes = num_classes
         self.teacher = EMATeacher(self, **(ema or dict(momentum=0.001, interval=1, warm_up=10)))
         self.state = None
@@ -258,14 +263,14 @@ class VoteNetNesie(VoteNet):
         else:
             cls_threshold, iou_threshold = 0.9, 0.25
         cls_mask = max_cls > cls_threshold  # sic: raw class logits, not probabilities
-        obj = torch.softmax(preds['obj_scores'], dim=2)
+        obj = torch.softmax(preds[self.objectness_key], dim=2)
         pos_obj, neg_obj = obj[..., 1], obj[..., 0]
         objectness_mask = pos_obj > 0.9
         iou_pred = preds['iou_scores'].gather(2, argmax_cls.unsqueeze(-1)).squeeze(-1)
         final_mask = cls_mask & objectness_mask & (iou_pred > iou_threshold)
         side = preds['side_scores'].detach()  # (B,K,6,C)
         s = side.gather(3, argmax_cls[:, :, None, None].expand(-1, -1, 6, 1)).squeeze(-1)
-        quality = 5 / 3 * s * s - 8 / 3 * s + torch.ones_like(s)
+        quality = self.quality_coef[0] * s * s - self.quality_coef[1] * s + torch.ones_like(s)
 
         score = pos_obj * iou_pred * final_mask
         inds = torch.argsort(score, dim=1, descending=True, stable=True)[:, :MAX_NUM_OBJ]
@@ -330,7 +335,7 @@ class VoteNetNesie(VoteNet):
             boxes = transform_boxes(untransform_boxes(boxes, meta_t), meta_s)
             self.teacher.swap()                      # call_hook("switch_to_student")
         sup_idx, uns_idx = self._batch_index(use_label, points_s.device)
-        sup_losses = self.bbox_head.loss(self._select(preds_s, sup_idx),
+        sup_losses = getattr(self.bbox_head, self.sup_loss_name)(self._select(preds_s, sup_idx),
                                          points_s.index_select(0, sup_idx), gt_labeled, None)
         u = lambda t: t.index_select(0, uns_idx)  # noqa: E731
         self.state.update(unlabeled_rows, u(labels), u(valid))
@@ -339,6 +344,26 @@ class VoteNetNesie(VoteNet):
             self._pseudo_gt(u(labels), u(boxes), u(valid)), None,
             pseudo_quality_score=u(quality) * u(valid).unsqueeze(-1))
         return {**sup_losses, **unsup_losses}
+
+
+class VoteNetSAQE(VoteNetNesie):
+    """``mmdet3d/models/detectors/votenet_saqe.py``: the same step with the SAQE head's
+    ``sup_loss``, the quality head's objectness for the pseudo-label filter and the
+    0.8 s^2 - 1.8 s + 1 side quality."""
+    objectness_key = 'R_obj_scores'
+    quality_coef = (0.8, 1.8)
+    sup_loss_name = 'sup_loss'
+
+
+def build_saqe_votenet_semi(cfg=None):
+    """SAQE-VoteNet semi-supervised (``configs/SAQE/saqe-votenet-scannet-train-010.py``)."""
+    import copy
+    from .detector import saqe_votenet_scannet_cfg
+    cfg = copy.deepcopy(cfg or saqe_votenet_scannet_cfg())
+    cfg['bbox_head']['iou_pred_loss']['loss_weight'] = 1.0
+    cfg['train_cfg'].update(dataset_name='ScanNet', thresh_warmup=True, use_cbl=True)
+    return VoteNetSAQE(cfg['backbone'], cfg['bbox_head'], cfg['train_cfg'], cfg['test_cfg'],
+                       ema=dict(momentum=0.001, interval=1, warm_up=10), head_type='SAQEHead')
 
 
 def build_nesie_votenet_semi(cfg=None):

@@ -49,6 +49,29 @@ def build_my_head():
     return head
 
 
+def saqe_head_cfg():
+    cfg = head_cfg()
+    cfg['bbox_head'].update(
+        angle_loss=dict(type='SmoothL1Loss', reduction='sum', loss_weight=10.0),
+        angle_pred_loss=dict(type='MSELoss', reduction='sum', loss_weight=1.0))
+    return cfg
+
+
+def build_my_saqe_head():
+    from nesie_amd.votenet.saqe_head import SAQEHead
+    cfg = saqe_head_cfg()
+    torch.manual_seed(1)
+    head = SAQEHead(**cfg['bbox_head'], train_cfg=cfg['train_cfg'], test_cfg=cfg['test_cfg'])
+    head.train()
+    return head
+
+
+def pseudo_quality(boxes):
+    """Per-box (K_i, 6) side qualities for the unsup_loss goldens."""
+    g = torch.Generator().manual_seed(10)
+    return [torch.rand(b.shape[0], 6, generator=g) for b in boxes]
+
+
 def head_inputs():
     """feat_dict as the backbone would hand it over, points, GT boxes, GT labels."""
     pts, boxes, labels = make_batch(77, 2, num_points=2048)

@@ -367,6 +367,42 @@ def main():
                  'box_loss_weights', 'valid_gt_weights', 'assignment']
         for n, t in zip(names, targets):
             out[f'head/target/{n}'] = (torch.cat(t, 0) if isinstance(t, list) else t).detach().clone()
+        # Nesie unsup_loss (GT boxes stand in for pseudo boxes, seeded side qualities)
+        q = golden_inputs.pseudo_quality(boxes)
+        ul = ref.unsup_loss(preds, [p for p in points], [DepthInstance3DBoxes(b) for b in boxes],
+                            [l.clone() for l in labels], None, q)
+        for k, v in ul.items():
+            out[f'head/unsup/{k}'] = v.detach().clone()
+        # ---- (4) SAQE head: saqe_head.py + quelity_estimation_module.py -------------------
+        saqe_mod = importlib.import_module('mmdet3d.models.dense_heads.saqe_head')
+        scfg = golden_inputs.saqe_head_cfg()
+        scfg['bbox_head']['grid_conv_cfg']['mean_size_arr_path'] = os.path.join(
+            REF, 'data/scannet/meta_data/scannet_means.npz')
+        smine = golden_inputs.build_my_saqe_head()
+        sref = saqe_mod.SAQEHead(**scfg['bbox_head'], train_cfg=scfg['train_cfg'],
+                                 test_cfg=scfg['test_cfg'])
+        missing, unexpected = sref.load_state_dict(smine.state_dict(), strict=False)
+        assert not unexpected, unexpected
+        assert all(k.endswith('num_batches_tracked') or 'project' in k for k in missing), missing
+        sref.train()
+        draws = iter(noise)
+        torch.randn = lambda *a, **k: next(draws)
+        try:
+            spreds = sref(feat, 'vote')
+        finally:
+            torch.randn = real_randn
+        mk = lambda: ([p for p in points], [DepthInstance3DBoxes(b) for b in boxes],  # noqa: E731
+                      [l.clone() for l in labels])
+        for name, fn in (('loss', sref.loss), ('sup_loss', sref.sup_loss)):
+            for k, v in fn(spreds, *mk()).items():
+                out[f'saqe/{name}/{k}'] = v.detach().clone()
+        for k, v in sref.unsup_loss(spreds, *mk(), None, q).items():
+            out[f'saqe/unsup/{k}'] = v.detach().clone()
+        for k in ['surface_pred', 'surface_scale', 'bbox_preds', 'jitter_bbox_preds',
+                  'jitter_surface_preds', 'iou_scores', 'iou_scores_jitter', 'side_scores',
+                  'side_scores_jitter', 'rotate_scores', 'rotate_scores_jitter', 'R_obj_scores',
+                  'R_obj_scores_jitter']:
+            out[f'saqe/pred/{k}'] = spreds[k].detach().clone()
         # vote targets are big (B,N,9): keep a checksum + the non-zero rows count instead
         vt = out.pop('head/target/vote_targets')
         out['head/target/vote_targets_sum'] = vt.double().sum()

@@ -151,3 +151,49 @@ def test_teacher_to_student_box_reaugmentation(gold, pseudo):
         torch.testing.assert_close(moved[i, :n, :6], want[:, :6], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(torch.sin(moved[i, :n, 6]), torch.sin(want[:, 6]), rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(torch.cos(moved[i, :n, 6]), torch.cos(want[:, 6]), rtol=1e-4, atol=1e-5)
+
+
+# ---- Nesie unsup_loss and the SAQE head (saqe_head.py + quelity_estimation_module.py) ----------
+def test_nesie_unsup_loss_matches_reference(gold, oracle_kernels):
+    head = golden_inputs.build_my_head()
+    feat, points, boxes, labels = golden_inputs.head_inputs()
+    head.jitter_noise = golden_inputs.jitter_noise()
+    q = golden_inputs.pseudo_quality(boxes)
+    with kernels.use_backend(oracle_kernels):
+        preds = head(feat, "vote")
+        got = head.unsup_loss(preds, points, [DepthInstance3DBoxes(b) for b in boxes],
+                              [l.clone() for l in labels], None, q)
+    assert set(got) == {"unsup_semantic_loss", "unsup_center_loss", "unsup_iou_loss",
+                        "unsup_surface_loss"}
+    for k, v in got.items():
+        torch.testing.assert_close(v.detach(), gold[f"head/unsup/{k}"], rtol=1e-4, atol=1e-6, msg=k)
+
+
+@pytest.fixture(scope="module")
+def saqe_run(oracle_kernels):
+    head = golden_inputs.build_my_saqe_head()
+    feat, points, boxes, labels = golden_inputs.head_inputs()
+    head.jitter_noise = golden_inputs.jitter_noise()
+    mk = lambda: (points, [DepthInstance3DBoxes(b) for b in boxes], [l.clone() for l in labels])  # noqa: E731
+    with kernels.use_backend(oracle_kernels):
+        preds = head(feat, "vote")
+        return (preds, head.loss(preds, *mk()), head.sup_loss(preds, *mk()),
+                head.unsup_loss(preds, *mk(), None, golden_inputs.pseudo_quality(boxes)))
+
+
+def test_saqe_forward_matches_reference_code(gold, saqe_run):
+    preds = saqe_run[0]
+    keys = [k.split("/")[-1] for k in gold if k.startswith("saqe/pred/")]
+    assert len(keys) == 13
+    for key in keys:
+        torch.testing.assert_close(preds[key], gold[f"saqe/pred/{key}"], rtol=1e-4, atol=1e-5,
+                                   msg=key)
+
+
+@pytest.mark.parametrize("which,idx", [("loss", 1), ("sup_loss", 2), ("unsup", 3)])
+def test_saqe_losses_match_reference_code(gold, saqe_run, which, idx):
+    got = saqe_run[idx]
+    want = {k.split("/")[-1]: v for k, v in gold.items() if k.startswith(f"saqe/{which}/")}
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k, v in got.items():
+        torch.testing.assert_close(v.detach(), want[k], rtol=1e-4, atol=1e-6, msg=f"{which}/{k}")

@@ -132,3 +132,31 @@ def test_semi_supervised_step_on_gpu(hip_device):
     assert torch.isfinite(total)
     assert len(losses) == 12
     assert float(model.state.ulb_flag.sum()) == 106
+
+
+def test_saqe_model_losses_match_cpu_oracle(oracle_kernels, hip_device):
+    """SAQE head (BASELINE configs[4]): HIP path vs CPU oracle path on a reduced config."""
+    from nesie_amd.votenet import build_saqe_votenet
+    from nesie_amd.votenet.detector import saqe_votenet_scannet_cfg
+    cfg = _small.small_cfg()
+    scfg = saqe_votenet_scannet_cfg()
+    cfg['bbox_head'].update(angle_loss=scfg['bbox_head']['angle_loss'],
+                            angle_pred_loss=scfg['bbox_head']['angle_pred_loss'])
+    cfg['head_type'] = 'SAQEHead'
+    cfg['train_cfg'].update(pos_distance_thr=1.0, neg_distance_thr=1.5)
+    torch.manual_seed(0)
+    model = build_saqe_votenet(cfg)
+    pts, boxes, labels = _small.small_batch()
+    model.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
+    with kernels.use_backend(oracle_kernels):
+        want_l, want_g = _small.train_step_losses(model, pts, boxes, labels)
+    gmodel = copy.deepcopy(model).to(hip_device)
+    got_l, got_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
+    assert set(want_l) == {'vote_loss', 'objectness_loss', 'semantic_loss', 'center_loss',
+                           'surface_loss', 'angle_loss', 'angle_pred_loss', 'iou_loss',
+                           'iou_pred_loss', 'side_loss'}
+    for k in want_l:
+        torch.testing.assert_close(got_l[k], want_l[k], rtol=1e-4, atol=1e-5, msg=k)
+    flat_w = torch.cat([want_g[n].flatten() for n in sorted(want_g)]).double()
+    flat_g = torch.cat([got_g[n].flatten() for n in sorted(want_g)]).double()
+    assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-3

@@ -87,3 +87,28 @@ def test_student_teacher_step_runs_and_updates_state(oracle_kernels):
     assert torch.isfinite(total)
     assert model.state.ulb_flag[5] == 0 and model.state.ulb_flag[17] == 0
     assert model.state.ulb_flag.sum() == 106
+
+
+def test_saqe_student_teacher_step_runs(oracle_kernels):
+    cfg = _small.small_cfg()
+    from nesie_amd.votenet.detector import saqe_votenet_scannet_cfg
+    scfg = saqe_votenet_scannet_cfg()
+    cfg['bbox_head'].update(angle_loss=scfg['bbox_head']['angle_loss'],
+                            angle_pred_loss=scfg['bbox_head']['angle_pred_loss'])
+    cfg['head_type'] = 'SAQEHead'
+    torch.manual_seed(0)
+    model = semi.build_saqe_votenet_semi(cfg)
+    assert isinstance(model, semi.VoteNetSAQE)
+    model.init_label_state(12, 108, torch.device('cpu'))
+    pts, boxes, labels = _small.small_batch(batch=3, n=2048)
+    g = torch.Generator().manual_seed(1)
+    meta_t = semi.AugMeta.random(3, pts.device, g, strong=False)
+    meta_s = semi.AugMeta.random(3, pts.device, g, strong=True)
+    gt = GTBatch.collate(boxes[:1], labels[:1], pts.device)
+    with kernels.use_backend(oracle_kernels):
+        losses = model.forward_train(meta_s.apply_points(pts), meta_t.apply_points(pts), gt,
+                                     [True, False, False], meta_s, meta_t, torch.tensor([0, 1]))
+        total = model.parse_losses(losses)
+        total.backward()
+    assert 'angle_loss' in losses and 'unsup_iou_loss' in losses and 'angle_pred_loss' not in losses
+    assert torch.isfinite(total)
