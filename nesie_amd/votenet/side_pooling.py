@@ -16,7 +16,7 @@ import torch.nn as nn
 from ..mmdet3d_ops import three_interpolate, three_nn
 from ..mmdet3d_ops.pool import group_max_pool
 from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
-from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d
+from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d, pointwise_conv
 
 
 def rot_gpu(t):
@@ -41,12 +41,28 @@ class MiniPointNet(nn.Module):
             nn.Identity(), PointwiseConv2d(hide_dim, feature_dim, 1))
 
     def forward(self, points):
-        feature = self.first_conv(points)
-        feature_global = group_max_pool(feature).unsqueeze(-1)
-        feature = torch.cat([feature_global.expand(-1, -1, -1, feature.shape[-1]), feature],
-                            dim=1)
-        feature = self.second_conv(feature)
-        return group_max_pool(feature)
+        """Same function as the reference's
+            f = first_conv(x); g = max_G f; y = second_conv(cat[g expanded, f]); out = max_G y
+        evaluated without materialising the (B, 2*128, K, G) concatenation: the first 1x1 conv
+        of ``second_conv`` is linear, so  W @ cat[g, f] = W[:, :H] @ g + W[:, H:] @ f  -- the
+        global half is ONE column per proposal instead of G identical ones (a quarter of this
+        net's MACs), and the biases of the two convs that feed a max commute with it
+        (max_G (c + b) = max_G c + b), so they are added on the pooled (B, C, K) tensors.
+        Differences from the concatenated form are summation-order rounding only."""
+        conv0, bn0, _, conv3 = self.first_conv
+        sconv0, sbn0, _, sconv3 = self.second_conv
+        c = pointwise_conv(bn0(conv0(points)), conv3.weight)          # f without its bias
+        g = group_max_pool(c)                                          # (B, H, K): max_G f - b
+        half = conv3.out_channels
+        w = sconv0.weight.reshape(sconv0.out_channels, -1)
+        w_g, w_l = w[:, :half], w[:, half:]
+        b3 = conv3.bias if conv3.bias is not None else c.new_zeros(half)
+        # global half + everything the bias b contributes:  W_g (g + b) + W_l b
+        small = pointwise_conv(g, w_g.unsqueeze(-1)) + (w @ torch.cat([b3, b3])).view(1, -1, 1)
+        y = pointwise_conv(c, w_l.reshape(w_l.shape[0], half, 1, 1)) + small.unsqueeze(-1)
+        y = sbn0(y)
+        out = group_max_pool(pointwise_conv(y, sconv3.weight))
+        return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
 
 def _score_head(in_ch, out_ch):
