@@ -150,20 +150,66 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     if not (graph and on_gpu):
         return model, eager_step, bucket
 
-    side = torch.cuda.Stream(device)
-    side.wait_stream(torch.cuda.current_stream(device))
+    # ---- software pipeline: the FPS + ball-query index chain of the backbone depends only on
+    # the input coordinates, never on the weights, so the chain for the NEXT step runs on a
+    # side stream (it occupies one CU per scene) while this step trains.  Every step still
+    # executes one full index chain and one full fwd+bwd+update; nothing is cached.
+    pipelined = workload == 'pretrain'
+    side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
+    main = torch.cuda.current_stream(device)
+
+    def flat(tree):
+        out = []
+        for d in tree:
+            out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
+        return out
+
+    if pipelined:
+        idx_next = model.backbone.sample_and_group_indices(pts)
+        idx_cur = [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
+                        group_idx=[t.clone() for t in d['group_idx']]) for d in idx_next]
+
+        def fwd_bwd_pre():
+            bucket.zero_()
+            losses = model.forward_train(pts, None, gt, None, precomputed=idx_cur)
+            total = model.parse_losses(losses)
+            total.backward()
+            loss_out.copy_(total.detach())
+    else:
+        fwd_bwd_pre = fwd_bwd
+
+    side.wait_stream(main)
     with torch.cuda.stream(side):
         for _ in range(2):  # warm allocator / library handles before capture
-            eager_step()
-    torch.cuda.current_stream(device).wait_stream(side)
+            fwd_bwd_pre()
+            bucket.all_reduce_mean()
+            update()
+    main.wait_stream(side)
     torch.cuda.synchronize(device)
     g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(g1):
-        fwd_bwd()
+        fwd_bwd_pre()
     with torch.cuda.graph(g2, pool=g1.pool()):
         update()
+    if pipelined:
+        g_idx = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_idx, stream=side):
+            fresh = model.backbone.sample_and_group_indices(pts)
+            torch._foreach_copy_(flat(idx_next), flat(fresh))
+        ready, copied = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(side):
+            g_idx.replay()
+            ready.record(side)
 
     def graph_step():
+        if pipelined:
+            main.wait_event(ready)                       # this step's indices are complete
+            torch._foreach_copy_(flat(idx_cur), flat(idx_next))
+            copied.record(main)
+            side.wait_event(copied)
+            with torch.cuda.stream(side):                # next step's index chain, overlapped
+                g_idx.replay()
+                ready.record(side)
         g1.replay()
         bucket.all_reduce_mean()
         g2.replay()
@@ -283,6 +329,7 @@ def main():
                        'points_per_scene': NUM_POINTS,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'hip_graph': bool(args.graph),
+                       'index_chain_pipelined': bool(args.graph) and args.workload == 'pretrain',
                        'grad_allreduce_bytes': bucket.nbytes()},
             'roofline': {'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048, latency-bound: '
                                    '2047 dependent rounds)',

@@ -68,9 +68,16 @@ class QueryAndGroup(nn.Module):
         if self.uniform_sample:
             raise NotImplementedError('uniform_sample is not used by any shipped config')
 
-    def forward(self, points_xyz, center_xyz, features=None):
-        idx = ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
-                         center_xyz)
+    def ball_indices(self, points_xyz, center_xyz):
+        return ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
+                          center_xyz)
+
+    def forward(self, points_xyz, center_xyz, features=None, idx=None):
+        """``idx`` (optional, not in the reference): ball-query indices computed ahead of time
+        for exactly these points/centres (they depend on coordinates only, never on weights)."""
+        if idx is None:
+            idx = ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
+                             center_xyz)
         xyz_trans = points_xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, sample_num)
         grouped_xyz = grouped_xyz - center_xyz.transpose(1, 2).unsqueeze(-1)

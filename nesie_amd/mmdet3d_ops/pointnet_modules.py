@@ -170,11 +170,26 @@ class BasePointSAModule(nn.Module):
             raise NotImplementedError
         return new_features.squeeze(-1).contiguous()
 
-    def forward(self, points_xyz, features=None, indices=None, target_xyz=None):
+    def sample_and_group_indices(self, points_xyz):
+        """The weight-independent half of forward(): FPS indices, sampled centres and the
+        ball-query indices of every scale.  A training loop can run this for the NEXT batch
+        on a side stream while the current step computes (see bench.py)."""
+        new_xyz, indices = self._sample_points(points_xyz, None, None, None)
+        group_idx = [g.ball_indices(points_xyz, new_xyz) for g in self.groupers]
+        return dict(indices=indices, new_xyz=new_xyz, group_idx=group_idx)
+
+    def forward(self, points_xyz, features=None, indices=None, target_xyz=None, precomputed=None):
         new_features_list = []
-        new_xyz, indices = self._sample_points(points_xyz, features, indices, target_xyz)
+        if precomputed is not None:
+            new_xyz, indices = precomputed['new_xyz'], precomputed['indices']
+        else:
+            new_xyz, indices = self._sample_points(points_xyz, features, indices, target_xyz)
         for i in range(len(self.groupers)):
-            grouped_results = self.groupers[i](points_xyz, new_xyz, features)
+            if precomputed is not None:
+                grouped_results = self.groupers[i](points_xyz, new_xyz, features,
+                                                   idx=precomputed['group_idx'][i])
+            else:
+                grouped_results = self.groupers[i](points_xyz, new_xyz, features)
             new_features = self.mlps[i](grouped_results)
             new_features = self._pool_features(new_features)
             new_features_list.append(new_features)

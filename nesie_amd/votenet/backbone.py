@@ -47,14 +47,28 @@ class PointNet2SASSG(nn.Module):
         features = points[..., 3:].transpose(1, 2).contiguous() if points.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, points):
-        """(B,N,3+C) -> dict of fp_xyz / fp_features / fp_indices (+ the sa_* lists)."""
+    def sample_and_group_indices(self, points):
+        """FPS + ball-query indices of all SA layers: they depend on the input coordinates
+        only, so a loop may compute them for the next batch while this one trains."""
+        xyz = points[..., 0:3].contiguous()
+        out = []
+        for sa in self.SA_modules:
+            pre = sa.sample_and_group_indices(xyz)
+            out.append(pre)
+            xyz = pre['new_xyz']
+        return out
+
+    def forward(self, points, precomputed=None):
+        """(B,N,3+C) -> dict of fp_xyz / fp_features / fp_indices (+ the sa_* lists).
+        ``precomputed`` = sample_and_group_indices(points) evaluated earlier (optional)."""
         xyz, features = self._split_point_feats(points)
         batch, num_points = xyz.shape[:2]
         indices = torch.arange(num_points, device=xyz.device).unsqueeze(0).repeat(batch, 1).long()
         sa_xyz, sa_features, sa_indices = [xyz], [features], [indices]
         for i in range(self.num_sa):
-            cur_xyz, cur_features, cur_indices = self.SA_modules[i](sa_xyz[i], sa_features[i])
+            cur_xyz, cur_features, cur_indices = self.SA_modules[i](
+                sa_xyz[i], sa_features[i],
+                precomputed=None if precomputed is None else precomputed[i])
             sa_xyz.append(cur_xyz)
             sa_features.append(cur_features)
             sa_indices.append(torch.gather(sa_indices[-1], 1, cur_indices.long()))

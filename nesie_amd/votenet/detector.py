@@ -80,13 +80,14 @@ class VoteNet(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
 
-    def extract_feat(self, points):
-        return self.backbone(points)
+    def extract_feat(self, points, precomputed=None):
+        return self.backbone(points, precomputed=precomputed)
 
     def forward_train(self, points, img_metas, gt_bboxes_3d, gt_labels_3d,
-                      pts_semantic_mask=None, pts_instance_mask=None, gt_bboxes_ignore=None):
+                      pts_semantic_mask=None, pts_instance_mask=None, gt_bboxes_ignore=None,
+                      precomputed=None):
         points_cat = torch.stack(points) if isinstance(points, (list, tuple)) else points
-        x = self.extract_feat(points_cat)
+        x = self.extract_feat(points_cat, precomputed)
         bbox_preds = self.bbox_head(x, self.train_cfg['sample_mod'])
         return self.bbox_head.loss(bbox_preds, points_cat, gt_bboxes_3d, gt_labels_3d,
                                    pts_semantic_mask, pts_instance_mask, img_metas,

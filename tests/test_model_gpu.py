@@ -162,3 +162,26 @@ def test_saqe_model_losses_match_cpu_oracle(oracle_kernels, hip_device):
     # 5e-3: the error sits in the backbone convs (BatchNorm backward over 2 tiny scenes
     # cancels in fp32 on either device: the two GPU runs agree to 1e-6, tools/debug_saqe.py)
     assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 5e-3
+
+
+def test_precomputed_index_chain_is_equivalent(hip_device):
+    """bench.py computes the FPS / ball-query chain of the NEXT batch on a side stream; feeding
+    those indices must reproduce the in-line forward bit for bit."""
+    from nesie_amd.scenes import make_batch
+    from nesie_amd.votenet import build_nesie_votenet
+    from nesie_amd.votenet.nesie_head import GTBatch
+    torch.manual_seed(0)
+    model = build_nesie_votenet().to(hip_device)
+    g = torch.Generator().manual_seed(11)
+    model.bbox_head.jitter_noise = tuple(torch.randn(2, 256, 3, generator=g).to(hip_device)
+                                         for _ in range(2))
+    pts, boxes, labels = make_batch(1000, 2)
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    with torch.no_grad():
+        a = model.forward_train(pts, None, gt, None)
+        pre = model.backbone.sample_and_group_indices(pts)
+        b = model.forward_train(pts, None, gt, None, precomputed=pre)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert pre[0]['indices'].shape == (2, 2048) and pre[0]['group_idx'][0].shape == (2, 2048, 64)
