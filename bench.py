@@ -208,7 +208,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
             copied.record(main)
             side.wait_event(copied)
             with torch.cuda.stream(side):                # next step's index chain, overlapped
-                g_idx.replay()
+                if not os.environ.get('NESIE_DIAG_SKIP_CHAIN'):  # diagnostic only
+                    g_idx.replay()
                 ready.record(side)
         g1.replay()
         bucket.all_reduce_mean()

@@ -20,6 +20,41 @@ from .norm import FusedBNReLU1d, FusedBNReLU2d
 from .pool import group_max_pool
 
 
+class _PointwiseConvFn(torch.autograd.Function):
+    """out[b] = W @ x[b] with a weight gradient that is split along the position axis.
+
+    The default autograd of bmm(expand(W), x) computes dW as B GEMMs with K = P each, which
+    leaves most of the chip idle when P is long (a 256x259 output is ~4 tiles per scene).
+    For P >= 32768 the reduction is cut into S = 16 chunks per scene, evaluated as one
+    strided-batched GEMM per scene over views (no copies), and the partials are summed."""
+
+    SPLIT_MIN_P, SPLIT = 32768, 16
+
+    @staticmethod
+    def forward(ctx, x3, w2):
+        ctx.save_for_backward(x3, w2)
+        return torch.bmm(w2.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, w2 = ctx.saved_tensors
+        B, co, P = dy.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), dy)
+        if ctx.needs_input_grad[1]:
+            S = _PointwiseConvFn.SPLIT
+            if P >= _PointwiseConvFn.SPLIT_MIN_P and P % S == 0:
+                pc, ci = P // S, x3.shape[1]
+                parts = [torch.bmm(dy[b].view(co, S, pc).permute(1, 0, 2),
+                                   x3[b].view(ci, S, pc).permute(1, 2, 0)) for b in range(B)]
+                dw = torch.stack(parts).sum((0, 1))
+            else:
+                dw = torch.bmm(dy, x3.transpose(1, 2)).sum(0)
+        return dx, dw
+
+
 def pointwise_conv(x, weight, bias=None):
     """1x1 Conv1d/Conv2d as ONE strided-batched GEMM  out[b] = W @ x[b].
 
@@ -30,7 +65,7 @@ def pointwise_conv(x, weight, bias=None):
     """
     B, cin = x.shape[:2]
     w2 = weight.reshape(weight.shape[0], cin)
-    out = torch.bmm(w2.unsqueeze(0).expand(B, -1, -1), x.reshape(B, cin, -1))
+    out = _PointwiseConvFn.apply(x.reshape(B, cin, -1), w2)
     if bias is not None:
         out = out + bias.view(1, -1, 1)
     return out.view(B, w2.shape[0], *x.shape[2:])
