@@ -342,7 +342,7 @@ def main():
         }
         # HBM-streaming kernels, priced on their largest launch (tensor = 537 MB at B = 8,
         # far beyond the 256 MB Infinity Cache): forward = stats + apply = 3 tensor passes,
-        # backward = reduce + apply = 7 passes
+        # backward = reduce + apply = 5 passes
         tensor_bytes = big * 4
         def _stream(name, ms, passes):
             if not ms:
@@ -355,7 +355,7 @@ def main():
             _stream('nesie::bn_stats_kernel + bn_apply_kernel<relu> (B,128,2048,64)',
                     bn_fwd_timer.mean_ms(), 3),
             _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,128,2048,64)',
-                    bn_bwd_timer.mean_ms(), 7)]
+                    bn_bwd_timer.mean_ms(), 5)]
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)

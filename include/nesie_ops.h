@@ -163,19 +163,21 @@ int nesie_iou3d_forward(int n, const float *box1, const float *box2, float *iou,
  * (point_sa_module.py:277-289, side_pooling_module.py:55-78,346-358).
  * forward : y = relu?(gamma * (x - mean) * invstd + beta); writes save_mean/save_invstd
  *           [C] and updates running_mean/var [C] in place (NULL = skip) with `momentum`.
- * backward: dx, dgamma [C], dbeta [C] from dy, x, y (y only read when relu != 0).
+ * backward: dx, dgamma [C], dbeta [C] from dy, x, y (y only read when relu != 0) and the
+ *           forward's fwd_coef [C,4] = (scale, bias, mean, invstd).
  * workspace: nesie_bn_workspace_bytes(b, c, p) bytes, 16-byte aligned tensors. */
 size_t nesie_bn_workspace_bytes(int b, int c, long long p);
 int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float *gamma,
                           const float *beta, float *running_mean, float *running_var,
                           float momentum, float eps, int relu, float *y, float *save_mean,
-                          float *save_invstd, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          float *save_invstd, float *fwd_coef /* [C,4] out */, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const float *x,
-                           const float *y, const float *gamma, const float *save_mean,
-                           const float *save_invstd, int relu, float *dx, float *dgamma,
-                           float *dbeta, void *workspace, size_t workspace_bytes,
-                           void *stream);
+                           const float *y, const float *gamma, const float *beta,
+                           const float *save_mean, const float *save_invstd,
+                           const float *fwd_coef /* from the forward */, int relu, float *dx,
+                           float *dgamma, float *dbeta, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

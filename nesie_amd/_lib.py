@@ -35,9 +35,9 @@ SIGNATURES = {
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],
     "nesie_lhs_nms_samecls": [_I, _I, _P, _F, _P, _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
-                              _P, _P, ctypes.c_size_t, _P],
-    "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P,
-                               _P, ctypes.c_size_t, _P],
+                              _P, _P, _P, ctypes.c_size_t, _P],
+    "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
+                               _P, _P, _P, ctypes.c_size_t, _P],
 }
 
 _lib = None

@@ -8,9 +8,10 @@
 //
 // All kernels are pure HBM streaming (float4 per lane, no re-reads inside a kernel):
 //   forward : stats  (read x)            -> finalize (C threads) -> apply (read x, write y)
-//   backward: reduce (read dy, x, [y])   -> finalize             -> apply (read dy, x, [y]; write dx)
-// i.e. 3 tensor passes forward and 7 backward, ReLU and its mask included (the unfused
-// pair costs 5 and 10).  Sums are taken about a per-channel shift (the channel's first
+//   backward: reduce (read dy, y)        -> finalize             -> apply (read dy, x; write dx)
+// i.e. 3 tensor passes forward and 5 backward, ReLU and its mask included (the unfused
+// pair costs 5 and 10): the reduce rebuilds xhat from y where y > 0 (the only places the
+// sums need it), the apply re-derives the mask from x with the forward's own scale/bias.  Sums are taken about a per-channel shift (the channel's first
 // element) so E[x^2]-E[x]^2 does not cancel; partials are combined in double.
 #include "common.h"
 
@@ -129,20 +130,28 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     int c_total, long long p, int sp, const float *__restrict__ dy,
     const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ partial) {
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c_total + c) * p;
-  const float mean = save_mean[c], invstd = save_invstd[c];
+  float mean = save_mean[c], invstd = save_invstd[c];
+  // With the ReLU fused, xhat is only needed where y > 0, and there y = gamma*xhat + beta:
+  // xhat = (y - beta) / gamma needs no read of x (one tensor pass less).  Channels whose
+  // gamma is ~0 keep the x path.  `src` is the tensor xhat is rebuilt from.
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const bool from_y = RELU && fabsf(gm) > 1e-4f;
+  const float *__restrict__ src = from_y ? y : x;
+  if (from_y) { mean = bt; invstd = 1.f / gm; }
   const long long lo = (long long)s * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   float a0 = 0.f, a1 = 0.f;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       float4 g = *(const float4 *)(dy + base + i);
-      const float4 v = *(const float4 *)(x + base + i);
+      const float4 v = *(const float4 *)(src + base + i);
       if (RELU) {
-        const float4 o = *(const float4 *)(y + base + i);
+        const float4 o = from_y ? v : *(const float4 *)(y + base + i);
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
@@ -153,8 +162,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
-      if (RELU) g = y[base + i] > 0.f ? g : 0.f;
-      a0 += g; a1 += g * ((x[base + i] - mean) * invstd);
+      const float v = src[base + i];
+      if (RELU) g = (from_y ? v : y[base + i]) > 0.f ? g : 0.f;
+      a0 += g; a1 += g * ((v - mean) * invstd);
     }
   }
   a0 = block_sum(a0, sh);
@@ -187,12 +197,15 @@ __global__ void bn_bwd_finalize_kernel(int c_total, int nslice, double n, const 
 template <bool RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
-    const float *__restrict__ y, const float *__restrict__ save_mean,
-    const float *__restrict__ save_invstd, const float *__restrict__ coef,
+    const float *__restrict__ fwd_coef, const float *__restrict__ coef,
     float *__restrict__ dx) {
+  // dx = a * (g - k1 - xhat * k2) for EVERY position, masked ones included, so x is needed
+  // everywhere; the ReLU mask is re-derived from x with the forward's own scale/bias
+  // (same two fp32 operations as bn_apply_kernel, hence the same bits) instead of reading y.
   const int c = blockIdx.y, b = blockIdx.z;
   const float a = coef[c * 4 + 0], k1 = coef[c * 4 + 1], k2 = coef[c * 4 + 2];
-  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
+  const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const size_t base = ((size_t)b * c_total + c) * p;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
@@ -201,9 +214,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
       float4 g = *(const float4 *)(dy + base + i);
       const float4 v = *(const float4 *)(x + base + i);
       if (RELU) {
-        const float4 o = *(const float4 *)(y + base + i);
-        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        g.x = v.x * sc + bi > 0.f ? g.x : 0.f; g.y = v.y * sc + bi > 0.f ? g.y : 0.f;
+        g.z = v.z * sc + bi > 0.f ? g.z : 0.f; g.w = v.w * sc + bi > 0.f ? g.w : 0.f;
       }
       float4 r;
       r.x = a * (g.x - k1 - (v.x - mean) * invstd * k2);
@@ -215,8 +227,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
-      if (RELU) g = y[base + i] > 0.f ? g : 0.f;
-      dx[base + i] = a * (g - k1 - (x[base + i] - mean) * invstd * k2);
+      const float v = x[base + i];
+      if (RELU) g = v * sc + bi > 0.f ? g : 0.f;
+      dx[base + i] = a * (g - k1 - (v - mean) * invstd * k2);
     }
   }
 }
@@ -245,16 +258,16 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
                                      const float *gamma, const float *beta,
                                      float *running_mean, float *running_var,
                                      float momentum, float eps, int relu, float *y,
-                                     float *save_mean, float *save_invstd, void *workspace,
-                                     size_t workspace_bytes, void *stream) {
+                                     float *save_mean, float *save_invstd, float *fwd_coef,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "bn_relu_forward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
-  NESIE_REQUIRE(x && y && save_mean && save_invstd, W);
+  NESIE_REQUIRE(x && y && save_mean && save_invstd && fwd_coef, W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
-  float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
+  float *partial = (float *)workspace, *coef = fwd_coef;  // [C][4]: scale, bias, mean, invstd
   dim3 grid(sp, c, b);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
@@ -267,13 +280,14 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
 
 extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy,
                                       const float *x, const float *y, const float *gamma,
-                                      const float *save_mean, const float *save_invstd,
+                                      const float *beta, const float *save_mean,
+                                      const float *save_invstd, const float *fwd_coef,
                                       int relu, float *dx, float *dgamma, float *dbeta,
                                       void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "bn_relu_backward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
-  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && (!relu || y), W);
+  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && fwd_coef && (!relu || y), W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
@@ -281,17 +295,17 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   dim3 grid(sp, c, b);
   if (relu)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x, y,
-                       save_mean, save_invstd, partial);
+                       save_mean, save_invstd, gamma, beta, partial);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x,
-                       y, save_mean, save_invstd, partial);
+                       y, save_mean, save_invstd, gamma, beta, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
                      (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
   if (relu)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, y,
-                       save_mean, save_invstd, coef, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
+                       coef, dx);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, y,
-                       save_mean, save_invstd, coef, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
+                       coef, dx);
   return check_launch(W);
 }

@@ -207,7 +207,7 @@ class HipKernels:
                       0 if jac is None else _ptr(jac), _stream(box1))
 
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                        y, save_mean, save_invstd):
+                        y, save_mean, save_invstd, fwd_coef):
         """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place."""
         _check(x, y, save_mean, save_invstd); _f32(x, y, save_mean, save_invstd)
         b, c = x.shape[:2]
@@ -218,10 +218,11 @@ class HipKernels:
             opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
             _lib.call("nesie_bn_relu_forward", b, c, p, _ptr(x), opt(gamma), opt(beta),
                       opt(running_mean), opt(running_var), float(momentum), float(eps),
-                      int(bool(relu)), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws),
-                      need, _stream(x))
+                      int(bool(relu)), _ptr(y), _ptr(save_mean), _ptr(save_invstd),
+                      _ptr(fwd_coef), _ptr(ws), need, _stream(x))
 
-    def bn_relu_backward(self, dy, x, y, gamma, save_mean, save_invstd, relu, dx, dgamma, dbeta):
+    def bn_relu_backward(self, dy, x, y, gamma, beta, save_mean, save_invstd, fwd_coef, relu,
+                         dx, dgamma, dbeta):
         _check(dy, x, dx, save_mean, save_invstd); _f32(dy, x, dx)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
@@ -230,8 +231,9 @@ class HipKernels:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
             opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
             _lib.call("nesie_bn_relu_backward", b, c, p, _ptr(dy), _ptr(x), opt(y), opt(gamma),
-                      _ptr(save_mean), _ptr(save_invstd), int(bool(relu)), _ptr(dx), opt(dgamma),
-                      opt(dbeta), _ptr(ws), need, _stream(x))
+                      opt(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(fwd_coef),
+                      int(bool(relu)), _ptr(dx), opt(dgamma), opt(dbeta), _ptr(ws), need,
+                      _stream(x))
 
 
 _hip = None

@@ -5,7 +5,7 @@ The reference builds conv -> BN -> ReLU from mmcv ``ConvModule`` and from
 side_pooling_module.py:55-78, 346-358); these classes ARE ``nn.BatchNorm{1,2}d`` (same
 parameters, buffers and state-dict keys) whose training forward runs
 ``nesie_bn_relu_forward`` (3 streaming passes) instead of batch_norm + relu (5), and whose
-backward runs ``nesie_bn_relu_backward`` (7 passes instead of 10).  Evaluation mode and the
+backward runs ``nesie_bn_relu_backward`` (5 passes instead of 10).  Evaluation mode and the
 injected CPU back end use the ATen path.
 """
 import torch
@@ -24,21 +24,22 @@ class BNReLUTrain(Function):
         y = torch.empty_like(x)
         save_mean = x.new_empty(c)
         save_invstd = x.new_empty(c)
+        fwd_coef = x.new_empty(c, 4)  # scale, bias, mean, invstd as the forward applied them
         backend_for(x).bn_relu_forward(x, weight, bias, running_mean, running_var, momentum,
-                                       eps, relu, y, save_mean, save_invstd)
+                                       eps, relu, y, save_mean, save_invstd, fwd_coef)
         ctx.relu = relu
-        ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
+        ctx.save_for_backward(x, y, weight, bias, save_mean, save_invstd, fwd_coef)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        x, y, weight, bias, save_mean, save_invstd, fwd_coef = ctx.saved_tensors
         dy = dy.contiguous()
         c = x.shape[1]
         dx = torch.empty_like(x)
         dgamma, dbeta = x.new_empty(c), x.new_empty(c)
-        backend_for(dy).bn_relu_backward(dy, x, y, weight, save_mean, save_invstd, ctx.relu,
-                                         dx, dgamma, dbeta)
+        backend_for(dy).bn_relu_backward(dy, x, y, weight, bias, save_mean, save_invstd, fwd_coef,
+                                         ctx.relu, dx, dgamma, dbeta)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
