@@ -61,16 +61,16 @@ class KernelTimer:
         self.events, self.enabled = [], False
         inner = getattr(backend, method)
 
-        def wrapped(*args):
+        def wrapped(*args, **kw):
             if self.enabled and select(*args):
                 s = torch.cuda.Event(enable_timing=True)
                 e = torch.cuda.Event(enable_timing=True)
                 s.record()
-                inner(*args)
+                inner(*args, **kw)
                 e.record()
                 self.events.append((s, e))
             else:
-                inner(*args)
+                inner(*args, **kw)
         setattr(backend, method, wrapped)
 
     def mean_ms(self):

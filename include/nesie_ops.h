@@ -110,6 +110,18 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
                                     const float *weight, float *out,
                                     void *stream);
 
+/* The same blend written in the layout of the side-aware quality head
+ * (dense_heads/side_pooling_module.py:226-243 builds cat([rel_xyz, interpolated]) and :304-313
+ * splits it per face and makes each face contiguous): the n = K*segs*seg_len queries are
+ * ordered (proposal k, face s, grid point g) and out is (B, segs, c_total, K*seg_len);
+ * query (k,s,g), channel ch lands at out[b, s, c_offset+ch, k*seg_len+g].  Channels outside
+ * [c_offset, c_offset+c) are left untouched for the caller.  Values are bit-identical to
+ * three_interpolate_wrapper's. */
+int nesie_three_interpolate_segmented(int b, int c, int m, int n, const float *points,
+                                      const int *idx, const float *weight, float *out,
+                                      int segs, int seg_len, int c_total, int c_offset,
+                                      void *stream);
+
 /* interpolate.cpp:77-93  three_interpolate_grad_wrapper
  * (b, c, n, m, grad_out[B,C,N], idx, weight, grad_points[B,C,M] zeroed). */
 int nesie_three_interpolate_grad_wrapper(int b, int c, int n, int m,
@@ -165,19 +177,27 @@ int nesie_iou3d_forward(int n, const float *box1, const float *box2, float *iou,
  *           [C] and updates running_mean/var [C] in place (NULL = skip) with `momentum`.
  * backward: dx, dgamma [C], dbeta [C] from dy, x, y (y only read when relu != 0) and the
  *           forward's fwd_coef [C,4] = (scale, bias, mean, invstd).
+ * row_bias (NULL = none): the normalised input is x[b,c,i] + row_bias[b,c,i/group] with
+ *           row_bias[B, C, P/group] -- the per-proposal half of side_pooling_module.py:359-368's
+ *           second_conv input (the max-pooled global feature repeated over the `group` grid
+ *           points of a proposal), added on the fly instead of materialising the repeat+concat;
+ *           group must be a power of two in 4..256.  backward writes d_row_bias (same shape)
+ *           = sum of dx over each group.
  * workspace: nesie_bn_workspace_bytes(b, c, p) bytes, 16-byte aligned tensors. */
 size_t nesie_bn_workspace_bytes(int b, int c, long long p);
 int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float *gamma,
                           const float *beta, float *running_mean, float *running_var,
                           float momentum, float eps, int relu, float *y, float *save_mean,
-                          float *save_invstd, float *fwd_coef /* [C,4] out */, void *workspace,
+                          float *save_invstd, float *fwd_coef /* [C,4] out */,
+                          const float *row_bias, int group, void *workspace,
                           size_t workspace_bytes, void *stream);
 int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const float *x,
                            const float *y, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_invstd,
                            const float *fwd_coef /* from the forward */, int relu, float *dx,
-                           float *dgamma, float *dbeta, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           float *dgamma, float *dbeta, const float *row_bias, int group,
+                           float *d_row_bias, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 #ifdef __cplusplus
 }

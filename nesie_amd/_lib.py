@@ -28,6 +28,7 @@ SIGNATURES = {
     "nesie_three_nn_wrapper": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_three_interpolate_segmented": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_group_max_pool_forward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
@@ -35,9 +36,9 @@ SIGNATURES = {
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],
     "nesie_lhs_nms_samecls": [_I, _I, _P, _F, _P, _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
-                              _P, _P, _P, ctypes.c_size_t, _P],
+                              _P, _P, _P, _I, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
-                               _P, _P, _P, ctypes.c_size_t, _P],
+                               _P, _P, _P, _I, _P, _P, ctypes.c_size_t, _P],
 }
 
 _lib = None

@@ -36,24 +36,29 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {
 // partial[(c * nslice + b * sp + s) * 2 + {0,1}] = sum(x - shift), sum((x - shift)^2)
 __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
     int c_total, long long p, int sp, const float *__restrict__ x,
-    float *__restrict__ partial) {
+    const float *__restrict__ row_bias, int group, float *__restrict__ partial) {
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const float *row = x + ((size_t)b * c_total + c) * p;
-  const float shift = x[(size_t)c * p];  // first element of the channel (b = 0)
+  // row_bias (optional): x_eff[b,c,i] = x[b,c,i] + row_bias[b,c,i / group]  (a per-proposal
+  // term broadcast over its `group` grid points, never materialised)
+  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
+  const float shift = x[(size_t)c * p] + (row_bias ? row_bias[(size_t)c * (p / group)] : 0.f);
   const long long lo = (long long)s * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   float a0 = 0.f, a1 = 0.f;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       const float4 v = *(const float4 *)(row + i);
-      const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+      const float r = rb ? rb[i / group] : 0.f;  // group % 4 == 0: one term per float4
+      const float d0 = v.x + r - shift, d1 = v.y + r - shift, d2 = v.z + r - shift,
+                  d3 = v.w + r - shift;
       a0 += (d0 + d1) + (d2 + d3);
       a1 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
-      const float d = row[i] - shift;
+      const float d = row[i] + (rb ? rb[i / group] : 0.f) - shift;
       a0 += d; a1 += d * d;
     }
   }
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
 
 // coef[c*4 + {0,1,2,3}] = scale, bias, mean, invstd
 __global__ void bn_finalize_kernel(int c_total, int nslice, double n, const float *x, long long p,
+                                   const float *row_bias, int group,
                                    const float *partial, const float *gamma,
                                    const float *beta, float *running_mean,
                                    float *running_var, float momentum, float eps,
@@ -78,7 +84,8 @@ __global__ void bn_finalize_kernel(int c_total, int nslice, double n, const floa
     s0 += (double)partial[((size_t)c * nslice + i) * 2];
     s1 += (double)partial[((size_t)c * nslice + i) * 2 + 1];
   }
-  const double shift = (double)x[(size_t)c * p];
+  const double shift = (double)(x[(size_t)c * p] +
+                                (row_bias ? row_bias[(size_t)c * (p / group)] : 0.f));
   const double m = s0 / n;
   double var = s1 / n - m * m;
   if (var < 0.0) var = 0.0;
@@ -100,16 +107,18 @@ __global__ void bn_finalize_kernel(int c_total, int nslice, double n, const floa
 
 template <bool RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
-    int c_total, long long p, const float *__restrict__ x, const float *__restrict__ coef,
-    float *__restrict__ y) {
+    int c_total, long long p, const float *__restrict__ x, const float *__restrict__ row_bias,
+    int group, const float *__restrict__ coef, float *__restrict__ y) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
   const size_t base = ((size_t)b * c_total + c) * p;
+  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
-      const float4 v = *(const float4 *)(x + base + i);
+      float4 v = *(const float4 *)(x + base + i);
+      if (rb) { const float r = rb[i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
       float4 o = make_float4(v.x * sc + bi, v.y * sc + bi, v.z * sc + bi, v.w * sc + bi);
       if (RELU) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
-      float o = x[base + i] * sc + bi;
+      float o = (x[base + i] + (rb ? rb[i / group] : 0.f)) * sc + bi;
       y[base + i] = RELU ? fmaxf(o, 0.f) : o;
     }
   }
@@ -131,10 +140,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta,
-    float *__restrict__ partial) {
+    const float *__restrict__ row_bias, int group, float *__restrict__ partial) {
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c_total + c) * p;
+  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
   float mean = save_mean[c], invstd = save_invstd[c];
   // With the ReLU fused, xhat is only needed where y > 0, and there y = gamma*xhat + beta:
   // xhat = (y - beta) / gamma needs no read of x (one tensor pass less).  Channels whose
@@ -149,12 +159,13 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       float4 g = *(const float4 *)(dy + base + i);
-      const float4 v = *(const float4 *)(src + base + i);
+      float4 v = *(const float4 *)(src + base + i);
       if (RELU) {
         const float4 o = from_y ? v : *(const float4 *)(y + base + i);
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
+      if (rb && !from_y) { const float r = rb[i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
       a0 += (g.x + g.y) + (g.z + g.w);
       a1 += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) +
             (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
@@ -162,8 +173,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
-      const float v = src[base + i];
+      float v = src[base + i];
       if (RELU) g = (from_y ? v : y[base + i]) > 0.f ? g : 0.f;
+      if (rb && !from_y) v += rb[i / group];
       a0 += g; a1 += g * ((v - mean) * invstd);
     }
   }
@@ -198,6 +210,7 @@ template <bool RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
     const float *__restrict__ fwd_coef, const float *__restrict__ coef,
+    const float *__restrict__ row_bias, int group, float *__restrict__ d_row_bias,
     float *__restrict__ dx) {
   // dx = a * (g - k1 - xhat * k2) for EVERY position, masked ones included, so x is needed
   // everywhere; the ReLU mask is re-derived from x with the forward's own scale/bias
@@ -207,12 +220,14 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const size_t base = ((size_t)b * c_total + c) * p;
+  const size_t rbase = row_bias ? ((size_t)b * c_total + c) * (p / group) : 0;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       float4 g = *(const float4 *)(dy + base + i);
-      const float4 v = *(const float4 *)(x + base + i);
+      float4 v = *(const float4 *)(x + base + i);
+      if (row_bias) { const float r = row_bias[rbase + i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
       if (RELU) {
         g.x = v.x * sc + bi > 0.f ? g.x : 0.f; g.y = v.y * sc + bi > 0.f ? g.y : 0.f;
         g.z = v.z * sc + bi > 0.f ? g.z : 0.f; g.w = v.w * sc + bi > 0.f ? g.w : 0.f;
@@ -223,11 +238,18 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
       r.z = a * (g.z - k1 - (v.z - mean) * invstd * k2);
       r.w = a * (g.w - k1 - (v.w - mean) * invstd * k2);
       *(float4 *)(dx + base + i) = r;
+      if (d_row_bias) {
+        // gradient of the broadcast term = sum of dx over its `group` positions = the
+        // group/4 consecutive lanes that hold them (group in {4..256}, power of two)
+        float t = (r.x + r.y) + (r.z + r.w);
+        for (int off = 1; off < group / 4; off <<= 1) t += __shfl_xor(t, off, 64);
+        if (((threadIdx.x & 63) & (group / 4 - 1)) == 0) d_row_bias[rbase + i / group] = t;
+      }
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
-      const float v = x[base + i];
+      const float v = x[base + i];  // the row-bias form requires p % 4 == 0 (checked on the host)
       if (RELU) g = v * sc + bi > 0.f ? g : 0.f;
       dx[base + i] = a * (g - k1 - (v - mean) * invstd * k2);
     }
@@ -259,22 +281,30 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
                                      float *running_mean, float *running_var,
                                      float momentum, float eps, int relu, float *y,
                                      float *save_mean, float *save_invstd, float *fwd_coef,
+                                     const float *row_bias, int group,
                                      void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "bn_relu_forward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
   NESIE_REQUIRE(x && y && save_mean && save_invstd && fwd_coef, W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
+  if (!row_bias) group = 1;
+  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
+  if (row_bias && (group < 4 || group > 256 || (group & (group - 1)) || (BN_SPAN % group))) {
+    set_error("%s: row_bias group %d (needs a power of two in 4..256)", W, group);
+    return NESIE_ERR_UNSUPPORTED;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
   float *partial = (float *)workspace, *coef = fwd_coef;  // [C][4]: scale, bias, mean, invstd
   dim3 grid(sp, c, b);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, partial);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, row_bias, group,
+                     partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
-                     (double)b * (double)p, x, p, partial, gamma, beta, running_mean,
+                     (double)b * (double)p, x, p, row_bias, group, partial, gamma, beta, running_mean,
                      running_var, momentum, eps, save_mean, save_invstd, coef);
-  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, coef, y);
-  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, coef, y);
+  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, coef, y);
+  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, coef, y);
   return check_launch(W);
 }
 
@@ -283,11 +313,15 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
                                       const float *beta, const float *save_mean,
                                       const float *save_invstd, const float *fwd_coef,
                                       int relu, float *dx, float *dgamma, float *dbeta,
+                                      const float *row_bias, int group, float *d_row_bias,
                                       void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "bn_relu_backward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
   NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && fwd_coef && (!relu || y), W);
+  if (!row_bias) { group = 1; d_row_bias = nullptr; }
+  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
+  NESIE_REQUIRE(!row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
@@ -295,17 +329,17 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   dim3 grid(sp, c, b);
   if (relu)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x, y,
-                       save_mean, save_invstd, gamma, beta, partial);
+                       save_mean, save_invstd, gamma, beta, row_bias, group, partial);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x,
-                       y, save_mean, save_invstd, gamma, beta, partial);
+                       y, save_mean, save_invstd, gamma, beta, row_bias, group, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
                      (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
   if (relu)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       coef, dx);
+                       coef, row_bias, group, d_row_bias, dx);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       coef, dx);
+                       coef, row_bias, group, d_row_bias, dx);
   return check_launch(W);
 }

@@ -92,6 +92,44 @@ __global__ __launch_bounds__(TI_BLOCK) void three_interpolate_kernel(
   }
 }
 
+// Same blend, written straight into the layout the side-aware quality head consumes:
+// query p = (k, s, g) of n = K * segs * seg_len (proposal, face, grid point) goes to
+// out[b, s, c_offset + ch, k * seg_len + g] of out (B, segs, c_total, K * seg_len), i.e. one
+// (c_total, K, seg_len) block per face with c_offset leading channels left for the caller
+// (relative xyz).  Replaces interpolate -> view -> cat -> split -> contiguous
+// (side_pooling_module.py:226-243, 304-313).  Threads enumerate the OUTPUT order so the
+// stores stay coalesced; the idx/weight reads are short strided runs from a small array.
+__global__ __launch_bounds__(TI_BLOCK) void three_interpolate_segmented_kernel(
+    int c, int m, int n, int segs, int seg_len, int c_total, int c_offset,
+    const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out) {
+  const int q = blockIdx.x * TI_BLOCK + threadIdx.x;  // s * (K*seg_len) + k * seg_len + g
+  const int c0 = blockIdx.y * TI_CH;
+  const int bi = blockIdx.z;
+  if (q >= n) return;
+  const int per_seg = n / segs;
+  const int sg = q / per_seg, r = q - sg * per_seg;
+  const int k = r / seg_len, g = r - k * seg_len;
+  const int p = (k * segs + sg) * seg_len + g;
+  const int *ix = idx + ((size_t)bi * n + p) * 3;
+  const float *w = weight + ((size_t)bi * n + p) * 3;
+  int j0 = ix[0], j1 = ix[1], j2 = ix[2];
+  j0 = j0 < 0 ? 0 : (j0 >= m ? m - 1 : j0);
+  j1 = j1 < 0 ? 0 : (j1 >= m ? m - 1 : j1);
+  j2 = j2 < 0 ? 0 : (j2 >= m ? m - 1 : j2);
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  const int cend = c - c0 < TI_CH ? c - c0 : TI_CH;
+  float *dst = out + (((size_t)bi * segs + sg) * c_total + c_offset + c0) * per_seg + r;
+#pragma unroll
+  for (int i = 0; i < TI_CH; ++i) {
+    if (i < cend) {
+      const float *src = points + ((size_t)bi * c + c0 + i) * m;
+      dst[(size_t)i * per_seg] = __fadd_rn(
+          __fadd_rn(__fmul_rn(w0, src[j0]), __fmul_rn(w1, src[j1])), __fmul_rn(w2, src[j2]));
+    }
+  }
+}
+
 // grad_out (B,C,N) -> grad_points (B,C,M) += w * g   (3 float atomics, .cu:81-83)
 __global__ __launch_bounds__(TI_BLOCK) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
@@ -149,6 +187,23 @@ extern "C" int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
   hipLaunchKernelGGL(three_interpolate_kernel, dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b),
                      dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, points, idx, weight,
                      out);
+  return check_launch(W);
+}
+
+extern "C" int nesie_three_interpolate_segmented(int b, int c, int m, int n, const float *points,
+                                                 const int *idx, const float *weight,
+                                                 float *out, int segs, int seg_len,
+                                                 int c_total, int c_offset, void *stream) {
+  const char *W = "three_interpolate_segmented";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0 && segs >= 1 && seg_len >= 1, W);
+  NESIE_REQUIRE(c_offset >= 0 && c_offset + c <= c_total && n % (segs * seg_len) == 0, W);
+  if (b == 0 || c == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 1 && points && idx && weight && out, W);
+  NESIE_REQUIRE(b <= 65535 && cdiv(c, TI_CH) <= 65535, W);
+  hipLaunchKernelGGL(three_interpolate_segmented_kernel,
+                     dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b), dim3(TI_BLOCK), 0,
+                     (hipStream_t)stream, c, m, n, segs, seg_len, c_total, c_offset, points, idx,
+                     weight, out);
   return check_launch(W);
 }
 

@@ -133,6 +133,19 @@ class HipKernels:
             _lib.call("nesie_three_interpolate_wrapper", b, c, m, n, _ptr(points),
                       _ptr(idx), _ptr(weight), _ptr(out), _stream(points))
 
+    def three_interpolate_segmented(self, b, c, m, n, points, idx, weight, out, segs, seg_len,
+                                    c_offset):
+        """out (B, segs, c_total, n/segs): query (k, s, g) -> out[b, s, c_offset+ch, k*seg_len+g]."""
+        _check(points, idx, weight, out); _f32(points, weight, out); _i32(idx)
+        assert points.numel() == b * c * m and idx.numel() == b * n * 3
+        assert weight.numel() == b * n * 3 and n % (segs * seg_len) == 0
+        assert out.dim() == 4 and out.shape[0] == b and out.shape[1] == segs
+        assert out.shape[3] * segs == n and c_offset + c <= out.shape[2]
+        with torch.cuda.device(points.device):
+            _lib.call("nesie_three_interpolate_segmented", b, c, m, n, _ptr(points), _ptr(idx),
+                      _ptr(weight), _ptr(out), segs, seg_len, int(out.shape[2]), c_offset,
+                      _stream(points))
+
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):
         _check(grad_out, idx, weight, grad_points); _f32(grad_out, weight, grad_points)
@@ -207,11 +220,13 @@ class HipKernels:
                       0 if jac is None else _ptr(jac), _stream(box1))
 
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                        y, save_mean, save_invstd, fwd_coef):
-        """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place."""
+                        y, save_mean, save_invstd, fwd_coef, row_bias=None):
+        """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place.
+        row_bias (B, C, K): added to x broadcast over the last axis of x (B, C, K, G)."""
         _check(x, y, save_mean, save_invstd); _f32(x, y, save_mean, save_invstd)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
+        group = _row_bias_group(x, row_bias)
         need = _lib.load().nesie_bn_workspace_bytes(b, c, p)
         with torch.cuda.device(x.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
@@ -219,21 +234,34 @@ class HipKernels:
             _lib.call("nesie_bn_relu_forward", b, c, p, _ptr(x), opt(gamma), opt(beta),
                       opt(running_mean), opt(running_var), float(momentum), float(eps),
                       int(bool(relu)), _ptr(y), _ptr(save_mean), _ptr(save_invstd),
-                      _ptr(fwd_coef), _ptr(ws), need, _stream(x))
+                      _ptr(fwd_coef), opt(row_bias), group, _ptr(ws), need, _stream(x))
 
     def bn_relu_backward(self, dy, x, y, gamma, beta, save_mean, save_invstd, fwd_coef, relu,
-                         dx, dgamma, dbeta):
+                         dx, dgamma, dbeta, row_bias=None, d_row_bias=None):
         _check(dy, x, dx, save_mean, save_invstd); _f32(dy, x, dx)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
+        group = _row_bias_group(x, row_bias)
+        if row_bias is not None:
+            _check(d_row_bias); _f32(d_row_bias)
+            assert d_row_bias.shape == row_bias.shape
         need = _lib.load().nesie_bn_workspace_bytes(b, c, p)
         with torch.cuda.device(x.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
             opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
             _lib.call("nesie_bn_relu_backward", b, c, p, _ptr(dy), _ptr(x), opt(y), opt(gamma),
                       opt(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(fwd_coef),
-                      int(bool(relu)), _ptr(dx), opt(dgamma), opt(dbeta), _ptr(ws), need,
-                      _stream(x))
+                      int(bool(relu)), _ptr(dx), opt(dgamma), opt(dbeta), opt(row_bias), group,
+                      opt(d_row_bias), _ptr(ws), need, _stream(x))
+
+
+def _row_bias_group(x, row_bias):
+    if row_bias is None:
+        return 1
+    _check(row_bias); _f32(row_bias)
+    assert x.dim() == 4 and tuple(row_bias.shape) == tuple(x.shape[:3]), \
+        (tuple(x.shape), tuple(row_bias.shape))
+    return int(x.shape[3])
 
 
 _hip = None

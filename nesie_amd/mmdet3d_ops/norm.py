@@ -18,29 +18,38 @@ from ..kernels import backend_for
 
 class BNReLUTrain(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu,
+                row_bias=None):
         x = x.contiguous()
+        if row_bias is not None:
+            row_bias = row_bias.contiguous()
         c = x.shape[1]
         y = torch.empty_like(x)
         save_mean = x.new_empty(c)
         save_invstd = x.new_empty(c)
         fwd_coef = x.new_empty(c, 4)  # scale, bias, mean, invstd as the forward applied them
         backend_for(x).bn_relu_forward(x, weight, bias, running_mean, running_var, momentum,
-                                       eps, relu, y, save_mean, save_invstd, fwd_coef)
+                                       eps, relu, y, save_mean, save_invstd, fwd_coef,
+                                       row_bias=row_bias)
         ctx.relu = relu
-        ctx.save_for_backward(x, y, weight, bias, save_mean, save_invstd, fwd_coef)
+        ctx.has_row_bias = row_bias is not None
+        saved = (x, y, weight, bias, save_mean, save_invstd, fwd_coef)
+        ctx.save_for_backward(*(saved + ((row_bias,) if ctx.has_row_bias else ())))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, bias, save_mean, save_invstd, fwd_coef = ctx.saved_tensors
+        x, y, weight, bias, save_mean, save_invstd, fwd_coef = ctx.saved_tensors[:7]
+        row_bias = ctx.saved_tensors[7] if ctx.has_row_bias else None
+        d_row_bias = torch.empty_like(row_bias) if ctx.has_row_bias else None
         dy = dy.contiguous()
         c = x.shape[1]
         dx = torch.empty_like(x)
         dgamma, dbeta = x.new_empty(c), x.new_empty(c)
         backend_for(dy).bn_relu_backward(dy, x, y, weight, bias, save_mean, save_invstd, fwd_coef,
-                                         ctx.relu, dx, dgamma, dbeta)
-        return dx, dgamma, dbeta, None, None, None, None, None
+                                         ctx.relu, dx, dgamma, dbeta, row_bias=row_bias,
+                                         d_row_bias=d_row_bias)
+        return dx, dgamma, dbeta, None, None, None, None, None, d_row_bias
 
 
 class _FusedBNReLU:
@@ -49,14 +58,21 @@ class _FusedBNReLU:
     def _init_fused(self, relu):
         self.fuse_relu = bool(relu)
 
-    def forward(self, x):
+    def forward(self, x, row_bias=None):
+        """``row_bias`` (B, C, K), optional: normalise ``x + row_bias[..., None]`` for
+        ``x`` (B, C, K, G) without materialising the sum (G a power of two in 4..256)."""
         backend = backend_for(x)  # raises for CPU tensors without an injected back end
         native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
                   and self.affine and self.track_running_stats and self.momentum is not None)
+        if row_bias is not None:
+            g = x.shape[-1]
+            if not (native and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
+                x, row_bias = x + row_bias.unsqueeze(-1), None
         if native:
             self.num_batches_tracked.add_(1)
             return BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean,
-                                     self.running_var, self.momentum, self.eps, self.fuse_relu)
+                                     self.running_var, self.momentum, self.eps, self.fuse_relu,
+                                     row_bias)
         y = super().forward(x)
         return F.relu(y) if self.fuse_relu else y
 

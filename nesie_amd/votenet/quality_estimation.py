@@ -67,12 +67,11 @@ class QualityEstimation(SidePooling):
         origin_xyz, origin_features = self.extract_features(end_points)
         whole_grid = self.generate_grid(size)
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
-        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center)
-        side_feats = torch.split(side_feats, self.grid_size * self.grid_size * 3, dim=-1)
+        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
         side_scores, side_features = [], []
         for i in range(6):
-            f = self.mlps_before[i](side_feats[i].contiguous())
+            f = self.mlps_before[i](side_feats[:, i])
             f = torch.cat((f, dist_feature[i]), dim=1)
             side_features.append(f)
             side_scores.append(self.mlps_head[i](f))

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..mmdet3d_ops import three_interpolate, three_nn
+from ..mmdet3d_ops import three_interpolate_segmented, three_nn
 from ..mmdet3d_ops.pool import group_max_pool
 from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d, pointwise_conv
@@ -59,8 +59,8 @@ class MiniPointNet(nn.Module):
         b3 = conv3.bias if conv3.bias is not None else c.new_zeros(half)
         # global half + everything the bias b contributes:  W_g (g + b) + W_l b
         small = pointwise_conv(g, w_g.unsqueeze(-1)) + (w @ torch.cat([b3, b3])).view(1, -1, 1)
-        y = pointwise_conv(c, w_l.reshape(w_l.shape[0], half, 1, 1)) + small.unsqueeze(-1)
-        y = sbn0(y)
+        # the per-proposal term is added inside the norm kernels (never materialised)
+        y = sbn0(pointwise_conv(c, w_l.reshape(w_l.shape[0], half, 1, 1)), row_bias=small)
         out = group_max_pool(pointwise_conv(y, sconv3.weight))
         return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
@@ -140,8 +140,13 @@ class SidePooling(nn.Module):
     def grid_for_bbox(self, whole_grid, center, heading):
         return self._to_scene(whole_grid, center, heading)
 
-    def grid_features(self, origin_xyz, origin_features, whole_grid, center):
-        """(B,N,3),(B,C,N),(B,K*G,3),(B,K,3) -> (B,3+C,K,G)  (:183-243)."""
+    def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
+        """(B,N,3),(B,C,N),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
+
+        The grid points of a proposal come as ``segs`` = S consecutive groups of G (the six
+        faces, or one group for the box grid); the result holds one contiguous (3+C, K, G)
+        block per group, i.e. what the reference reaches with
+        cat([rel_xyz, interpolated]) -> split(G, dim=-1) -> .contiguous() (:304-313)."""
         B, K = center.shape[:2]
         grid_size = whole_grid.shape[1] // K
         _, idx = three_nn(whole_grid, origin_xyz)  # (B, K*G, 3) int32
@@ -153,10 +158,12 @@ class SidePooling(nn.Module):
             .reshape(B, -1, 3)
         weight = (1 / (dist + 1e-8)).view(B, -1, 3)
         weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
-        interpolated = three_interpolate(origin_features, idx, weight)  # (B, C, K*G)
-        interpolated = interpolated.view(B, -1, K, grid_size)
-        return torch.cat([relative_grid.transpose(1, 2).reshape(B, -1, K, grid_size),
-                          interpolated], dim=1)
+        G, C = grid_size // segs, origin_features.shape[1]
+        out = origin_features.new_empty(B, segs, 3 + C, K * G)
+        out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(0, 2, 4, 1, 3) \
+            .reshape(B, segs, 3, K * G)
+        three_interpolate_segmented(origin_features, idx, weight, out, segs, G, 3)
+        return out.view(B, segs, 3 + C, K, G)
 
     def dist_feature(self, end_points, prefix=''):
         """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
@@ -172,13 +179,12 @@ class SidePooling(nn.Module):
         whole_grid = self.generate_grid(size)
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
         bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
-        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center)
-        side_feats = torch.split(side_feats, self.grid_size * self.grid_size, dim=-1)
-        bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)
+        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
+        bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
         dist_feature = self.dist_feature(end_points, prefix)
         side_scores = []
         for i in range(6):
-            f = self.mlps_before[i](side_feats[i].contiguous())
+            f = self.mlps_before[i](side_feats[:, i])
             f = torch.cat((f, dist_feature[i]), dim=1)
             side_scores.append(self.mlps_head[i](f))
         end_points[f'{prefix}side_scores'] = torch.stack(side_scores, 0)

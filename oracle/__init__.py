@@ -136,6 +136,15 @@ class OracleKernels:
         lib().oracle_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
                                        weight.data_ptr(), out.data_ptr())
 
+    def three_interpolate_segmented(self, b, c, m, n, points, idx, weight, out, segs, seg_len,
+                                    c_offset):
+        """The plain blend, then the reference's view/split order restated with a permute."""
+        flat = points.new_empty(b, c, n)
+        self.three_interpolate_wrapper(b, c, m, n, points, idx, weight, flat)
+        k = n // (segs * seg_len)
+        out[:, :, c_offset:c_offset + c] = flat.view(b, c, k, segs, seg_len) \
+            .permute(0, 3, 1, 2, 4).reshape(b, segs, c, k * seg_len)
+
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):
         _cpu(grad_out, idx, weight, grad_points)

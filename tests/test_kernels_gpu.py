@@ -175,6 +175,61 @@ def test_group_gather_interpolate_forward_exact_and_grads_close(oracle_kernels, 
         torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 70, 16), (2, 5, 300, 64), (2, 4, 9, 4)])
+def test_fused_bn_row_bias_matches_materialised_sum(hip_device, shape):
+    """row_bias form of the norm kernels (the per-proposal half of MiniPointNet's second
+    conv, side_pooling_module.py:359-368) vs the same kernels on x + row_bias[..., None]."""
+    import copy
+    from nesie_amd.mmdet3d_ops.norm import FusedBNReLU2d
+    g = torch.Generator().manual_seed(shape[2])
+    B, C, K, G = shape
+    x = torch.randn(shape, generator=g).to(hip_device)
+    rb = (torch.randn(B, C, K, generator=g) * 1.5 + 0.5).to(hip_device)
+    go = torch.randn(shape, generator=g).to(hip_device)
+    a = FusedBNReLU2d(C, relu=True).to(hip_device)
+    with torch.no_grad():
+        a.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        a.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    b = copy.deepcopy(a)
+    x1, r1 = x.clone().requires_grad_(True), rb.clone().requires_grad_(True)
+    y1 = a(x1, row_bias=r1)
+    y1.backward(go)
+    x2, r2 = x.clone().requires_grad_(True), rb.clone().requires_grad_(True)
+    y2 = b(x2 + r2.unsqueeze(-1))
+    y2.backward(go)
+    # same arithmetic (x + r is rounded once in both), so values agree to summation order
+    torch.testing.assert_close(y1, y2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(a.running_var, b.running_var, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(r1.grad, r2.grad, rtol=1e-5, atol=2e-6 * G)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("k,segs,g,c", [(256, 6, 16, 256), (40, 6, 27, 19), (33, 1, 64, 8)])
+def test_three_interpolate_segmented_bit_exact(oracle_kernels, hip_device, k, segs, g, c):
+    """Per-face layout of the quality head (side_pooling_module.py:226-243, 304-313) vs the
+    oracle's plain three_interpolate followed by the reference's view/cat/split order."""
+    gen = torch.Generator().manual_seed(k + g)
+    b, m, n = 2, 300, k * segs * g
+    feats = torch.randn(b, c, m, generator=gen)
+    idx = torch.randint(0, m, (b, n, 3), generator=gen, dtype=torch.int32)
+    w = torch.rand(b, n, 3, generator=gen)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    lead = torch.randn(b, segs, 3, k * g, generator=gen)
+    with kernels.use_backend(oracle_kernels):
+        plain = ops.three_interpolate(feats, idx, w)                     # (b, c, n)
+    full = torch.cat([lead.view(b, segs, 3, k, g).permute(0, 2, 3, 1, 4).reshape(b, 3, k, segs * g),
+                      plain.view(b, c, k, segs * g)], 1)                 # reference's cat
+    want = [t.contiguous() for t in torch.split(full, g, dim=-1)]        # reference's split
+    out = torch.empty(b, segs, 3 + c, k * g, device=hip_device)
+    out[:, :, :3] = lead.to(hip_device)
+    ops.three_interpolate_segmented(feats.to(hip_device), idx.to(hip_device), w.to(hip_device),
+                                    out, segs, g, 3)
+    for s_ in range(segs):
+        assert torch.equal(out[:, s_].view(b, 3 + c, k, g).cpu(), want[s_]), s_
+
+
 @pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])
 def test_sort_vertices_bit_exact(oracle_kernels, hip_device, mode):
     from tests.test_oracle import _vertices_for
