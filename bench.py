@@ -120,23 +120,25 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
         model = build_nesie_votenet().to(device)
         gt = GTBatch.collate(boxes, labels, device)
     model.train()
-    bucket = dp.FlatGradBucket(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd,
+    # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
+    # all-reduce, the clip and AdamW each see ONE tensor
+    bucket = dp.FlatTrainState(model.parameters())
+    opt = torch.optim.AdamW([bucket.flat_param], lr=lr, weight_decay=wd,
                             capturable=graph and on_gpu, foreach=True)
 
     def fwd_bwd():
-        bucket.zero_()
+        bucket.begin()
         if workload in ('semi', 'saqe'):
             losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows)
         else:
             losses = model.forward_train(pts, None, gt, None)
         total = model.parse_losses(losses)
         total.backward()
+        bucket.collect()
         loss_out.copy_(total.detach())
 
     def update():
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, norm_type=2,
-                                       foreach=True)
+        torch.nn.utils.clip_grad_norm_([bucket.flat_param], max_norm=10, norm_type=2)
         opt.step()
         if workload in ('semi', 'saqe'):
             model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)
@@ -170,10 +172,11 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
                         group_idx=[t.clone() for t in d['group_idx']]) for d in idx_next]
 
         def fwd_bwd_pre():
-            bucket.zero_()
+            bucket.begin()
             losses = model.forward_train(pts, None, gt, None, precomputed=idx_cur)
             total = model.parse_losses(losses)
             total.backward()
+            bucket.collect()
             loss_out.copy_(total.detach())
     else:
         fwd_bwd_pre = fwd_bwd

@@ -115,9 +115,10 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
  * splits it per face and makes each face contiguous): the n = K*segs*seg_len queries are
  * ordered (proposal k, face s, grid point g) and out is (B, segs, c_total, K*seg_len);
  * query (k,s,g), channel ch lands at out[b, s, c_offset+ch, k*seg_len+g].  Channels outside
- * [c_offset, c_offset+c) are left untouched for the caller.  Values are bit-identical to
- * three_interpolate_wrapper's. */
-int nesie_three_interpolate_segmented(int b, int c, int m, int n, const float *points,
+ * [c_offset, c_offset+c) are left untouched for the caller.  The features are passed
+ * POINT-major, points_t[B, M, C] (the transpose of three_interpolate_wrapper's points), so a
+ * query's taps are dense rows.  Values are bit-identical to three_interpolate_wrapper's. */
+int nesie_three_interpolate_segmented(int b, int c, int m, int n, const float *points_t,
                                       const int *idx, const float *weight, float *out,
                                       int segs, int seg_len, int c_total, int c_offset,
                                       void *stream);

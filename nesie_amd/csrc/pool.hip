@@ -65,29 +65,55 @@ __global__ __launch_bounds__(256) void group_max_bwd_kernel(
 
 // ---- scatter-add of grouped gradients through LDS --------------------------------
 // grad_points[b, c, idx[b, e]] += grad_out[b, c, e].  A workgroup owns CH channel rows of
-// one scene: their n accumulators sit in LDS (n * CH * 4 <= 64 KB), the grouped gradient
-// streams through once with dense reads, float adds go to LDS (ds_add_f32) instead of HBM
-// atomics, and the rows are written back once, dense.  Sum order is not fixed (as in the
-// reference's atomicAdd kernel, group_points_cuda.cu:10-31).
-__global__ __launch_bounds__(512) void group_bwd_lds_kernel(
-    int c, int n, int e_total, int ch, const float *__restrict__ grad_out,
+// one scene: their n accumulators sit in LDS, the grouped gradient streams through once as
+// float4s with the matching int4 of indices, float adds go to LDS (ds_add_f32) instead of
+// HBM atomics, and the rows are written back once, dense.  CH is kept small (the launcher
+// aims at >= 512 workgroups of 16-32 KB LDS) so that enough loads are in flight to stream at
+// HBM rate; the index array is re-read per workgroup from L2.  Sum order is not fixed (as in
+// the reference's atomicAdd kernel, group_points_cuda.cu:10-31).
+template <int CH>
+__global__ __launch_bounds__(256) void group_bwd_lds_kernel(
+    int c, int n, int e_total, int vec, const float *__restrict__ grad_out,
     const int *__restrict__ idx, float *__restrict__ grad_points) {
-  extern __shared__ float acc[];  // [ch][n]
+  extern __shared__ float acc[];  // [CH][n]
   const int bi = blockIdx.y;
-  const int c0 = blockIdx.x * ch;
-  const int cend = c - c0 < ch ? c - c0 : ch;
-  for (int i = threadIdx.x; i < cend * n; i += 512) acc[i] = 0.f;
+  const int c0 = blockIdx.x * CH;
+  const int cend = c - c0 < CH ? c - c0 : CH;
+  for (int i = threadIdx.x; i < cend * n; i += 256) acc[i] = 0.f;
   __syncthreads();
   const int *ix = idx + (size_t)bi * e_total;
-  for (int e = threadIdx.x; e < e_total; e += 512) {
-    int dst = ix[e];
-    dst = dst < 0 ? 0 : (dst >= n ? n - 1 : dst);
-    for (int i = 0; i < cend; ++i)
-      atomicAdd(&acc[i * n + dst], grad_out[((size_t)bi * c + c0 + i) * e_total + e]);
+  const float *src = grad_out + ((size_t)bi * c + c0) * e_total;
+  if (vec) {  // e_total % 4 == 0 and 16-byte aligned bases: rows and index runs are float4s
+    for (int e = threadIdx.x * 4; e < e_total; e += 256 * 4) {
+      int4 d = *(const int4 *)(ix + e);
+      d.x = d.x < 0 ? 0 : (d.x >= n ? n - 1 : d.x);
+      d.y = d.y < 0 ? 0 : (d.y >= n ? n - 1 : d.y);
+      d.z = d.z < 0 ? 0 : (d.z >= n ? n - 1 : d.z);
+      d.w = d.w < 0 ? 0 : (d.w >= n ? n - 1 : d.w);
+      float4 g[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        g[i] = i < cend ? *(const float4 *)(src + (size_t)i * e_total + e) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (i < cend) {
+          atomicAdd(&acc[i * n + d.x], g[i].x);
+          atomicAdd(&acc[i * n + d.y], g[i].y);
+          atomicAdd(&acc[i * n + d.z], g[i].z);
+          atomicAdd(&acc[i * n + d.w], g[i].w);
+        }
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < e_total; e += 256) {
+      int dst = ix[e];
+      dst = dst < 0 ? 0 : (dst >= n ? n - 1 : dst);
+      for (int i = 0; i < cend; ++i) atomicAdd(&acc[i * n + dst], src[(size_t)i * e_total + e]);
+    }
   }
   __syncthreads();
   float *dst_rows = grad_points + ((size_t)bi * c + c0) * n;
-  for (int i = threadIdx.x; i < cend * n; i += 512) dst_rows[i] += acc[i];
+  for (int i = threadIdx.x; i < cend * n; i += 256) dst_rows[i] += acc[i];
 }
 
 }  // namespace nesie
@@ -148,12 +174,17 @@ extern "C" int nesie_group_max_pool_backward(long long rows, int nsample,
 namespace nesie {
 int launch_group_bwd_lds(int b, int c, int n, long long e_total, const float *grad_out,
                          const int *idx, float *grad_points, hipStream_t s) {
-  int ch = 16384 / n;  // n * ch * 4 bytes <= 64 KB
-  if (ch > 32) ch = 32;
-  if (ch > c) ch = c;
+  int ch = (int)((long long)c * b / 512);  // aim at >= 512 workgroups
+  if (ch > 16384 / n) ch = 16384 / n;      // n * ch * 4 bytes <= 64 KB
+  ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
   const size_t lds = (size_t)ch * n * sizeof(float);
-  hipLaunchKernelGGL(group_bwd_lds_kernel, dim3(cdiv(c, ch), b), dim3(512), lds, s, c, n,
-                     (int)e_total, ch, grad_out, idx, grad_points);
+  const dim3 grid(cdiv(c, ch), b);
+  const int e = (int)e_total;
+  const int vec = (e & 3) == 0 && (((uintptr_t)grad_out | (uintptr_t)idx) & 15) == 0;
+#define L(N) hipLaunchKernelGGL(group_bwd_lds_kernel<N>, grid, dim3(256), lds, s, c, n, e, vec, \
+                                grad_out, idx, grad_points)
+  if (ch == 8) L(8); else if (ch == 4) L(4); else if (ch == 2) L(2); else L(1);
+#undef L
   return check_launch("group_points_backward");
 }
 }  // namespace nesie

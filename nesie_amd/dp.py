@@ -63,6 +63,64 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
 
+class FlatTrainState(FlatGradBucket):
+    """Parameters AND gradients of a model as two contiguous vectors.
+
+    * Every ``p.data`` becomes a view into ``flat_param``; ``flat_param.grad`` is the bucket's
+      flat gradient.  An optimiser built on ``[flat_param]`` (uniform hyper-parameters, as in
+      the reference configs: AdamW lr/wd with no paramwise_cfg, grad_clip max_norm=10) runs
+      its element-wise update as a handful of launches instead of one multi-tensor sweep per
+      operation over ~220 tensors; element for element the arithmetic is the per-tensor
+      optimiser's.  ``clip_grad_norm_([flat_param])`` is the same total 2-norm.
+    * ``begin()`` drops the ``.grad``s so autograd hands each finished gradient over instead
+      of adding it into a zeroed view (one launch per parameter); ``collect()`` gathers them
+      into the flat vector with one multi-tensor copy, zero-fills parameters the loss did not
+      reach (their ``.grad`` would have stayed zero), and re-attaches the views.
+    Both calls are capture-safe: under a hipGraph the python bookkeeping runs once at capture
+    time and the gradient tensors live in the graph's pool at fixed addresses."""
+
+    def __init__(self, params):
+        super().__init__(params)
+        ref = self.params[0]
+        flat_p = torch.empty(self.flat.numel(), dtype=ref.dtype, device=ref.device)
+        self.views, self.grad_views, off = [], [], 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                v = flat_p[off:off + n].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                self.views.append(v)
+                self.grad_views.append(p.grad)
+                off += n
+        self.flat_param = torch.nn.Parameter(flat_p)
+        self.flat_param.grad = self.flat
+        self._held = []
+
+    def begin(self):
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        src, dst, missing = [], [], []
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is None:
+                missing.append(v)
+            else:
+                src.append(p.grad)
+                dst.append(v)
+        self._held = src  # keeps graph-pool gradients alive between capture and replays
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if missing:
+            torch._foreach_zero_(missing)
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+
+    def zero_(self):
+        self.flat.zero_()
+
+
 def shard_range(total, rank, world):
     """Scenes [lo, hi) of a global batch owned by ``rank`` (contiguous blocks)."""
     per = total // world

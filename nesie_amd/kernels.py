@@ -133,11 +133,13 @@ class HipKernels:
             _lib.call("nesie_three_interpolate_wrapper", b, c, m, n, _ptr(points),
                       _ptr(idx), _ptr(weight), _ptr(out), _stream(points))
 
-    def three_interpolate_segmented(self, b, c, m, n, points, idx, weight, out, segs, seg_len,
+    def three_interpolate_segmented(self, b, c, m, n, points_t, idx, weight, out, segs, seg_len,
                                     c_offset):
-        """out (B, segs, c_total, n/segs): query (k, s, g) -> out[b, s, c_offset+ch, k*seg_len+g]."""
+        """points_t (B, M, C) point-major; out (B, segs, c_total, n/segs): query (k, s, g) ->
+        out[b, s, c_offset+ch, k*seg_len+g]."""
+        points = points_t
         _check(points, idx, weight, out); _f32(points, weight, out); _i32(idx)
-        assert points.numel() == b * c * m and idx.numel() == b * n * 3
+        assert tuple(points.shape) == (b, m, c) and idx.numel() == b * n * 3
         assert weight.numel() == b * n * 3 and n % (segs * seg_len) == 0
         assert out.dim() == 4 and out.shape[0] == b and out.shape[1] == segs
         assert out.shape[3] * segs == n and c_offset + c <= out.shape[2]

@@ -62,18 +62,18 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
-def three_interpolate_segmented(features, indices, weight, out, segs, seg_len, c_offset):
-    """Blend ``features`` (B,C,M) at the n = K*segs*seg_len queries ordered (proposal, face,
-    grid point) into ``out`` (B, segs, c_total, K*seg_len) at channels
+def three_interpolate_segmented(features_t, indices, weight, out, segs, seg_len, c_offset):
+    """Blend point-major ``features_t`` (B,M,C) at the n = K*segs*seg_len queries ordered
+    (proposal, face, grid point) into ``out`` (B, segs, c_total, K*seg_len) at channels
     [c_offset, c_offset+C): the per-face contiguous blocks that
     side_pooling_module.py:226-243, 304-313 reaches through cat -> split -> contiguous.
     Not differentiable (the quality head reads detached seed features, :176-181)."""
-    assert not (features.requires_grad and torch.is_grad_enabled()), \
+    assert not (features_t.requires_grad and torch.is_grad_enabled()), \
         'three_interpolate_segmented serves the detached quality-head path only'
-    assert features.is_contiguous() and indices.is_contiguous() and weight.is_contiguous()
+    assert features_t.is_contiguous() and indices.is_contiguous() and weight.is_contiguous()
     assert out.is_contiguous()
-    B, c, m = features.shape
+    B, m, c = features_t.shape
     n = indices.shape[1]
-    backend_for(features).three_interpolate_segmented(B, c, m, n, features, indices, weight, out,
-                                                      segs, seg_len, c_offset)
+    backend_for(features_t).three_interpolate_segmented(B, c, m, n, features_t, indices, weight,
+                                                        out, segs, seg_len, c_offset)
     return out

@@ -16,6 +16,30 @@ from torch.autograd import Function
 from ..kernels import backend_for
 
 
+_counter_sink = None
+
+
+class deferred_bn_counters:
+    """Within this context the fused norms queue their ``num_batches_tracked += 1`` (a
+    one-element launch per layer, ~50 per VoteNet step) and the exit applies them all with
+    one multi-tensor add.  Same buffer values after the block."""
+
+    def __enter__(self):
+        global _counter_sink
+        self.prev, _counter_sink = _counter_sink, []
+        return self
+
+    def __exit__(self, *exc):
+        global _counter_sink
+        queued, _counter_sink = _counter_sink, self.prev
+        if queued and exc[0] is None:
+            seen = {}
+            for t in queued:  # a layer called twice in the block counts twice
+                seen.setdefault(id(t), [t, 0])[1] += 1
+            torch._foreach_add_([t for t, _ in seen.values()], [n for _, n in seen.values()])
+        return False
+
+
 class BNReLUTrain(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu,
@@ -69,7 +93,10 @@ class _FusedBNReLU:
             if not (native and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
                 x, row_bias = x + row_bias.unsqueeze(-1), None
         if native:
-            self.num_batches_tracked.add_(1)
+            if _counter_sink is not None:
+                _counter_sink.append(self.num_batches_tracked)
+            else:
+                self.num_batches_tracked.add_(1)
             return BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean,
                                      self.running_var, self.momentum, self.eps, self.fuse_relu,
                                      row_bias)

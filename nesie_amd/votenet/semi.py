@@ -21,6 +21,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..kernels import backend_for
+from ..mmdet3d_ops.norm import deferred_bn_counters
 from .detector import VoteNet
 from .nesie_head import GTBatch
 
@@ -325,12 +326,14 @@ class VoteNetNesie(VoteNet):
         unlabeled scenes in the unlabeled set."""
         cfg = self.train_cfg
         name = cfg.get('dataset_name', 'ScanNet')
-        x_s = self.extract_feat(points_s)
-        preds_s = self.bbox_head(x_s, cfg['sample_mod'], name)
+        with deferred_bn_counters():
+            x_s = self.extract_feat(points_s)
+            preds_s = self.bbox_head(x_s, cfg['sample_mod'], name)
+            with torch.no_grad():
+                self.teacher.swap()                  # call_hook("switch_to_teacher")
+                x_t = self.extract_feat(points_t)
+                preds_t = self.bbox_head(x_t, cfg['sample_mod'], name)
         with torch.no_grad():
-            self.teacher.swap()                      # call_hook("switch_to_teacher")
-            x_t = self.extract_feat(points_t)
-            preds_t = self.bbox_head(x_t, cfg['sample_mod'], name)
             labels, boxes, quality, valid = self.get_pseudo_labels(preds_t, name)
             boxes = transform_boxes(untransform_boxes(boxes, meta_t), meta_s)
             self.teacher.swap()                      # call_hook("switch_to_student")

@@ -109,8 +109,9 @@ class SidePooling(nn.Module):
         self.mlps_head = nn.ModuleList(head)
 
     def extract_features(self, end_points):
+        """-> seed xyz (B,N,3), seed features POINT-major (B,N,C) for the blend kernel."""
         return (end_points['seed_points'].detach().contiguous(),
-                end_points['seed_features'].detach().contiguous())
+                end_points['seed_features'].detach().transpose(1, 2).contiguous())
 
     def generate_grid(self, size):
         """(B,K,3) sizes -> (B,K,g^3,3) box-frame grid, x slowest, z fastest (:87-122)."""
@@ -141,7 +142,7 @@ class SidePooling(nn.Module):
         return self._to_scene(whole_grid, center, heading)
 
     def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
-        """(B,N,3),(B,C,N),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
+        """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
 
         The grid points of a proposal come as ``segs`` = S consecutive groups of G (the six
         faces, or one group for the box grid); the result holds one contiguous (3+C, K, G)
@@ -158,7 +159,7 @@ class SidePooling(nn.Module):
             .reshape(B, -1, 3)
         weight = (1 / (dist + 1e-8)).view(B, -1, 3)
         weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
-        G, C = grid_size // segs, origin_features.shape[1]
+        G, C = grid_size // segs, origin_features.shape[2]
         out = origin_features.new_empty(B, segs, 3 + C, K * G)
         out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(0, 2, 4, 1, 3) \
             .reshape(B, segs, 3, K * G)

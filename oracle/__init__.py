@@ -136,9 +136,10 @@ class OracleKernels:
         lib().oracle_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
                                        weight.data_ptr(), out.data_ptr())
 
-    def three_interpolate_segmented(self, b, c, m, n, points, idx, weight, out, segs, seg_len,
+    def three_interpolate_segmented(self, b, c, m, n, points_t, idx, weight, out, segs, seg_len,
                                     c_offset):
         """The plain blend, then the reference's view/split order restated with a permute."""
+        points = points_t.transpose(1, 2).contiguous()  # back to the reference's (B, C, M)
         flat = points.new_empty(b, c, n)
         self.three_interpolate_wrapper(b, c, m, n, points, idx, weight, flat)
         k = n // (segs * seg_len)

@@ -78,3 +78,46 @@ def test_flat_bucket_views_track_autograd():
     bucket.zero_()
     assert bucket.flat.abs().sum() == 0 and lin.weight.grad.abs().sum() == 0
     assert bucket.nbytes() == (6 + 2) * 4
+
+
+def test_flat_train_state_matches_per_tensor_adamw():
+    """dp.FlatTrainState: stolen gradients gathered into the flat vector + AdamW/clip on ONE
+    flat parameter == zeroed .grad accumulation + per-tensor AdamW/clip (the reference's
+    optimizer config: AdamW, grad_clip max_norm=10)."""
+    import copy
+    from nesie_amd import dp
+    torch.manual_seed(3)
+    a = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3),
+                            torch.nn.Linear(3, 3))
+    unused = torch.nn.Parameter(torch.randn(4))       # a parameter the loss never reaches
+    a.register_parameter('unused', unused)
+    b = copy.deepcopy(a)
+    state = dp.FlatTrainState(a.parameters())
+    opt_a = torch.optim.AdamW([state.flat_param], lr=1e-2, weight_decay=0.05)
+    opt_b = torch.optim.AdamW(b.parameters(), lr=1e-2, weight_decay=0.05)
+    for p in b.parameters():
+        p.grad = torch.zeros_like(p)
+    for it, max_norm in enumerate([1e9, 1e9, 0.05, 0.05]):
+        x = torch.randn(7, 6)
+        state.begin()
+        a[:3](x).square().sum().backward()
+        state.collect()
+        for p in b.parameters():
+            p.grad.zero_()
+        b[:3](x).square().sum().backward()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert pa.grad.data_ptr() >= state.flat.data_ptr()
+            assert torch.equal(pa.grad, pb.grad)
+        state.all_reduce_mean()
+        na = torch.nn.utils.clip_grad_norm_([state.flat_param], max_norm)
+        nb = torch.nn.utils.clip_grad_norm_(b.parameters(), max_norm)
+        torch.testing.assert_close(na, nb, rtol=1e-6, atol=0)
+        opt_a.step()
+        opt_b.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert pa.data_ptr() >= state.flat_param.data_ptr()
+            if max_norm > 1:
+                assert torch.equal(pa, pb), it          # no clipping: bit-identical
+            else:
+                torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-7)
+    assert a.state_dict().keys() == b.state_dict().keys()

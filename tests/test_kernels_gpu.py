@@ -206,7 +206,8 @@ def test_fused_bn_row_bias_matches_materialised_sum(hip_device, shape):
     torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("k,segs,g,c", [(256, 6, 16, 256), (40, 6, 27, 19), (33, 1, 64, 8)])
+@pytest.mark.parametrize("k,segs,g,c", [(256, 6, 16, 256), (64, 6, 16, 128), (64, 1, 64, 64),
+                                        (40, 6, 27, 19), (33, 1, 64, 8), (256, 6, 27, 256)])
 def test_three_interpolate_segmented_bit_exact(oracle_kernels, hip_device, k, segs, g, c):
     """Per-face layout of the quality head (side_pooling_module.py:226-243, 304-313) vs the
     oracle's plain three_interpolate followed by the reference's view/cat/split order."""
@@ -224,8 +225,8 @@ def test_three_interpolate_segmented_bit_exact(oracle_kernels, hip_device, k, se
     want = [t.contiguous() for t in torch.split(full, g, dim=-1)]        # reference's split
     out = torch.empty(b, segs, 3 + c, k * g, device=hip_device)
     out[:, :, :3] = lead.to(hip_device)
-    ops.three_interpolate_segmented(feats.to(hip_device), idx.to(hip_device), w.to(hip_device),
-                                    out, segs, g, 3)
+    ops.three_interpolate_segmented(feats.transpose(1, 2).contiguous().to(hip_device),
+                                    idx.to(hip_device), w.to(hip_device), out, segs, g, 3)
     for s_ in range(segs):
         assert torch.equal(out[:, s_].view(b, 3 + c, k, g).cpu(), want[s_]), s_
 
