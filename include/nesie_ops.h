@@ -200,6 +200,49 @@ int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const flo
                            float *d_row_bias, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* Training BatchNorm + ReLU + max over the neighbourhood axis for the LAST layer of a
+ * set-abstraction MLP: x[B, C, M, ns] -> pooled[B, C, M] (+ argmax[B, C, M], one byte, smallest
+ * index on ties) without writing the normalised tensor.  Reference: ConvModule's BN2d + ReLU
+ * followed by F.max_pool2d(kernel=[1, ns]) (point_sa_module.py:277-289, 136-158); same
+ * values as nesie_bn_relu_forward followed by nesie_group_max_pool_forward.
+ * backward: dx[B, C, M, ns], dgamma, dbeta from grad_pooled[B, C, M], argmax, x, pooled and the
+ * forward's fwd_coef.  ns a power of two in 4..64; workspace =
+ * nesie_bn_workspace_bytes(b, c, m * ns). */
+int nesie_bn_relu_maxpool_forward(int b, int c, int m, int ns, const float *x,
+                                  const float *gamma, const float *beta, float *running_mean,
+                                  float *running_var, float momentum, float eps, float *pooled,
+                                  uint8_t *argmax, float *save_mean, float *save_invstd,
+                                  float *fwd_coef, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns, const float *grad_pooled,
+                                   const uint8_t *argmax, const float *x, const float *pooled,
+                                   const float *gamma, const float *save_invstd,
+                                   const float *fwd_coef, float *dx, float *dgamma,
+                                   float *dbeta, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+
+/* One shared-MLP layer of a grouped MLP on the matrix cores.  No extension entry in the
+ * reference: it evaluates mmcv ConvModule(Conv2d 1x1 -> BN2d -> ReLU) op by op
+ * (point_sa_module.py:277-289, side_pooling_module.py:346-358).
+ *   y[b] = W . act(x[b]),  x[b] (cin, p) at x + b*x_bstride, W (cout, cin), y (B, cout, p)
+ *   act(v) = in_coef ? relu?(in_coef[k][0] * v + in_coef[k][1]) : v   per input channel k --
+ *            the previous layer's folded BatchNorm (scale, bias, -, -) and ReLU, applied while
+ *            the tile is staged (the normalised activation is never stored);
+ *   stat_partial (NULL = skip): nesie_mlp_stat_partials(b, cout, p) x cout x 2 floats, the
+ *            per-workgroup (sum, sum of squares) of y for this layer's own batch statistics.
+ * nesie_mlp_stat_finalize folds them (fp64) into coef[c][4] = (scale, bias, mean, invstd) with
+ * scale = gamma * invstd, bias = beta - mean * scale, and updates the running statistics
+ * like torch.nn.BatchNorm2d in training mode (biased variance to normalise, unbiased into
+ * running_var). */
+long long nesie_mlp_stat_partials(int b, int cout, long long p);
+int nesie_mlp_layer_forward(int b, int cin, int cout, long long p, const float *x,
+                            long long x_bstride, const float *w, const float *in_coef,
+                            int in_relu, float *y, float *stat_partial, void *stream);
+int nesie_mlp_stat_finalize(int c, long long nparts, double count, const float *stat_partial,
+                            const float *gamma, const float *beta, float *running_mean,
+                            float *running_var, float momentum, float eps, float *coef,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,14 @@ SIGNATURES = {
     "nesie_group_max_pool_backward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],
     "nesie_lhs_nms_samecls": [_I, _I, _P, _F, _P, _P],
+    "nesie_bn_relu_maxpool_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P,
+                                      _P, _P, ctypes.c_size_t, _P],
+    "nesie_bn_relu_maxpool_backward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, ctypes.c_size_t, _P],
+    "nesie_mlp_layer_forward": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _I,
+                                _P, _P, _P],
+    "nesie_mlp_stat_finalize": [_I, ctypes.c_longlong, ctypes.c_double, _P, _P, _P, _P, _P, _F,
+                                _F, _P, _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
                               _P, _P, _P, _I, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
@@ -65,6 +73,8 @@ def load():
     lib.nesie_fps_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_bn_workspace_bytes.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_bn_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_mlp_stat_partials.argtypes = [_I, _I, ctypes.c_longlong]
+    lib.nesie_mlp_stat_partials.restype = ctypes.c_longlong
     lib.nesie_abi_version.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib

@@ -256,6 +256,84 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   }
 }
 
+// ---- BatchNorm + ReLU + max over the neighbourhood axis in one pass ------------------
+// The last layer of a set-abstraction MLP feeds F.max_pool2d([1, nsample])
+// (point_sa_module.py:136-158): only the pooled (B, C, M) tensor is needed downstream, so the
+// normalised (B, C, M, ns) tensor is never written.  Same arithmetic per element as
+// bn_apply_kernel<true> followed by group_max_fwd_kernel (smallest index on ties).
+template <int LPR>
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(
+    long long rows, int m, int c_total, const float4 *__restrict__ x,
+    const float *__restrict__ coef, float *__restrict__ out, uint8_t *__restrict__ arg) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 each
+  const long long row = t / LPR;
+  const int part = (int)(t % LPR);
+  const bool live = row < rows;
+  const int c = live ? (int)((row / m) % c_total) : 0;
+  const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
+  float4 q = live ? x[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+  q.x = fmaxf(q.x * sc + bi, 0.f); q.y = fmaxf(q.y * sc + bi, 0.f);
+  q.z = fmaxf(q.z * sc + bi, 0.f); q.w = fmaxf(q.w * sc + bi, 0.f);
+  float v; int i;
+  row_argmax4<LPR>(q, part, v, i);
+  if (live && part == 0) { out[row] = v; arg[row] = (uint8_t)i; }
+}
+
+// The gradient that reaches the normalised tensor is one value per row (at the arg-max, and
+// only where the pooled activation is positive), so the two BatchNorm sums need the pooled
+// gradient, the pooled activation and ONE gathered x per row -- not the dense tensors.
+__global__ __launch_bounds__(BN_BLOCK) void bn_pool_bwd_reduce_kernel(
+    int c_total, int m, int ns, int rows_per, const float *__restrict__ gpool,
+    const float *__restrict__ pooled, const uint8_t *__restrict__ arg,
+    const float *__restrict__ x, const float *__restrict__ fwd_coef,
+    float *__restrict__ partial) {
+  __shared__ float sh[BN_BLOCK / 64];
+  const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
+  const size_t base = ((size_t)b * c_total + c) * m;
+  const int lo = s * rows_per, hi = lo + rows_per < m ? lo + rows_per : m;
+  float a0 = 0.f, a1 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+    if (pooled[base + i] > 0.f) {
+      const float g = gpool[base + i];
+      const float xa = x[(base + i) * ns + arg[base + i]];
+      a0 += g;
+      a1 += g * ((xa - mean) * invstd);
+    }
+  }
+  a0 = block_sum(a0, sh);
+  a1 = block_sum(a1, sh);
+  if (threadIdx.x == 0) {
+    const size_t o = ((size_t)c * (gridDim.z * gridDim.x) + (size_t)b * gridDim.x + s) * 2;
+    partial[o] = a0; partial[o + 1] = a1;
+  }
+}
+
+// dx = a * (dy - k1 - xhat * k2) with dy rebuilt from (pooled gradient, arg-max, pooled > 0)
+template <int LPR>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
+    long long rows, int m, int c_total, const float4 *__restrict__ x,
+    const float *__restrict__ gpool, const float *__restrict__ pooled,
+    const uint8_t *__restrict__ arg, const float *__restrict__ fwd_coef,
+    const float *__restrict__ coef, float4 *__restrict__ dx) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = t / LPR;
+  const int part = (int)(t % LPR);
+  if (row >= rows) return;
+  const int c = (int)((row / m) % c_total);
+  const float a = coef[c * 4 + 0], k1 = coef[c * 4 + 1], k2 = coef[c * 4 + 2];
+  const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
+  const float g = pooled[row] > 0.f ? gpool[row] : 0.f;
+  const int ai = (int)arg[row] - part * 4;
+  const float4 v = x[t];
+  float4 r;
+  r.x = a * ((ai == 0 ? g : 0.f) - k1 - (v.x - mean) * invstd * k2);
+  r.y = a * ((ai == 1 ? g : 0.f) - k1 - (v.y - mean) * invstd * k2);
+  r.z = a * ((ai == 2 ? g : 0.f) - k1 - (v.z - mean) * invstd * k2);
+  r.w = a * ((ai == 3 ? g : 0.f) - k1 - (v.w - mean) * invstd * k2);
+  dx[t] = r;
+}
+
 static inline int bn_sp(long long p) { return (int)((p + BN_SPAN - 1) / BN_SPAN); }
 
 }  // namespace nesie
@@ -341,5 +419,87 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
                        coef, row_bias, group, d_row_bias, dx);
+  return check_launch(W);
+}
+
+
+static int bn_pool_dims(const char *W, int m, int ns) {
+  if (m <= 0 || ns < 4 || ns > 64 || (ns & (ns - 1))) {
+    set_error("%s: m %d, nsample %d (needs a power of two in 4..64)", W, m, ns);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  return NESIE_OK;
+}
+
+extern "C" int nesie_bn_relu_maxpool_forward(int b, int c, int m, int ns, const float *x,
+                                             const float *gamma, const float *beta,
+                                             float *running_mean, float *running_var,
+                                             float momentum, float eps, float *pooled,
+                                             uint8_t *argmax, float *save_mean,
+                                             float *save_invstd, float *fwd_coef,
+                                             void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+  const char *W = "bn_relu_maxpool_forward";
+  NESIE_REQUIRE(b >= 0 && c >= 0, W);
+  if (b == 0 || c == 0) return NESIE_OK;
+  int st = bn_pool_dims(W, m, ns);
+  if (st) return st;
+  const long long p = (long long)m * ns;
+  st = bn_check(W, b, c, p, workspace, workspace_bytes);
+  if (st) return st;
+  NESIE_REQUIRE(x && pooled && argmax && save_mean && save_invstd && fwd_coef, W);
+  NESIE_REQUIRE(((uintptr_t)x & 15) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  const int sp = bn_sp(p), nslice = b * sp;
+  float *partial = (float *)workspace;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, p, sp, x,
+                     (const float *)nullptr, 1, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
+                     (double)b * (double)p, x, p, (const float *)nullptr, 1, partial, gamma, beta,
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, fwd_coef);
+  const long long rows = (long long)b * c * m;
+  const int lpr = ns / 4;
+  const dim3 grid((unsigned)cdiv(rows * lpr, 256));
+#define L(N) hipLaunchKernelGGL(bn_pool_fwd_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
+                                (const float4 *)x, fwd_coef, pooled, argmax)
+  if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
+  else if (lpr == 8) L(8); else L(16);
+#undef L
+  return check_launch(W);
+}
+
+extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
+                                              const float *grad_pooled, const uint8_t *argmax,
+                                              const float *x, const float *pooled,
+                                              const float *gamma, const float *save_invstd,
+                                              const float *fwd_coef, float *dx, float *dgamma,
+                                              float *dbeta, void *workspace,
+                                              size_t workspace_bytes, void *stream) {
+  const char *W = "bn_relu_maxpool_backward";
+  NESIE_REQUIRE(b >= 0 && c >= 0, W);
+  if (b == 0 || c == 0) return NESIE_OK;
+  int st = bn_pool_dims(W, m, ns);
+  if (st) return st;
+  const long long p = (long long)m * ns;
+  st = bn_check(W, b, c, p, workspace, workspace_bytes);
+  if (st) return st;
+  NESIE_REQUIRE(grad_pooled && argmax && x && pooled && save_invstd && fwd_coef && dx, W);
+  NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dx) & 15) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  const int sp = bn_sp(p), nslice = b * sp, rows_per = cdiv(m, sp);
+  float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, m, ns,
+                     rows_per, grad_pooled, pooled, argmax, x, fwd_coef, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
+                     (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
+  const long long rows = (long long)b * c * m;
+  const int lpr = ns / 4;
+  const dim3 grid((unsigned)cdiv(rows * lpr, 256));
+#define L(N) hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
+                                (const float4 *)x, grad_pooled, pooled, argmax, fwd_coef, coef, \
+                                (float4 *)dx)
+  if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
+  else if (lpr == 8) L(8); else L(16);
+#undef L
   return check_launch(W);
 }

@@ -46,4 +46,34 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
+// ---- DPP helpers for reductions inside a row of <= 16 lanes (no LDS, full rate)
+template <int CTRL>
+__device__ __forceinline__ unsigned dppm(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// (value, index) max with smallest-index tie-break, exchanged with the lane given by CTRL
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float &v, int &i) {
+  const float ov = __uint_as_float(dppm<CTRL>(__float_as_uint(v)));
+  const int oi = (int)dppm<CTRL>((unsigned)i);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+
+// arg-max over the 4 elements a lane holds, then over the LPR lanes of its row (LPR <= 16):
+// smallest index on ties, result in every lane of the row
+template <int LPR>
+__device__ __forceinline__ void row_argmax4(const float4 q, int part, float &v, int &i) {
+  v = q.x; i = part * 4;
+  if (q.y > v) { v = q.y; i = part * 4 + 1; }
+  if (q.z > v) { v = q.z; i = part * 4 + 2; }
+  if (q.w > v) { v = q.w; i = part * 4 + 3; }
+  if (LPR >= 2) argmax_step<0xB1>(v, i);    // lane ^ 1
+  if (LPR >= 4) argmax_step<0x4E>(v, i);    // lane ^ 2
+  if (LPR >= 8) argmax_step<0x141>(v, i);   // row_half_mirror: 7 - lane (within 8)
+  if (LPR >= 16) argmax_step<0x140>(v, i);  // row_mirror: 15 - lane (within 16)
+}
+
 }  // namespace nesie

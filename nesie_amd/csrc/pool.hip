@@ -13,21 +13,6 @@
 
 namespace nesie {
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dppm(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-
-// (value, index) max with smallest-index tie-break, exchanged with the lane given by CTRL
-template <int CTRL>
-__device__ __forceinline__ void argmax_step(float &v, int &i) {
-  const float ov = __uint_as_float(dppm<CTRL>(__float_as_uint(v)));
-  const int oi = (int)dppm<CTRL>((unsigned)i);
-  const bool take = ov > v || (ov == v && oi < i);
-  v = take ? ov : v;
-  i = take ? oi : i;
-}
-
 // LPR = lanes per row = ns / 4
 template <int LPR>
 __global__ __launch_bounds__(256) void group_max_fwd_kernel(
@@ -38,14 +23,8 @@ __global__ __launch_bounds__(256) void group_max_fwd_kernel(
   const int part = (int)(t % LPR);
   const bool live = row < rows;
   const float4 q = live ? x[t] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  float v = q.x; int i = part * 4;
-  if (q.y > v) { v = q.y; i = part * 4 + 1; }
-  if (q.z > v) { v = q.z; i = part * 4 + 2; }
-  if (q.w > v) { v = q.w; i = part * 4 + 3; }
-  if (LPR >= 2) argmax_step<0xB1>(v, i);    // lane ^ 1
-  if (LPR >= 4) argmax_step<0x4E>(v, i);    // lane ^ 2
-  if (LPR >= 8) argmax_step<0x141>(v, i);   // row_half_mirror: 7 - lane (within 8)
-  if (LPR >= 16) argmax_step<0x140>(v, i);  // row_mirror: 15 - lane (within 16)
+  float v; int i;
+  row_argmax4<LPR>(q, part, v, i);
   if (live && part == 0) { out[row] = v; arg[row] = (uint8_t)i; }
 }
 

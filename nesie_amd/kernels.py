@@ -49,7 +49,42 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-class HipKernels:
+class _BNPoolMixin:
+    def bn_relu_maxpool_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps,
+                                pooled, argmax, save_mean, save_invstd, fwd_coef):
+        """x (B, C, M, ns) -> pooled (B, C, M) fp32, argmax (B, C, M) uint8."""
+        _check(x, pooled, argmax, save_mean, save_invstd, fwd_coef); _f32(x, pooled)
+        b, c, m, ns = x.shape
+        assert tuple(pooled.shape) == (b, c, m) and argmax.dtype == torch.uint8
+        with torch.cuda.device(x.device):
+            ws, need = _bn_pool_ws(x)
+            opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+            _lib.call("nesie_bn_relu_maxpool_forward", b, c, m, ns, _ptr(x), opt(gamma),
+                      opt(beta), opt(running_mean), opt(running_var), float(momentum),
+                      float(eps), _ptr(pooled), _ptr(argmax), _ptr(save_mean),
+                      _ptr(save_invstd), _ptr(fwd_coef), _ptr(ws), need, _stream(x))
+
+    def bn_relu_maxpool_backward(self, grad_pooled, argmax, x, pooled, gamma, save_invstd,
+                                 fwd_coef, dx, dgamma, dbeta):
+        _check(grad_pooled, argmax, x, pooled, dx); _f32(grad_pooled, x, pooled, dx)
+        b, c, m, ns = x.shape
+        assert tuple(grad_pooled.shape) == (b, c, m) and dx.shape == x.shape
+        with torch.cuda.device(x.device):
+            ws, need = _bn_pool_ws(x)
+            opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+            _lib.call("nesie_bn_relu_maxpool_backward", b, c, m, ns, _ptr(grad_pooled),
+                      _ptr(argmax), _ptr(x), _ptr(pooled), opt(gamma), _ptr(save_invstd),
+                      _ptr(fwd_coef), _ptr(dx), opt(dgamma), opt(dbeta), _ptr(ws), need,
+                      _stream(x))
+
+
+def _bn_pool_ws(x):
+    b, c, m, ns = x.shape
+    need = _lib.load().nesie_bn_workspace_bytes(b, c, m * ns)
+    return torch.empty(max(need, 16), dtype=torch.uint8, device=x.device), need
+
+
+class HipKernels(_BNPoolMixin):
     """libnesie_hip.so, asynchronous on torch's current HIP stream."""
 
     name = "hip"

@@ -76,6 +76,37 @@ class BNReLUTrain(Function):
         return dx, dgamma, dbeta, None, None, None, None, None, d_row_bias
 
 
+class BNReLUMaxPoolTrain(Function):
+    """x (B, C, M, ns) -> max_ns relu(bn(x)) (B, C, M): the tail of a set-abstraction MLP
+    (ConvModule's BN2d + ReLU, then F.max_pool2d([1, ns]): point_sa_module.py:277-289,
+    136-158) without materialising the normalised tensor, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        b, c, m, _ = x.shape
+        pooled = x.new_empty(b, c, m)
+        argmax = torch.empty(b, c, m, dtype=torch.uint8, device=x.device)
+        save_mean, save_invstd = x.new_empty(c), x.new_empty(c)
+        fwd_coef = x.new_empty(c, 4)
+        backend_for(x).bn_relu_maxpool_forward(x, weight, bias, running_mean, running_var,
+                                               momentum, eps, pooled, argmax, save_mean,
+                                               save_invstd, fwd_coef)
+        ctx.save_for_backward(x, pooled, argmax, weight, save_invstd, fwd_coef)
+        ctx.mark_non_differentiable(argmax)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        x, pooled, argmax, weight, save_invstd, fwd_coef = ctx.saved_tensors
+        c = x.shape[1]
+        dx = torch.empty_like(x)
+        dgamma, dbeta = x.new_empty(c), x.new_empty(c)
+        backend_for(x).bn_relu_maxpool_backward(g.contiguous(), argmax, x, pooled, weight,
+                                                save_invstd, fwd_coef, dx, dgamma, dbeta)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
 class _FusedBNReLU:
     """Mixin over nn.BatchNorm{1,2}d: ``relu=True`` folds the activation into the norm."""
 
@@ -102,6 +133,25 @@ class _FusedBNReLU:
                                      row_bias)
         y = super().forward(x)
         return F.relu(y) if self.fuse_relu else y
+
+
+    def forward_max_pool(self, x):
+        """relu(bn(x)) followed by the max over the last axis of x (B, C, M, ns) -> (B, C, M),
+        in one fused pass when the native training path applies; else the two-step form."""
+        backend = backend_for(x)
+        ns = x.shape[-1]
+        native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
+                  and self.affine and self.track_running_stats and self.momentum is not None
+                  and self.fuse_relu and x.dim() == 4 and 4 <= ns <= 64 and ns & (ns - 1) == 0)
+        if not native:
+            from .pool import group_max_pool
+            return group_max_pool(self.forward(x))
+        if _counter_sink is not None:
+            _counter_sink.append(self.num_batches_tracked)
+        else:
+            self.num_batches_tracked.add_(1)
+        return BNReLUMaxPoolTrain.apply(x, self.weight, self.bias, self.running_mean,
+                                        self.running_var, self.momentum, self.eps)
 
 
 class FusedBNReLU1d(_FusedBNReLU, nn.BatchNorm1d):

@@ -205,6 +205,19 @@ class BasePointSAModule(nn.Module):
             raise NotImplementedError
         return new_features.squeeze(-1).contiguous()
 
+    def _mlp_and_pool(self, mlp, grouped):
+        """Shared MLP then pooling; with max pooling the last layer's BN + ReLU + max is one
+        fused op (the normalised (B, C, M, ns) tensor is never written)."""
+        layers = list(mlp)
+        last = layers[-1] if layers else None
+        if (self.pool_mod == 'max' and isinstance(last, ConvModule) and last.act_fused
+                and isinstance(last.norm, FusedBNReLU2d)):
+            x = grouped
+            for layer in layers[:-1]:
+                x = layer(x)
+            return last.norm.forward_max_pool(last.conv(x)).contiguous()
+        return self._pool_features(mlp(grouped))
+
     def sample_and_group_indices(self, points_xyz):
         """The weight-independent half of forward(): FPS indices, sampled centres and the
         ball-query indices of every scale.  A training loop can run this for the NEXT batch
@@ -225,9 +238,7 @@ class BasePointSAModule(nn.Module):
                                                    idx=precomputed['group_idx'][i])
             else:
                 grouped_results = self.groupers[i](points_xyz, new_xyz, features)
-            new_features = self.mlps[i](grouped_results)
-            new_features = self._pool_features(new_features)
-            new_features_list.append(new_features)
+            new_features_list.append(self._mlp_and_pool(self.mlps[i], grouped_results))
         return new_xyz, torch.cat(new_features_list, dim=1), indices
 
 

@@ -409,3 +409,86 @@ def test_lhs_nms_bit_exact(oracle_kernels, hip_device, k):
     kernels.backend_for(got).lhs_nms_samecls(more.contiguous().to(hip_device), 0.25, got)
     eq(got, want)
     assert 0 < int(want.sum()) < want.numel() or k == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 128, 64), (3, 8, 70, 16), (2, 5, 33, 4), (1, 7, 9, 32)])
+def test_fused_bn_relu_maxpool_matches_two_step(hip_device, shape):
+    """nesie_bn_relu_maxpool_* (tail of an SA MLP: BN2d + ReLU + F.max_pool2d([1, ns]),
+    point_sa_module.py:277-289, 136-158) vs the separate norm and pool kernels, which are
+    themselves pinned against ATen above: same arithmetic per element, so values and arg-max
+    agree exactly and gradients to summation order."""
+    import copy
+    from nesie_amd.mmdet3d_ops.norm import FusedBNReLU2d
+    from nesie_amd.mmdet3d_ops.pool import group_max_pool
+    g = torch.Generator().manual_seed(sum(shape))
+    B, C, M, ns = shape
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(hip_device)
+    go = torch.randn(B, C, M, generator=g).to(hip_device)
+    a = FusedBNReLU2d(C, relu=True).to(hip_device)
+    with torch.no_grad():
+        a.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        a.weight[0] = -0.7            # a negative scale flips which element is the max
+        a.bias.copy_(torch.randn(C, generator=g) * 0.5)
+        a.bias[1] = -50.0             # a channel whose activations are all clipped to zero
+    b = copy.deepcopy(a)
+    x1 = x.clone().requires_grad_(True)
+    y1 = a.forward_max_pool(x1)
+    y1.backward(go)
+    x2 = x.clone().requires_grad_(True)
+    y2 = group_max_pool(b(x2))
+    y2.backward(go)
+    assert torch.equal(y1, y2)
+    assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+    assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+    scale = x2.grad.abs().max().item()
+    assert (x1.grad - x2.grad).abs().max().item() <= 1e-5 * max(scale, 1e-3)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-5)
+    assert y1[:, 1].abs().max() == 0 and x1.grad[:, 1].abs().max() == 0
+
+
+@pytest.mark.parametrize("cout,cin,p,b", [(64, 4, 1024, 2), (128, 64, 640, 2), (256, 259, 384, 2),
+                                         (18, 128, 100, 3), (70, 33, 257, 1), (128, 131, 4096, 2)])
+def test_mlp_layer_forward_matches_fp64(hip_device, cout, cin, p, b):
+    """nesie_mlp_layer_forward (1x1 conv on the matrix cores with the previous layer's folded
+    BN + ReLU applied on load and this layer's batch statistics from the epilogue) and
+    nesie_mlp_stat_finalize vs an fp64 evaluation of ConvModule's conv -> BN statistics
+    (point_sa_module.py:277-289).  north_star tolerance 1e-4."""
+    from nesie_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cout + cin + p)
+    x = torch.randn(b, cin, p, generator=g).to(hip_device)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(hip_device)
+    coef = torch.rand(cin, 4, generator=g).to(hip_device) + 0.5
+    coef[:, 1] -= 1.0
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(hip_device)
+    beta = torch.randn(cout, generator=g).to(hip_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    for use_coef in (False, True):
+        y = torch.full((b, cout, p), float('nan'), device=hip_device)
+        nparts = lib.nesie_mlp_stat_partials(b, cout, p)
+        part = torch.zeros(nparts, cout, 2, device=hip_device)
+        _lib.call('nesie_mlp_layer_forward', b, cin, cout, p, x.data_ptr(), cin * p,
+                  w.data_ptr(), coef.data_ptr() if use_coef else 0, 1, y.data_ptr(),
+                  part.data_ptr(), stream)
+        a = x.double()
+        if use_coef:
+            a = torch.relu(a * coef[:, 0].double().view(1, -1, 1) + coef[:, 1].double().view(1, -1, 1))
+        want = torch.matmul(w.double().unsqueeze(0), a)
+        tol = 1e-4 * max(1.0, want.abs().max().item())
+        assert (y.double() - want).abs().max().item() <= tol
+        rm, rv = torch.zeros(cout, device=hip_device), torch.ones(cout, device=hip_device)
+        out = torch.empty(cout, 4, device=hip_device)
+        _lib.call('nesie_mlp_stat_finalize', cout, nparts, float(b * p), part.data_ptr(),
+                  gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
+                  out.data_ptr(), stream)
+        mean, var = want.mean((0, 2)), want.var((0, 2), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        torch.testing.assert_close(out[:, 2].double(), mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out[:, 3].double(), invstd, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out[:, 0].double(), gamma.double() * invstd, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out[:, 1].double(), beta.double() - mean * gamma.double() * invstd,
+                                   rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-4, atol=1e-6)
+        n = b * p
+        torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-4, atol=1e-6)
