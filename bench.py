@@ -270,14 +270,20 @@ def main():
                                      cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
                                      graph=bool(args.graph), workload=args.workload)
     hip = kernels.backend_for(torch.empty(1, device=device))
-    # dominant hand-written kernel (profiles/): D-FPS over the 40 000-point scene
+    # longest single launch: D-FPS over the 40 000-point scene (latency-bound; in graph mode it
+    # runs on a side stream under the previous step, off the critical path)
     fps_timer = KernelTimer(hip, 'furthest_point_sampling_wrapper',
                             lambda b, n, m, *_: n == NUM_POINTS)
-    # largest streaming launches: BatchNorm+ReLU over the SA1 output (B,128,2048,64)
+    # largest streaming launches on the critical path: the SA1 MLP tail (B,128,2048,64) through
+    # the fused norm+ReLU+max-pool kernels, and the (B,64,2048,64) layers through norm+ReLU
     big = args.batch * 128 * 2048 * 64
-    bn_fwd_timer = KernelTimer(hip, 'bn_relu_forward', lambda x, *_: x.numel() == big)
-    bn_bwd_timer = KernelTimer(hip, 'bn_relu_backward', lambda dy, *_: dy.numel() == big)
-    timers = (fps_timer, bn_fwd_timer, bn_bwd_timer)
+    mid = args.batch * 64 * 2048 * 64
+    pool_fwd_timer = KernelTimer(hip, 'bn_relu_maxpool_forward', lambda x, *_: x.numel() == big)
+    pool_bwd_timer = KernelTimer(hip, 'bn_relu_maxpool_backward',
+                                 lambda g, a, x, *_: x.numel() == big)
+    bn_fwd_timer = KernelTimer(hip, 'bn_relu_forward', lambda x, *_: x.numel() == mid)
+    bn_bwd_timer = KernelTimer(hip, 'bn_relu_backward', lambda dy, *_: dy.numel() == mid)
+    timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer)
 
     def sync():
         if world > 1:
@@ -335,30 +341,40 @@ def main():
                        'hip_graph': bool(args.graph),
                        'index_chain_pipelined': bool(args.graph) and args.workload == 'pretrain',
                        'grad_allreduce_bytes': bucket.nbytes()},
-            'roofline': {'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048, latency-bound: '
-                                   '2047 dependent rounds)',
-                         'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS if achieved else None,
-                         'traffic': None, 'avg_launch_ms': fps_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes},
         }
-        # HBM-streaming kernels, priced on their largest launch (tensor = 537 MB at B = 8,
-        # far beyond the 256 MB Infinity Cache): forward = stats + apply = 3 tensor passes,
-        # backward = reduce + apply = 5 passes
-        tensor_bytes = big * 4
-        def _stream(name, ms, passes):
+        # HBM-streaming kernels, priced on their largest launches (537 MB / 268 MB tensors at
+        # B = 8, beyond the 256 MB Infinity Cache).  Algorithmic bytes:
+        #   SA tail backward = gather sums (pooled-size) + read x + write dx      = 2 passes
+        #   SA tail forward  = stats read + pool read                             = 2 passes
+        #   norm+ReLU fwd    = stats read + apply read/write                      = 3 passes
+        #   norm+ReLU bwd    = reduce (dy, y) + apply (dy, x -> dx)               = 5 passes
+        def _stream(name, ms, passes, tensor_bytes, extra=0):
             if not ms:
                 return None
-            a = passes * tensor_bytes / (ms * 1e-3) / 1e9
+            nbytes = passes * tensor_bytes + extra
+            a = nbytes / (ms * 1e-3) / 1e9
             return {'kernel': name, 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'avg_launch_ms': ms,
-                    'algorithmic_bytes_per_launch': passes * tensor_bytes}
+                    'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'traffic': None,
+                    'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes}
+        pooled_bytes = args.batch * 128 * 2048 * 4
+        out['roofline'] = _stream(
+            'nesie::bn_pool_bwd_reduce_kernel + bn_pool_bwd_apply_kernel<16> (SA1 MLP tail, '
+            'x (B,128,2048,64)): largest launch on the critical path', pool_bwd_timer.mean_ms(),
+            2, big * 4, extra=3 * pooled_bytes + pooled_bytes // 4)
         out['roofline_streaming'] = [
-            _stream('nesie::bn_stats_kernel + bn_apply_kernel<relu> (B,128,2048,64)',
-                    bn_fwd_timer.mean_ms(), 3),
-            _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,128,2048,64)',
-                    bn_bwd_timer.mean_ms(), 5)]
+            _stream('nesie::bn_stats_kernel + bn_pool_fwd_kernel<16> (B,128,2048,64)',
+                    pool_fwd_timer.mean_ms(), 2, big * 4, extra=pooled_bytes + pooled_bytes // 4),
+            _stream('nesie::bn_stats_kernel + bn_apply_kernel<relu> (B,64,2048,64)',
+                    bn_fwd_timer.mean_ms(), 3, mid * 4),
+            _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,64,2048,64)',
+                    bn_bwd_timer.mean_ms(), 5, mid * 4)]
+        out['roofline_latency_bound'] = {
+            'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048: 2047 dependent rounds; '
+                      'longest single launch, overlapped with the previous step on a side '
+                      'stream in graph mode)',
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
+            'avg_launch_ms': fps_ms, 'algorithmic_bytes_per_launch': alg_bytes}
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -28,7 +28,9 @@ SIGNATURES = {
     "nesie_three_nn_wrapper": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "nesie_three_interpolate_segmented": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                                 _P],
+    "nesie_blend_conv_backward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_group_max_pool_forward": [ctypes.c_longlong, _I, _P, _P, _P, _P],

@@ -13,6 +13,7 @@
 // are used here.  Ties keep the earlier index in the better slot (strict <).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace nesie {
 
@@ -94,25 +95,34 @@ __global__ __launch_bounds__(TI_BLOCK) void three_interpolate_kernel(
   }
 }
 
-// Same blend, written straight into the layout the side-aware quality head consumes:
-// query p = (k, s, g) of n = K * segs * seg_len (proposal, face, grid point) goes to
-// out[b, s, c_offset + ch, k * seg_len + g] of out (B, segs, c_total, K * seg_len), i.e. one
-// (c_total, K, seg_len) block per face with c_offset leading channels left for the caller
-// (relative xyz).  Replaces interpolate -> view -> cat -> split -> contiguous
-// (side_pooling_module.py:226-243, 304-313).  The features come POINT-major, points_t
-// (B, M, C), so the three taps of a query are three dense 256-byte rows per 64 channels
-// (lane = channel) instead of 3 * 64 scattered words; a 64 x 64 tile is turned through LDS
-// and leaves as dense rows along the query axis (lane = query).
+// ---- the quality head's grid features, blended straight into their consumer's layout ----
+// Query p = (k, s, g) of n = K * segs * seg_len (proposal, face, grid point) goes to
+// out[s, b, c_offset + ch, k * seg_len + g] of out (segs, B, c_total, K * seg_len): one
+// contiguous (B, c_total, K, seg_len) block per face -- what the reference reaches with
+// interpolate -> view -> cat -> split -> contiguous (side_pooling_module.py:226-243, 304-313).
+//
+//   out = w0 * T[j0] + w1 * T[j1] + w2 * T[j2]  (+ wx . rel)
+//
+// T is a POINT-major table (B, M, pitch): the three taps of a query are dense 256-byte rows
+// per 64 channels (lane = channel); a 64 x 64 tile turns through LDS and leaves as dense rows
+// along the query axis (lane = query).  With T = the seed features this is three_interpolate
+// in the segmented layout.  With T = F . W_f^T (the seed features already multiplied by the
+// feature columns of a MiniPointNet's first 1x1 conv, one column block per face: seg_off) and
+// wx = that conv's three xyz columns, it IS the first conv's output,
+//   W . cat[rel_xyz, blend(F)] = W_xyz . rel_xyz + blend(W_f . F)      (the conv is linear),
+// at ~1/250 of the multiply-adds and without ever storing the 259-channel feature tensor.
 constexpr int TS_Q = 64;  // queries per workgroup (one tile side; per_seg % 64 == 0)
 
-__global__ __launch_bounds__(256) void three_interpolate_segmented_kernel(
-    int c, int m, int n, int segs, int seg_len, int c_total, int c_offset,
-    const float *__restrict__ points_t, const int *__restrict__ idx,
-    const float *__restrict__ weight, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void blend_fwd_kernel(
+    int c, int m, int n, int segs, int seg_len, int c_total, int c_offset, int pitch,
+    int seg_off, const float *__restrict__ table, const int *__restrict__ idx,
+    const float *__restrict__ weight, const float *__restrict__ rel,
+    const float *__restrict__ wx, float *__restrict__ out) {
   __shared__ float tile[64][TS_Q + 1];
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
-  const int bi = blockIdx.y;
+  __shared__ float sr[TS_Q][3];
+  const int bi = blockIdx.y, nb = gridDim.y;
   const int q0 = blockIdx.x * TS_Q;  // output order: s * per_seg + k * seg_len + g
   const int per_seg = n / segs;
   const int sg = q0 / per_seg, r0 = q0 - sg * per_seg;
@@ -126,22 +136,32 @@ __global__ __launch_bounds__(256) void three_interpolate_segmented_kernel(
       int j = idx[p * 3 + t];
       sj[threadIdx.x][t] = j < 0 ? 0 : (j >= m ? m - 1 : j);
       sw[threadIdx.x][t] = weight[p * 3 + t];
+      sr[threadIdx.x][t] = rel ? rel[p * 3 + t] : 0.f;
     }
   }
   __syncthreads();
-  const float *feat = points_t + (size_t)bi * m * c;
-  float *dst = out + (((size_t)bi * segs + sg) * c_total + c_offset) * per_seg + r0;
+  const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off;
+  float *dst = out + (((size_t)sg * nb + bi) * c_total + c_offset) * per_seg + r0;
   for (int c0 = 0; c0 < c; c0 += 64) {
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (wx) {
+      const float *wr = wx + ((size_t)sg * c + c0 + lane) * 3;
+      x0 = wr[0]; x1 = wr[1]; x2 = wr[2];
+    }
     // wave wv blends queries wv*16 .. wv*16+15 for channels c0 .. c0+63 (lane = channel)
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int qi = wv * 16 + i;
       const float *f = feat + c0 + lane;
-      const float a0 = f[(size_t)sj[qi][0] * c], a1 = f[(size_t)sj[qi][1] * c],
-                  a2 = f[(size_t)sj[qi][2] * c];
+      const float a0 = f[(size_t)sj[qi][0] * pitch], a1 = f[(size_t)sj[qi][1] * pitch],
+                  a2 = f[(size_t)sj[qi][2] * pitch];
       // products rounded one by one, summed left to right (three_interpolate_cuda.cu:33-34)
-      tile[lane][qi] = __fadd_rn(__fadd_rn(__fmul_rn(sw[qi][0], a0), __fmul_rn(sw[qi][1], a1)),
-                                 __fmul_rn(sw[qi][2], a2));
+      float v = __fadd_rn(__fadd_rn(__fmul_rn(sw[qi][0], a0), __fmul_rn(sw[qi][1], a1)),
+                          __fmul_rn(sw[qi][2], a2));
+      if (wx)
+        v = __fadd_rn(__fadd_rn(__fadd_rn(v, __fmul_rn(x0, sr[qi][0])), __fmul_rn(x1, sr[qi][1])),
+                      __fmul_rn(x2, sr[qi][2]));
+      tile[lane][qi] = v;
     }
     __syncthreads();
     // wave wv stores channels c0 + wv*16 .. +15 (lane = query): dense 256-byte rows
@@ -155,34 +175,190 @@ __global__ __launch_bounds__(256) void three_interpolate_segmented_kernel(
 }
 
 // Any shape (c % 64 != 0 or per_seg % 64 != 0): one thread per output-order query.
-__global__ __launch_bounds__(TI_BLOCK) void three_interpolate_segmented_generic_kernel(
-    int c, int m, int n, int segs, int seg_len, int c_total, int c_offset,
-    const float *__restrict__ points_t, const int *__restrict__ idx,
-    const float *__restrict__ weight, float *__restrict__ out) {
+__global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
+    int c, int m, int n, int segs, int seg_len, int c_total, int c_offset, int pitch,
+    int seg_off, const float *__restrict__ table, const int *__restrict__ idx,
+    const float *__restrict__ weight, const float *__restrict__ rel,
+    const float *__restrict__ wx, float *__restrict__ out) {
   const int q = blockIdx.x * TI_BLOCK + threadIdx.x;
   const int c0 = blockIdx.y * TI_CH;
-  const int bi = blockIdx.z;
+  const int bi = blockIdx.z, nb = gridDim.z;
   if (q >= n) return;
   const int per_seg = n / segs;
   const int sg = q / per_seg, r = q - sg * per_seg;
   const int k = r / seg_len, g = r - k * seg_len;
-  const int p = (k * segs + sg) * seg_len + g;
-  const int *ix = idx + ((size_t)bi * n + p) * 3;
-  const float *w = weight + ((size_t)bi * n + p) * 3;
-  int j0 = ix[0], j1 = ix[1], j2 = ix[2];
+  const size_t p = (size_t)bi * n + (size_t)(k * segs + sg) * seg_len + g;
+  int j0 = idx[p * 3], j1 = idx[p * 3 + 1], j2 = idx[p * 3 + 2];
   j0 = j0 < 0 ? 0 : (j0 >= m ? m - 1 : j0);
   j1 = j1 < 0 ? 0 : (j1 >= m ? m - 1 : j1);
   j2 = j2 < 0 ? 0 : (j2 >= m ? m - 1 : j2);
-  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  const float w0 = weight[p * 3], w1 = weight[p * 3 + 1], w2 = weight[p * 3 + 2];
+  const float rx = rel ? rel[p * 3] : 0.f, ry = rel ? rel[p * 3 + 1] : 0.f,
+              rz = rel ? rel[p * 3 + 2] : 0.f;
   const int cend = c - c0 < TI_CH ? c - c0 : TI_CH;
-  const float *feat = points_t + (size_t)bi * m * c + c0;
-  float *dst = out + (((size_t)bi * segs + sg) * c_total + c_offset + c0) * per_seg + r;
+  const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off + c0;
+  float *dst = out + (((size_t)sg * nb + bi) * c_total + c_offset + c0) * per_seg + r;
 #pragma unroll
   for (int i = 0; i < TI_CH; ++i) {
     if (i < cend) {
-      dst[(size_t)i * per_seg] = __fadd_rn(
-          __fadd_rn(__fmul_rn(w0, feat[(size_t)j0 * c + i]), __fmul_rn(w1, feat[(size_t)j1 * c + i])),
-          __fmul_rn(w2, feat[(size_t)j2 * c + i]));
+      float v = __fadd_rn(
+          __fadd_rn(__fmul_rn(w0, feat[(size_t)j0 * pitch + i]), __fmul_rn(w1, feat[(size_t)j1 * pitch + i])),
+          __fmul_rn(w2, feat[(size_t)j2 * pitch + i]));
+      if (wx) {
+        const float *wr = wx + ((size_t)sg * c + c0 + i) * 3;
+        v = __fadd_rn(__fadd_rn(__fadd_rn(v, __fmul_rn(wr[0], rx)), __fmul_rn(wr[1], ry)),
+                      __fmul_rn(wr[2], rz));
+      }
+      dst[(size_t)i * per_seg] = v;
+    }
+  }
+}
+
+// Backward of the blended first conv: d_table[b, j, s*seg_off + ch] += sum over the queries
+// of face s whose tap t lands on seed j of w_t * dy, and d_wx[s, ch, :] += sum_q dy * rel.
+// It replaces the reference's atomicAdd scatter (three_interpolate_cuda.cu:61-84) together
+// with the first conv's weight-gradient GEMM.
+// Measured here (tools/clk/lds_atomic.hip): ds_add_f32 sustains 0.32 lanes/clk/CU and
+// ds_add_u32/u64 0.93, i.e. 0.2-0.57 T adds/s chip-wide, and global float atomics ~1.3 TB/s of
+// added bytes; this scatter has 0.5 G adds.  So the number of adds must shrink: lane = channel (the
+// mirror image of blend_fwd_kernel: dy tiles turn through LDS), a wave walks a run of
+// consecutive queries and keeps the last BL_SLOTS destinations (seed, running sum) in
+// REGISTERS -- the grid points of one face share their few nearest seeds, so most taps hit a
+// live slot -- and a slot leaves as ONE 256-byte global_atomic_add_f32 row only when it is
+// evicted.  Keys are wave-uniform (scalar compares, no divergence).  d_table and d_wx must be
+// zero on entry.
+constexpr int BL_SLOTS = 8;
+constexpr int BL_RUN = 128;  // consecutive queries per workgroup
+constexpr int BL_MAX_FACES = 8;
+
+struct BlendFaces { const float *dy[BL_MAX_FACES]; };  // per face: (B, c, per_seg) or NULL
+
+// CPT = c / 64 channels per lane: a wave covers ALL c channels of its quarter of the tile's
+// queries (16 consecutive ones = one face of one proposal when seg_len = 16), so the per-tap
+// slot bookkeeping, which is scalar work, is paid once per c channels.
+template <int CPT>
+__global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
+    int m, int n, int segs, int seg_len, int pitch, int seg_off, BlendFaces faces,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    const float *__restrict__ rel, float *__restrict__ d_table, float *__restrict__ d_wx) {
+  constexpr int C = CPT * 64;
+  __shared__ float tile[C * (TS_Q + 1)];
+  __shared__ int sj[TS_Q][3];
+  __shared__ float sw[TS_Q][3];
+  __shared__ float sr[TS_Q][3];
+  const int bi = blockIdx.y, sg = blockIdx.z;
+  const float *dy = faces.dy[sg];
+  if (!dy) return;
+  const int per_seg = n / segs;
+  const int run0 = blockIdx.x * BL_RUN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float *src = dy + (size_t)bi * C * per_seg;
+  float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
+  // slot keys: lane i (< BL_SLOTS) of `keys` holds the seed of slot i, -1 = empty
+  int keys = -1;
+  float sum[BL_SLOTS][CPT];
+#pragma unroll
+  for (int i = 0; i < BL_SLOTS; ++i)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) sum[i][e] = 0.f;
+  int rr = 0;
+  float dx[CPT][3];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) dx[e][0] = dx[e][1] = dx[e][2] = 0.f;
+  const int run_end = run0 + BL_RUN < per_seg ? run0 + BL_RUN : per_seg;
+  for (int r0 = run0; r0 < run_end; r0 += TS_Q) {
+    __syncthreads();
+    if (threadIdx.x < TS_Q) {
+      const int r = r0 + threadIdx.x;
+      const int k = r / seg_len, g = r - k * seg_len;
+      const size_t p = (size_t)bi * n + (size_t)(k * segs + sg) * seg_len + g;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        int j = idx[p * 3 + t];
+        sj[threadIdx.x][t] = j < 0 ? 0 : (j >= m ? m - 1 : j);
+        sw[threadIdx.x][t] = weight[p * 3 + t];
+        sr[threadIdx.x][t] = rel ? rel[p * 3 + t] : 0.f;
+      }
+    }
+    // dy tile: C rows x 64 queries, dense 256-byte row reads (lane = query)
+    // (16 independent loads in flight per wave before the first LDS store)
+#pragma unroll
+    for (int rb = 0; rb < C / 4; rb += 16) {
+      float t16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        t16[u] = src[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tile[((rb + u) * 4 + wv) * (TS_Q + 1) + lane] = t16[u];
+    }
+    __syncthreads();
+    for (int q0 = wv * 16; q0 < wv * 16 + 16; q0 += 4) {
+      // four queries' operands at once (the LDS reads overlap; all but v are broadcasts)
+      float v[4][CPT], ww[4][3], rl[4][3];
+      int jj[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) v[u][e] = tile[(e * 64 + lane) * (TS_Q + 1) + q0 + u];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          jj[u][t] = sj[q0 + u][t]; ww[u][t] = sw[q0 + u][t]; rl[u][t] = sr[q0 + u][t];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+          dx[e][0] += v[u][e] * rl[u][0]; dx[e][1] += v[u][e] * rl[u][1];
+          dx[e][2] += v[u][e] * rl[u][2];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int j = __builtin_amdgcn_readfirstlane(jj[u][t]);
+          const unsigned long long hit = __ballot(keys == j) & (BL_SLOTS >= 64 ? ~0ull : ((1ull << BL_SLOTS) - 1ull));
+          int slot;
+          if (hit) {
+            slot = __builtin_ctzll(hit);
+          } else {  // evict the round-robin slot: CPT 256-byte rows of adds
+            slot = rr;
+            const int old = __builtin_amdgcn_readlane(keys, slot);
+            if (old >= 0) {
+              float o[CPT];
+#pragma unroll
+              for (int i = 0; i < BL_SLOTS; ++i)
+                if (slot == i) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) { o[e] = sum[i][e]; sum[i][e] = 0.f; }
+                }
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)old * pitch + e * 64, o[e]);
+            }
+            keys = lane == slot ? j : keys;
+            rr = (rr + 1) & (BL_SLOTS - 1);
+          }
+#pragma unroll
+          for (int i = 0; i < BL_SLOTS; ++i)
+            if (slot == i) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) sum[i][e] += v[u][e] * ww[u][t];
+            }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BL_SLOTS; ++i) {
+    const int k = __builtin_amdgcn_readlane(keys, i);
+    if (k >= 0) {
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)k * pitch + e * 64, sum[i][e]);
+    }
+  }
+  if (d_wx) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      float *dw = d_wx + ((size_t)sg * C + e * 64 + lane) * 3;
+      atomicAdd(dw + 0, dx[e][0]); atomicAdd(dw + 1, dx[e][1]); atomicAdd(dw + 2, dx[e][2]);
     }
   }
 }
@@ -247,26 +423,63 @@ extern "C" int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
   return check_launch(W);
 }
 
-extern "C" int nesie_three_interpolate_segmented(int b, int c, int m, int n,
-                                                 const float *points_t, const int *idx,
-                                                 const float *weight, float *out, int segs,
-                                                 int seg_len, int c_total, int c_offset,
-                                                 void *stream) {
-  const char *W = "three_interpolate_segmented";
+static int blend_check(const char *W, int b, int c, int m, int n, int segs, int seg_len,
+                       int pitch, int seg_off) {
   NESIE_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0 && segs >= 1 && seg_len >= 1, W);
-  NESIE_REQUIRE(c_offset >= 0 && c_offset + c <= c_total && n % (segs * seg_len) == 0, W);
-  if (b == 0 || c == 0 || n == 0) return NESIE_OK;
-  NESIE_REQUIRE(m >= 1 && points_t && idx && weight && out, W);
+  NESIE_REQUIRE(n % (segs * seg_len) == 0 && seg_off >= 0, W);
+  NESIE_REQUIRE(pitch >= (long long)(segs - 1) * seg_off + c, W);
   NESIE_REQUIRE(b <= 65535 && cdiv(c, TI_CH) <= 65535, W);
+  return NESIE_OK;
+}
+
+extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float *table,
+                                        int pitch, int seg_off, const int *idx,
+                                        const float *weight, const float *rel, const float *wx,
+                                        float *out, int segs, int seg_len, int c_total,
+                                        int c_offset, void *stream) {
+  const char *W = "blend_conv_forward";
+  int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
+  if (st) return st;
+  NESIE_REQUIRE(c_offset >= 0 && c_offset + c <= c_total && (wx == nullptr) == (rel == nullptr), W);
+  if (b == 0 || c == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 1 && table && idx && weight && out, W);
   if (c % 64 == 0 && (n / segs) % TS_Q == 0)
-    hipLaunchKernelGGL(three_interpolate_segmented_kernel, dim3(n / TS_Q, b), dim3(256), 0,
-                       (hipStream_t)stream, c, m, n, segs, seg_len, c_total, c_offset, points_t,
-                       idx, weight, out);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(n / TS_Q, b), dim3(256), 0, (hipStream_t)stream, c,
+                       m, n, segs, seg_len, c_total, c_offset, pitch, seg_off, table, idx, weight,
+                       rel, wx, out);
   else
-    hipLaunchKernelGGL(three_interpolate_segmented_generic_kernel,
-                       dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b), dim3(TI_BLOCK), 0,
-                       (hipStream_t)stream, c, m, n, segs, seg_len, c_total, c_offset, points_t,
-                       idx, weight, out);
+    hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b),
+                       dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, segs, seg_len, c_total,
+                       c_offset, pitch, seg_off, table, idx, weight, rel, wx, out);
+  return check_launch(W);
+}
+
+extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n,
+                                         const float *const *dy_faces, int pitch, int seg_off,
+                                         const int *idx, const float *weight, const float *rel,
+                                         float *d_table, float *d_wx, int segs, int seg_len,
+                                         void *stream) {
+  const char *W = "blend_conv_backward";
+  int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
+  if (st) return st;
+  NESIE_REQUIRE(segs <= BL_MAX_FACES && dy_faces, W);
+  if (b == 0 || c == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 1 && idx && weight && d_table, W);
+  NESIE_REQUIRE((d_wx == nullptr) || rel, W);
+  const int per_seg = n / segs;
+  if (c % 64 != 0 || c > 256 || per_seg % TS_Q != 0) {
+    set_error("%s: c %d (needs 64, 128, 192 or 256) / %d queries per face (needs a multiple "
+              "of %d)", W, c, per_seg, TS_Q);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  BlendFaces faces;
+  for (int i = 0; i < BL_MAX_FACES; ++i) faces.dy[i] = i < segs ? dy_faces[i] : nullptr;
+  const dim3 grid(cdiv(per_seg, BL_RUN), b, segs);
+#define L(N) hipLaunchKernelGGL(blend_bwd_rows_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, \
+                                m, n, segs, seg_len, pitch, seg_off, faces, idx, weight, rel,     \
+                                d_table, d_wx)
+  if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
+#undef L
   return check_launch(W);
 }
 

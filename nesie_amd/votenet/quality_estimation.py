@@ -8,6 +8,7 @@ from torch import nn
 
 from ..mmdet3d_ops.norm import FusedBNReLU1d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d
+from ..kernels import backend_for
 from .side_pooling import MiniPointNet, SidePooling
 
 
@@ -67,11 +68,17 @@ class QualityEstimation(SidePooling):
         origin_xyz, origin_features = self.extract_features(end_points)
         whole_grid = self.generate_grid(size)
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
-        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
+        fused = backend_for(origin_xyz).name == 'hip'
+        if fused:
+            side_c0 = self.first_conv_through_blend(self.mlps_before[:6], origin_xyz,
+                                                    origin_features, side_grid, center)
+        else:
+            side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
         side_scores, side_features = [], []
         for i in range(6):
-            f = self.mlps_before[i](side_feats[:, i])
+            f = self.mlps_before[i](conv0_out=side_c0[i]) if fused \
+                else self.mlps_before[i](side_feats[i])
             f = torch.cat((f, dist_feature[i]), dim=1)
             side_features.append(f)
             side_scores.append(self.mlps_head[i](f))

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..mmdet3d_ops import three_interpolate_segmented, three_nn
+from ..kernels import backend_for
+from ..mmdet3d_ops import blend_conv, three_interpolate_segmented, three_nn
 from ..mmdet3d_ops.pool import group_max_pool
 from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d, pointwise_conv
@@ -40,8 +41,11 @@ class MiniPointNet(nn.Module):
             PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), FusedBNReLU2d(hide_dim),
             nn.Identity(), PointwiseConv2d(hide_dim, feature_dim, 1))
 
-    def forward(self, points):
-        """Same function as the reference's
+    def forward(self, points=None, conv0_out=None):
+        """``points`` (B,C,K,G) grid features, or ``conv0_out`` (B,H,K,G) = the first conv
+        already applied through the blend (SidePooling._first_conv_through_blend).
+
+        Same function as the reference's
             f = first_conv(x); g = max_G f; y = second_conv(cat[g expanded, f]); out = max_G y
         evaluated without materialising the (B, 2*128, K, G) concatenation: the first 1x1 conv
         of ``second_conv`` is linear, so  W @ cat[g, f] = W[:, :H] @ g + W[:, H:] @ f  -- the
@@ -51,7 +55,9 @@ class MiniPointNet(nn.Module):
         Differences from the concatenated form are summation-order rounding only."""
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
-        c = pointwise_conv(bn0(conv0(points)), conv3.weight)          # f without its bias
+        if conv0_out is None:
+            conv0_out = conv0(points)
+        c = pointwise_conv(bn0(conv0_out), conv3.weight)              # f without its bias
         g = group_max_pool(c)                                          # (B, H, K): max_G f - b
         half = conv3.out_channels
         w = sconv0.weight.reshape(sconv0.out_channels, -1)
@@ -141,16 +147,12 @@ class SidePooling(nn.Module):
     def grid_for_bbox(self, whole_grid, center, heading):
         return self._to_scene(whole_grid, center, heading)
 
-    def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
-        """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
-
-        The grid points of a proposal come as ``segs`` = S consecutive groups of G (the six
-        faces, or one group for the box grid); the result holds one contiguous (3+C, K, G)
-        block per group, i.e. what the reference reaches with
-        cat([rel_xyz, interpolated]) -> split(G, dim=-1) -> .contiguous() (:304-313)."""
+    def _blend_taps(self, origin_xyz, whole_grid, center):
+        """3-NN of every grid point among the seeds -> idx (B,n,3) int32, inverse-distance
+        weights (B,n,3), grid xyz relative to the proposal centre (B,n,3)  (:204-225)."""
         B, K = center.shape[:2]
         grid_size = whole_grid.shape[1] // K
-        _, idx = three_nn(whole_grid, origin_xyz)  # (B, K*G, 3) int32
+        _, idx = three_nn(whole_grid, origin_xyz)
         interp_points = torch.gather(origin_xyz, 1, idx.view(B, -1, 1).expand(-1, -1, 3).long())
         expanded = whole_grid.unsqueeze(2).expand(-1, -1, 3, -1).reshape(B, -1, 3)
         dist = interp_points - expanded
@@ -159,12 +161,39 @@ class SidePooling(nn.Module):
             .reshape(B, -1, 3)
         weight = (1 / (dist + 1e-8)).view(B, -1, 3)
         weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
+        return idx, weight, relative_grid.contiguous()
+
+    def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center):
+        """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
+        S consecutive point groups of every proposal: [(B,H,K,G)] * S, evaluated as
+        W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
+        conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points."""
+        B, K = center.shape[:2]
+        segs = len(nets)
+        G = whole_grid.shape[1] // (K * segs)
+        idx, weight, rel = self._blend_taps(origin_xyz, whole_grid, center)
+        w = torch.stack([net.first_conv[0].weight.flatten(1) for net in nets])   # (S, H, 3+C)
+        H = w.shape[1]
+        table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
+        out = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G)    # S x (B, H, K*G)
+        return [o.view(B, H, K, G) for o in out]
+
+    def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
+        """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (S,B,3+C,K,G)  (:183-243).
+
+        The grid points of a proposal come as ``segs`` = S consecutive groups of G (the six
+        faces, or one group for the box grid); the result holds one contiguous (3+C, K, G)
+        block per group, i.e. what the reference reaches with
+        cat([rel_xyz, interpolated]) -> split(G, dim=-1) -> .contiguous() (:304-313)."""
+        B, K = center.shape[:2]
+        grid_size = whole_grid.shape[1] // K
+        idx, weight, relative_grid = self._blend_taps(origin_xyz, whole_grid, center)
         G, C = grid_size // segs, origin_features.shape[2]
-        out = origin_features.new_empty(B, segs, 3 + C, K * G)
-        out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(0, 2, 4, 1, 3) \
-            .reshape(B, segs, 3, K * G)
+        out = origin_features.new_empty(segs, B, 3 + C, K * G)
+        out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(2, 0, 4, 1, 3) \
+            .reshape(segs, B, 3, K * G)
         three_interpolate_segmented(origin_features, idx, weight, out, segs, G, 3)
-        return out.view(B, segs, 3 + C, K, G)
+        return out.view(segs, B, 3 + C, K, G)
 
     def dist_feature(self, end_points, prefix=''):
         """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
@@ -180,15 +209,24 @@ class SidePooling(nn.Module):
         whole_grid = self.generate_grid(size)
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
         bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
-        side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
-        bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
+        fused = backend_for(origin_xyz).name == 'hip'
+        if fused:   # first convs through the blend; the literal form stays the CPU checker's
+            side_c0 = self.first_conv_through_blend(self.mlps_before[:6], origin_xyz,
+                                                    origin_features, side_grid, center)
+            bbox_c0 = self.first_conv_through_blend(self.mlps_before[6:7], origin_xyz,
+                                                    origin_features, bbox_grid, center)[0]
+        else:
+            side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
+            bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[0]
         dist_feature = self.dist_feature(end_points, prefix)
         side_scores = []
         for i in range(6):
-            f = self.mlps_before[i](side_feats[:, i])
+            f = self.mlps_before[i](conv0_out=side_c0[i]) if fused \
+                else self.mlps_before[i](side_feats[i])
             f = torch.cat((f, dist_feature[i]), dim=1)
             side_scores.append(self.mlps_head[i](f))
         end_points[f'{prefix}side_scores'] = torch.stack(side_scores, 0)
-        bbox_feats = self.mlps_before[6](bbox_feats)
+        bbox_feats = self.mlps_before[6](conv0_out=bbox_c0) if fused \
+            else self.mlps_before[6](bbox_feats)
         end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)
         return end_points

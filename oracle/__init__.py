@@ -136,15 +136,42 @@ class OracleKernels:
         lib().oracle_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
                                        weight.data_ptr(), out.data_ptr())
 
-    def three_interpolate_segmented(self, b, c, m, n, points_t, idx, weight, out, segs, seg_len,
-                                    c_offset):
-        """The plain blend, then the reference's view/split order restated with a permute."""
-        points = points_t.transpose(1, 2).contiguous()  # back to the reference's (B, C, M)
-        flat = points.new_empty(b, c, n)
-        self.three_interpolate_wrapper(b, c, m, n, points, idx, weight, flat)
+    def blend_conv_forward(self, table, seg_off, idx, weight, rel, wx, out, segs, seg_len,
+                           c, c_offset):
+        """Restated from the reference's pieces: per face, three_interpolate on the (C, M)
+        table, the view/split order of side_pooling_module.py:226-243, 304-313, and the xyz
+        term of the first conv as a plain matmul."""
+        b, m, _ = table.shape
+        n = idx.shape[1]
         k = n // (segs * seg_len)
-        out[:, :, c_offset:c_offset + c] = flat.view(b, c, k, segs, seg_len) \
-            .permute(0, 3, 1, 2, 4).reshape(b, segs, c, k * seg_len)
+        for s_ in range(segs):
+            pts = table[:, :, s_ * seg_off:s_ * seg_off + c].transpose(1, 2).contiguous()
+            flat = pts.new_empty(b, c, n)
+            self.three_interpolate_wrapper(b, c, m, n, pts, idx, weight, flat)
+            face = flat.view(b, c, k, segs, seg_len)[:, :, :, s_].reshape(b, c, k * seg_len)
+            if wx is not None:
+                r = rel.view(b, k, segs, seg_len, 3)[:, :, s_].reshape(b, k * seg_len, 3)
+                face = face + torch.matmul(wx[s_].unsqueeze(0), r.transpose(1, 2))
+            out[s_, :, c_offset:c_offset + c] = face
+
+    def blend_conv_backward(self, dy_faces, seg_off, idx, weight, rel, d_table, d_wx, segs,
+                            seg_len):
+        b, m, _ = d_table.shape
+        n = idx.shape[1]
+        k = n // (segs * seg_len)
+        for face, dy_face in enumerate(dy_faces):
+            if dy_face is None:
+                continue
+            c = dy_face.shape[1]
+            full = dy_face.new_zeros(b, c, k, segs, seg_len)
+            full[:, :, :, face] = dy_face.view(b, c, k, seg_len)
+            gp = dy_face.new_zeros(b, c, m)
+            self.three_interpolate_grad_wrapper(b, c, n, m, full.view(b, c, n).contiguous(),
+                                                idx, weight, gp)
+            d_table[:, :, face * seg_off:face * seg_off + c] += gp.transpose(1, 2)
+            if d_wx is not None:
+                r = rel.view(b, k, segs, seg_len, 3)[:, :, face].reshape(b, k * seg_len, 3)
+                d_wx[face] += torch.matmul(dy_face, r).sum(0)
 
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):

@@ -206,29 +206,59 @@ def test_fused_bn_row_bias_matches_materialised_sum(hip_device, shape):
     torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5)
 
 
+def _blend_case(k, segs, g, c, seed, b=2, m=300):
+    gen = torch.Generator().manual_seed(seed)
+    n = k * segs * g
+    idx = torch.randint(0, m, (b, n, 3), generator=gen, dtype=torch.int32)
+    w = torch.rand(b, n, 3, generator=gen)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    rel = torch.randn(b, n, 3, generator=gen)
+    return gen, b, m, n, idx, w, rel
+
+
 @pytest.mark.parametrize("k,segs,g,c", [(256, 6, 16, 256), (64, 6, 16, 128), (64, 1, 64, 64),
                                         (40, 6, 27, 19), (33, 1, 64, 8), (256, 6, 27, 256)])
 def test_three_interpolate_segmented_bit_exact(oracle_kernels, hip_device, k, segs, g, c):
     """Per-face layout of the quality head (side_pooling_module.py:226-243, 304-313) vs the
     oracle's plain three_interpolate followed by the reference's view/cat/split order."""
-    gen = torch.Generator().manual_seed(k + g)
-    b, m, n = 2, 300, k * segs * g
+    gen, b, m, n, idx, w, _ = _blend_case(k, segs, g, c, k + g)
     feats = torch.randn(b, c, m, generator=gen)
-    idx = torch.randint(0, m, (b, n, 3), generator=gen, dtype=torch.int32)
-    w = torch.rand(b, n, 3, generator=gen)
-    w = (w / w.sum(-1, keepdim=True)).contiguous()
     lead = torch.randn(b, segs, 3, k * g, generator=gen)
     with kernels.use_backend(oracle_kernels):
         plain = ops.three_interpolate(feats, idx, w)                     # (b, c, n)
     full = torch.cat([lead.view(b, segs, 3, k, g).permute(0, 2, 3, 1, 4).reshape(b, 3, k, segs * g),
                       plain.view(b, c, k, segs * g)], 1)                 # reference's cat
     want = [t.contiguous() for t in torch.split(full, g, dim=-1)]        # reference's split
-    out = torch.empty(b, segs, 3 + c, k * g, device=hip_device)
-    out[:, :, :3] = lead.to(hip_device)
+    out = torch.empty(segs, b, 3 + c, k * g, device=hip_device)
+    out[:, :, :3] = lead.transpose(0, 1).to(hip_device)
     ops.three_interpolate_segmented(feats.transpose(1, 2).contiguous().to(hip_device),
                                     idx.to(hip_device), w.to(hip_device), out, segs, g, 3)
     for s_ in range(segs):
-        assert torch.equal(out[:, s_].view(b, 3 + c, k, g).cpu(), want[s_]), s_
+        assert torch.equal(out[s_].view(b, 3 + c, k, g).cpu(), want[s_]), s_
+
+
+@pytest.mark.parametrize("k,segs,g,h", [(64, 6, 16, 64), (32, 1, 64, 128), (64, 6, 27, 128),
+                                        (512, 6, 16, 256)])
+def test_blend_conv_matches_oracle(oracle_kernels, hip_device, k, segs, g, h):
+    """BlendConv (first MiniPointNet conv through the 3-NN blend) on the HIP kernels vs the
+    oracle's restatement from three_interpolate(+grad) and matmul: forward 1e-5, gradients of
+    the table and of the xyz weight columns to summation order."""
+    gen, b, m, n, idx, w, rel = _blend_case(k, segs, g, h, k + h)
+    table = torch.randn(b, m, segs * h, generator=gen)
+    wx = torch.randn(segs, h, 3, generator=gen)
+    go = torch.randn(segs, b, h, k * g, generator=gen)
+    with kernels.use_backend(oracle_kernels):
+        t0, x0 = table.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+        want = torch.stack(ops.blend_conv(t0, x0, idx, w, rel, segs, g))
+        want.backward(go)
+    t1 = table.to(hip_device).requires_grad_(True)
+    x1 = wx.to(hip_device).requires_grad_(True)
+    got = torch.stack(ops.blend_conv(t1, x1, idx.to(hip_device), w.to(hip_device),
+                                     rel.to(hip_device), segs, g))
+    got.backward(go.to(hip_device))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(t1.grad.cpu(), t0.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x1.grad.cpu(), x0.grad, rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])
