@@ -40,6 +40,14 @@ class deferred_bn_counters:
         return False
 
 
+def count_batch(counter):
+    """``num_batches_tracked += 1`` (queued inside ``deferred_bn_counters``)."""
+    if _counter_sink is not None:
+        _counter_sink.append(counter)
+    else:
+        counter.add_(1)
+
+
 class BNReLUTrain(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu,

@@ -9,7 +9,7 @@ from torch import nn
 from ..mmdet3d_ops.norm import FusedBNReLU1d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d
 from ..kernels import backend_for
-from .side_pooling import MiniPointNet, SidePooling
+from .side_pooling import MiniPointNet, SidePooling, batched_heads, heads_batchable
 
 
 class QualityEstimation(SidePooling):
@@ -75,15 +75,19 @@ class QualityEstimation(SidePooling):
         else:
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
-        side_scores, side_features = [], []
-        for i in range(6):
-            f = self.mlps_before[i](conv0_out=side_c0[i]) if fused \
-                else self.mlps_before[i](side_feats[i])
-            f = torch.cat((f, dist_feature[i]), dim=1)
-            side_features.append(f)
-            side_scores.append(self.mlps_head[i](f))
-        end_points[f'{prefix}side_scores'] = torch.stack(side_scores, 0)
-        global_scores = self.mlps_head[6](torch.cat(side_features, dim=1)).transpose(2, 1)
+        pooled = [self.mlps_before[i](conv0_out=side_c0[i]) if fused
+                  else self.mlps_before[i](side_feats[i]) for i in range(6)]
+        heads = list(self.mlps_head[:6])
+        if heads_batchable(heads, pooled[0]):
+            x = torch.cat([torch.stack(pooled, 1), dist_feature.transpose(0, 1)], dim=2)
+            side_scores = batched_heads(heads, x).transpose(0, 1).contiguous()
+            all_features = x.flatten(1, 2)               # == cat of the six (B,166,2K) inputs
+        else:
+            side_features = [torch.cat((pooled[i], dist_feature[i]), dim=1) for i in range(6)]
+            side_scores = torch.stack([self.mlps_head[i](side_features[i]) for i in range(6)], 0)
+            all_features = torch.cat(side_features, dim=1)
+        end_points[f'{prefix}side_scores'] = side_scores
+        global_scores = self.mlps_head[6](all_features).transpose(2, 1)
         n = self.iou_size
         end_points[f'{prefix}iou_scores'] = global_scores[..., :n]
         end_points[f'{prefix}rotate_scores'] = global_scores[..., n:n * 2]

@@ -71,6 +71,62 @@ class MiniPointNet(nn.Module):
         return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
 
+def batched_heads(heads, x):
+    """S structurally identical score heads on S inputs in one pass: ``heads`` = S
+    nn.Sequential of PointwiseConv1d / FusedBNReLU1d / Identity, ``x`` (B, S, Cin, P) ->
+    (B, S, Cout, P).  The convs run as one broadcast batched GEMM over the stacked weights and
+    every norm layer as ONE BatchNorm over the S*C stacked channels (statistics are per channel,
+    so stacking heads along the channel axis changes nothing) -- the same arithmetic as calling
+    the heads one by one (side_pooling_module.py:314-321), at a sixth of the launches."""
+    from ..mmdet3d_ops import norm as _norm
+    B, S = x.shape[:2]
+    for layers in zip(*heads):
+        first = layers[0]
+        if isinstance(first, nn.Identity):
+            continue
+        if isinstance(first, PointwiseConv1d):
+            w = torch.stack([l.weight.flatten(1) for l in layers])             # (S, Co, Ci)
+            x = torch.matmul(w.unsqueeze(0), x)
+            if first.bias is not None:
+                x = x + torch.stack([l.bias for l in layers]).view(1, S, -1, 1)
+        elif isinstance(first, FusedBNReLU1d):
+            C, P = x.shape[2], x.shape[3]
+            rm = torch.cat([l.running_mean for l in layers])
+            rv = torch.cat([l.running_var for l in layers])
+            x = _norm.BNReLUTrain.apply(
+                x.reshape(B, S * C, P), torch.cat([l.weight for l in layers]),
+                torch.cat([l.bias for l in layers]), rm, rv, first.momentum, first.eps,
+                first.fuse_relu).view(B, S, C, P)
+            with torch.no_grad():
+                torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
+                torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
+                for l in layers:
+                    _norm.count_batch(l.num_batches_tracked)
+        else:
+            raise TypeError(f'batched_heads: unsupported layer {type(first).__name__}')
+    return x
+
+
+def heads_batchable(heads, x):
+    """True when ``batched_heads`` reproduces the per-head loop: native training BatchNorm on
+    the HIP back end, fp32, same layer types and hyper-parameters in every head."""
+    if backend_for(x).name != 'hip' or x.dtype != torch.float32:
+        return False
+    for layers in zip(*heads):
+        t = type(layers[0])
+        if any(type(l) is not t for l in layers):
+            return False
+        if isinstance(layers[0], FusedBNReLU1d):
+            f = layers[0]
+            if not all(l.training and l.affine and l.track_running_stats
+                       and l.momentum is not None and l.momentum == f.momentum
+                       and l.eps == f.eps and l.fuse_relu == f.fuse_relu for l in layers):
+                return False
+        elif not isinstance(layers[0], (PointwiseConv1d, nn.Identity)):
+            return False
+    return True
+
+
 def _score_head(in_ch, out_ch):
     # indices as in the reference Sequential (conv, bn, relu, conv, bn, relu, conv); the
     # ReLUs are folded into the norm layers, Identity keeps the state-dict positions
@@ -219,13 +275,16 @@ class SidePooling(nn.Module):
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
             bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[0]
         dist_feature = self.dist_feature(end_points, prefix)
-        side_scores = []
-        for i in range(6):
-            f = self.mlps_before[i](conv0_out=side_c0[i]) if fused \
-                else self.mlps_before[i](side_feats[i])
-            f = torch.cat((f, dist_feature[i]), dim=1)
-            side_scores.append(self.mlps_head[i](f))
-        end_points[f'{prefix}side_scores'] = torch.stack(side_scores, 0)
+        pooled = [self.mlps_before[i](conv0_out=side_c0[i]) if fused
+                  else self.mlps_before[i](side_feats[i]) for i in range(6)]
+        heads = list(self.mlps_head[:6])
+        if heads_batchable(heads, pooled[0]):
+            x = torch.cat([torch.stack(pooled, 1), dist_feature.transpose(0, 1)], dim=2)
+            side_scores = batched_heads(heads, x).transpose(0, 1).contiguous()
+        else:
+            side_scores = torch.stack([self.mlps_head[i](torch.cat((pooled[i], dist_feature[i]),
+                                                                   dim=1)) for i in range(6)], 0)
+        end_points[f'{prefix}side_scores'] = side_scores
         bbox_feats = self.mlps_before[6](conv0_out=bbox_c0) if fused \
             else self.mlps_before[6](bbox_feats)
         end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)

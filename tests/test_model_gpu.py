@@ -185,3 +185,37 @@ def test_precomputed_index_chain_is_equivalent(hip_device):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert pre[0]['indices'].shape == (2, 2048) and pre[0]['group_idx'][0].shape == (2, 2048, 64)
+
+
+@pytest.mark.gpu
+def test_batched_score_heads_equal_the_per_head_loop(hip_device):
+    """side_pooling.batched_heads (six heads as one broadcast GEMM + one stacked BatchNorm per
+    layer) vs calling the six nn.Sequential heads one by one (side_pooling_module.py:314-321):
+    outputs, parameter gradients, running statistics and batch counters."""
+    import copy
+    from nesie_amd.votenet.side_pooling import _score_head, batched_heads, heads_batchable
+    torch.manual_seed(11)
+    B, P = 3, 96
+    heads = [_score_head(166, 18).to(hip_device) for _ in range(6)]
+    for h in heads:
+        for m in h.modules():
+            if hasattr(m, 'running_mean'):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.3)
+    ref = copy.deepcopy(heads)
+    x = torch.randn(B, 6, 166, P, device=hip_device)
+    go = torch.randn(B, 6, 18, P, device=hip_device)
+    assert heads_batchable(heads, x[:, 0])
+    x1 = x.clone().requires_grad_(True)
+    got = batched_heads(heads, x1)
+    got.backward(go)
+    x2 = x.clone().requires_grad_(True)
+    want = torch.stack([ref[i](x2[:, i]) for i in range(6)], 1)
+    want.backward(go)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-3, atol=1e-5)
+    for a, b in zip(heads, ref):
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-3, atol=2e-5, msg=n)
+        for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+            torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-5, atol=1e-6, msg=n)
