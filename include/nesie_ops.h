@@ -115,8 +115,8 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
  * Reference: dense_heads/side_pooling_module.py:226-243 builds cat([rel_xyz, interpolated]),
  * :304-313 splits it per face and makes each face contiguous, :346-349 feeds it to
  * Conv2d(3+C, H, 1, bias=False).  The n = K*segs*seg_len queries are ordered (proposal k,
- * face s, grid point g); out is (segs, B, c_total, K*seg_len) and query (k,s,g), channel ch
- * lands at out[s, b, c_offset+ch, k*seg_len+g]:
+ * face s, grid point g); out is (B, segs, c_total, K*seg_len) and query (k,s,g), channel ch
+ * lands at out[b, s, c_offset+ch, k*seg_len+g]:
  *     out = w0*T[j0] + w1*T[j1] + w2*T[j2]  (+ wx[s][ch] . rel[q])
  * with T = table[b, j, s*seg_off + ch], a POINT-major table of row pitch `pitch` floats.
  *   - table = seed features (B, M, C), seg_off = 0, rel = wx = NULL, c_offset = 3:
@@ -124,10 +124,9 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
  *   - table = F . W_f^T (seed features times the feature columns of each face's first conv,
  *     (B, M, segs*H), seg_off = H) and wx = the conv's xyz columns (segs, H, 3): the first
  *     conv's OUTPUT, W . cat[rel, blend(F)] = W_xyz . rel + blend(W_f . F) by linearity.
- * backward (second form): dy_faces = HOST array of segs device pointers, dy_faces[s] (B, c,
- * K*seg_len) = the gradient of out[s] (NULL = that face has none); ADDS into d_table (B, M,
- * pitch) columns [s*seg_off, +c) and into d_wx (segs, c, 3) (NULL = skip), both zeroed by
- * the caller; segs <= 8, c in
+ * backward (second form): dy (B, segs, c, K*seg_len) = the gradient of out; ADDS into
+ * d_table (B, M, pitch) columns [s*seg_off, +c) and into d_wx (segs, c, 3) (NULL = skip),
+ * both zeroed by the caller; c in
  * {64, 128, 192, 256} and K*seg_len % 64 == 0.  Sum order is not fixed (float atomics), like
  * the reference's scatter.  Channels outside [c_offset, c_offset+c) of out are left
  * untouched by the forward. */
@@ -135,8 +134,7 @@ int nesie_blend_conv_forward(int b, int c, int m, int n, const float *table, int
                              int seg_off, const int *idx, const float *weight,
                              const float *rel, const float *wx, float *out, int segs,
                              int seg_len, int c_total, int c_offset, void *stream);
-int nesie_blend_conv_backward(int b, int c, int m, int n, const float *const *dy_faces,
-                              int pitch, int seg_off, const int *idx, const float *weight,
+int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy, int pitch, int seg_off, const int *idx, const float *weight,
                               const float *rel, float *d_table, float *d_wx, int segs,
                               int seg_len, void *stream);
 

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(TI_BLOCK) void three_interpolate_kernel(
 
 // ---- the quality head's grid features, blended straight into their consumer's layout ----
 // Query p = (k, s, g) of n = K * segs * seg_len (proposal, face, grid point) goes to
-// out[s, b, c_offset + ch, k * seg_len + g] of out (segs, B, c_total, K * seg_len): one
-// contiguous (B, c_total, K, seg_len) block per face -- what the reference reaches with
+// out[b, s, c_offset + ch, k * seg_len + g] of out (B, segs, c_total, K * seg_len): one
+// (c_total, K, seg_len) block per scene and face -- what the reference reaches with
 // interpolate -> view -> cat -> split -> contiguous (side_pooling_module.py:226-243, 304-313).
 //
 //   out = w0 * T[j0] + w1 * T[j1] + w2 * T[j2]  (+ wx . rel)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
   __shared__ float sr[TS_Q][3];
-  const int bi = blockIdx.y, nb = gridDim.y;
+  const int bi = blockIdx.y;
   const int q0 = blockIdx.x * TS_Q;  // output order: s * per_seg + k * seg_len + g
   const int per_seg = n / segs;
   const int sg = q0 / per_seg, r0 = q0 - sg * per_seg;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
   }
   __syncthreads();
   const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off;
-  float *dst = out + (((size_t)sg * nb + bi) * c_total + c_offset) * per_seg + r0;
+  float *dst = out + (((size_t)bi * segs + sg) * c_total + c_offset) * per_seg + r0;
   for (int c0 = 0; c0 < c; c0 += 64) {
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (wx) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
     const float *__restrict__ wx, float *__restrict__ out) {
   const int q = blockIdx.x * TI_BLOCK + threadIdx.x;
   const int c0 = blockIdx.y * TI_CH;
-  const int bi = blockIdx.z, nb = gridDim.z;
+  const int bi = blockIdx.z;
   if (q >= n) return;
   const int per_seg = n / segs;
   const int sg = q / per_seg, r = q - sg * per_seg;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
               rz = rel ? rel[p * 3 + 2] : 0.f;
   const int cend = c - c0 < TI_CH ? c - c0 : TI_CH;
   const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off + c0;
-  float *dst = out + (((size_t)sg * nb + bi) * c_total + c_offset + c0) * per_seg + r;
+  float *dst = out + (((size_t)bi * segs + sg) * c_total + c_offset + c0) * per_seg + r;
 #pragma unroll
   for (int i = 0; i < TI_CH; ++i) {
     if (i < cend) {
@@ -229,17 +229,14 @@ __global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
 // zero on entry.
 constexpr int BL_SLOTS = 8;
 constexpr int BL_RUN = 128;  // consecutive queries per workgroup
-constexpr int BL_MAX_FACES = 8;
-
-struct BlendFaces { const float *dy[BL_MAX_FACES]; };  // per face: (B, c, per_seg) or NULL
 
 // CPT = c / 64 channels per lane: a wave covers ALL c channels of its quarter of the tile's
 // queries (16 consecutive ones = one face of one proposal when seg_len = 16), so the per-tap
 // slot bookkeeping, which is scalar work, is paid once per c channels.
 template <int CPT>
 __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
-    int m, int n, int segs, int seg_len, int pitch, int seg_off, BlendFaces faces,
-    const int *__restrict__ idx, const float *__restrict__ weight,
+    int m, int n, int segs, int seg_len, int pitch, int seg_off,
+    const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx, const float *__restrict__ weight,
     const float *__restrict__ rel, float *__restrict__ d_table, float *__restrict__ d_wx) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
@@ -247,12 +244,10 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
   __shared__ float sw[TS_Q][3];
   __shared__ float sr[TS_Q][3];
   const int bi = blockIdx.y, sg = blockIdx.z;
-  const float *dy = faces.dy[sg];
-  if (!dy) return;
   const int per_seg = n / segs;
   const int run0 = blockIdx.x * BL_RUN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float *src = dy + (size_t)bi * C * per_seg;
+  const float *src = dy + ((size_t)bi * segs + sg) * C * per_seg;
   float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
   // slot keys: lane i (< BL_SLOTS) of `keys` holds the seed of slot i, -1 = empty
   int keys = -1;
@@ -454,17 +449,16 @@ extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float 
   return check_launch(W);
 }
 
-extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n,
-                                         const float *const *dy_faces, int pitch, int seg_off,
-                                         const int *idx, const float *weight, const float *rel,
+extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy,
+                                         int pitch, int seg_off, const int *idx,
+                                         const float *weight, const float *rel,
                                          float *d_table, float *d_wx, int segs, int seg_len,
                                          void *stream) {
   const char *W = "blend_conv_backward";
   int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
   if (st) return st;
-  NESIE_REQUIRE(segs <= BL_MAX_FACES && dy_faces, W);
   if (b == 0 || c == 0 || n == 0) return NESIE_OK;
-  NESIE_REQUIRE(m >= 1 && idx && weight && d_table, W);
+  NESIE_REQUIRE(m >= 1 && dy && idx && weight && d_table && segs <= 65535, W);
   NESIE_REQUIRE((d_wx == nullptr) || rel, W);
   const int per_seg = n / segs;
   if (c % 64 != 0 || c > 256 || per_seg % TS_Q != 0) {
@@ -472,11 +466,9 @@ extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n,
               "of %d)", W, c, per_seg, TS_Q);
     return NESIE_ERR_UNSUPPORTED;
   }
-  BlendFaces faces;
-  for (int i = 0; i < BL_MAX_FACES; ++i) faces.dy[i] = i < segs ? dy_faces[i] : nullptr;
   const dim3 grid(cdiv(per_seg, BL_RUN), b, segs);
 #define L(N) hipLaunchKernelGGL(blend_bwd_rows_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, \
-                                m, n, segs, seg_len, pitch, seg_off, faces, idx, weight, rel,     \
+                                m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel,        \
                                 d_table, d_wx)
   if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
 #undef L

@@ -170,14 +170,14 @@ class HipKernels(_BNPoolMixin):
 
     def blend_conv_forward(self, table, seg_off, idx, weight, rel, wx, out, segs, seg_len,
                            c, c_offset):
-        """table (B, M, pitch) point-major; out (segs, B, c_total, n/segs): query (k, s, g) ->
-        out[s, b, c_offset+ch, k*seg_len+g] = blend(table[..., s*seg_off+ch]) (+ wx[s,ch].rel)."""
+        """table (B, M, pitch) point-major; out (B, segs, c_total, n/segs): query (k, s, g) ->
+        out[b, s, c_offset+ch, k*seg_len+g] = blend(table[..., s*seg_off+ch]) (+ wx[s,ch].rel)."""
         _check(table, idx, weight, out); _f32(table, weight, out); _i32(idx)
         b, m, pitch = table.shape
         n = idx.shape[1]
         assert idx.numel() == b * n * 3 and weight.numel() == b * n * 3
         assert n % (segs * seg_len) == 0 and out.dim() == 4
-        assert out.shape[0] == segs and out.shape[1] == b and out.shape[3] * segs == n
+        assert out.shape[0] == b and out.shape[1] == segs and out.shape[3] * segs == n
         assert c_offset + c <= out.shape[2] and (rel is None) == (wx is None)
         if wx is not None:
             _check(rel, wx); _f32(rel, wx)
@@ -188,29 +188,21 @@ class HipKernels(_BNPoolMixin):
                       _ptr(idx), _ptr(weight), opt(rel), opt(wx), _ptr(out), segs, seg_len,
                       int(out.shape[2]), c_offset, _stream(table))
 
-    def blend_conv_backward(self, dy_faces, seg_off, idx, weight, rel, d_table, d_wx, segs,
-                            seg_len):
-        """dy_faces: list of segs tensors (B, c, n/segs) (None = no gradient for that face);
-        adds into d_table (B, M, pitch) columns [s*seg_off, +c) and d_wx (segs, c, 3); both
-        zeroed by the caller."""
-        import ctypes
-        ref = next(g for g in dy_faces if g is not None)
-        _check(idx, weight, d_table, *[g for g in dy_faces if g is not None])
-        _f32(weight, d_table); _i32(idx)
+    def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len):
+        """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c) and
+        d_wx (segs, c, 3); both zeroed by the caller."""
+        _check(dy, idx, weight, d_table); _f32(dy, weight, d_table); _i32(idx)
         b, m, pitch = d_table.shape
-        n, c = idx.shape[1], ref.shape[1]
-        assert len(dy_faces) == segs
-        for g in dy_faces:
-            assert g is None or (tuple(g.shape) == (b, c, n // segs) and g.dtype == torch.float32)
+        n, c = idx.shape[1], dy.shape[2]
+        assert tuple(dy.shape) == (b, segs, c, n // segs)
         if d_wx is not None:
             _check(rel, d_wx); _f32(rel, d_wx)
             assert tuple(d_wx.shape) == (segs, c, 3)
-        ptrs = (ctypes.c_void_p * segs)(*[None if g is None else g.data_ptr() for g in dy_faces])
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
-        with torch.cuda.device(ref.device):
-            _lib.call("nesie_blend_conv_backward", b, c, m, n, ptrs, pitch, seg_off, _ptr(idx),
-                      _ptr(weight), opt(rel), _ptr(d_table), opt(d_wx), segs, seg_len,
-                      _stream(ref))
+        with torch.cuda.device(dy.device):
+            _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
+                      _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(d_wx), segs, seg_len,
+                      _stream(dy))
 
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):

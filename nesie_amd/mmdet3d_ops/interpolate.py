@@ -64,7 +64,7 @@ three_interpolate = ThreeInterpolate.apply
 
 def three_interpolate_segmented(features_t, indices, weight, out, segs, seg_len, c_offset):
     """Blend point-major ``features_t`` (B,M,C) at the n = K*segs*seg_len queries ordered
-    (proposal, face, grid point) into ``out`` (segs, B, c_total, K*seg_len) at channels
+    (proposal, face, grid point) into ``out`` (B, segs, c_total, K*seg_len) at channels
     [c_offset, c_offset+C): the per-face contiguous blocks that
     side_pooling_module.py:226-243, 304-313 reaches through cat -> split -> contiguous.
     Not differentiable (the quality head reads detached seed features, :176-181)."""
@@ -86,7 +86,7 @@ class BlendConv(Function):
     F^T W_f^T (B, M, segs*H) is one small GEMM over the M seeds instead of one over the
     K*G*segs grid points, and the 259-channel feature tensor is never built.
     table (B, M, segs*H) differentiable, wx (segs, H, 3) differentiable, idx/weight/rel
-    (B, n, 3) constants -> segs tensors (B, H, n/segs), one per face."""
+    (B, n, 3) constants -> (B, segs, H, n/segs)."""
 
     @staticmethod
     def forward(ctx, table, wx, idx, weight, rel, segs, seg_len):
@@ -94,26 +94,21 @@ class BlendConv(Function):
         b, m, pitch = table.shape
         h = pitch // segs
         n = idx.shape[1]
-        out = table.new_empty(segs, b, h, n // segs)
+        out = table.new_empty(b, segs, h, n // segs)
         backend_for(table).blend_conv_forward(table, h, idx, weight, rel, wx, out, segs,
                                               seg_len, h, 0)
         ctx.save_for_backward(idx, weight, rel)
         ctx.dims = (segs, seg_len, b, m, pitch, h)
-        # one output per face (each a contiguous (B, H, K*G) block of `out`): the consumers are
-        # separate networks, and a single stacked output would make autograd rebuild and add
-        # full-size zero-padded gradients for every face
-        return tuple(out.unbind(0))
+        return out
 
     @staticmethod
-    def backward(ctx, *grads):
+    def backward(ctx, dy):
         idx, weight, rel = ctx.saved_tensors
         segs, seg_len, b, m, pitch, h = ctx.dims
-        ref = next(g for g in grads if g is not None)
-        d_table = ref.new_zeros(b, m, pitch)
-        d_wx = ref.new_zeros(segs, h, 3)
-        faces = [None if g is None else g.contiguous() for g in grads]
-        backend_for(ref).blend_conv_backward(faces, h, idx, weight, rel, d_table, d_wx, segs,
-                                             seg_len)
+        d_table = dy.new_zeros(b, m, pitch)
+        d_wx = dy.new_zeros(segs, h, 3)
+        backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
+                                            segs, seg_len)
         return d_table, d_wx, None, None, None, None, None
 
 

@@ -9,7 +9,8 @@ from torch import nn
 from ..mmdet3d_ops.norm import FusedBNReLU1d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d
 from ..kernels import backend_for
-from .side_pooling import MiniPointNet, SidePooling, batched_heads, heads_batchable
+from .side_pooling import (MiniPointNet, SidePooling, batched_heads, grouped_mini_pointnets,
+                           heads_batchable, mini_pointnets_groupable)
 
 
 class QualityEstimation(SidePooling):
@@ -69,23 +70,25 @@ class QualityEstimation(SidePooling):
         whole_grid = self.generate_grid(size)
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
         fused = backend_for(origin_xyz).name == 'hip'
+        side_nets = list(self.mlps_before[:6])
         if fused:
-            side_c0 = self.first_conv_through_blend(self.mlps_before[:6], origin_xyz,
-                                                    origin_features, side_grid, center)
+            side_c0 = self.first_conv_through_blend(side_nets, origin_xyz, origin_features,
+                                                    side_grid, center)
         else:
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
-        pooled = [self.mlps_before[i](conv0_out=side_c0[i]) if fused
-                  else self.mlps_before[i](side_feats[i]) for i in range(6)]
-        heads = list(self.mlps_head[:6])
-        if heads_batchable(heads, pooled[0]):
-            x = torch.cat([torch.stack(pooled, 1), dist_feature.transpose(0, 1)], dim=2)
-            side_scores = batched_heads(heads, x).transpose(0, 1).contiguous()
-            all_features = x.flatten(1, 2)               # == cat of the six (B,166,2K) inputs
+        if fused and mini_pointnets_groupable(side_nets, side_c0):
+            pooled = grouped_mini_pointnets(side_nets, side_c0)
         else:
-            side_features = [torch.cat((pooled[i], dist_feature[i]), dim=1) for i in range(6)]
-            side_scores = torch.stack([self.mlps_head[i](side_features[i]) for i in range(6)], 0)
-            all_features = torch.cat(side_features, dim=1)
+            pooled = torch.stack([side_nets[i](conv0_out=side_c0[:, i]) if fused
+                                  else side_nets[i](side_feats[:, i]) for i in range(6)], 1)
+        heads = list(self.mlps_head[:6])
+        x = torch.cat([pooled, dist_feature.transpose(0, 1)], dim=2)      # (B,6,166,2K)
+        if heads_batchable(heads, x[:, 0]):
+            side_scores = batched_heads(heads, x).transpose(0, 1).contiguous()
+        else:
+            side_scores = torch.stack([self.mlps_head[i](x[:, i]) for i in range(6)], 0)
+        all_features = x.flatten(1, 2)                   # == cat of the six (B,166,2K) inputs
         end_points[f'{prefix}side_scores'] = side_scores
         global_scores = self.mlps_head[6](all_features).transpose(2, 1)
         n = self.iou_size

@@ -71,6 +71,72 @@ class MiniPointNet(nn.Module):
         return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
 
+def _stacked_bn(layers, x, row_bias=None):
+    """ONE fused BatchNorm(+ReLU) over the S*C channels of x (B, S*C, ...) for the S norm
+    layers ``layers`` (each C channels): statistics are per channel, so stacking the layers
+    along the channel axis is the same arithmetic as calling them one by one.  Running
+    statistics and batch counters of every layer are updated as its own forward would."""
+    from ..mmdet3d_ops import norm as _norm
+    first, C = layers[0], layers[0].num_features
+    rm = torch.cat([l.running_mean for l in layers])
+    rv = torch.cat([l.running_var for l in layers])
+    y = _norm.BNReLUTrain.apply(x, torch.cat([l.weight for l in layers]),
+                                torch.cat([l.bias for l in layers]), rm, rv, first.momentum,
+                                first.eps, first.fuse_relu, row_bias)
+    with torch.no_grad():
+        torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
+        torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
+        for l in layers:
+            _norm.count_batch(l.num_batches_tracked)
+    return y
+
+
+def _stackable_bn(layers):
+    f = layers[0]
+    return all(type(l) is type(f) and l.training and l.affine and l.track_running_stats
+               and l.momentum is not None and l.momentum == f.momentum and l.eps == f.eps
+               and l.fuse_relu == f.fuse_relu and l.num_features == f.num_features
+               for l in layers)
+
+
+def grouped_mini_pointnets(nets, c0):
+    """S structurally identical MiniPointNets on S inputs at once: ``c0`` (B, S, H, K, G) =
+    the outputs of their first convs -> (B, S, F, K).  Same function as calling
+    ``net(conv0_out=c0[:, i])`` for each net (see MiniPointNet.forward for the algebra); every
+    1x1 conv is one broadcast batched GEMM over the stacked weights (48 instead of 8 matrices
+    per launch at B = 8) and every norm layer one stacked BatchNorm."""
+    B, S, H, K, G = c0.shape
+    f, sc = [n.first_conv for n in nets], [n.second_conv for n in nets]
+    stack = lambda ws: torch.stack([w.flatten(1) for w in ws]).unsqueeze(0)  # noqa: E731
+    a0 = _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G)).view(B, S, H, K * G)
+    c = torch.matmul(stack([x[3].weight for x in f]), a0)               # (B,S,half,K*G)
+    half = c.shape[2]
+    g = group_max_pool(c.view(B, S, half, K, G))                         # (B,S,half,K)
+    w = stack([x[0].weight for x in sc])                                 # (1,S,H2,2*half)
+    H2 = w.shape[2]
+    b3 = torch.stack([x[3].bias if x[3].bias is not None else c.new_zeros(half) for x in f])
+    small = torch.matmul(w[..., :half], g) \
+        + torch.matmul(w[0], torch.cat([b3, b3], 1).unsqueeze(-1)).view(1, S, H2, 1)
+    y = _stacked_bn([x[1] for x in sc],
+                    torch.matmul(w[..., half:], c).view(B, S * H2, K, G),
+                    row_bias=small.reshape(B, S * H2, K))
+    out = torch.matmul(stack([x[3].weight for x in sc]), y.view(B, S, H2, K * G))
+    out = group_max_pool(out.view(B, S, -1, K, G))
+    if sc[0][3].bias is not None:
+        out = out + torch.stack([x[3].bias for x in sc]).view(1, S, -1, 1)
+    return out
+
+
+def mini_pointnets_groupable(nets, c0):
+    if backend_for(c0).name != 'hip' or c0.dtype != torch.float32:
+        return False
+    G = c0.shape[-1]
+    if not (4 <= G <= 64 and G & (G - 1) == 0):   # row-bias norm and max-pool kernels
+        return False
+    return _stackable_bn([n.first_conv[1] for n in nets]) \
+        and _stackable_bn([n.second_conv[1] for n in nets])
+
+
 def batched_heads(heads, x):
     """S structurally identical score heads on S inputs in one pass: ``heads`` = S
     nn.Sequential of PointwiseConv1d / FusedBNReLU1d / Identity, ``x`` (B, S, Cin, P) ->
@@ -78,7 +144,6 @@ def batched_heads(heads, x):
     every norm layer as ONE BatchNorm over the S*C stacked channels (statistics are per channel,
     so stacking heads along the channel axis changes nothing) -- the same arithmetic as calling
     the heads one by one (side_pooling_module.py:314-321), at a sixth of the launches."""
-    from ..mmdet3d_ops import norm as _norm
     B, S = x.shape[:2]
     for layers in zip(*heads):
         first = layers[0]
@@ -91,17 +156,7 @@ def batched_heads(heads, x):
                 x = x + torch.stack([l.bias for l in layers]).view(1, S, -1, 1)
         elif isinstance(first, FusedBNReLU1d):
             C, P = x.shape[2], x.shape[3]
-            rm = torch.cat([l.running_mean for l in layers])
-            rv = torch.cat([l.running_var for l in layers])
-            x = _norm.BNReLUTrain.apply(
-                x.reshape(B, S * C, P), torch.cat([l.weight for l in layers]),
-                torch.cat([l.bias for l in layers]), rm, rv, first.momentum, first.eps,
-                first.fuse_relu).view(B, S, C, P)
-            with torch.no_grad():
-                torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
-                torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
-                for l in layers:
-                    _norm.count_batch(l.num_batches_tracked)
+            x = _stacked_bn(layers, x.reshape(B, S * C, P)).view(B, S, C, P)
         else:
             raise TypeError(f'batched_heads: unsupported layer {type(first).__name__}')
     return x
@@ -117,10 +172,7 @@ def heads_batchable(heads, x):
         if any(type(l) is not t for l in layers):
             return False
         if isinstance(layers[0], FusedBNReLU1d):
-            f = layers[0]
-            if not all(l.training and l.affine and l.track_running_stats
-                       and l.momentum is not None and l.momentum == f.momentum
-                       and l.eps == f.eps and l.fuse_relu == f.fuse_relu for l in layers):
+            if not _stackable_bn(layers):
                 return False
         elif not isinstance(layers[0], (PointwiseConv1d, nn.Identity)):
             return False
@@ -221,7 +273,7 @@ class SidePooling(nn.Module):
 
     def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center):
         """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
-        S consecutive point groups of every proposal: [(B,H,K,G)] * S, evaluated as
+        S consecutive point groups of every proposal: (B,S,H,K,G), evaluated as
         W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
         conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points."""
         B, K = center.shape[:2]
@@ -231,11 +283,11 @@ class SidePooling(nn.Module):
         w = torch.stack([net.first_conv[0].weight.flatten(1) for net in nets])   # (S, H, 3+C)
         H = w.shape[1]
         table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
-        out = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G)    # S x (B, H, K*G)
-        return [o.view(B, H, K, G) for o in out]
+        out = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G)    # (B, S, H, K*G)
+        return out.view(B, segs, H, K, G)
 
     def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
-        """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (S,B,3+C,K,G)  (:183-243).
+        """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
 
         The grid points of a proposal come as ``segs`` = S consecutive groups of G (the six
         faces, or one group for the box grid); the result holds one contiguous (3+C, K, G)
@@ -245,11 +297,11 @@ class SidePooling(nn.Module):
         grid_size = whole_grid.shape[1] // K
         idx, weight, relative_grid = self._blend_taps(origin_xyz, whole_grid, center)
         G, C = grid_size // segs, origin_features.shape[2]
-        out = origin_features.new_empty(segs, B, 3 + C, K * G)
-        out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(2, 0, 4, 1, 3) \
-            .reshape(segs, B, 3, K * G)
+        out = origin_features.new_empty(B, segs, 3 + C, K * G)
+        out[:, :, :3] = relative_grid.view(B, K, segs, G, 3).permute(0, 2, 4, 1, 3) \
+            .reshape(B, segs, 3, K * G)
         three_interpolate_segmented(origin_features, idx, weight, out, segs, G, 3)
-        return out.view(segs, B, 3 + C, K, G)
+        return out.view(B, segs, 3 + C, K, G)
 
     def dist_feature(self, end_points, prefix=''):
         """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
@@ -266,24 +318,27 @@ class SidePooling(nn.Module):
         side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
         bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
         fused = backend_for(origin_xyz).name == 'hip'
+        side_nets = list(self.mlps_before[:6])
         if fused:   # first convs through the blend; the literal form stays the CPU checker's
-            side_c0 = self.first_conv_through_blend(self.mlps_before[:6], origin_xyz,
-                                                    origin_features, side_grid, center)
+            side_c0 = self.first_conv_through_blend(side_nets, origin_xyz, origin_features,
+                                                    side_grid, center)
             bbox_c0 = self.first_conv_through_blend(self.mlps_before[6:7], origin_xyz,
-                                                    origin_features, bbox_grid, center)[0]
+                                                    origin_features, bbox_grid, center)[:, 0]
         else:
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
-            bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[0]
+            bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
         dist_feature = self.dist_feature(end_points, prefix)
-        pooled = [self.mlps_before[i](conv0_out=side_c0[i]) if fused
-                  else self.mlps_before[i](side_feats[i]) for i in range(6)]
+        if fused and mini_pointnets_groupable(side_nets, side_c0):
+            pooled = grouped_mini_pointnets(side_nets, side_c0)            # (B,6,128,2K)
+        else:
+            pooled = torch.stack([side_nets[i](conv0_out=side_c0[:, i]) if fused
+                                  else side_nets[i](side_feats[:, i]) for i in range(6)], 1)
         heads = list(self.mlps_head[:6])
-        if heads_batchable(heads, pooled[0]):
-            x = torch.cat([torch.stack(pooled, 1), dist_feature.transpose(0, 1)], dim=2)
+        x = torch.cat([pooled, dist_feature.transpose(0, 1)], dim=2)      # (B,6,166,2K)
+        if heads_batchable(heads, x[:, 0]):
             side_scores = batched_heads(heads, x).transpose(0, 1).contiguous()
         else:
-            side_scores = torch.stack([self.mlps_head[i](torch.cat((pooled[i], dist_feature[i]),
-                                                                   dim=1)) for i in range(6)], 0)
+            side_scores = torch.stack([self.mlps_head[i](x[:, i]) for i in range(6)], 0)
         end_points[f'{prefix}side_scores'] = side_scores
         bbox_feats = self.mlps_before[6](conv0_out=bbox_c0) if fused \
             else self.mlps_before[6](bbox_feats)

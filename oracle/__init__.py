@@ -152,26 +152,23 @@ class OracleKernels:
             if wx is not None:
                 r = rel.view(b, k, segs, seg_len, 3)[:, :, s_].reshape(b, k * seg_len, 3)
                 face = face + torch.matmul(wx[s_].unsqueeze(0), r.transpose(1, 2))
-            out[s_, :, c_offset:c_offset + c] = face
+            out[:, s_, c_offset:c_offset + c] = face
 
-    def blend_conv_backward(self, dy_faces, seg_off, idx, weight, rel, d_table, d_wx, segs,
-                            seg_len):
+    def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len):
         b, m, _ = d_table.shape
-        n = idx.shape[1]
+        n, c = idx.shape[1], dy.shape[2]
         k = n // (segs * seg_len)
-        for face, dy_face in enumerate(dy_faces):
-            if dy_face is None:
-                continue
-            c = dy_face.shape[1]
-            full = dy_face.new_zeros(b, c, k, segs, seg_len)
-            full[:, :, :, face] = dy_face.view(b, c, k, seg_len)
-            gp = dy_face.new_zeros(b, c, m)
-            self.three_interpolate_grad_wrapper(b, c, n, m, full.view(b, c, n).contiguous(),
+        full = dy.view(b, segs, c, k, seg_len).permute(0, 2, 3, 1, 4).reshape(b, c, n)
+        for face in range(segs):
+            only = torch.zeros_like(full).view(b, c, k, segs, seg_len)
+            only[:, :, :, face] = full.view(b, c, k, segs, seg_len)[:, :, :, face]
+            gp = dy.new_zeros(b, c, m)
+            self.three_interpolate_grad_wrapper(b, c, n, m, only.view(b, c, n).contiguous(),
                                                 idx, weight, gp)
             d_table[:, :, face * seg_off:face * seg_off + c] += gp.transpose(1, 2)
             if d_wx is not None:
                 r = rel.view(b, k, segs, seg_len, 3)[:, :, face].reshape(b, k * seg_len, 3)
-                d_wx[face] += torch.matmul(dy_face, r).sum(0)
+                d_wx[face] += torch.matmul(dy[:, face], r).sum(0)
 
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):

@@ -229,12 +229,12 @@ def test_three_interpolate_segmented_bit_exact(oracle_kernels, hip_device, k, se
     full = torch.cat([lead.view(b, segs, 3, k, g).permute(0, 2, 3, 1, 4).reshape(b, 3, k, segs * g),
                       plain.view(b, c, k, segs * g)], 1)                 # reference's cat
     want = [t.contiguous() for t in torch.split(full, g, dim=-1)]        # reference's split
-    out = torch.empty(segs, b, 3 + c, k * g, device=hip_device)
-    out[:, :, :3] = lead.transpose(0, 1).to(hip_device)
+    out = torch.empty(b, segs, 3 + c, k * g, device=hip_device)
+    out[:, :, :3] = lead.to(hip_device)
     ops.three_interpolate_segmented(feats.transpose(1, 2).contiguous().to(hip_device),
                                     idx.to(hip_device), w.to(hip_device), out, segs, g, 3)
     for s_ in range(segs):
-        assert torch.equal(out[s_].view(b, 3 + c, k, g).cpu(), want[s_]), s_
+        assert torch.equal(out[:, s_].reshape(b, 3 + c, k, g).cpu(), want[s_]), s_
 
 
 @pytest.mark.parametrize("k,segs,g,h", [(64, 6, 16, 64), (32, 1, 64, 128), (64, 6, 27, 128),
@@ -246,15 +246,14 @@ def test_blend_conv_matches_oracle(oracle_kernels, hip_device, k, segs, g, h):
     gen, b, m, n, idx, w, rel = _blend_case(k, segs, g, h, k + h)
     table = torch.randn(b, m, segs * h, generator=gen)
     wx = torch.randn(segs, h, 3, generator=gen)
-    go = torch.randn(segs, b, h, k * g, generator=gen)
+    go = torch.randn(b, segs, h, k * g, generator=gen)
     with kernels.use_backend(oracle_kernels):
         t0, x0 = table.clone().requires_grad_(True), wx.clone().requires_grad_(True)
-        want = torch.stack(ops.blend_conv(t0, x0, idx, w, rel, segs, g))
+        want = ops.blend_conv(t0, x0, idx, w, rel, segs, g)
         want.backward(go)
     t1 = table.to(hip_device).requires_grad_(True)
     x1 = wx.to(hip_device).requires_grad_(True)
-    got = torch.stack(ops.blend_conv(t1, x1, idx.to(hip_device), w.to(hip_device),
-                                     rel.to(hip_device), segs, g))
+    got = ops.blend_conv(t1, x1, idx.to(hip_device), w.to(hip_device), rel.to(hip_device), segs, g)
     got.backward(go.to(hip_device))
     torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(t1.grad.cpu(), t0.grad, rtol=1e-4, atol=1e-4)

@@ -148,13 +148,13 @@ def test_first_conv_through_blend_equals_conv_of_grid_features(oracle_kernels):
         grid = sp.grid_for_side(sp.generate_grid(size), center, heading).view(B, -1, 3).contiguous()
         nets = sp.mlps_before[:6]
         go = [torch.randn(B, 256, K, 16) for _ in range(6)]
-        got = sp.first_conv_through_blend(nets, xyz, feats_t, grid, center)
+        got = sp.first_conv_through_blend(nets, xyz, feats_t, grid, center).unbind(1)
         sum((g * o).sum() for g, o in zip(go, got)).backward()
         g_fused = [n.first_conv[0].weight.grad.clone() for n in nets]
         for n in nets:
             n.first_conv[0].weight.grad = None
         feats = sp.grid_features(xyz, feats_t, grid, center, segs=6)
-        want = [n.first_conv[0](feats[i]) for i, n in enumerate(nets)]
+        want = [n.first_conv[0](feats[:, i]) for i, n in enumerate(nets)]
         sum((g * o).sum() for g, o in zip(go, want)).backward()
     for i in range(6):
         torch.testing.assert_close(got[i], want[i], rtol=1e-4, atol=1e-5)

@@ -219,3 +219,48 @@ def test_batched_score_heads_equal_the_per_head_loop(hip_device):
             torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-3, atol=2e-5, msg=n)
         for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
             torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-5, atol=1e-6, msg=n)
+
+
+def test_grouped_mini_pointnets_equal_the_per_net_loop(hip_device):
+    """side_pooling.grouped_mini_pointnets (six MiniPointNets as broadcast GEMMs + stacked
+    BatchNorms) vs the six nets called one by one on the same first-conv outputs
+    (side_pooling_module.py:343-370): outputs, gradients, running statistics."""
+    import copy
+    from nesie_amd.votenet.side_pooling import (MiniPointNet, grouped_mini_pointnets,
+                                                mini_pointnets_groupable)
+    torch.manual_seed(12)
+    B, K, G = 2, 40, 16
+    nets = [MiniPointNet(19, 32, hide_dim=64).to(hip_device) for _ in range(6)]
+    for n in nets:
+        for m in n.modules():
+            if hasattr(m, 'running_mean'):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.3)
+    ref = copy.deepcopy(nets)
+    c0 = torch.randn(B, 6, 64, K, G, device=hip_device)
+    go = torch.randn(B, 6, 32, K, device=hip_device)
+    assert mini_pointnets_groupable(nets, c0)
+    x1 = c0.clone().requires_grad_(True)
+    got = grouped_mini_pointnets(nets, x1)
+    got.backward(go)
+    x2 = c0.clone().requires_grad_(True)
+    want = torch.stack([ref[i](conv0_out=x2[:, i]) for i in range(6)], 1)
+    want.backward(go)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    # a ReLU mask or a max-pool winner within rounding of a tie may flip between the two
+    # evaluation orders; one flip moves the BatchNorm sums of its whole channel, so the input
+    # gradient is compared in norm (a handful of flips among 5e5 entries)
+    rel = ((x1.grad - x2.grad).norm() / x2.grad.norm()).item()
+    assert rel < 2e-2, rel
+    for a, b in zip(nets, ref):
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            if pb.grad is None:        # first_conv[0] is bypassed by conv0_out
+                assert pa.grad is None, n
+                continue
+            # per-channel sums (norm weight/bias) move by one term per flipped mask entry
+            # (a bias in front of a norm layer has an analytically zero gradient: rounding noise
+            # on both sides, hence the absolute floor)
+            err = (pa.grad - pb.grad).norm().item()
+            assert err < 2e-2 * pb.grad.norm().item() + 1e-4 * pb.numel() ** 0.5, (n, err)
+        for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+            torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-5, atol=1e-6, msg=n)
