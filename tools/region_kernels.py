@@ -53,6 +53,10 @@ for i, m in enumerate(gc.mlps_before):
     wrap(m, 'forward', 'R:qh_minipointnet')
 for i, m in enumerate(gc.mlps_head):
     wrap(m, 'forward', 'R:qh_scorehead')
+import nesie_amd.votenet.side_pooling as _sp
+wrap(_sp, 'grouped_mini_pointnets', 'R:qh_minipointnet')
+wrap(_sp, 'batched_heads', 'R:qh_scorehead')
+wrap(gc, 'first_conv_through_blend', 'R:qh_features')
 for nm in ['objectness_loss', 'center_loss', 'surface_loss', 'semantic_loss', 'iou_loss',
            'iou_pred_loss', 'side_loss']:
     if hasattr(head, nm):
