@@ -156,7 +156,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     # the input coordinates, never on the weights, so the chain for the NEXT step runs on a
     # side stream (it occupies one CU per scene) while this step trains.  Every step still
     # executes one full index chain and one full fwd+bwd+update; nothing is cached.
-    pipelined = workload == 'pretrain'
+    pipelined = True
     side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
     main = torch.cuda.current_stream(device)
 
@@ -166,20 +166,37 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
             out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
         return out
 
-    if pipelined:
-        idx_next = model.backbone.sample_and_group_indices(pts)
-        idx_cur = [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
-                        group_idx=[t.clone() for t in d['group_idx']]) for d in idx_next]
+    def clone_tree(tree):
+        return [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
+                     group_idx=[t.clone() for t in d['group_idx']]) for d in tree]
 
-        def fwd_bwd_pre():
-            bucket.begin()
-            losses = model.forward_train(pts, None, gt, None, precomputed=idx_cur)
-            total = model.parse_losses(losses)
-            total.backward()
-            bucket.collect()
-            loss_out.copy_(total.detach())
-    else:
-        fwd_bwd_pre = fwd_bwd
+    semi_like = workload in ('semi', 'saqe')
+    # weight-independent work of a step: the backbone's index chain(s) and, for the supervised
+    # step, the per-point vote targets (points-in-boxes over 40 000 x T)
+    def input_only_work():
+        if semi_like:
+            return (model.backbone.sample_and_group_indices(pts_s)
+                    + model.backbone.sample_and_group_indices(pts_t), [])
+        return (model.backbone.sample_and_group_indices(pts),
+                list(model.bbox_head.vote_targets_of(pts, gt)))
+    idx_next, votes_next = input_only_work()
+    idx_cur, votes_cur = clone_tree(idx_next), [t.clone() for t in votes_next]
+    nlev = len(idx_cur) // 2 if semi_like else len(idx_cur)
+
+    def fwd_bwd_pre():
+        bucket.begin()
+        if semi_like:
+            losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows,
+                                         precomputed=dict(student=idx_cur[:nlev],
+                                                          teacher=idx_cur[nlev:]))
+        else:
+            losses = model.forward_train(pts, None, gt, None,
+                                         precomputed=dict(indices=idx_cur,
+                                                          vote_targets=tuple(votes_cur)))
+        total = model.parse_losses(losses)
+        total.backward()
+        bucket.collect()
+        loss_out.copy_(total.detach())
 
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -197,8 +214,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     if pipelined:
         g_idx = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_idx, stream=side):
-            fresh = model.backbone.sample_and_group_indices(pts)
-            torch._foreach_copy_(flat(idx_next), flat(fresh))
+            fresh, fresh_votes = input_only_work()
+            torch._foreach_copy_(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
         ready, copied = torch.cuda.Event(), torch.cuda.Event()
         with torch.cuda.stream(side):
             g_idx.replay()
@@ -207,7 +224,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     def graph_step():
         if pipelined:
             main.wait_event(ready)                       # this step's indices are complete
-            torch._foreach_copy_(flat(idx_cur), flat(idx_next))
+            torch._foreach_copy_(flat(idx_cur) + votes_cur, flat(idx_next) + votes_next)
             copied.record(main)
             side.wait_event(copied)
             with torch.cuda.stream(side):                # next step's index chain, overlapped
@@ -339,7 +356,7 @@ def main():
                        'points_per_scene': NUM_POINTS,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'hip_graph': bool(args.graph),
-                       'index_chain_pipelined': bool(args.graph) and args.workload == 'pretrain',
+                       'index_chain_pipelined': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes()},
         }
         # HBM-streaming kernels, priced on their largest launches (537 MB / 268 MB tensors at

@@ -88,12 +88,15 @@ class VoteNet(nn.Module):
                       pts_semantic_mask=None, pts_instance_mask=None, gt_bboxes_ignore=None,
                       precomputed=None):
         points_cat = torch.stack(points) if isinstance(points, (list, tuple)) else points
+        votes = None
+        if isinstance(precomputed, dict):   # {'indices': [...], 'vote_targets': (t, mask)}
+            precomputed, votes = precomputed.get('indices'), precomputed.get('vote_targets')
         with deferred_bn_counters():  # one launch for all num_batches_tracked increments
             x = self.extract_feat(points_cat, precomputed)
             bbox_preds = self.bbox_head(x, self.train_cfg['sample_mod'])
         return self.bbox_head.loss(bbox_preds, points_cat, gt_bboxes_3d, gt_labels_3d,
                                    pts_semantic_mask, pts_instance_mask, img_metas,
-                                   gt_bboxes_ignore=gt_bboxes_ignore)
+                                   gt_bboxes_ignore=gt_bboxes_ignore, vote_targets=votes)
 
     @staticmethod
     def parse_losses(losses):

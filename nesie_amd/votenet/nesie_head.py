@@ -218,9 +218,12 @@ class NesieHead(nn.Module):
 
     def loss(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
              pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None,
-             ret_target=False):
+             ret_target=False, vote_targets=None):
+        """``vote_targets``: optional result of ``vote_targets_of`` for this batch (the
+        per-point half of the targets depends on the inputs only, so a training loop may
+        compute it ahead of the step, like the backbone's index chain)."""
         targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask,
-                                   pts_instance_mask, bbox_preds)
+                                   pts_instance_mask, bbox_preds, vote_targets=vote_targets)
         (vote_targets, vote_target_masks, center_targets, bbox_targets, mask_targets,
          valid_gt_masks, objectness_targets, objectness_weights, box_loss_weights,
          valid_gt_weights, assignment) = targets
@@ -342,8 +345,11 @@ class NesieHead(nn.Module):
                     unsup_surface_loss=un_label_weight * unsup_surface_loss)
 
     # ---- targets (:511-679), batched on the device ------------------------------
-    def get_targets(self, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
-                    pts_instance_mask=None, bbox_preds=None):
+    @staticmethod
+    def vote_targets_of(points, gt_bboxes_3d, gt_labels_3d=None):
+        """Per-point vote targets (B,N,9) and masks (B,N) of ``get_targets_single``
+        (nesie_head.py:593-654), batched on the device.  Depends on the points and the GT
+        boxes only -- not on any network output."""
         pts = torch.stack(points) if isinstance(points, (list, tuple)) else points
         device = pts.device
         gt = gt_bboxes_3d if isinstance(gt_bboxes_3d, GTBatch) else \
@@ -382,6 +388,21 @@ class NesieHead(nn.Module):
         vote_targets = torch.where(has, torch.cat([v1, v2, v3], dim=-1),
                                    xyz.new_zeros(B, N, 9))
         vote_target_masks = (cnt > 0).long()
+        return vote_targets, vote_target_masks
+
+    def get_targets(self, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
+                    pts_instance_mask=None, bbox_preds=None, vote_targets=None):
+        pts = torch.stack(points) if isinstance(points, (list, tuple)) else points
+        device = pts.device
+        gt = gt_bboxes_3d if isinstance(gt_bboxes_3d, GTBatch) else \
+            GTBatch.collate(gt_bboxes_3d, gt_labels_3d, device)
+        T = gt.boxes.shape[1]
+        col = torch.arange(T, device=device).unsqueeze(0)
+        is_col = col < gt.count.unsqueeze(1)
+        centres = torch.cat([gt.boxes[..., :2],
+                             (gt.boxes[..., 2] + gt.boxes[..., 5] * 0.5).unsqueeze(-1)], -1)
+        vote_targets, vote_target_masks = vote_targets if vote_targets is not None \
+            else self.vote_targets_of(pts, gt)
 
         # --- proposal <-> GT assignment (:656-676) ---
         aggregated_points = bbox_preds['aggregated_points']

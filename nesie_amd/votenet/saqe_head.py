@@ -144,8 +144,10 @@ class SAQEHead(NesieHead):
                                (label_cls, label_iou_j), weight=w)
         return a + b, label_cls, targets_b
 
-    def _common(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, sem, ins):
-        targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, sem, ins, bbox_preds)
+    def _common(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, sem, ins,
+                vote_targets=None):
+        targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, sem, ins, bbox_preds,
+                                   vote_targets=vote_targets)
         (vote_targets, vote_target_masks, center_targets, bbox_targets, mask_targets,
          valid_gt_masks, objectness_targets, objectness_weights, box_loss_weights,
          valid_gt_weights, assignment) = targets
@@ -178,9 +180,11 @@ class SAQEHead(NesieHead):
 
     # ---- pre-training loss (:331-521) ------------------------------------------------------
     def loss(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
-             pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None, ret_target=False):
+             pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None, ret_target=False,
+             vote_targets=None):
         out, surface, iou, angle, blw, targets_b = self._common(
-            bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask, pts_instance_mask)
+            bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask, pts_instance_mask,
+            vote_targets=vote_targets)
         out['surface_loss'] = surface.sum()
         out['iou_loss'] = iou.sum()
         out['angle_loss'] = angle.sum()

@@ -319,19 +319,22 @@ class VoteNetNesie(VoteNet):
 
     # -- the step (:69-127) -------------------------------------------------------------------
     def forward_train(self, points_s, points_t, gt_labeled, use_label, meta_s, meta_t,
-                      unlabeled_rows):
+                      unlabeled_rows, precomputed=None):
         """points_* (B,N,4) student / teacher views of the same B scenes; gt_labeled =
         GTBatch of the labeled scenes (in batch order); use_label = python list of B bools;
         meta_* = AugMeta of each view; unlabeled_rows (U,) long = positions of the batch's
-        unlabeled scenes in the unlabeled set."""
+        unlabeled scenes in the unlabeled set.  ``precomputed`` = dict(student=..., teacher=...)
+        of ``backbone.sample_and_group_indices`` results for the two views (optional: the
+        index chains depend on the input coordinates only)."""
+        pre = precomputed or {}
         cfg = self.train_cfg
         name = cfg.get('dataset_name', 'ScanNet')
         with deferred_bn_counters():
-            x_s = self.extract_feat(points_s)
+            x_s = self.extract_feat(points_s, pre.get('student'))
             preds_s = self.bbox_head(x_s, cfg['sample_mod'], name)
             with torch.no_grad():
                 self.teacher.swap()                  # call_hook("switch_to_teacher")
-                x_t = self.extract_feat(points_t)
+                x_t = self.extract_feat(points_t, pre.get('teacher'))
                 preds_t = self.bbox_head(x_t, cfg['sample_mod'], name)
         with torch.no_grad():
             labels, boxes, quality, valid = self.get_pseudo_labels(preds_t, name)
