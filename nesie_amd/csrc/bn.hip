@@ -71,46 +71,77 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
 }
 
 // coef[c*4 + {0,1,2,3}] = scale, bias, mean, invstd
-__global__ void bn_finalize_kernel(int c_total, int nslice, double n, const float *x, long long p,
-                                   const float *row_bias, int group,
-                                   const float *partial, const float *gamma,
-                                   const float *beta, float *running_mean,
-                                   float *running_var, float momentum, float eps,
-                                   float *save_mean, float *save_invstd, float *coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= c_total) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nslice; ++i) {
-    s0 += (double)partial[((size_t)c * nslice + i) * 2];
-    s1 += (double)partial[((size_t)c * nslice + i) * 2 + 1];
+// Everything the statistics -> coefficients step needs (the per-slice partial sums and where
+// the results go).  The step runs inside the apply kernels: every block of a channel folds the
+// channel's partials itself (wave 0, fp64; <= a few hundred values from L2) and the first block
+// of the channel also writes the saved statistics / running statistics -- no separate
+// one-block "finalize" launch between the two streaming passes.
+struct BnFwdFin {
+  int nslice; double n; const float *x; long long p; const float *row_bias; int group;
+  const float *partial; const float *gamma; const float *beta; float *running_mean;
+  float *running_var; float momentum; float eps; float *save_mean; float *save_invstd;
+  float *coef;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// -> sh[0] = scale, sh[1] = bias (valid for every thread after the barrier inside)
+__device__ __forceinline__ void bn_fwd_finalize(const BnFwdFin &f, int c, bool writer, float *sh) {
+  if (threadIdx.x < 64) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < f.nslice; i += 64) {
+      s0 += (double)f.partial[((size_t)c * f.nslice + i) * 2];
+      s1 += (double)f.partial[((size_t)c * f.nslice + i) * 2 + 1];
+    }
+    s0 = wave_sum_f64(s0);
+    s1 = wave_sum_f64(s1);
+    if (threadIdx.x == 0) {
+      const double shift = (double)(f.x[(size_t)c * f.p] +
+                                    (f.row_bias ? f.row_bias[(size_t)c * (f.p / f.group)] : 0.f));
+      const double m = s0 / f.n;
+      double var = s1 / f.n - m * m;
+      if (var < 0.0) var = 0.0;
+      const double mean = shift + m;
+      const double invstd = 1.0 / sqrt(var + (double)f.eps);
+      const double g = f.gamma ? (double)f.gamma[c] : 1.0, bt = f.beta ? (double)f.beta[c] : 0.0;
+      sh[0] = (float)(g * invstd);
+      sh[1] = (float)(bt - mean * g * invstd);
+      if (writer) {
+        if (f.running_mean) {
+          f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
+          const double unbiased = f.n > 1.0 ? var * f.n / (f.n - 1.0) : var;
+          f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unbiased);
+        }
+        f.save_mean[c] = (float)mean;
+        f.save_invstd[c] = (float)invstd;
+        f.coef[c * 4 + 0] = sh[0];
+        f.coef[c * 4 + 1] = sh[1];
+        f.coef[c * 4 + 2] = (float)mean;
+        f.coef[c * 4 + 3] = (float)invstd;
+      }
+    }
   }
-  const double shift = (double)(x[(size_t)c * p] +
-                                (row_bias ? row_bias[(size_t)c * (p / group)] : 0.f));
-  const double m = s0 / n;
-  double var = s1 / n - m * m;
-  if (var < 0.0) var = 0.0;
-  const double mean = shift + m;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  if (running_mean) {
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)invstd;
-  const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
-  coef[c * 4 + 0] = (float)(g * invstd);
-  coef[c * 4 + 1] = (float)(bt - mean * g * invstd);
-  coef[c * 4 + 2] = (float)mean;
-  coef[c * 4 + 3] = (float)invstd;
+  __syncthreads();
+}
+
+// the same step as a kernel of its own, for the pooled forward (whose blocks span channels)
+__global__ void bn_finalize_kernel(BnFwdFin f, int c_total) {
+  __shared__ float sh[2];
+  if ((int)blockIdx.x < c_total) bn_fwd_finalize(f, blockIdx.x, true, sh);
 }
 
 template <bool RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
     int c_total, long long p, const float *__restrict__ x, const float *__restrict__ row_bias,
-    int group, const float *__restrict__ coef, float *__restrict__ y) {
+    int group, BnFwdFin fin, float *__restrict__ y) {
+  __shared__ float shc[2];
   const int c = blockIdx.y, b = blockIdx.z;
-  const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
+  bn_fwd_finalize(fin, c, blockIdx.x == 0 && b == 0, shc);
+  const float sc = shc[0], bi = shc[1];
   const size_t base = ((size_t)b * c_total + c) * p;
   const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
@@ -188,35 +219,57 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
 }
 
 // coef[c*4 + {0,1,2}] = gamma*invstd, sum(g)/n, sum(g*xhat)/n ; dgamma, dbeta written
-__global__ void bn_bwd_finalize_kernel(int c_total, int nslice, double n, const float *partial,
-                                       const float *gamma, const float *save_invstd,
-                                       float *dgamma, float *dbeta, float *coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= c_total) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nslice; ++i) {
-    s0 += (double)partial[((size_t)c * nslice + i) * 2];
-    s1 += (double)partial[((size_t)c * nslice + i) * 2 + 1];
+struct BnBwdFin {
+  int nslice; double n; const float *partial; const float *gamma; const float *save_invstd;
+  float *dgamma; float *dbeta;
+};
+
+// -> sh[0] = gamma * invstd, sh[1] = sum(dy) / n, sh[2] = sum(dy * xhat) / n
+__device__ __forceinline__ void bn_bwd_finalize(const BnBwdFin &f, int c, bool writer, float *sh) {
+  if (threadIdx.x < 64) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < f.nslice; i += 64) {
+      s0 += (double)f.partial[((size_t)c * f.nslice + i) * 2];
+      s1 += (double)f.partial[((size_t)c * f.nslice + i) * 2 + 1];
+    }
+    s0 = wave_sum_f64(s0);
+    s1 = wave_sum_f64(s1);
+    if (threadIdx.x == 0) {
+      const double g = f.gamma ? (double)f.gamma[c] : 1.0;
+      sh[0] = (float)(g * (double)f.save_invstd[c]);
+      sh[1] = (float)(s0 / f.n);
+      sh[2] = (float)(s1 / f.n);
+      if (writer) {
+        if (f.dbeta) f.dbeta[c] = (float)s0;
+        if (f.dgamma) f.dgamma[c] = (float)s1;
+      }
+    }
   }
-  if (dbeta) dbeta[c] = (float)s0;
-  if (dgamma) dgamma[c] = (float)s1;
-  const double g = gamma ? (double)gamma[c] : 1.0;
-  coef[c * 4 + 0] = (float)(g * (double)save_invstd[c]);
-  coef[c * 4 + 1] = (float)(s0 / n);
-  coef[c * 4 + 2] = (float)(s1 / n);
+  __syncthreads();
+}
+
+// kernel form for the pooled backward; coef[c] = (a, k1, k2, -)
+__global__ void bn_bwd_finalize_kernel(BnBwdFin f, int c_total, float *coef) {
+  __shared__ float sh[3];
+  const int c = blockIdx.x;
+  if (c >= c_total) return;
+  bn_bwd_finalize(f, c, true, sh);
+  if (threadIdx.x == 0) { coef[c * 4 + 0] = sh[0]; coef[c * 4 + 1] = sh[1]; coef[c * 4 + 2] = sh[2]; }
 }
 
 template <bool RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
-    const float *__restrict__ fwd_coef, const float *__restrict__ coef,
+    const float *__restrict__ fwd_coef, BnBwdFin fin,
     const float *__restrict__ row_bias, int group, float *__restrict__ d_row_bias,
     float *__restrict__ dx) {
   // dx = a * (g - k1 - xhat * k2) for EVERY position, masked ones included, so x is needed
   // everywhere; the ReLU mask is re-derived from x with the forward's own scale/bias
   // (same two fp32 operations as bn_apply_kernel, hence the same bits) instead of reading y.
+  __shared__ float shc[3];
   const int c = blockIdx.y, b = blockIdx.z;
-  const float a = coef[c * 4 + 0], k1 = coef[c * 4 + 1], k2 = coef[c * 4 + 2];
+  bn_bwd_finalize(fin, c, blockIdx.x == 0 && b == 0, shc);
+  const float a = shc[0], k1 = shc[1], k2 = shc[2];
   const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const size_t base = ((size_t)b * c_total + c) * p;
@@ -378,11 +431,10 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
   dim3 grid(sp, c, b);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, row_bias, group,
                      partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
-                     (double)b * (double)p, x, p, row_bias, group, partial, gamma, beta, running_mean,
-                     running_var, momentum, eps, save_mean, save_invstd, coef);
-  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, coef, y);
-  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, coef, y);
+  const BnFwdFin fin{nslice, (double)b * (double)p, x, p, row_bias, group, partial, gamma, beta,
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, coef};
+  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);
+  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);
   return check_launch(W);
 }
 
@@ -411,14 +463,14 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x,
                        y, save_mean, save_invstd, gamma, beta, row_bias, group, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
-                     (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  (void)coef;
   if (relu)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       coef, row_bias, group, d_row_bias, dx);
+                       fin, row_bias, group, d_row_bias, dx);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       coef, row_bias, group, d_row_bias, dx);
+                       fin, row_bias, group, d_row_bias, dx);
   return check_launch(W);
 }
 
@@ -454,9 +506,9 @@ extern "C" int nesie_bn_relu_maxpool_forward(int b, int c, int m, int ns, const 
   float *partial = (float *)workspace;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, p, sp, x,
                      (const float *)nullptr, 1, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
-                     (double)b * (double)p, x, p, (const float *)nullptr, 1, partial, gamma, beta,
-                     running_mean, running_var, momentum, eps, save_mean, save_invstd, fwd_coef);
+  const BnFwdFin fin{nslice, (double)b * (double)p, x, p, nullptr, 1, partial, gamma, beta,
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, fwd_coef};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c);
   const long long rows = (long long)b * c * m;
   const int lpr = ns / 4;
   const dim3 grid((unsigned)cdiv(rows * lpr, 256));
@@ -490,8 +542,8 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
   float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, m, ns,
                      rows_per, grad_pooled, pooled, argmax, x, fwd_coef, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, s, c, nslice,
-                     (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta, coef);
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c, coef);
   const long long rows = (long long)b * c * m;
   const int lpr = ns / 4;
   const dim3 grid((unsigned)cdiv(rows * lpr, 256));
