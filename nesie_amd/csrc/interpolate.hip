@@ -220,24 +220,37 @@ __global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
 // with the first conv's weight-gradient GEMM.
 // Measured here (tools/clk/lds_atomic.hip): ds_add_f32 sustains 0.32 lanes/clk/CU and
 // ds_add_u32/u64 0.93, i.e. 0.2-0.57 T adds/s chip-wide, and global float atomics ~1.3 TB/s of
-// added bytes; this scatter has 0.5 G adds.  So the number of adds must shrink: lane = channel (the
-// mirror image of blend_fwd_kernel: dy tiles turn through LDS), a wave walks a run of
-// consecutive queries and keeps the last BL_SLOTS destinations (seed, running sum) in
-// REGISTERS -- the grid points of one face share their few nearest seeds, so most taps hit a
-// live slot -- and a slot leaves as ONE 256-byte global_atomic_add_f32 row only when it is
-// evicted.  Keys are wave-uniform (scalar compares, no divergence).  d_table and d_wx must be
-// zero on entry.
-constexpr int BL_SLOTS = 8;
+// added bytes; this scatter has 0.5 G adds.  So the number of adds must shrink: lane = channel
+// (the mirror image of blend_fwd_kernel: dy tiles turn through LDS) and a wave owns 16
+// consecutive queries = 48 taps (one face of one proposal when seg_len = 16).  The taps of such
+// a group land on ~19 distinct seeds (tools/blend_locality.py), so the wave sorts its 48
+// (seed, tap) keys -- a 64-lane bitonic network in registers -- walks them in seed order with
+// ONE running sum per lane, and emits one 256-byte global_atomic_add_f32 row per channel
+// block only when the seed changes: ~2.5x fewer adds, no slot bookkeeping, and all control
+// flow wave-uniform.  d_table and d_wx must be zero on entry.
 constexpr int BL_RUN = 128;  // consecutive queries per workgroup
 
-// CPT = c / 64 channels per lane: a wave covers ALL c channels of its quarter of the tile's
-// queries (16 consecutive ones = one face of one proposal when seg_len = 16), so the per-tap
-// slot bookkeeping, which is scalar work, is paid once per c channels.
+__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)v, j, 64);
+      const bool up = (lane & k) == 0;           // this block sorts ascending
+      const bool lower = (lane & j) == 0;        // this lane keeps the smaller of the pair
+      v = (up == lower) ? (v < o ? v : o) : (v > o ? v : o);
+    }
+  }
+  return v;
+}
+
+// CPT = c / 64 channels per lane: a wave covers ALL c channels of its 16 queries.
 template <int CPT>
 __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
-    const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx, const float *__restrict__ weight,
-    const float *__restrict__ rel, float *__restrict__ d_table, float *__restrict__ d_wx) {
+    const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
+    const float *__restrict__ weight, const float *__restrict__ rel,
+    float *__restrict__ d_table, float *__restrict__ d_wx) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
@@ -249,14 +262,6 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float *src = dy + ((size_t)bi * segs + sg) * C * per_seg;
   float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
-  // slot keys: lane i (< BL_SLOTS) of `keys` holds the seed of slot i, -1 = empty
-  int keys = -1;
-  float sum[BL_SLOTS][CPT];
-#pragma unroll
-  for (int i = 0; i < BL_SLOTS; ++i)
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) sum[i][e] = 0.f;
-  int rr = 0;
   float dx[CPT][3];
 #pragma unroll
   for (int e = 0; e < CPT; ++e) dx[e][0] = dx[e][1] = dx[e][2] = 0.f;
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
         sr[threadIdx.x][t] = rel ? rel[p * 3 + t] : 0.f;
       }
     }
-    // dy tile: C rows x 64 queries, dense 256-byte row reads (lane = query)
-    // (16 independent loads in flight per wave before the first LDS store)
+    // dy tile: C rows x 64 queries, dense 256-byte row reads (lane = query);
+    // 16 independent loads in flight per wave before the first LDS store
 #pragma unroll
     for (int rb = 0; rb < C / 4; rb += 16) {
       float t16[16];
@@ -287,67 +292,59 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
       for (int u = 0; u < 16; ++u) tile[((rb + u) * 4 + wv) * (TS_Q + 1) + lane] = t16[u];
     }
     __syncthreads();
-    for (int q0 = wv * 16; q0 < wv * 16 + 16; q0 += 4) {
-      // four queries' operands at once (the LDS reads overlap; all but v are broadcasts)
-      float v[4][CPT], ww[4][3], rl[4][3];
-      int jj[4][3];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int e = 0; e < CPT; ++e) v[u][e] = tile[(e * 64 + lane) * (TS_Q + 1) + q0 + u];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          jj[u][t] = sj[q0 + u][t]; ww[u][t] = sw[q0 + u][t]; rl[u][t] = sr[q0 + u][t];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    const int q0 = wv * 16;
+    // d_wx: sum_q dy * rel over this wave's 16 queries (lane = channel)
+    if (d_wx) {
+#pragma unroll 4
+      for (int u = 0; u < 16; ++u) {
+        const float r0x = sr[q0 + u][0], r1x = sr[q0 + u][1], r2x = sr[q0 + u][2];
 #pragma unroll
         for (int e = 0; e < CPT; ++e) {
-          dx[e][0] += v[u][e] * rl[u][0]; dx[e][1] += v[u][e] * rl[u][1];
-          dx[e][2] += v[u][e] * rl[u][2];
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int j = __builtin_amdgcn_readfirstlane(jj[u][t]);
-          const unsigned long long hit = __ballot(keys == j) & (BL_SLOTS >= 64 ? ~0ull : ((1ull << BL_SLOTS) - 1ull));
-          int slot;
-          if (hit) {
-            slot = __builtin_ctzll(hit);
-          } else {  // evict the round-robin slot: CPT 256-byte rows of adds
-            slot = rr;
-            const int old = __builtin_amdgcn_readlane(keys, slot);
-            if (old >= 0) {
-              float o[CPT];
-#pragma unroll
-              for (int i = 0; i < BL_SLOTS; ++i)
-                if (slot == i) {
-#pragma unroll
-                  for (int e = 0; e < CPT; ++e) { o[e] = sum[i][e]; sum[i][e] = 0.f; }
-                }
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)old * pitch + e * 64, o[e]);
-            }
-            keys = lane == slot ? j : keys;
-            rr = (rr + 1) & (BL_SLOTS - 1);
-          }
-#pragma unroll
-          for (int i = 0; i < BL_SLOTS; ++i)
-            if (slot == i) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) sum[i][e] += v[u][e] * ww[u][t];
-            }
+          const float v = tile[(e * 64 + lane) * (TS_Q + 1) + q0 + u];
+          dx[e][0] += v * r0x; dx[e][1] += v * r1x; dx[e][2] += v * r2x;
         }
       }
     }
-  }
+    // the 48 taps of these 16 queries in seed order: key = seed << 6 | tap
+    unsigned key = 0xFFFFFFFFu;
+    if (lane < 48) key = ((unsigned)sj[q0 + lane / 3][lane % 3] << 6) | (unsigned)lane;
+    key = bitonic_sort64(key, lane);
+    int cur = -1;
+    float acc[CPT];
 #pragma unroll
-  for (int i = 0; i < BL_SLOTS; ++i) {
-    const int k = __builtin_amdgcn_readlane(keys, i);
-    if (k >= 0) {
+    for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+    for (int i0 = 0; i0 < 48; i0 += 8) {
+      // phase A: eight taps' products, all loads independent (they overlap in the LDS queue)
+      int seeds[8];
+      float x[8][CPT];
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)k * pitch + e * 64, sum[i][e]);
+      for (int i = 0; i < 8; ++i) {
+        const unsigned u = (unsigned)__builtin_amdgcn_readlane((int)key, i0 + i);
+        const int tap = (int)(u & 63u);
+        const int q = q0 + tap / 3, t = tap % 3;
+        seeds[i] = (int)(u >> 6);
+        const float w = sw[q][t];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) x[i][e] = tile[(e * 64 + lane) * (TS_Q + 1) + q] * w;
+      }
+      // phase B: the running sum; a row of adds leaves only when the seed changes
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (seeds[i] != cur) {
+          if (cur >= 0) {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+          }
+          cur = seeds[i];
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc[e] += x[i][e];
+      }
     }
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
   }
   if (d_wx) {
 #pragma unroll

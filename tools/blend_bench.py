@@ -10,7 +10,7 @@ hip = kernels.backend_for(torch.empty(1, device=dev))
 B, c, m, K, segs, G = 8, 256, 1024, 512, 6, 16
 n = K * segs * G
 g = torch.Generator(device=dev).manual_seed(0)
-dy = torch.randn(B, c, K * G, device=dev, generator=g)
+dy = torch.randn(B, segs, c, K * G, device=dev, generator=g)
 w = torch.rand(B, n, 3, device=dev, generator=g)
 rel = torch.randn(B, n, 3, device=dev, generator=g)
 d_table = torch.zeros(B, m, segs * c, device=dev)
@@ -19,7 +19,7 @@ d_wx = torch.zeros(segs, c, 3, device=dev)
 
 def run(idx, label):
     def f():
-        hip.blend_conv_backward([dy] * segs, c, idx, w, rel, d_table, d_wx, segs, G)
+        hip.blend_conv_backward(dy, c, idx, w, rel, d_table, d_wx, segs, G)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for _ in range(3):
