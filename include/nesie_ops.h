@@ -125,8 +125,9 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
  *     (B, M, segs*H), seg_off = H) and wx = the conv's xyz columns (segs, H, 3): the first
  *     conv's OUTPUT, W . cat[rel, blend(F)] = W_xyz . rel + blend(W_f . F) by linearity.
  * backward (second form): dy (B, segs, c, K*seg_len) = the gradient of out; ADDS into
- * d_table (B, M, pitch) columns [s*seg_off, +c) and into d_wx (segs, c, 3) (NULL = skip),
- * both zeroed by the caller; c in
+ * d_table (B, M, pitch) columns [s*seg_off, +c) (zeroed by the caller) and WRITES
+ * d_wx (B, R, segs, c, 3), R = nesie_blend_conv_runs(n, segs), one partial sum of dy x rel per
+ * workgroup for the caller to add up (NULL = skip); c in
  * {64, 128, 192, 256} and K*seg_len % 64 == 0.  Sum order is not fixed (float atomics), like
  * the reference's scatter.  Channels outside [c_offset, c_offset+c) of out are left
  * untouched by the forward. */
@@ -134,6 +135,7 @@ int nesie_blend_conv_forward(int b, int c, int m, int n, const float *table, int
                              int seg_off, const int *idx, const float *weight,
                              const float *rel, const float *wx, float *out, int segs,
                              int seg_len, int c_total, int c_offset, void *stream);
+int nesie_blend_conv_runs(int n, int segs);
 int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy, int pitch, int seg_off, const int *idx, const float *weight,
                               const float *rel, float *d_table, float *d_wx, int segs,
                               int seg_len, void *stream);

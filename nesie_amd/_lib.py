@@ -75,6 +75,8 @@ def load():
     lib.nesie_fps_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_bn_workspace_bytes.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_bn_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_blend_conv_runs.argtypes = [_I, _I]
+    lib.nesie_blend_conv_runs.restype = _I
     lib.nesie_mlp_stat_partials.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_mlp_stat_partials.restype = ctypes.c_longlong
     lib.nesie_abi_version.restype = _I

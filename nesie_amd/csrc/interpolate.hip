@@ -227,8 +227,11 @@ __global__ __launch_bounds__(TI_BLOCK) void blend_fwd_generic_kernel(
 // (seed, tap) keys -- a 64-lane bitonic network in registers -- walks them in seed order with
 // ONE running sum per lane, and emits one 256-byte global_atomic_add_f32 row per channel
 // block only when the seed changes: ~2.5x fewer adds, no slot bookkeeping, and all control
-// flow wave-uniform.  d_table and d_wx must be zero on entry.
-constexpr int BL_RUN = 128;  // consecutive queries per workgroup
+// flow wave-uniform.  d_table must be zero on entry; d_wx leaves as one partial per workgroup
+// (plain stores: thousands of workgroups adding into the same few KB serialise at the memory
+// side), summed by the caller.
+constexpr int BL_RUN = 512;  // consecutive queries per workgroup (long runs: the per-workgroup
+                             // set-up and the d_wx partial are paid once per run)
 
 __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
 #pragma unroll
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
     const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
-    float *__restrict__ d_table, float *__restrict__ d_wx) {
+    float *__restrict__ d_table, float *__restrict__ d_wx_part) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     __syncthreads();
     const int q0 = wv * 16;
     // d_wx: sum_q dy * rel over this wave's 16 queries (lane = channel)
-    if (d_wx) {
+    if (d_wx_part) {
 #pragma unroll 4
       for (int u = 0; u < 16; ++u) {
         const float r0x = sr[q0 + u][0], r1x = sr[q0 + u][1], r2x = sr[q0 + u][2];
@@ -346,12 +349,18 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
 #pragma unroll
     for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
   }
-  if (d_wx) {
+  if (d_wx_part) {
+    // partial[b][run][s][c][3]: the four waves hold different queries of the same channels
+    __syncthreads();
+    float *red = tile;  // [4][C][3]
 #pragma unroll
-    for (int e = 0; e < CPT; ++e) {
-      float *dw = d_wx + ((size_t)sg * C + e * 64 + lane) * 3;
-      atomicAdd(dw + 0, dx[e][0]); atomicAdd(dw + 1, dx[e][1]); atomicAdd(dw + 2, dx[e][2]);
-    }
+    for (int e = 0; e < CPT; ++e)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) red[(wv * C + e * 64 + lane) * 3 + d] = dx[e][d];
+    __syncthreads();
+    float *dst = d_wx_part + ((((size_t)bi * gridDim.x + blockIdx.x) * segs + sg) * C) * 3;
+    for (int i = threadIdx.x; i < C * 3; i += 256)
+      dst[i] = (red[i] + red[C * 3 + i]) + (red[2 * C * 3 + i] + red[3 * C * 3 + i]);
   }
 }
 
@@ -444,6 +453,10 @@ extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float 
                        dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, segs, seg_len, c_total,
                        c_offset, pitch, seg_off, table, idx, weight, rel, wx, out);
   return check_launch(W);
+}
+
+extern "C" int nesie_blend_conv_runs(int n, int segs) {
+  return segs >= 1 && n >= 0 ? cdiv(n / segs, BL_RUN) : 0;
 }
 
 extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy,

@@ -189,8 +189,8 @@ class HipKernels(_BNPoolMixin):
                       int(out.shape[2]), c_offset, _stream(table))
 
     def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len):
-        """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c) and
-        d_wx (segs, c, 3); both zeroed by the caller."""
+        """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c)
+        (zeroed by the caller) and adds sum(dy x rel) into d_wx (segs, c, 3)."""
         _check(dy, idx, weight, d_table); _f32(dy, weight, d_table); _i32(idx)
         b, m, pitch = d_table.shape
         n, c = idx.shape[1], dy.shape[2]
@@ -200,9 +200,15 @@ class HipKernels(_BNPoolMixin):
             assert tuple(d_wx.shape) == (segs, c, 3)
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
         with torch.cuda.device(dy.device):
+            part = None
+            if d_wx is not None:   # one partial per workgroup, summed here
+                runs = _lib.load().nesie_blend_conv_runs(n, segs)
+                part = torch.empty(b * runs, segs, c, 3, dtype=torch.float32, device=dy.device)
             _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
-                      _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(d_wx), segs, seg_len,
+                      _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part), segs, seg_len,
                       _stream(dy))
+            if part is not None:
+                d_wx += part.sum(0)
 
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):
