@@ -260,6 +260,17 @@ int nesie_mlp_stat_finalize(int c, long long nparts, double count, const float *
                             float *running_var, float momentum, float eps, float *coef,
                             void *stream);
 
+/* Weight gradient of a 1x1 conv on the matrix cores: dw[cout][cin] = sum over scenes and
+ * positions of dy[b][m][p] * act(x[b][k][p]); dy (B, cout, p), x[b] (cin, p) at x + b*x_bstride,
+ * act as in nesie_mlp_layer_forward (x_coef NULL = identity).  Reference: the conv2d backward
+ * that autograd runs for ConvModule's Conv2d (point_sa_module.py:277-289).  Partials are added in
+ * a fixed order (bitwise reproducible).  cout <= 256, cin <= 160 (128 when cout > 128);
+ * workspace = nesie_conv_wgrad_workspace_bytes(b, cout, cin, p). */
+size_t nesie_conv_wgrad_workspace_bytes(int b, int cout, int cin, long long p);
+int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy, const float *x,
+                     long long x_bstride, const float *x_coef, int x_relu, float *dw,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,3 +293,217 @@ extern "C" int nesie_mlp_stat_finalize(int c, long long nparts, double count,
                      momentum, eps, coef);
   return check_launch(W);
 }
+
+// ---- weight gradient of a 1x1 conv: dW[m][k] = sum_{b,p} dy[b][m][p] * x[b][k][p] -------------
+// Both operands are (channels x positions) row-major with the reduction axis contiguous, the
+// output is tiny (Cout x Cin) and the reduction is over B*P >= 10^5 positions: a workgroup owns
+// a run of positions of one scene, stages (Cout + Cin) x 64-position tiles in LDS (row pitch 65:
+// the 32 rows a half-wave reads sit on 32 banks), accumulates the WHOLE Cout x Cin product on
+// the matrix cores and leaves one partial per workgroup; a second kernel adds the partials in a
+// fixed order (bitwise reproducible).  rocBLAS reaches these shapes through per-scene split-K
+// batched GEMMs at 30-70 TFLOP/s; the SA1/SA2 layers are HBM-bound here.
+//   optional x_coef [cin][4] = (scale, bias, -, -): the operand is relu?(scale * x + bias)
+//   recomputed on load -- the activation a fused forward never stored (mlp_fwd_kernel).
+namespace nesie {
+
+constexpr int WG_Q = 64;  // positions per LDS tile
+
+template <int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    int cout, int cin, long long p, long long x_bstride, int run, int vec_ok,
+    const float *__restrict__ dy, const float *__restrict__ x,
+    const float *__restrict__ x_coef, int x_relu, float *__restrict__ partial) {
+  constexpr int MT = WM * MB * 32, NT = WN * NB * 32;  // padded Cout, Cin covered
+  extern __shared__ float lds[];                      // [MT + NT][WG_Q + 1]
+  float *sa = lds, *sb = lds + MT * (WG_Q + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bi = blockIdx.y;
+  const long long p0 = (long long)blockIdx.x * run;
+  const long long p1 = p0 + run < p ? p0 + run : p;
+  const float *dyb = dy + (size_t)bi * cout * p;
+  const float *xb = x + (size_t)bi * x_bstride;
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int half = lane >> 5, l32 = lane & 31;
+  // rows of 64 positions: 16 lanes x float4 per row, 16 rows per pass of the workgroup.  The
+  // loads of tile t+1 are issued before the MFMAs of tile t and land in LDS after them.
+  constexpr int ROWS = MT + NT, PASSES = ROWS / 16;
+  const bool vec = vec_ok != 0;  // float4 rows: p, batch stride and both bases 16-byte aligned
+  float4 v[PASSES];
+  auto load_tile = [&](long long q0) {
+    const long long q = q0 + (tid & 15) * 4;
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int r = u * 16 + (tid >> 4);
+      const bool is_a = r < MT;
+      const int row = is_a ? r : r - MT;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < (is_a ? cout : cin)) {
+        const float *src = (is_a ? dyb : xb) + (size_t)row * p + q;
+        if (vec && q + 3 < p1) {
+          v[u] = *(const float4 *)src;
+        } else {
+          if (q < p1) v[u].x = src[0];
+          if (q + 1 < p1) v[u].y = src[1];
+          if (q + 2 < p1) v[u].z = src[2];
+          if (q + 3 < p1) v[u].w = src[3];
+        }
+        if (!is_a && x_coef) {
+          const float sc = x_coef[row * 4 + 0], bs = x_coef[row * 4 + 1];
+          v[u].x = v[u].x * sc + bs; v[u].y = v[u].y * sc + bs;
+          v[u].z = v[u].z * sc + bs; v[u].w = v[u].w * sc + bs;
+          if (x_relu) {
+            v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+            v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+          }
+          if (q >= p1) v[u].x = 0.f;
+          if (q + 1 >= p1) v[u].y = 0.f;
+          if (q + 2 >= p1) v[u].z = 0.f;
+          if (q + 3 >= p1) v[u].w = 0.f;
+        }
+      }
+    }
+  };
+  if (p0 < p1) load_tile(p0);
+  for (long long q0 = p0; q0 < p1; q0 += WG_Q) {
+    __syncthreads();  // the previous tile's MFMA operand reads are done
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int r = u * 16 + (tid >> 4);
+      float *dst = (r < MT ? sa + r * (WG_Q + 1) : sb + (r - MT) * (WG_Q + 1)) + (tid & 15) * 4;
+      dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+    }
+    __syncthreads();
+    if (q0 + WG_Q < p1) load_tile(q0 + WG_Q);
+    const float *pa = sa + (wm * MB * 32 + l32) * (WG_Q + 1) + half;
+    const float *pb = sb + (wn * NB * 32 + l32) * (WG_Q + 1) + half;
+#pragma unroll 8
+    for (int k2 = 0; k2 < WG_Q / 2; ++k2) {
+      float a[MB], b[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) a[i] = pa[i * 32 * (WG_Q + 1) + k2 * 2];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = pb[j * 32 * (WG_Q + 1) + k2 * 2];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // partial[(b * runs + run)][cout][cin]
+  float *dst = partial + ((size_t)bi * gridDim.x + blockIdx.x) * cout * cin;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int k = (wn * NB + j) * 32 + l32;
+        if (m < cout && k < cin) dst[(size_t)m * cin + k] = acc[i][j][r];
+      }
+}
+
+// dw[i] = sum over the partials, in a fixed order: 64 consecutive outputs per workgroup (dense
+// 256-byte reads), 16 waves striding the partials with 8 independent loads in flight each.
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(int total, int nparts,
+                                                                 const float *__restrict__ partial,
+                                                                 float *__restrict__ dw) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < total) {
+    int r = wave;
+    for (; r + 7 * 16 < nparts; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + u * 16) * total + i];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < nparts; r += 16) s += partial[(size_t)r * total + i];
+  }
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w][lane];
+    dw[i] = t;
+  }
+}
+
+static int wgrad_runs(int b, int cout, int cin, long long p, int *run_len) {
+  // ~1024 workgroups, but no more partial bytes than ~32 MB
+  long long want = 1024 / (b > 0 ? b : 1);
+  const long long cap = (32ll << 20) / ((long long)cout * cin * 4) / (b > 0 ? b : 1);
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  long long run = (p + want - 1) / want;
+  run = (run + WG_Q - 1) / WG_Q * WG_Q;
+  if (run < WG_Q) run = WG_Q;
+  *run_len = (int)run;
+  return (int)((p + run - 1) / run);
+}
+
+}  // namespace nesie
+
+extern "C" size_t nesie_conv_wgrad_workspace_bytes(int b, int cout, int cin, long long p) {
+  if (b <= 0 || cout <= 0 || cin <= 0 || p <= 0) return 0;
+  int run;
+  const int runs = wgrad_runs(b, cout, cin, p, &run);
+  return (size_t)b * runs * cout * cin * sizeof(float);
+}
+
+extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
+                                const float *x, long long x_bstride, const float *x_coef,
+                                int x_relu, float *dw, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+  const char *W = "conv_wgrad";
+  NESIE_REQUIRE(b >= 0 && cout >= 1 && cin >= 1 && p >= 0, W);
+  NESIE_REQUIRE(dw, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (b == 0 || p == 0) {
+    (void)hipMemsetAsync(dw, 0, (size_t)cout * cin * sizeof(float), s);
+    return NESIE_OK;
+  }
+  NESIE_REQUIRE(dy && x && workspace && x_bstride >= (long long)cin * p && b <= 65535, W);
+  NESIE_REQUIRE(workspace_bytes >= nesie_conv_wgrad_workspace_bytes(b, cout, cin, p), W);
+  const int vec_ok = (((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (p & 3) == 0 && (x_bstride & 3) == 0;
+  const int mb32 = cdiv(cout, 32), nb32 = cdiv(cin, 32);
+  int run;
+  const int runs = wgrad_runs(b, cout, cin, p, &run);
+  float *partial = (float *)workspace;
+  const dim3 grid(runs, b);
+#define L(WM, WN, MB, NB)                                                                        \
+  do {                                                                                           \
+    const size_t lds = (size_t)(WM * MB + WN * NB) * 32 * (WG_Q + 1) * sizeof(float);            \
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MB, NB>), grid, dim3(256), lds, s, cout, cin, \
+                       p, x_bstride, run, vec_ok, dy, x, x_coef, x_relu, partial);                       \
+  } while (0)
+  // (Cout/32) x (Cin/32) output blocks over 4 waves
+  if (mb32 <= 2 && nb32 <= 2) L(2, 2, 1, 1);
+  else if (mb32 <= 2 && nb32 <= 4) L(2, 2, 1, 2);
+  else if (mb32 <= 4 && nb32 <= 1) L(4, 1, 1, 1);
+  else if (mb32 <= 4 && nb32 <= 2) L(4, 1, 1, 2);
+  else if (mb32 <= 4 && nb32 <= 4) L(4, 1, 1, 4);
+  else if (mb32 <= 4 && nb32 <= 5) L(4, 1, 1, 5);
+  else if (mb32 <= 8 && nb32 <= 2) L(4, 1, 2, 2);
+  else if (mb32 <= 8 && nb32 <= 4) L(4, 1, 2, 4);
+  else {
+    set_error("%s: %d x %d output (built for Cout <= 256, Cin <= 160)", W, cout, cin);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+#undef L
+  const int total = cout * cin;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(1024), 0, s, total,
+                     b * runs, partial, dw);
+  return check_launch(W);
+}

@@ -283,6 +283,24 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_iou3d_forward", n, _ptr(box1), _ptr(box2), _ptr(iou),
                       0 if jac is None else _ptr(jac), _stream(box1))
 
+    def conv_wgrad(self, dy, x, dw, x_coef=None, x_relu=False):
+        """dw (cout, cin) = sum_b dy[b] (cout, P) @ act(x[b]) (cin, P)^T on the matrix cores;
+        x may be a batch-strided view (each x[b] contiguous)."""
+        _f32(dy, x, dw)
+        if not (dy.is_cuda and dy.is_contiguous() and dw.is_contiguous()):
+            raise ValueError("conv_wgrad: dy / dw must be contiguous HIP tensors")
+        b, cout, p = dy.shape
+        cin = x.shape[1]
+        assert x.shape[0] == b and x.shape[2] == p and tuple(dw.shape) == (cout, cin)
+        assert x.stride(2) == 1 and x.stride(1) == p, "each x[b] must be (cin, P) contiguous"
+        lib = _lib.load()
+        need = lib.nesie_conv_wgrad_workspace_bytes(b, cout, cin, p)
+        with torch.cuda.device(dy.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
+            _lib.call("nesie_conv_wgrad", b, cout, cin, p, _ptr(dy), _ptr(x),
+                      x.stride(0) if b > 1 else cin * p, 0 if x_coef is None else _ptr(x_coef),
+                      int(bool(x_relu)), _ptr(dw), _ptr(ws), need, _stream(dy))
+
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
                         y, save_mean, save_invstd, fwd_coef, row_bias=None):
         """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place.

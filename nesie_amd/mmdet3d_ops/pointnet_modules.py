@@ -12,6 +12,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..kernels import backend_for
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup
@@ -45,7 +46,15 @@ class _PointwiseConvFn(torch.autograd.Function):
             dx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), dy)
         if ctx.needs_input_grad[1]:
             S = _PointwiseConvFn.SPLIT
-            if P >= _PointwiseConvFn.SPLIT_MIN_P and P % S == 0:
+            backend = backend_for(dy)
+            if (backend.name == 'hip' and co <= 64 and x3.shape[1] <= 64 and P >= 32768
+                    and dy.dtype == torch.float32 and x3.stride(2) == 1 and x3.stride(1) == P):
+                # HBM-bound skinny reductions (SA1): one pass over (dy, x) on the matrix cores
+                # with per-workgroup partials (tools/wgrad_bench.py: 0.12 vs 0.29 ms at 64x4,
+                # 0.18 vs 0.22 ms at 64x64, P = 131072, B = 8)
+                dw = dy.new_empty(co, x3.shape[1])
+                backend.conv_wgrad(dy, x3, dw)
+            elif P >= _PointwiseConvFn.SPLIT_MIN_P and P % S == 0:
                 pc, ci = P // S, x3.shape[1]
                 parts = [torch.bmm(dy[b].view(co, S, pc).permute(1, 0, 2),
                                    x3[b].view(ci, S, pc).permute(1, 2, 0)) for b in range(B)]

@@ -521,3 +521,29 @@ def test_mlp_layer_forward_matches_fp64(hip_device, cout, cin, p, b):
         torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-4, atol=1e-6)
         n = b * p
         torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("cout,cin,p,b", [(64, 4, 4096, 2), (64, 64, 1000, 3), (128, 131, 640, 2),
+                                         (256, 128, 320, 2), (18, 7, 130, 1), (128, 64, 8192, 2)])
+def test_conv_wgrad_matches_fp64(hip_device, cout, cin, p, b):
+    """nesie_conv_wgrad (weight gradient of a 1x1 conv on the matrix cores, fixed-order
+    partial sums) vs an fp64 einsum, with and without the recomputed BN + ReLU operand, and on
+    a batch-strided x view.  north_star tolerance 1e-4."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    g = torch.Generator().manual_seed(cout + cin + p)
+    dy = torch.randn(b, cout, p, generator=g).to(hip_device)
+    xfull = torch.randn(b, cin + 3, p, generator=g).to(hip_device)
+    x = xfull[:, 3:]                                   # batch stride (cin + 3) * p
+    coef = (torch.rand(cin, 4, generator=g) + 0.5).to(hip_device)
+    coef[:, 1] -= 1.0
+    dw = torch.empty(cout, cin, device=hip_device)
+    hip.conv_wgrad(dy, x, dw)
+    want = torch.einsum('bmp,bkp->mk', dy.double(), x.double())
+    assert ((dw.double() - want).norm() / want.norm()).item() < 1e-5
+    first = dw.clone()
+    hip.conv_wgrad(dy, x, dw)
+    assert torch.equal(first, dw)                      # fixed summation order
+    hip.conv_wgrad(dy, x, dw, x_coef=coef, x_relu=True)
+    a = torch.relu(x.double() * coef[:, 0].double().view(1, -1, 1) + coef[:, 1].double().view(1, -1, 1))
+    want = torch.einsum('bmp,bkp->mk', dy.double(), a)
+    assert ((dw.double() - want).norm() / want.norm()).item() < 1e-5
