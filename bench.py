@@ -123,8 +123,10 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
     # all-reduce, the clip and AdamW each see ONE tensor
     bucket = dp.FlatTrainState(model.parameters())
+    # on the GPU: torch's single-kernel ("fused") AdamW over the one flat parameter
     opt = torch.optim.AdamW([bucket.flat_param], lr=lr, weight_decay=wd,
-                            capturable=graph and on_gpu, foreach=True)
+                            capturable=graph and on_gpu, **(dict(fused=True) if on_gpu
+                                                             else dict(foreach=True)))
 
     def fwd_bwd():
         bucket.begin()

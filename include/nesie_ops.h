@@ -110,6 +110,18 @@ int nesie_three_interpolate_wrapper(int b, int c, int m, int n,
                                     const float *weight, float *out,
                                     void *stream);
 
+/* Grid points of the side-aware quality head and their 3-NN taps among the seeds, one launch
+ * per grid set (dense_heads/side_pooling_module.py:87-157 builds the box-frame grid, selects
+ * the faces, rotates and translates it; :204-225 finds the 3 nearest seeds and the
+ * inverse-distance weights).  centre/size (B,K,3), heading (B,K), mult/plane (gp,3) = box-frame
+ * multipliers of the gp grid points of a proposal and the +-10 % plane factors of the SAQE
+ * variant (quelity_estimation_module.py:142-167; zeros otherwise), known (B,m,3) ->
+ * idx (B,K*gp,3) i32 (three_nn_wrapper's order), weight (B,K*gp,3), rel (B,K*gp,3) = grid point
+ * relative to the proposal centre. */
+int nesie_grid_taps(int b, int kprop, int gp, int m, const float *centre, const float *size,
+                    const float *heading, const float *mult, const float *plane,
+                    const float *known, int *idx, float *weight, float *rel, void *stream);
+
 /* The quality head's grid features in their consumer's layout, optionally folded with the
  * first 1x1 conv of the MiniPointNet that consumes them.
  * Reference: dense_heads/side_pooling_module.py:226-243 builds cat([rel_xyz, interpolated]),

@@ -64,6 +64,77 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(
   }
 }
 
+// ---- grid points of the quality head + their 3-NN taps, in one kernel -------------------------
+// Per proposal k and grid point g (gp points per proposal, box-frame multipliers mult[g] in
+// [-1, 1]^3 and plane[g] = the +-10 % plane offsets of the SAQE variant, else 0):
+//   f     = mult * size / 2;  local = f + f * plane                (generate_grid / planes)
+//   world = R(heading) . local + centre                            (_to_scene)
+//   3-NN of `world` among the seeds (three_nn, same compare order), then
+//   weight_t = (1 / (sqrt(d2_t) + 1e-8)) / sum_t(...),  rel = world - centre
+// Stands in for side_pooling_module.py:87-157 (grids) and :204-225 (taps): ~55 ATen launches.
+__global__ __launch_bounds__(NN_BLOCK) void grid_taps_kernel(
+    int kprop, int gp, int m, const float *__restrict__ centre, const float *__restrict__ size,
+    const float *__restrict__ heading, const float *__restrict__ mult,
+    const float *__restrict__ plane, const float *__restrict__ known, int *__restrict__ idx,
+    float *__restrict__ weight, float *__restrict__ rel) {
+  __shared__ float4 kk[NN_TILE];
+  const int bi = blockIdx.y;
+  const int n = kprop * gp;
+  const int q = blockIdx.x * NN_BLOCK + threadIdx.x;
+  const bool live = q < n;
+  const int qq = live ? q : n - 1;
+  const int k = qq / gp, g = qq - k * gp;
+  const float *c3 = centre + ((size_t)bi * kprop + k) * 3;
+  const float *s3 = size + ((size_t)bi * kprop + k) * 3;
+  const float cx = c3[0], cy = c3[1], cz = c3[2];
+  float l[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float f = __fmul_rn(mult[g * 3 + d], s3[d]) / 2.f;
+    l[d] = __fadd_rn(f, __fmul_rn(f, plane[g * 3 + d]));
+  }
+  const float h = heading[(size_t)bi * kprop + k];
+  const float ch = cosf(h), sh = sinf(h);
+  const float ux = __fadd_rn(__fadd_rn(__fmul_rn(l[0], ch), __fmul_rn(l[1], sh)), cx);
+  const float uy = __fadd_rn(__fadd_rn(__fmul_rn(l[0], -sh), __fmul_rn(l[1], ch)), cy);
+  const float uz = __fadd_rn(l[2], cz);
+  known += (size_t)bi * m * 3;
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int t0 = 0; t0 < m; t0 += NN_TILE) {
+    const int tn = m - t0 < NN_TILE ? m - t0 : NN_TILE;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tn; i += NN_BLOCK)
+      kk[i] = make_float4(known[(t0 + i) * 3 + 0], known[(t0 + i) * 3 + 1],
+                          known[(t0 + i) * 3 + 2], 0.f);
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < tn; ++i) {
+      const float4 kp = kk[i];
+      const float d = sqdist_nofma(ux - kp.x, uy - kp.y, uz - kp.z);
+      if (d < b3) {
+        const int kidx = t0 + i;
+        if (d < b1) {
+          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kidx;
+        } else if (d < b2) {
+          b3 = b2; i3 = i2; b2 = d; i2 = kidx;
+        } else {
+          b3 = d; i3 = kidx;
+        }
+      }
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)bi * n + q) * 3;
+    const float w1 = 1.f / __fadd_rn(sqrtf(b1), 1e-8f), w2 = 1.f / __fadd_rn(sqrtf(b2), 1e-8f),
+                w3 = 1.f / __fadd_rn(sqrtf(b3), 1e-8f);
+    const float ws = __fadd_rn(__fadd_rn(w1, w2), w3);
+    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    weight[o] = w1 / ws; weight[o + 1] = w2 / ws; weight[o + 2] = w3 / ws;
+    rel[o] = ux - cx; rel[o + 1] = uy - cy; rel[o + 2] = uz - cz;
+  }
+}
+
 constexpr int TI_BLOCK = 256;
 constexpr int TI_CH = 8;
 
@@ -406,6 +477,21 @@ extern "C" int nesie_three_nn_wrapper(int b, int n, int m, const float *unknown,
   NESIE_REQUIRE(b <= 65535 && (long long)n * 3 < (1ll << 31) && (long long)m * 3 < (1ll << 31), W);
   hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, NN_BLOCK), b), dim3(NN_BLOCK), 0,
                      (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+  return check_launch(W);
+}
+
+extern "C" int nesie_grid_taps(int b, int kprop, int gp, int m, const float *centre,
+                               const float *size, const float *heading, const float *mult,
+                               const float *plane, const float *known, int *idx, float *weight,
+                               float *rel, void *stream) {
+  const char *W = "grid_taps";
+  NESIE_REQUIRE(b >= 0 && kprop >= 0 && gp >= 0 && m >= 0, W);
+  if (b == 0 || kprop == 0 || gp == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 3 && centre && size && heading && mult && plane && known, W);
+  NESIE_REQUIRE(idx && weight && rel && b <= 65535 && (long long)kprop * gp * 3 < (1ll << 31), W);
+  hipLaunchKernelGGL(grid_taps_kernel, dim3(cdiv((long long)kprop * gp, NN_BLOCK), b),
+                     dim3(NN_BLOCK), 0, (hipStream_t)stream, kprop, gp, m, centre, size, heading,
+                     mult, plane, known, idx, weight, rel);
   return check_launch(W);
 }
 

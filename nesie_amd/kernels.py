@@ -168,6 +168,23 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_three_interpolate_wrapper", b, c, m, n, _ptr(points),
                       _ptr(idx), _ptr(weight), _ptr(out), _stream(points))
 
+    def grid_taps(self, centre, size, heading, mult, plane, known):
+        """-> idx (B,K*gp,3) int32, weight, rel (B,K*gp,3) for the gp grid points per proposal."""
+        _check(centre, size, heading, mult, plane, known)
+        _f32(centre, size, heading, mult, plane, known)
+        b, k = centre.shape[:2]
+        gp, m = mult.shape[0], known.shape[1]
+        assert tuple(size.shape) == (b, k, 3) and tuple(heading.shape) == (b, k)
+        assert tuple(plane.shape) == (gp, 3) and known.shape[0] == b
+        idx = torch.empty(b, k * gp, 3, dtype=torch.int32, device=centre.device)
+        weight = torch.empty(b, k * gp, 3, dtype=torch.float32, device=centre.device)
+        rel = torch.empty_like(weight)
+        with torch.cuda.device(centre.device):
+            _lib.call("nesie_grid_taps", b, k, gp, m, _ptr(centre), _ptr(size), _ptr(heading),
+                      _ptr(mult), _ptr(plane), _ptr(known), _ptr(idx), _ptr(weight), _ptr(rel),
+                      _stream(centre))
+        return idx, weight, rel
+
     def blend_conv_forward(self, table, seg_off, idx, weight, rel, wx, out, segs, seg_len,
                            c, c_offset):
         """table (B, M, pitch) point-major; out (B, segs, c_total, n/segs): query (k, s, g) ->

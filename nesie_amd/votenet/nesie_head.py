@@ -267,13 +267,21 @@ class NesieHead(nn.Module):
                                       targets_b).detach().view(-1)
         label_cls = mask_targets.reshape(-1)
         w = box_loss_weights.reshape(-1)
-        loss_iou = self.iou_pred_loss(
-            bbox_preds['iou_scores'].reshape(-1, self.num_classes), (label_cls, label_iou),
-            weight=w)
-        loss_iou_jitter = self.iou_pred_loss(
-            bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes),
-            (label_cls, label_iou_jitter), weight=w)
-        iou_pred_loss = loss_iou + loss_iou_jitter
+        if getattr(self.iou_pred_loss, 'reduction', None) == 'sum':
+            # the plain and the jittered half in one pass (a sum-reduced loss is additive)
+            iou_pred_loss = self.iou_pred_loss(
+                torch.cat([bbox_preds['iou_scores'].reshape(-1, self.num_classes),
+                           bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes)]),
+                (torch.cat([label_cls, label_cls]), torch.cat([label_iou, label_iou_jitter])),
+                weight=torch.cat([w, w]))
+        else:
+            loss_iou = self.iou_pred_loss(
+                bbox_preds['iou_scores'].reshape(-1, self.num_classes), (label_cls, label_iou),
+                weight=w)
+            loss_iou_jitter = self.iou_pred_loss(
+                bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes),
+                (label_cls, label_iou_jitter), weight=w)
+            iou_pred_loss = loss_iou + loss_iou_jitter
 
         side_pred = bbox_preds['side_scores'].reshape(-1, 6, self.num_classes)
         side_pred = self._pick_class(side_pred, label_cls)

@@ -55,6 +55,7 @@ class QualityEstimation(SidePooling):
         for f, a in enumerate([0, 0, 2, 2, 1, 1]):
             axis[f, a] = 0.1
         self.register_buffer('_plane_axis', axis, persistent=False)
+        self._register_grid_tables(face_idx, plane=axis)
 
     def grid_for_side(self, whole_grid, center, heading):
         B, K = center.shape[:2]
@@ -67,14 +68,15 @@ class QualityEstimation(SidePooling):
     def forward(self, center, size, heading, end_points, prefix=''):
         B, K = size.shape[:2]
         origin_xyz, origin_features = self.extract_features(end_points)
-        whole_grid = self.generate_grid(size)
-        side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
         fused = backend_for(origin_xyz).name == 'hip'
         side_nets = list(self.mlps_before[:6])
         if fused:
-            side_c0 = self.first_conv_through_blend(side_nets, origin_xyz, origin_features,
-                                                    side_grid, center)
+            side_c0 = self.first_conv_through_blend(
+                side_nets, origin_xyz, origin_features, None, center,
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'))
         else:
+            whole_grid = self.generate_grid(size)
+            side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
         if fused and mini_pointnets_groupable(side_nets, side_c0):

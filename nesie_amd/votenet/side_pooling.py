@@ -212,6 +212,7 @@ class SidePooling(nn.Module):
                     + self.left_mask + self.right_mask)
         self.register_buffer('_face_idx', torch.tensor(face_idx, dtype=torch.long),
                              persistent=False)
+        self._register_grid_tables(face_idx)
         self.iou_size = num_class if iou_class_depend else 1
         before, head = [], []
         for _ in range(6):
@@ -221,6 +222,35 @@ class SidePooling(nn.Module):
         head.append(_score_head(128, self.iou_size))
         self.mlps_before = nn.ModuleList(before)
         self.mlps_head = nn.ModuleList(head)
+
+    def _register_grid_tables(self, face_idx, plane=None):
+        """Box-frame multipliers of the grid points of one proposal, in the order the grids are
+        consumed: ``_mult_box`` (g^3,3) for the box grid, ``_mult_side`` for the six face groups
+        (with ``_plane_side`` = their +-10 % plane factors in the SAQE variant, else zeros)."""
+        g = self.grid_size
+        step = torch.linspace(-1, 1, g)
+        full = torch.stack([step.view(g, 1, 1).expand(g, g, g), step.view(1, g, 1).expand(g, g, g),
+                            step.view(1, 1, g).expand(g, g, g)], -1).reshape(-1, 3)
+        side = full[torch.tensor(face_idx)]
+        if plane is not None:            # (6,3) axis factors -> three planes per face
+            g2 = g * g
+            side = side.view(6, g2, 3)
+            pl = plane.view(6, 1, 3).expand(6, g2, 3)
+            side, plane = (torch.cat([side, side, side], 1).reshape(-1, 3),
+                           torch.cat([-pl, torch.zeros_like(pl), pl], 1).reshape(-1, 3))
+        else:
+            plane = torch.zeros_like(side)
+        self.register_buffer('_mult_box', full.contiguous(), persistent=False)
+        self.register_buffer('_mult_side', side.contiguous(), persistent=False)
+        self.register_buffer('_plane_side', plane.contiguous(), persistent=False)
+
+    def fused_taps(self, origin_xyz, center, size, heading, which):
+        """idx, weight, rel of one grid set ('side' or 'box') straight from the proposal
+        parameters: one launch instead of generate_grid / grid_for_* / _blend_taps."""
+        mult = self._mult_side if which == 'side' else self._mult_box
+        plane = self._plane_side if which == 'side' else torch.zeros_like(mult)
+        return backend_for(origin_xyz).grid_taps(center.contiguous(), size.contiguous(),
+                                                 heading.contiguous(), mult, plane, origin_xyz)
 
     def extract_features(self, end_points):
         """-> seed xyz (B,N,3), seed features POINT-major (B,N,C) for the blend kernel."""
@@ -271,15 +301,17 @@ class SidePooling(nn.Module):
         weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
         return idx, weight, relative_grid.contiguous()
 
-    def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center):
+    def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center,
+                                 taps=None):
         """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
         S consecutive point groups of every proposal: (B,S,H,K,G), evaluated as
         W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
         conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points."""
         B, K = center.shape[:2]
         segs = len(nets)
-        G = whole_grid.shape[1] // (K * segs)
-        idx, weight, rel = self._blend_taps(origin_xyz, whole_grid, center)
+        idx, weight, rel = taps if taps is not None \
+            else self._blend_taps(origin_xyz, whole_grid, center)
+        G = idx.shape[1] // (K * segs)
         w = torch.stack([net.first_conv[0].weight.flatten(1) for net in nets])   # (S, H, 3+C)
         H = w.shape[1]
         table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
@@ -314,17 +346,20 @@ class SidePooling(nn.Module):
     def forward(self, center, size, heading, end_points, prefix=''):
         B, K = size.shape[:2]
         origin_xyz, origin_features = self.extract_features(end_points)
-        whole_grid = self.generate_grid(size)
-        side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
-        bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
         fused = backend_for(origin_xyz).name == 'hip'
         side_nets = list(self.mlps_before[:6])
-        if fused:   # first convs through the blend; the literal form stays the CPU checker's
-            side_c0 = self.first_conv_through_blend(side_nets, origin_xyz, origin_features,
-                                                    side_grid, center)
-            bbox_c0 = self.first_conv_through_blend(self.mlps_before[6:7], origin_xyz,
-                                                    origin_features, bbox_grid, center)[:, 0]
+        if fused:   # grids + taps in one launch each, first convs through the blend; the
+            #         literal form below stays the CPU checker's
+            side_c0 = self.first_conv_through_blend(
+                side_nets, origin_xyz, origin_features, None, center,
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'))
+            bbox_c0 = self.first_conv_through_blend(
+                self.mlps_before[6:7], origin_xyz, origin_features, None, center,
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'box'))[:, 0]
         else:
+            whole_grid = self.generate_grid(size)
+            side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
+            bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
             bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
         dist_feature = self.dist_feature(end_points, prefix)

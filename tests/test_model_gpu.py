@@ -264,3 +264,34 @@ def test_grouped_mini_pointnets_equal_the_per_net_loop(hip_device):
             assert err < 2e-2 * pb.grad.norm().item() + 1e-4 * pb.numel() ** 0.5, (n, err)
         for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
             torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-5, atol=1e-6, msg=n)
+
+
+@pytest.mark.parametrize("variant", ["nesie", "saqe"])
+def test_fused_grid_taps_match_the_literal_chain(hip_device, variant):
+    """nesie_grid_taps (grid generation + face selection + rotation + 3-NN + inverse-distance
+    weights in one launch) vs the literal torch chain generate_grid -> grid_for_side/bbox ->
+    _blend_taps (side_pooling_module.py:87-157, 204-225; quelity_estimation_module.py:142-167)."""
+    from nesie_amd.votenet.quality_estimation import QualityEstimation
+    from nesie_amd.votenet.side_pooling import SidePooling
+    torch.manual_seed(21)
+    cls = SidePooling if variant == "nesie" else QualityEstimation
+    sp = cls(num_class=3, num_heading_bin=1, num_size_cluster=3, mean_size_arr_path=None,
+             num_proposal=40, sampling='vote_fps', seed_feat_dim=16).to(hip_device)
+    B, K, N = 2, 40, 300
+    xyz = (torch.rand(B, N, 3, device=hip_device) * 4).contiguous()
+    center = torch.rand(B, K, 3, device=hip_device) * 4
+    size = torch.rand(B, K, 3, device=hip_device) + 0.3
+    heading = torch.rand(B, K, device=hip_device) * 6.28 - 3.14
+    whole = sp.generate_grid(size)
+    sets = [('side', sp.grid_for_side(whole, center, heading))]
+    if variant == "nesie":
+        sets.append(('box', sp.grid_for_bbox(whole, center, heading)))
+    for which, grid in sets:
+        grid = grid.reshape(B, -1, 3).contiguous()
+        idx0, w0, rel0 = sp._blend_taps(xyz, grid, center)
+        idx1, w1, rel1 = sp.fused_taps(xyz, center, size, heading, which)
+        assert idx1.shape == idx0.shape and idx1.dtype == torch.int32
+        torch.testing.assert_close(rel1, rel0, rtol=1e-5, atol=2e-6)
+        same = (idx1 == idx0).all(-1)
+        assert same.float().mean().item() > 0.995          # near-ties may order differently
+        torch.testing.assert_close(w1[same], w0[same], rtol=1e-4, atol=1e-6)
