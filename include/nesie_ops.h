@@ -272,6 +272,15 @@ int nesie_mlp_stat_finalize(int c, long long nparts, double count, const float *
                             float *running_var, float momentum, float eps, float *coef,
                             void *stream);
 
+/* nesie_mlp_layer_forward for skinny HBM-bound layers (cin <= 64, cout <= 128): W stays in
+ * LDS / registers and every wave streams its own 32-position columns straight from global
+ * memory into the MFMA operand registers (no LDS tile, no barrier in the main loop).
+ * stat_partial: nesie_mlp_stream_partials(b, p) x cout x 2 floats. */
+long long nesie_mlp_stream_partials(int b, long long p);
+int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p, const float *x,
+                                   long long x_bstride, const float *w, const float *in_coef,
+                                   int in_relu, float *y, float *stat_partial, void *stream);
+
 /* Weight gradient of a 1x1 conv on the matrix cores: dw[cout][cin] = sum over scenes and
  * positions of dy[b][m][p] * act(x[b][k][p]); dy (B, cout, p), x[b] (cin, p) at x + b*x_bstride,
  * act as in nesie_mlp_layer_forward (x_coef NULL = identity).  Reference: the conv2d backward

@@ -46,6 +46,8 @@ SIGNATURES = {
                                 _P, _P, _P],
     "nesie_conv_wgrad": [_I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _I, _P, _P,
                          ctypes.c_size_t, _P],
+    "nesie_mlp_layer_forward_stream": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P,
+                                       _I, _P, _P, _P],
     "nesie_mlp_stat_finalize": [_I, ctypes.c_longlong, ctypes.c_double, _P, _P, _P, _P, _P, _F,
                                 _F, _P, _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
@@ -82,6 +84,8 @@ def load():
     lib.nesie_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_blend_conv_runs.argtypes = [_I, _I]
     lib.nesie_blend_conv_runs.restype = _I
+    lib.nesie_mlp_stream_partials.argtypes = [_I, ctypes.c_longlong]
+    lib.nesie_mlp_stream_partials.restype = ctypes.c_longlong
     lib.nesie_mlp_stat_partials.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_mlp_stat_partials.restype = ctypes.c_longlong
     lib.nesie_abi_version.restype = _I

@@ -507,3 +507,177 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
                      b * runs, partial, dw);
   return check_launch(W);
 }
+
+// ---- streaming form of the layer kernel for skinny layers (Cin <= 64) --------------------------
+// When W is tiny and the layer is HBM-bound (SA1: 4->64, 64->64, 64->128 over 10^6 positions)
+// the LDS tile + barrier per K step of mlp_fwd_kernel is pure overhead.  Here W (k-major) sits
+// in LDS once per workgroup, and every WAVE streams its own 32-position columns: the MFMA B
+// operand (lane = (k & 1) * 32 + position) is loaded straight from global memory into its
+// register -- two dense 128-byte row segments per instruction -- so X never touches LDS and
+// the main loop has no barrier.  The loads of the next column block are in flight during the
+// MFMAs of the current one.
+namespace nesie {
+
+template <int MB, int KP>  // MB = Cout blocks of 32 (padded), KP = Cin pairs (padded Cin / 2)
+__global__ __launch_bounds__(256) void mlp_stream_kernel(
+    int cin, int cout, long long p, long long x_bstride, int cols_per_wg,
+    const float *__restrict__ w, const float *__restrict__ x,
+    const float *__restrict__ in_coef, int in_relu, float *__restrict__ y,
+    float *__restrict__ stat_partial) {
+  constexpr int LDW = MB * 32 + 32;
+  __shared__ float ws[2 * KP * LDW];   // [k][m]
+  __shared__ float scs[2 * KP], bis[2 * KP];
+  __shared__ float sstat[MB * 32][2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: row bases stay scalar
+  const int half = lane >> 5, l32 = lane & 31;
+  const int bi = blockIdx.y;
+  for (int e = tid; e < 2 * KP * MB * 32; e += 256) {
+    const int k = e / (MB * 32), m = e % (MB * 32);
+    ws[k * LDW + m] = (k < cin && m < cout) ? w[(size_t)m * cin + k] : 0.f;
+  }
+  for (int k = tid; k < 2 * KP; k += 256) {
+    scs[k] = (in_coef && k < cin) ? in_coef[k * 4 + 0] : 1.f;
+    bis[k] = (in_coef && k < cin) ? in_coef[k * 4 + 1] : 0.f;
+  }
+  if (stat_partial)
+    for (int i = tid; i < MB * 32 * 2; i += 256) (&sstat[0][0])[i] = 0.f;
+  __syncthreads();
+  const float *xb = x + (size_t)bi * x_bstride;
+  float *yb = y + (size_t)bi * cout * p;
+  const long long c0 = (long long)blockIdx.x * cols_per_wg;
+  const long long c1 = c0 + cols_per_wg < p ? c0 + cols_per_wg : p;
+  // statistics: sum(y^2) per accumulator element; sum(y) = W . (column sums of the operand),
+  // so only the operand's per-lane sums are carried (KP registers instead of 16 * MB)
+  float qrow[MB][16], ax[KP];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qrow[i][r] = 0.f;
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) ax[kp] = 0.f;
+  float xn[KP];
+  // per-lane 32-bit offsets on top of wave-uniform row bases (one address register per access
+  // instead of a 64-bit pointer per row)
+  const unsigned ld_off = (unsigned)(half * p + l32);
+  const unsigned st_off = (unsigned)(4 * half * p + l32);
+  auto load_cols = [&](long long n0) {
+    const bool ok = n0 + l32 < c1;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const float *row = xb + (size_t)(kp * 2) * p + n0;   // uniform
+      xn[kp] = (kp * 2 + half < cin && ok) ? row[ld_off] : 0.f;
+    }
+  };
+  long long n0 = c0 + wave * 32;
+  if (n0 < c1) load_cols(n0);
+  for (; n0 < c1; n0 += 4 * 32) {
+    const bool in_range = n0 + l32 < c1;
+    if (in_coef) {
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const int k = kp * 2 + half;
+        float v = xn[kp] * scs[k] + bis[k];
+        if (in_relu) v = fmaxf(v, 0.f);
+        xn[kp] = (!in_range || k >= cin) ? 0.f : v;
+      }
+    }
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) ax[kp] += xn[kp];
+    // one 32-row block of outputs at a time: a single 16-register accumulator chain
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const float a = ws[(kp * 2 + half) * LDW + i * 32 + l32];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xn[kp], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = i * 32 + (r & 3) + 8 * (r >> 2);       // uniform part of the row
+        const float v = acc[r];
+        float *row = yb + (size_t)mu * p + n0;                // uniform
+        if (mu + 4 * half < cout && in_range) row[st_off] = v;
+        qrow[i][r] += v * v;      // out-of-range columns are exact zeros
+      }
+    }
+    if (n0 + 4 * 32 < c1) load_cols(n0 + 4 * 32);
+  }
+  if (stat_partial) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float q = half_wave_sum(qrow[i][r]);
+        if (l32 == 0) atomicAdd(&sstat[m][1], q);
+      }
+    // column sums of the operand per k, then sum(y)[m] = sum_k W[m][k] * colsum[k]
+    __shared__ float colsum[2 * KP];
+    if (tid < 2 * KP) colsum[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const float t = half_wave_sum(ax[kp]);
+      if (l32 == 0) atomicAdd(&colsum[kp * 2 + half], t);
+    }
+    __syncthreads();
+    for (int m = tid; m < cout; m += 256) {
+      float t = 0.f;
+      for (int k = 0; k < cin; ++k) t += ws[k * LDW + m] * colsum[k];
+      sstat[m][0] = t;
+    }
+    __syncthreads();
+    float *dst = stat_partial + (((size_t)bi * gridDim.x + blockIdx.x) * cout) * 2;
+    for (int i = tid; i < cout * 2; i += 256) dst[i] = (&sstat[0][0])[i];
+  }
+}
+
+static int stream_cols(int b, long long p) {
+  // ~2048 workgroups of whole 128-column groups
+  long long per = (p * b + 2047) / 2048;
+  per = (per + 127) / 128 * 128;
+  if (per < 128) per = 128;
+  return (int)per;
+}
+
+}  // namespace nesie
+
+extern "C" long long nesie_mlp_stream_partials(int b, long long p) {
+  return (long long)b * cdiv(p, stream_cols(b, p));
+}
+
+extern "C" int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p,
+                                              const float *x, long long x_bstride,
+                                              const float *w, const float *in_coef,
+                                              int in_relu, float *y, float *stat_partial,
+                                              void *stream) {
+  const char *W = "mlp_layer_forward_stream";
+  NESIE_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && p >= 0, W);
+  if (b == 0 || p == 0) return NESIE_OK;
+  NESIE_REQUIRE(x && w && y && x_bstride >= (long long)cin * p && b <= 65535, W);
+  NESIE_REQUIRE(p < (1ll << 28), W);
+  if (cin > 64 || cout > 128) {
+    set_error("%s: %d -> %d (built for Cin <= 64, Cout <= 128)", W, cin, cout);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  const int cols = stream_cols(b, p);
+  const dim3 grid(cdiv(p, cols), b);
+  hipStream_t s = (hipStream_t)stream;
+  const int mb = cdiv(cout, 32), kp = cdiv(cin, 2);
+#define L(MB, KP)                                                                              \
+  hipLaunchKernelGGL((mlp_stream_kernel<MB, KP>), grid, dim3(256), 0, s, cin, cout, p,         \
+                     x_bstride, cols, w, x, in_coef, in_relu, y, stat_partial)
+  if (mb <= 2 && kp <= 2) L(2, 2);
+  else if (mb <= 2 && kp <= 32) L(2, 32);
+  else if (mb <= 4 && kp <= 32) L(4, 32);
+  else {
+    set_error("%s: no build for %d -> %d", W, cin, cout);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+#undef L
+  return check_launch(W);
+}

@@ -547,3 +547,33 @@ def test_conv_wgrad_matches_fp64(hip_device, cout, cin, p, b):
     a = torch.relu(x.double() * coef[:, 0].double().view(1, -1, 1) + coef[:, 1].double().view(1, -1, 1))
     want = torch.einsum('bmp,bkp->mk', dy.double(), a)
     assert ((dw.double() - want).norm() / want.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("cout,cin,p,b", [(64, 4, 4096, 2), (64, 64, 1000, 2), (33, 7, 257, 1)])
+def test_mlp_layer_forward_stream_matches_fp64(hip_device, cout, cin, p, b):
+    """nesie_mlp_layer_forward_stream (the barrier-free form for skinny HBM-bound layers) vs
+    fp64: output, and the (sum, sum of squares) partials of its statistics epilogue."""
+    from nesie_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cout * 3 + cin + p)
+    x = torch.randn(b, cin, p, generator=g).to(hip_device)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(hip_device)
+    coef = torch.rand(cin, 4, generator=g).to(hip_device) + 0.5
+    coef[:, 1] -= 1.0
+    stream = torch.cuda.current_stream().cuda_stream
+    for use_coef in (False, True):
+        y = torch.full((b, cout, p), float('nan'), device=hip_device)
+        nparts = lib.nesie_mlp_stream_partials(b, p)
+        part = torch.zeros(nparts, cout, 2, device=hip_device)
+        _lib.call('nesie_mlp_layer_forward_stream', b, cin, cout, p, x.data_ptr(), cin * p,
+                  w.data_ptr(), coef.data_ptr() if use_coef else 0, 1, y.data_ptr(),
+                  part.data_ptr(), stream)
+        a = x.double()
+        if use_coef:
+            a = torch.relu(a * coef[:, 0].double().view(1, -1, 1) + coef[:, 1].double().view(1, -1, 1))
+        want = torch.matmul(w.double().unsqueeze(0), a)
+        assert (y.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+        torch.testing.assert_close(part[..., 0].double().sum(0), want.sum((0, 2)), rtol=1e-4,
+                                   atol=1e-3)
+        torch.testing.assert_close(part[..., 1].double().sum(0), (want ** 2).sum((0, 2)),
+                                   rtol=1e-4, atol=1e-3)

@@ -17,6 +17,14 @@ def fwd(x, w, coef, relu, y, part):
               part.data_ptr() if part is not None else 0, S())
 
 
+def fwd_stream(x, w, coef, relu, y, part):
+    b, cin, p = x.shape
+    cout = w.shape[0]
+    _lib.call('nesie_mlp_layer_forward_stream', b, cin, cout, p, x.data_ptr(), cin * p,
+              w.data_ptr(), coef.data_ptr() if coef is not None else 0, int(relu), y.data_ptr(),
+              part.data_ptr() if part is not None else 0, S())
+
+
 def timeit(f, n=20):
     for _ in range(3):
         f()
@@ -57,6 +65,15 @@ for cout, cin, p in shapes:
     err2 = (y.double() - ref2).abs().max().item()
     s_err = (part[..., 0].double().sum(0) - ref2.sum((0, 2))).abs().max().item() / max(1.0, ref2.sum((0, 2)).abs().max().item())
     q_err = ((part[..., 1].double().sum(0) - (ref2 ** 2).sum((0, 2))).abs() / (ref2 ** 2).sum((0, 2))).max().item()
+    if cin <= 64 and cout <= 64:
+        np2 = lib.nesie_mlp_stream_partials(B, p)
+        part2 = torch.empty(np2, cout, 2, device=dev)
+        t_s = timeit(lambda: fwd_stream(x, w, coef, 1, y, part2))
+        e3 = (y.double() - ref2).abs().max().item()
+        s3 = (part2[..., 0].double().sum(0) - ref2.sum((0, 2))).abs().max().item() / max(1.0, ref2.sum((0, 2)).abs().max().item())
+        q3 = ((part2[..., 1].double().sum(0) - (ref2 ** 2).sum((0, 2))).abs() / (ref2 ** 2).sum((0, 2))).max().item()
+        print('   stream fused: %.4f ms  %.0f GB/s  err %.1e sum %.1e sq %.1e' % (
+            t_s, 4.0 * B * p * (cin + cout) / t_s / 1e6, e3, s3, q3), flush=True)
     fl = 2.0 * B * cout * cin * p
     by = 4.0 * B * p * (cin + cout)
     print('%-22s %9.4f %9.4f %9.4f %9.1f %8.0f %8.1e  fused err %.1e sum %.1e sq %.1e' % (
