@@ -182,6 +182,10 @@ int nesie_group_max_pool_forward(long long rows, int nsample, const float *x, fl
                                  uint8_t *argmax, void *stream);
 int nesie_group_max_pool_backward(long long rows, int nsample, const float *grad_out,
                                   const uint8_t *argmax, float *grad_x, void *stream);
+/* grad_x[row, argmax[row]] += grad_out[row] into an existing dense gradient (a tensor that
+ * feeds both the max and another consumer: MiniPointNet's f, side_pooling_module.py:359-365). */
+int nesie_group_max_pool_backward_add(long long rows, int nsample, const float *grad_out,
+                                      const uint8_t *argmax, float *grad_x, void *stream);
 
 /* Same-class LHS-NMS of the teacher's pseudo boxes, on the device: boxes[B,K,8] f32 =
  * axis-aligned (x1,y1,z1,x2,y2,z2,score,class), K <= 64; keep[B,K] u8 = 1 for every box

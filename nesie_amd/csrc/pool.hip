@@ -42,6 +42,17 @@ __global__ __launch_bounds__(256) void group_max_bwd_kernel(
                           a == 3 ? g : 0.f);
 }
 
+// grad_x[row, argmax[row]] += grad_out[row]: the pooled gradient added into a dense gradient
+// that already exists (a tensor that feeds both the max and another consumer), instead of
+// materialising a one-hot tensor and adding the two.
+__global__ __launch_bounds__(256) void group_max_bwd_add_kernel(
+    long long rows, int ns, const float *__restrict__ grad_out, const uint8_t *__restrict__ arg,
+    float *__restrict__ grad_x) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  grad_x[row * ns + arg[row]] += grad_out[row];
+}
+
 // ---- scatter-add of grouped gradients through LDS --------------------------------
 // grad_points[b, c, idx[b, e]] += grad_out[b, c, e].  A workgroup owns CH channel rows of
 // one scene: their n accumulators sit in LDS, the grouped gradient streams through once as
@@ -146,6 +157,18 @@ extern "C" int nesie_group_max_pool_backward(long long rows, int nsample,
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L
+  return check_launch(W);
+}
+
+extern "C" int nesie_group_max_pool_backward_add(long long rows, int nsample,
+                                                 const float *grad_out, const uint8_t *argmax,
+                                                 float *grad_x, void *stream) {
+  const char *W = "group_max_pool_backward_add";
+  NESIE_REQUIRE(rows >= 0 && nsample >= 1, W);
+  if (rows == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && argmax && grad_x && rows / 256 + 1 < (1ll << 31), W);
+  hipLaunchKernelGGL(group_max_bwd_add_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rows, nsample, grad_out, argmax, grad_x);
   return check_launch(W);
 }
 

@@ -279,6 +279,16 @@ class HipKernels(_BNPoolMixin):
                       _ptr(argmax), _ptr(grad_x), _stream(grad_x))
 
 
+    def group_max_pool_backward_add(self, grad_out, argmax, grad_x):
+        """grad_x[..., argmax] += grad_out, in place (grad_x (..., ns) contiguous)."""
+        _check(grad_out, argmax, grad_x); _f32(grad_out, grad_x)
+        ns = grad_x.shape[-1]
+        rows = grad_x.numel() // ns
+        assert grad_out.numel() == rows and argmax.numel() == rows
+        with torch.cuda.device(grad_x.device):
+            _lib.call("nesie_group_max_pool_backward_add", rows, ns, _ptr(grad_out),
+                      _ptr(argmax), _ptr(grad_x), _stream(grad_x))
+
     def lhs_nms_samecls(self, boxes, thr, keep):
         """boxes (B,K,8) f32, keep (B,K) uint8."""
         _check(boxes, keep); _f32(boxes)

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ..kernels import backend_for
 from ..mmdet3d_ops import blend_conv, three_interpolate_segmented, three_nn
-from ..mmdet3d_ops.pool import group_max_pool
+from ..mmdet3d_ops.pool import group_max_pool, group_max_pool_shared
 from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d, pointwise_conv
 
@@ -58,7 +58,7 @@ class MiniPointNet(nn.Module):
         if conv0_out is None:
             conv0_out = conv0(points)
         c = pointwise_conv(bn0(conv0_out), conv3.weight)              # f without its bias
-        g = group_max_pool(c)                                          # (B, H, K): max_G f - b
+        g, c = group_max_pool_shared(c)                                # (B, H, K): max_G f - b
         half = conv3.out_channels
         w = sconv0.weight.reshape(sconv0.out_channels, -1)
         w_g, w_l = w[:, :half], w[:, half:]
@@ -111,7 +111,8 @@ def grouped_mini_pointnets(nets, c0):
     a0 = _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G)).view(B, S, H, K * G)
     c = torch.matmul(stack([x[3].weight for x in f]), a0)               # (B,S,half,K*G)
     half = c.shape[2]
-    g = group_max_pool(c.view(B, S, half, K, G))                         # (B,S,half,K)
+    g, c5 = group_max_pool_shared(c.view(B, S, half, K, G))              # (B,S,half,K)
+    c = c5.view(B, S, half, K * G)
     w = stack([x[0].weight for x in sc])                                 # (1,S,H2,2*half)
     H2 = w.shape[2]
     b3 = torch.stack([x[3].bias if x[3].bias is not None else c.new_zeros(half) for x in f])

@@ -210,6 +210,11 @@ class OracleKernels:
         grad_x.zero_()
         grad_x.scatter_(-1, argmax.long().unsqueeze(-1), grad_out.unsqueeze(-1))
 
+    def group_max_pool_backward_add(self, grad_out, argmax, grad_x):
+        flat = grad_x.view(-1, grad_x.shape[-1])
+        flat.scatter_add_(1, argmax.reshape(-1, 1).long(), grad_out.reshape(-1, 1))
+
+
 
 def num_threads():
     return lib().oracle_num_threads()
