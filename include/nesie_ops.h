@@ -84,6 +84,20 @@ int nesie_group_points_backward(int b, int c, int n, int npoints, int nsample,
                                 const float *grad_out, const int *idx,
                                 float *grad_points, void *stream);
 
+/* QueryAndGroup's data movement in one pass (mmdet3d/ops/group_points/group_points.py:100-128
+ * transposes the points, groups xyz and features separately, subtracts the centre, divides by
+ * the radius and concatenates): out[B, 3+C, M, ns] = cat[(xyz[idx] - centre) / radius,
+ * features[idx]]; xyz (B,N,3), centres (B,M,3), features (B,C,N) (c = 0: xyz only),
+ * radius <= 0: no division.  backward: grad_features (B,C,N, zeroed) += channels 3.. of
+ * grad_out (B, 3+C, M, ns), read in place (no slice copy). */
+int nesie_query_and_group_forward(int b, int c, int n, int npoints, int nsample,
+                                  const float *xyz, const float *centres,
+                                  const float *features, const int *idx, float radius,
+                                  float *out, void *stream);
+int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample,
+                                   const float *grad_out, const int *idx, float *grad_features,
+                                   void *stream);
+
 /* mmdet3d/ops/gather_points/src/gather_points.cpp:28-42  gather_points_wrapper
  * (b, c, n, npoints, points[B,C,N], idx[B,M], out[B,C,M]). */
 int nesie_gather_points_wrapper(int b, int c, int n, int npoints,

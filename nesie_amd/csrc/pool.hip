@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void group_max_bwd_add_kernel(
 // the reference's atomicAdd kernel, group_points_cuda.cu:10-31).
 template <int CH>
 __global__ __launch_bounds__(256) void group_bwd_lds_kernel(
-    int c, int n, int e_total, int vec, const float *__restrict__ grad_out,
+    int c, int n, int e_total, long long gstride, int vec, const float *__restrict__ grad_out,
     const int *__restrict__ idx, float *__restrict__ grad_points) {
   extern __shared__ float acc[];  // [CH][n]
   const int bi = blockIdx.y;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void group_bwd_lds_kernel(
   for (int i = threadIdx.x; i < cend * n; i += 256) acc[i] = 0.f;
   __syncthreads();
   const int *ix = idx + (size_t)bi * e_total;
-  const float *src = grad_out + ((size_t)bi * c + c0) * e_total;
+  const float *src = grad_out + (size_t)bi * gstride + (size_t)c0 * e_total;
   if (vec) {  // e_total % 4 == 0 and 16-byte aligned bases: rows and index runs are float4s
     for (int e = threadIdx.x * 4; e < e_total; e += 256 * 4) {
       int4 d = *(const int4 *)(ix + e);
@@ -174,16 +174,18 @@ extern "C" int nesie_group_max_pool_backward_add(long long rows, int nsample,
 
 // Called by nesie_group_points_backward (group_gather.hip) when n is small enough.
 namespace nesie {
-int launch_group_bwd_lds(int b, int c, int n, long long e_total, const float *grad_out,
-                         const int *idx, float *grad_points, hipStream_t s) {
+int launch_group_bwd_lds(int b, int c, int n, long long e_total, long long gstride,
+                         const float *grad_out, const int *idx, float *grad_points,
+                         hipStream_t s) {
   int ch = (int)((long long)c * b / 512);  // aim at >= 512 workgroups
   if (ch > 16384 / n) ch = 16384 / n;      // n * ch * 4 bytes <= 64 KB
   ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
   const size_t lds = (size_t)ch * n * sizeof(float);
   const dim3 grid(cdiv(c, ch), b);
   const int e = (int)e_total;
-  const int vec = (e & 3) == 0 && (((uintptr_t)grad_out | (uintptr_t)idx) & 15) == 0;
-#define L(N) hipLaunchKernelGGL(group_bwd_lds_kernel<N>, grid, dim3(256), lds, s, c, n, e, vec, \
+  const int vec = (e & 3) == 0 && (gstride & 3) == 0 &&
+                  (((uintptr_t)grad_out | (uintptr_t)idx) & 15) == 0;
+#define L(N) hipLaunchKernelGGL(group_bwd_lds_kernel<N>, grid, dim3(256), lds, s, c, n, e, gstride, vec, \
                                 grad_out, idx, grad_points)
   if (ch == 8) L(8); else if (ch == 4) L(4); else if (ch == 2) L(2); else L(1);
 #undef L

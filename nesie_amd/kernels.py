@@ -152,6 +152,31 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_gather_points_grad_wrapper", b, c, n, npoints,
                       _ptr(grad_out), _ptr(idx), _ptr(grad_points), _stream(grad_out))
 
+    def query_and_group_forward(self, xyz, centres, features, idx, radius, out):
+        """out (B, 3+C, M, ns) = cat[(xyz[idx] - centre) / radius, features[idx]]."""
+        _check(xyz, centres, idx, out); _f32(xyz, centres, out); _i32(idx)
+        b, n = xyz.shape[:2]
+        m, ns = idx.shape[1], idx.shape[2]
+        c = 0 if features is None else features.shape[1]
+        if features is not None:
+            _check(features); _f32(features)
+            assert tuple(features.shape) == (b, c, n)
+        assert tuple(out.shape) == (b, 3 + c, m, ns) and tuple(centres.shape) == (b, m, 3)
+        with torch.cuda.device(xyz.device):
+            _lib.call("nesie_query_and_group_forward", b, c, n, m, ns, _ptr(xyz), _ptr(centres),
+                      0 if features is None else _ptr(features), _ptr(idx), float(radius),
+                      _ptr(out), _stream(xyz))
+
+    def query_and_group_backward(self, grad_out, idx, grad_features):
+        """grad_features (B,C,N) zeroed += channels 3.. of grad_out (B, 3+C, M, ns)."""
+        _check(grad_out, idx, grad_features); _f32(grad_out, grad_features); _i32(idx)
+        b, c, n = grad_features.shape
+        m, ns = idx.shape[1], idx.shape[2]
+        assert tuple(grad_out.shape) == (b, 3 + c, m, ns)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_query_and_group_backward", b, c, n, m, ns, _ptr(grad_out), _ptr(idx),
+                      _ptr(grad_features), _stream(grad_out))
+
     def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
         _check(unknown, known, dist2, idx); _f32(unknown, known, dist2); _i32(idx)
         assert unknown.numel() == b * n * 3 and known.numel() == b * m * 3

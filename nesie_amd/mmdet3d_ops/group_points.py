@@ -40,6 +40,34 @@ grouping_operation = GroupingOperation.apply
 group_points = grouping_operation  # the name mmdet3d.ops re-exports
 
 
+class QueryGroupCat(Function):
+    """cat[(xyz[idx] - centre) (/ radius), features[idx]] -> (B, 3+C, M, ns) in one pass
+    (reference :100-128 transposes, groups twice, subtracts, divides, concatenates); the
+    backward scatters channels 3.. of the gradient in place (no slice copy).  Only the features
+    carry a gradient (the coordinates are inputs of the step)."""
+
+    @staticmethod
+    def forward(ctx, points_xyz, center_xyz, features, idx, radius):
+        points_xyz, center_xyz = points_xyz.contiguous(), center_xyz.contiguous()
+        features = features.contiguous()
+        b, n = points_xyz.shape[:2]
+        out = points_xyz.new_empty(b, 3 + features.shape[1], idx.shape[1], idx.shape[2])
+        backend_for(points_xyz).query_and_group_forward(points_xyz, center_xyz, features, idx,
+                                                        radius, out)
+        ctx.save_for_backward(idx)
+        ctx.cn = (features.shape[1], n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        c, n = ctx.cn
+        grad_out = grad_out.contiguous()
+        grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
+        backend_for(grad_out).query_and_group_backward(grad_out, idx, grad_features)
+        return None, None, grad_features, None, None
+
+
 class QueryAndGroup(nn.Module):
     """ball query -> group xyz -> minus centre (-> / radius) -> group features ->
     concat [xyz(3), features(C)]  (reference :64-128).  kNN grouping
@@ -78,6 +106,11 @@ class QueryAndGroup(nn.Module):
         if idx is None:
             idx = ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
                              center_xyz)
+        if (features is not None and self.use_xyz and not self.return_grouped_xyz
+                and not self.return_grouped_idx and not points_xyz.requires_grad
+                and not center_xyz.requires_grad):
+            return QueryGroupCat.apply(points_xyz, center_xyz, features, idx,
+                                       float(self.max_radius) if self.normalize_xyz else 0.0)
         xyz_trans = points_xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, sample_num)
         grouped_xyz = grouped_xyz - center_xyz.transpose(1, 2).unsqueeze(-1)

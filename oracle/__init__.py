@@ -126,6 +126,29 @@ class OracleKernels:
         lib().oracle_gather_points_grad(b, c, n, npoints, grad_out.data_ptr(),
                                         idx.data_ptr(), grad_points.data_ptr())
 
+    def query_and_group_forward(self, xyz, centres, features, idx, radius, out):
+        """The reference's order: transpose, group, subtract, divide, concatenate."""
+        b, n = xyz.shape[:2]
+        m, ns = idx.shape[1], idx.shape[2]
+        xt = xyz.transpose(1, 2).contiguous()
+        g = xyz.new_empty(b, 3, m, ns)
+        self.group_points_forward(b, 3, n, m, ns, xt, idx, g)
+        g = g - centres.transpose(1, 2).unsqueeze(-1)
+        if radius > 0:
+            g = g / radius
+        out[:, :3] = g
+        if features is not None:
+            c = features.shape[1]
+            gf = xyz.new_empty(b, c, m, ns)
+            self.group_points_forward(b, c, n, m, ns, features.contiguous(), idx, gf)
+            out[:, 3:] = gf
+
+    def query_and_group_backward(self, grad_out, idx, grad_features):
+        b, c, n = grad_features.shape
+        m, ns = idx.shape[1], idx.shape[2]
+        self.group_points_backward(b, c, n, m, ns, grad_out[:, 3:].contiguous(), idx,
+                                   grad_features)
+
     def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
         _cpu(unknown, known, dist2, idx)
         lib().oracle_three_nn(b, n, m, unknown.data_ptr(), known.data_ptr(),
