@@ -166,11 +166,16 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
         out = []
         for d in tree:
             out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
+            for csr in d.get('group_csr', ()):
+                out += list(csr or ())
         return out
 
     def clone_tree(tree):
         return [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
-                     group_idx=[t.clone() for t in d['group_idx']]) for d in tree]
+                     group_idx=[t.clone() for t in d['group_idx']],
+                     group_csr=[None if csr is None else tuple(t.clone() for t in csr)
+                                for csr in d.get('group_csr', ())])
+                for d in tree]
 
     semi_like = workload in ('semi', 'saqe')
     # weight-independent work of a step: the backbone's index chain(s) and, for the supervised

@@ -97,6 +97,16 @@ int nesie_query_and_group_forward(int b, int c, int n, int npoints, int nsample,
 int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample,
                                    const float *grad_out, const int *idx, float *grad_features,
                                    void *stream);
+/* Same result through an inverted index of idx: order[B, M*ns] = the grouped columns sorted
+ * by their source point, sources[B, M*ns] = that point for each (nesie_inverted_index builds
+ * both, n <= 8192).  Lanes own sorted entries, a segmented scan inside each wave sums the runs
+ * and only the last lane of a run adds its total into grad_features (zeroed by the caller):
+ * a few float atomics per point instead of one per entry, balanced whatever the run lengths. */
+int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
+                         int *sources, void *stream);
+int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsample,
+                                       const float *grad_out, const int *order,
+                                       const int *sources, float *grad_features, void *stream);
 
 /* mmdet3d/ops/gather_points/src/gather_points.cpp:28-42  gather_points_wrapper
  * (b, c, n, npoints, points[B,C,N], idx[B,M], out[B,C,M]). */

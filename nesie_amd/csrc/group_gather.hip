@@ -90,6 +90,102 @@ static int launch_group(bool fwd, const char *W, int b, int c, int n, long long 
   return check_launch(W);
 }
 
+// Scatter-add through an inverted index: order[b][.] lists the grouped columns sorted by their
+// source point and src[b][.] the source point of each.  A LANE owns one sorted entry, a wave 64
+// consecutive ones; within the wave a segmented scan (keys are contiguous) sums the entries of
+// each point and only the last lane of a run adds its total -- one float atomic per (point,
+// wave) instead of one LDS atomic per entry (which run at 0.32 lanes/clk/CU here), and the
+// work per wave is the same whatever the run lengths.  The index depends on the coordinates
+// only, so a training loop builds it ahead of the step together with the ball-query indices.
+__global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
+    int c, int n, int e_total, long long gstride, const float *__restrict__ grad_out,
+    const int *__restrict__ order, const int *__restrict__ src, float *__restrict__ grad_points) {
+  const int e = blockIdx.x * GG_BLOCK + threadIdx.x;
+  const int c0 = blockIdx.y * GG_CH;
+  const int bi = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const bool live = e < e_total;
+  const int ee = live ? e : e_total - 1;
+  const int col = order[(size_t)bi * e_total + ee];
+  const int key = live ? src[(size_t)bi * e_total + ee] : -1;
+  // same[d]: the entry d lanes below belongs to the same point (then so do all in between)
+  bool same[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    const int kd = __shfl_up(key, 1 << d, 64);
+    same[d] = lane >= (1 << d) && kd == key;
+  }
+  const int knext = __shfl_down(key, 1, 64);
+  const bool tail = live && (lane == 63 || knext != key);
+  const float *g = grad_out + (size_t)bi * gstride + (size_t)c0 * e_total + col;
+  float *dst = grad_points + ((size_t)bi * c + c0) * n + (key < 0 ? 0 : key);
+  const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
+  float v[GG_CH];
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i) v[i] = (live && i < cend) ? g[(size_t)i * e_total] : 0.f;
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i) {
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const float t = __shfl_up(v[i], 1 << d, 64);
+      if (same[d]) v[i] += t;
+    }
+    if (tail && i < cend) atomicAdd(dst + (size_t)i * n, v[i]);
+  }
+}
+
+// Inverted index of idx[b][0..e_total) over n source points, one workgroup per scene: LDS
+// histogram (integer ds_add), exclusive scan, then each column takes the next free slot of its
+// point's run (returning ds_add).  Built on the side stream with the ball query: 8 workgroups,
+// tens of microseconds.  The order inside a run is not fixed.
+constexpr int II_BLOCK = 1024;
+
+__global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
+    int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
+    int *__restrict__ srcs) {
+  extern __shared__ int lds[];  // hist[n] then cursor[n]; scan scratch [II_BLOCK]
+  int *cur = lds, *scratch = lds + n;
+  const int bi = blockIdx.x, tid = threadIdx.x;
+  const int *ix = idx + (size_t)bi * e_total;
+  for (int j = tid; j < n; j += II_BLOCK) cur[j] = 0;
+  __syncthreads();
+  for (int e = tid; e < e_total; e += II_BLOCK) {
+    int s = ix[e];
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    atomicAdd(&cur[s], 1);
+  }
+  __syncthreads();
+  // exclusive scan over n bins: each thread owns a contiguous chunk
+  const int per = (n + II_BLOCK - 1) / II_BLOCK;
+  const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+  int sum = 0;
+  for (int j = lo; j < hi; ++j) sum += cur[j];
+  scratch[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < II_BLOCK; d <<= 1) {
+    const int v = tid >= d ? scratch[tid - d] : 0;
+    __syncthreads();
+    scratch[tid] += v;
+    __syncthreads();
+  }
+  int run = scratch[tid] - sum;  // exclusive prefix of this chunk
+  for (int j = lo; j < hi; ++j) {
+    const int cnt = cur[j];
+    cur[j] = run;  // becomes the cursor of point j
+    run += cnt;
+  }
+  __syncthreads();
+  int *ord = order + (size_t)bi * e_total;
+  int *sr = srcs + (size_t)bi * e_total;
+  for (int e = tid; e < e_total; e += II_BLOCK) {
+    int s = ix[e];
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    const int slot = atomicAdd(&cur[s], 1);
+    ord[slot] = e;
+    sr[slot] = s;
+  }
+}
+
 // channels 0..2 of QueryAndGroup's output: (xyz[idx] - centre) (/ radius), straight from the
 // (B,N,3) point array (the reference transposes it, groups it, subtracts, divides and
 // concatenates: group_points.py:100-118)
@@ -178,4 +274,38 @@ extern "C" int nesie_gather_points_grad_wrapper(int b, int c, int n, int npoints
   NESIE_REQUIRE(npoints >= 0, "gather_points_grad_wrapper");
   return launch_group(false, "gather_points_grad_wrapper", b, c, n, npoints, grad_out,
                       idx, grad_points, stream);
+}
+
+extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsample,
+                                                  const float *grad_out, const int *order,
+                                                  const int *sources, float *grad_features,
+                                                  void *stream) {
+  const char *W = "query_and_group_backward_csr";
+  NESIE_REQUIRE(b >= 0 && c >= 1 && n >= 0 && npoints >= 0 && nsample >= 0, W);
+  const long long e_total = (long long)npoints * nsample;
+  if (b == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && order && sources && grad_features, W);
+  if (e_total == 0) return NESIE_OK;
+  NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
+                     dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total,
+                     (long long)(3 + c) * e_total, grad_out + 3 * e_total, order, sources,
+                     grad_features);
+  return check_launch(W);
+}
+
+extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
+                                    int *sources, void *stream) {
+  const char *W = "inverted_index";
+  NESIE_REQUIRE(b >= 0 && n >= 1 && e_total >= 0 && e_total < (1ll << 31), W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(idx && order && sources, W);
+  if (n > 8192) {
+    set_error("%s: %d source points (built for n <= 8192: one LDS histogram per scene)", W, n);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  const size_t lds = ((size_t)n + II_BLOCK) * sizeof(int);
+  hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, (hipStream_t)stream, n,
+                     (int)e_total, idx, order, sources);
+  return check_launch(W);
 }

@@ -177,6 +177,31 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_query_and_group_backward", b, c, n, m, ns, _ptr(grad_out), _ptr(idx),
                       _ptr(grad_features), _stream(grad_out))
 
+    def inverted_index(self, idx, n):
+        """idx (B, M, ns) int32 in [0, n) -> order, sources (B, M*ns) int32: the grouped columns
+        sorted by source point and that point for each."""
+        _check(idx); _i32(idx)
+        b = idx.shape[0]
+        e = idx.numel() // b
+        order = torch.empty(b, e, dtype=torch.int32, device=idx.device)
+        sources = torch.empty(b, e, dtype=torch.int32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            _lib.call("nesie_inverted_index", b, n, e, _ptr(idx), _ptr(order), _ptr(sources),
+                      _stream(idx))
+        return order, sources
+
+    def query_and_group_backward_csr(self, grad_out, idx_shape, order, offsets, grad_features):
+        """grad_features (B,C,N, zeroed) += channels 3.. of grad_out through (order, sources)."""
+        _check(grad_out, order, offsets, grad_features); _f32(grad_out, grad_features)
+        _i32(order, offsets)
+        b, c, n = grad_features.shape
+        m, ns = idx_shape[1], idx_shape[2]
+        assert tuple(grad_out.shape) == (b, 3 + c, m, ns)
+        assert tuple(order.shape) == (b, m * ns) and tuple(offsets.shape) == (b, m * ns)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_query_and_group_backward_csr", b, c, n, m, ns, _ptr(grad_out),
+                      _ptr(order), _ptr(offsets), _ptr(grad_features), _stream(grad_out))
+
     def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
         _check(unknown, known, dist2, idx); _f32(unknown, known, dist2); _i32(idx)
         assert unknown.numel() == b * n * 3 and known.numel() == b * m * 3

@@ -40,6 +40,17 @@ grouping_operation = GroupingOperation.apply
 group_points = grouping_operation  # the name mmdet3d.ops re-exports
 
 
+def inverted_index(idx, n):
+    """idx (B, M, ns) int32 source-point indices -> (order, sources), both (B, M*ns) int32 = the
+    grouped columns sorted by source point and that point for each, or None when the back end
+    has no index builder for this size.  Pure index work: depends on coordinates only, so it is built ahead
+    of the step with the ball query."""
+    backend = backend_for(idx)
+    if not hasattr(backend, 'inverted_index') or n > 8192:
+        return None
+    return backend.inverted_index(idx.contiguous(), n)
+
+
 class QueryGroupCat(Function):
     """cat[(xyz[idx] - centre) (/ radius), features[idx]] -> (B, 3+C, M, ns) in one pass
     (reference :100-128 transposes, groups twice, subtracts, divides, concatenates); the
@@ -47,25 +58,33 @@ class QueryGroupCat(Function):
     carry a gradient (the coordinates are inputs of the step)."""
 
     @staticmethod
-    def forward(ctx, points_xyz, center_xyz, features, idx, radius):
+    def forward(ctx, points_xyz, center_xyz, features, idx, radius, csr=None):
         points_xyz, center_xyz = points_xyz.contiguous(), center_xyz.contiguous()
         features = features.contiguous()
         b, n = points_xyz.shape[:2]
         out = points_xyz.new_empty(b, 3 + features.shape[1], idx.shape[1], idx.shape[2])
         backend_for(points_xyz).query_and_group_forward(points_xyz, center_xyz, features, idx,
                                                         radius, out)
-        ctx.save_for_backward(idx)
+        ctx.has_csr = csr is not None
+        ctx.save_for_backward(idx, *(csr if ctx.has_csr else ()))
         ctx.cn = (features.shape[1], n)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         c, n = ctx.cn
         grad_out = grad_out.contiguous()
-        grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
-        backend_for(grad_out).query_and_group_backward(grad_out, idx, grad_features)
-        return None, None, grad_features, None, None
+        backend = backend_for(grad_out)
+        if ctx.has_csr and hasattr(backend, 'query_and_group_backward_csr'):
+            order, offsets = ctx.saved_tensors[1:]
+            grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
+            backend.query_and_group_backward_csr(grad_out, idx.shape, order, offsets,
+                                                 grad_features)
+        else:
+            grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
+            backend.query_and_group_backward(grad_out, idx, grad_features)
+        return None, None, grad_features, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -100,9 +119,10 @@ class QueryAndGroup(nn.Module):
         return ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
                           center_xyz)
 
-    def forward(self, points_xyz, center_xyz, features=None, idx=None):
+    def forward(self, points_xyz, center_xyz, features=None, idx=None, csr=None):
         """``idx`` (optional, not in the reference): ball-query indices computed ahead of time
-        for exactly these points/centres (they depend on coordinates only, never on weights)."""
+        for exactly these points/centres (they depend on coordinates only, never on weights);
+        ``csr`` (optional) = ``inverted_index(idx, N)`` for the backward gather-sum."""
         if idx is None:
             idx = ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz,
                              center_xyz)
@@ -110,7 +130,8 @@ class QueryAndGroup(nn.Module):
                 and not self.return_grouped_idx and not points_xyz.requires_grad
                 and not center_xyz.requires_grad):
             return QueryGroupCat.apply(points_xyz, center_xyz, features, idx,
-                                       float(self.max_radius) if self.normalize_xyz else 0.0)
+                                       float(self.max_radius) if self.normalize_xyz else 0.0,
+                                       csr)
         xyz_trans = points_xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, sample_num)
         grouped_xyz = grouped_xyz - center_xyz.transpose(1, 2).unsqueeze(-1)

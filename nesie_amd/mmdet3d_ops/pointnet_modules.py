@@ -15,7 +15,7 @@ from torch.nn import functional as F
 from ..kernels import backend_for
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
-from .group_points import GroupAll, QueryAndGroup
+from .group_points import GroupAll, QueryAndGroup, inverted_index
 from .interpolate import three_interpolate, three_nn
 from .norm import FusedBNReLU1d, FusedBNReLU2d
 from .pool import group_max_pool
@@ -233,7 +233,8 @@ class BasePointSAModule(nn.Module):
         on a side stream while the current step computes (see bench.py)."""
         new_xyz, indices = self._sample_points(points_xyz, None, None, None)
         group_idx = [g.ball_indices(points_xyz, new_xyz) for g in self.groupers]
-        return dict(indices=indices, new_xyz=new_xyz, group_idx=group_idx)
+        group_csr = [inverted_index(i, points_xyz.shape[1]) for i in group_idx]
+        return dict(indices=indices, new_xyz=new_xyz, group_idx=group_idx, group_csr=group_csr)
 
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None, precomputed=None):
         new_features_list = []
@@ -243,8 +244,9 @@ class BasePointSAModule(nn.Module):
             new_xyz, indices = self._sample_points(points_xyz, features, indices, target_xyz)
         for i in range(len(self.groupers)):
             if precomputed is not None:
+                csr = precomputed.get('group_csr') or [None] * len(self.groupers)
                 grouped_results = self.groupers[i](points_xyz, new_xyz, features,
-                                                   idx=precomputed['group_idx'][i])
+                                                   idx=precomputed['group_idx'][i], csr=csr[i])
             else:
                 grouped_results = self.groupers[i](points_xyz, new_xyz, features)
             new_features_list.append(self._mlp_and_pool(self.mlps[i], grouped_results))

@@ -602,3 +602,25 @@ def test_query_group_cat_matches_the_literal_chain(oracle_kernels, hip_device, n
     got.backward(go.to(hip_device))
     assert torch.equal(got.detach().cpu(), want.detach())
     torch.testing.assert_close(f1.grad.cpu(), f0.grad, rtol=1e-4, atol=1e-4)
+    # the same backward as a gather-sum through the inverted index (no atomics): run twice,
+    # bitwise equal, and equal to the scatter form within summation order
+    from nesie_amd.mmdet3d_ops.group_points import inverted_index
+    idx_d = idx.to(hip_device)
+    csr = inverted_index(idx_d, n)
+    if n > 8192:
+        assert csr is None     # one LDS histogram per scene: small point sets only
+        return
+    order, sources = csr
+    flat = idx.reshape(2, -1).long()
+    assert order.dtype == torch.int32 and tuple(sources.shape) == (2, m * ns)
+    assert torch.equal(torch.gather(flat, 1, order.cpu().long()), sources.cpu().long())
+    assert torch.equal(sources.cpu().long(), flat.sort(1).values)       # grouped by point
+    assert torch.equal(order.cpu().long().sort(1).values, torch.arange(m * ns).expand(2, -1))
+    grads = []
+    for _ in range(2):
+        f2 = feats.to(hip_device).requires_grad_(True)
+        qg(xyz.to(hip_device), centres.to(hip_device), f2, idx=idx_d, csr=csr).backward(
+            go.to(hip_device))
+        grads.append(f2.grad.clone())
+    torch.testing.assert_close(grads[0], grads[1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(grads[0].cpu(), f0.grad, rtol=1e-4, atol=1e-4)
