@@ -108,6 +108,13 @@ int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsa
                                        const float *grad_out, const int *order,
                                        const int *sources, float *grad_features, void *stream);
 
+/* three_interpolate_grad_wrapper through an inverted index of idx[B, n, 3] over the m known
+ * points (nesie_inverted_index with e_total = 3n): grad_points[B, C, m] (zeroed) +=
+ * weight * grad_out, one float atomic per (known point, wave) instead of three per target. */
+int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
+                                     const float *weight, const int *order, const int *sources,
+                                     float *grad_points, void *stream);
+
 /* mmdet3d/ops/gather_points/src/gather_points.cpp:28-42  gather_points_wrapper
  * (b, c, n, npoints, points[B,C,N], idx[B,M], out[B,C,M]). */
 int nesie_gather_points_wrapper(int b, int c, int n, int npoints,

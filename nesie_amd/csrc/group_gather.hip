@@ -98,8 +98,11 @@ static int launch_group(bool fwd, const char *W, int b, int c, int n, long long 
 // work per wave is the same whatever the run lengths.  The index depends on the coordinates
 // only, so a training loop builds it ahead of the step together with the ball-query indices.
 __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
-    int c, int n, int e_total, long long gstride, const float *__restrict__ grad_out,
-    const int *__restrict__ order, const int *__restrict__ src, float *__restrict__ grad_points) {
+    int c, int n, int e_total, long long gstride, int ediv, const float *__restrict__ grad_out,
+    const float *__restrict__ weight, const int *__restrict__ order,
+    const int *__restrict__ src, float *__restrict__ grad_points) {
+  // ediv / weight: the entries are (column, tap) pairs, ediv taps per column of grad_out, each
+  // scaled by weight[entry] (three_interpolate's backward); ediv = 1, weight = NULL for groups
   const int e = blockIdx.x * GG_BLOCK + threadIdx.x;
   const int c0 = blockIdx.y * GG_CH;
   const int bi = blockIdx.z;
@@ -117,12 +120,15 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
   }
   const int knext = __shfl_down(key, 1, 64);
   const bool tail = live && (lane == 63 || knext != key);
-  const float *g = grad_out + (size_t)bi * gstride + (size_t)c0 * e_total + col;
+  const int ncols = e_total / ediv;
+  const float wgt = weight ? weight[(size_t)bi * e_total + col] : 1.f;
+  const float *g = grad_out + (size_t)bi * gstride + (size_t)c0 * ncols + col / ediv;
   float *dst = grad_points + ((size_t)bi * c + c0) * n + (key < 0 ? 0 : key);
   const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
   float v[GG_CH];
 #pragma unroll
-  for (int i = 0; i < GG_CH; ++i) v[i] = (live && i < cend) ? g[(size_t)i * e_total] : 0.f;
+  for (int i = 0; i < GG_CH; ++i)
+    v[i] = (live && i < cend) ? __fmul_rn(g[(size_t)i * ncols], wgt) : 0.f;
 #pragma unroll
   for (int i = 0; i < GG_CH; ++i) {
 #pragma unroll
@@ -289,8 +295,8 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
   NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total,
-                     (long long)(3 + c) * e_total, grad_out + 3 * e_total, order, sources,
-                     grad_features);
+                     (long long)(3 + c) * e_total, 1, grad_out + 3 * e_total,
+                     (const float *)nullptr, order, sources, grad_features);
   return check_launch(W);
 }
 
@@ -307,5 +313,20 @@ extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *
   const size_t lds = ((size_t)n + II_BLOCK) * sizeof(int);
   hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, (hipStream_t)stream, n,
                      (int)e_total, idx, order, sources);
+  return check_launch(W);
+}
+
+extern "C" int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
+                                                const float *weight, const int *order,
+                                                const int *sources, float *grad_points,
+                                                void *stream) {
+  const char *W = "three_interpolate_grad_csr";
+  NESIE_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 1, W);
+  if (b == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && weight && order && sources && grad_points, W);
+  NESIE_REQUIRE((long long)n * 3 < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv((long long)n * 3, GG_BLOCK), cdiv(c, GG_CH), b),
+                     dim3(GG_BLOCK), 0, (hipStream_t)stream, c, m, n * 3, (long long)c * n, 3,
+                     grad_out, weight, order, sources, grad_points);
   return check_launch(W);
 }

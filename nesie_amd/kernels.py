@@ -177,6 +177,19 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_query_and_group_backward", b, c, n, m, ns, _ptr(grad_out), _ptr(idx),
                       _ptr(grad_features), _stream(grad_out))
 
+    def three_interpolate_grad_csr(self, grad_out, weight, order, sources, grad_points):
+        """grad_points (B,C,m, zeroed) += weight * grad_out (B,C,n) through (order, sources) =
+        inverted_index(idx (B,n,3), m)."""
+        _check(grad_out, weight, order, sources, grad_points); _f32(grad_out, weight, grad_points)
+        _i32(order, sources)
+        b, c, n = grad_out.shape
+        m = grad_points.shape[2]
+        assert weight.numel() == b * n * 3 and tuple(order.shape) == (b, n * 3)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_three_interpolate_grad_csr", b, c, n, m, _ptr(grad_out),
+                      _ptr(weight), _ptr(order), _ptr(sources), _ptr(grad_points),
+                      _stream(grad_out))
+
     def inverted_index(self, idx, n):
         """idx (B, M, ns) int32 in [0, n) -> order, sources (B, M*ns) int32: the grouped columns
         sorted by source point and that point for each."""

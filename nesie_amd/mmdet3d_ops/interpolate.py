@@ -36,13 +36,15 @@ class ThreeInterpolate(Function):
 
     @staticmethod
     def forward(ctx, features: torch.Tensor, indices: torch.Tensor,
-                weight: torch.Tensor) -> torch.Tensor:
+                weight: torch.Tensor, csr=None) -> torch.Tensor:
+        """``csr`` (optional, not in the reference) = inverted_index(indices, M): the backward
+        then scatters through it (few atomics) instead of three atomics per target."""
         assert features.is_contiguous()
         assert indices.is_contiguous()
         assert weight.is_contiguous()
         B, c, m = features.size()
         n = indices.size(1)
-        ctx.three_interpolate_for_backward = (indices, weight, m)
+        ctx.three_interpolate_for_backward = (indices, weight, m, csr)
         output = features.new_empty((B, c, n))
         backend_for(features).three_interpolate_wrapper(B, c, m, n, features, indices,
                                                         weight, output)
@@ -50,13 +52,18 @@ class ThreeInterpolate(Function):
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        idx, weight, m = ctx.three_interpolate_for_backward
+        idx, weight, m, csr = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
         grad_features = grad_out.new_zeros((B, c, m))
         grad_out_data = grad_out.data.contiguous()
-        backend_for(grad_out_data).three_interpolate_grad_wrapper(
-            B, c, n, m, grad_out_data, idx, weight, grad_features.data)
-        return grad_features, None, None
+        backend = backend_for(grad_out_data)
+        if csr is not None and hasattr(backend, 'three_interpolate_grad_csr'):
+            backend.three_interpolate_grad_csr(grad_out_data, weight, csr[0], csr[1],
+                                               grad_features.data)
+        else:
+            backend.three_interpolate_grad_wrapper(B, c, n, m, grad_out_data, idx, weight,
+                                                   grad_features.data)
+        return grad_features, None, None, None
 
 
 three_interpolate = ThreeInterpolate.apply

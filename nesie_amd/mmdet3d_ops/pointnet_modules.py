@@ -306,13 +306,20 @@ class PointFPModule(nn.Module):
                 ConvModule(mlp_channels[i], mlp_channels[i + 1], kernel_size=(1, 1),
                            stride=(1, 1), conv_cfg=dict(type='Conv2d'), norm_cfg=norm_cfg))
 
-    def forward(self, target, source, target_feats, source_feats):
+    @staticmethod
+    def interpolation_taps(target, source):
+        """3-NN indices, inverse-distance weights and the inverted index of the indices
+        (:56-61).  Coordinates only: a training loop may compute them ahead of the step."""
+        dist, idx = three_nn(target, source)
+        dist_reciprocal = 1.0 / (dist + 1e-8)
+        norm = torch.sum(dist_reciprocal, dim=2, keepdim=True)
+        weight = (dist_reciprocal / norm).contiguous()
+        return idx, weight, inverted_index(idx, source.shape[1])
+
+    def forward(self, target, source, target_feats, source_feats, taps=None):
         if source is not None:
-            dist, idx = three_nn(target, source)
-            dist_reciprocal = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_reciprocal, dim=2, keepdim=True)
-            weight = dist_reciprocal / norm
-            interpolated_feats = three_interpolate(source_feats, idx, weight)
+            idx, weight, csr = taps if taps is not None else self.interpolation_taps(target, source)
+            interpolated_feats = three_interpolate(source_feats, idx, weight, csr)
         else:
             interpolated_feats = source_feats.expand(*source_feats.size()[0:2],
                                                      target.size(1))

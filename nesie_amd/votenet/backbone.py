@@ -51,11 +51,15 @@ class PointNet2SASSG(nn.Module):
         """FPS + ball-query indices of all SA layers: they depend on the input coordinates
         only, so a loop may compute them for the next batch while this one trains."""
         xyz = points[..., 0:3].contiguous()
-        out = []
+        out, sa_xyz = [], [xyz]
         for sa in self.SA_modules:
             pre = sa.sample_and_group_indices(xyz)
             out.append(pre)
             xyz = pre['new_xyz']
+            sa_xyz.append(xyz)
+        # feature-propagation taps (3-NN between consecutive levels) ride on the first entry
+        out[0]['fp_taps'] = [self.FP_modules[i].interpolation_taps(
+            sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i]) for i in range(self.num_fp)]
         return out
 
     def forward(self, points, precomputed=None):
@@ -74,9 +78,11 @@ class PointNet2SASSG(nn.Module):
             sa_indices.append(torch.gather(sa_indices[-1], 1, cur_indices.long()))
         fp_xyz, fp_features, fp_indices = [sa_xyz[-1]], [sa_features[-1]], [sa_indices[-1]]
         for i in range(self.num_fp):
+            taps = None if precomputed is None else precomputed[0].get('fp_taps')
             fp_features.append(self.FP_modules[i](
                 sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i],
-                sa_features[self.num_sa - i - 1], fp_features[-1]))
+                sa_features[self.num_sa - i - 1], fp_features[-1],
+                taps=None if taps is None else taps[i]))
             fp_xyz.append(sa_xyz[self.num_sa - i - 1])
             fp_indices.append(sa_indices[self.num_sa - i - 1])
         return dict(fp_xyz=fp_xyz, fp_features=fp_features, fp_indices=fp_indices,

@@ -624,3 +624,28 @@ def test_query_group_cat_matches_the_literal_chain(oracle_kernels, hip_device, n
         grads.append(f2.grad.clone())
     torch.testing.assert_close(grads[0], grads[1], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(grads[0].cpu(), f0.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m,c", [(1024, 512, 256), (512, 256, 256), (100, 7, 5)])
+def test_three_interpolate_grad_through_inverted_index(oracle_kernels, hip_device, n, m, c):
+    """three_interpolate's backward as a scatter through inverted_index(idx, m) vs the
+    reference's atomicAdd scatter restated in the oracle (three_interpolate_cuda.cu:61-84)."""
+    from nesie_amd.mmdet3d_ops.group_points import inverted_index
+    g = torch.Generator().manual_seed(n + m)
+    feats = torch.randn(2, c, m, generator=g)
+    idx = torch.randint(0, m, (2, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(2, n, 3, generator=g)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    go = torch.randn(2, c, n, generator=g)
+    with kernels.use_backend(oracle_kernels):
+        f0 = feats.clone().requires_grad_(True)
+        want = ops.three_interpolate(f0, idx, w)
+        want.backward(go)
+    idx_d, w_d = idx.to(hip_device), w.to(hip_device)
+    csr = inverted_index(idx_d, m)
+    assert csr is not None
+    f1 = feats.to(hip_device).requires_grad_(True)
+    got = ops.three_interpolate(f1, idx_d, w_d, csr)
+    got.backward(go.to(hip_device))
+    assert torch.equal(got.detach().cpu(), want.detach())
+    torch.testing.assert_close(f1.grad.cpu(), f0.grad, rtol=1e-4, atol=1e-4)
