@@ -20,6 +20,7 @@ from ..mmdet3d_ops.rotated_iou import cal_iou_3d
 from .bbox_module import ReliableConvBboxHead
 from .boxes import depth_to_lidar_boxes, depth_to_lidar_points
 from .losses import build_loss
+from ..streams import fork_join
 from .side_pooling import SidePooling
 from .vote_module import VoteModule
 
@@ -106,6 +107,9 @@ class NesieHead(nn.Module):
             reg_max=self.reg_max)
         self.integral = Integral(self.reg_max)
         self.grid_conv = SidePooling(**grid_conv_cfg)
+        # independent loss terms on forked streams: measured on ROCm 7.2, a hipGraph captured
+        # with forked branches replays the whole step 2x slower (43 vs 20 ms), so off
+        self.parallel_loss_terms = False
         self.jitter_noise = None  # optional (noise_center, noise_size), each (B,K,3)
         # device-resident constants (no host->device copy inside the step: hipGraph-safe)
         self.register_buffer('_side_scale', torch.tensor(self.sizes + self.sizes), persistent=False)
@@ -229,66 +233,77 @@ class NesieHead(nn.Module):
          valid_gt_weights, assignment) = targets
         bbox_targets_cat = bbox_targets.reshape(-1, 7)
 
-        vote_loss = self.vote_module.get_loss(
-            bbox_preds['seed_points'], bbox_preds['vote_points'], bbox_preds['seed_indices'],
-            vote_target_masks, vote_targets)
-        objectness_loss = self.objectness_loss(
-            bbox_preds['obj_scores'].transpose(2, 1), objectness_targets,
-            weight=objectness_weights)
-        source2target_loss, target2source_loss = self.center_loss(
-            bbox_preds['bbox_preds'][..., :3], center_targets, src_weight=box_loss_weights,
-            dst_weight=valid_gt_weights)
-        center_loss = source2target_loss + target2source_loss
-
+        # shared by several terms
         surface_weight = box_loss_weights.reshape(-1).unsqueeze(-1).repeat(1, 6)
         probs = bbox_preds['bbox_probs'].permute(0, 3, 1, 2).reshape(-1, 6, self.reg_max + 1)
-        surface_loss = self.surface_loss(
-            bbox_preds['surface_pred'].reshape(-1, 6), bbox_targets_cat,
-            bbox_preds['surface_scale'].reshape(-1, 6),
-            bbox_preds['aggregated_points'].reshape(-1, 3), probs, weight=surface_weight,
-            reduction_override='none')
         sigma = self._sigma(bbox_preds)
-        surface_loss = torch.exp(-sigma) * surface_loss + self.alpha * sigma * surface_weight
-        surface_loss = surface_loss.sum()
-
-        semantic_loss = self.semantic_loss(
-            bbox_preds['sem_scores'].transpose(2, 1), mask_targets, weight=box_loss_weights)
-
         iou_weight = box_loss_weights.reshape(-1)
-        iou_loss = self.iou_loss(bbox_preds['bbox_preds'].reshape(-1, 7), bbox_targets_cat,
-                                 weight=iou_weight, reduction_override='none').reshape(-1)
-        sigma_mean = sigma.mean(dim=-1)
-        iou_loss = torch.exp(-sigma_mean) * iou_loss + self.alpha * sigma_mean * iou_weight
-        iou_loss = iou_loss.sum()
-
-        targets_b = bbox_targets_cat.view_as(bbox_preds['bbox_preds'])
-        label_iou = cal_iou_3d(bbox_preds['bbox_preds'], targets_b).detach().view(-1)
-        label_iou_jitter = cal_iou_3d(bbox_preds['jitter_bbox_preds'],
-                                      targets_b).detach().view(-1)
         label_cls = mask_targets.reshape(-1)
-        w = box_loss_weights.reshape(-1)
-        if getattr(self.iou_pred_loss, 'reduction', None) == 'sum':
-            # the plain and the jittered half in one pass (a sum-reduced loss is additive)
-            iou_pred_loss = self.iou_pred_loss(
-                torch.cat([bbox_preds['iou_scores'].reshape(-1, self.num_classes),
-                           bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes)]),
-                (torch.cat([label_cls, label_cls]), torch.cat([label_iou, label_iou_jitter])),
-                weight=torch.cat([w, w]))
-        else:
+        targets_b = bbox_targets_cat.view_as(bbox_preds['bbox_preds'])
+
+        def branch_votes():
+            vote_loss = self.vote_module.get_loss(
+                bbox_preds['seed_points'], bbox_preds['vote_points'], bbox_preds['seed_indices'],
+                vote_target_masks, vote_targets)
+            objectness_loss = self.objectness_loss(
+                bbox_preds['obj_scores'].transpose(2, 1), objectness_targets,
+                weight=objectness_weights)
+            semantic_loss = self.semantic_loss(
+                bbox_preds['sem_scores'].transpose(2, 1), mask_targets, weight=box_loss_weights)
+            return vote_loss, objectness_loss, semantic_loss
+
+        def branch_surface():
+            source2target_loss, target2source_loss = self.center_loss(
+                bbox_preds['bbox_preds'][..., :3], center_targets, src_weight=box_loss_weights,
+                dst_weight=valid_gt_weights)
+            surface_loss = self.surface_loss(
+                bbox_preds['surface_pred'].reshape(-1, 6), bbox_targets_cat,
+                bbox_preds['surface_scale'].reshape(-1, 6),
+                bbox_preds['aggregated_points'].reshape(-1, 3), probs, weight=surface_weight,
+                reduction_override='none')
+            surface_loss = torch.exp(-sigma) * surface_loss + self.alpha * sigma * surface_weight
+            return source2target_loss + target2source_loss, surface_loss.sum()
+
+        def branch_iou():
+            iou_loss = self.iou_loss(bbox_preds['bbox_preds'].reshape(-1, 7), bbox_targets_cat,
+                                     weight=iou_weight, reduction_override='none').reshape(-1)
+            sigma_mean = sigma.mean(dim=-1)
+            iou_loss = torch.exp(-sigma_mean) * iou_loss + self.alpha * sigma_mean * iou_weight
+            return (iou_loss.sum(),)
+
+        def branch_iou_pred():
+            label_iou = cal_iou_3d(bbox_preds['bbox_preds'], targets_b).detach().view(-1)
+            label_iou_jitter = cal_iou_3d(bbox_preds['jitter_bbox_preds'],
+                                          targets_b).detach().view(-1)
+            w = iou_weight
+            if getattr(self.iou_pred_loss, 'reduction', None) == 'sum':
+                # the plain and the jittered half in one pass (a sum-reduced loss is additive)
+                return (self.iou_pred_loss(
+                    torch.cat([bbox_preds['iou_scores'].reshape(-1, self.num_classes),
+                               bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes)]),
+                    (torch.cat([label_cls, label_cls]),
+                     torch.cat([label_iou, label_iou_jitter])), weight=torch.cat([w, w])),)
             loss_iou = self.iou_pred_loss(
                 bbox_preds['iou_scores'].reshape(-1, self.num_classes), (label_cls, label_iou),
                 weight=w)
             loss_iou_jitter = self.iou_pred_loss(
                 bbox_preds['iou_scores_jitter'].reshape(-1, self.num_classes),
                 (label_cls, label_iou_jitter), weight=w)
-            iou_pred_loss = loss_iou + loss_iou_jitter
+            return (loss_iou + loss_iou_jitter,)
 
-        side_pred = bbox_preds['side_scores'].reshape(-1, 6, self.num_classes)
-        side_pred = self._pick_class(side_pred, label_cls)
-        side_loss = self.side_loss(
-            side_pred, bbox_preds['surface_pred'].reshape(-1, 6), bbox_targets_cat,
-            bbox_preds['surface_scale'].reshape(-1, 6),
-            bbox_preds['aggregated_points'].reshape(-1, 3), probs, weight=surface_weight)
+        def branch_side():
+            side_pred = bbox_preds['side_scores'].reshape(-1, 6, self.num_classes)
+            side_pred = self._pick_class(side_pred, label_cls)
+            return (self.side_loss(
+                side_pred, bbox_preds['surface_pred'].reshape(-1, 6), bbox_targets_cat,
+                bbox_preds['surface_scale'].reshape(-1, 6),
+                bbox_preds['aggregated_points'].reshape(-1, 3), probs, weight=surface_weight),)
+
+        # the terms are independent chains of small launches (optionally parallel branches)
+        ((vote_loss, objectness_loss, semantic_loss), (center_loss, surface_loss), (iou_loss,),
+         (iou_pred_loss,), (side_loss,)) = fork_join(
+            [branch_votes, branch_surface, branch_iou, branch_iou_pred, branch_side],
+            like=bbox_targets_cat, enabled=self.parallel_loss_terms)
 
         losses = dict(vote_loss=vote_loss, objectness_loss=objectness_loss,
                       semantic_loss=semantic_loss, center_loss=center_loss,
