@@ -183,6 +183,33 @@ int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy, int p
                               const float *rel, float *d_table, float *d_wx, int segs,
                               int seg_len, void *stream);
 
+/* nesie_blend_conv_forward (second form) followed by the training BatchNorm + ReLU of
+ * MiniPointNet.first_conv[1:3] (side_pooling_module.py:346-348), fused by recomputation: the
+ * conv output and its gradient are never stored (4 tensor passes instead of 11).
+ *   forward : out (B, segs, c, K*seg_len) = relu(gamma * (c0 - mean) * invstd + beta) with the
+ *             statistics of c0 per stacked channel (segs*c of them; gamma, beta, running_*,
+ *             save_* are [segs*c]); fwd_coef [segs*c][4] = (scale, bias, mean, invstd).
+ *   backward: from dy (same shape as out): d_table (zeroed by the caller, ADDED into),
+ *             d_wx_part (B, R, segs, c, 3) partial sums (R = nesie_blend_conv_runs), dgamma,
+ *             dbeta [segs*c].
+ * workspace = nesie_blend_conv_bn_workspace_bytes(b, c, n, segs); c in {64,128,192,256},
+ * K*seg_len % 64 == 0. */
+size_t nesie_blend_conv_bn_workspace_bytes(int b, int c, int n, int segs);
+int nesie_blend_conv_bn_forward(int b, int c, int m, int n, const float *table, int pitch,
+                                int seg_off, const int *idx, const float *weight,
+                                const float *rel, const float *wx, const float *gamma,
+                                const float *beta, float *running_mean, float *running_var,
+                                float momentum, float eps, float *out, float *save_mean,
+                                float *save_invstd, float *fwd_coef, void *workspace,
+                                size_t workspace_bytes, int segs, int seg_len, void *stream);
+int nesie_blend_conv_bn_backward(int b, int c, int m, int n, const float *dy,
+                                 const float *table, int pitch, int seg_off, const int *idx,
+                                 const float *weight, const float *rel, const float *wx,
+                                 const float *gamma, const float *save_invstd,
+                                 const float *fwd_coef, float *d_table, float *d_wx_part,
+                                 float *dgamma, float *dbeta, void *workspace,
+                                 size_t workspace_bytes, int segs, int seg_len, void *stream);
+
 /* interpolate.cpp:77-93  three_interpolate_grad_wrapper
  * (b, c, n, m, grad_out[B,C,N], idx, weight, grad_points[B,C,M] zeroed). */
 int nesie_three_interpolate_grad_wrapper(int b, int c, int n, int m,

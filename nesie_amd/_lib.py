@@ -28,6 +28,10 @@ SIGNATURES = {
     "nesie_three_nn_wrapper": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_three_interpolate_grad_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_blend_conv_bn_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                    _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
+    "nesie_blend_conv_bn_backward": [_I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
     "nesie_grid_taps": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                  _P],
@@ -88,6 +92,8 @@ def load():
     lib.nesie_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_conv_wgrad_workspace_bytes.argtypes = [_I, _I, _I, ctypes.c_longlong]
     lib.nesie_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_blend_conv_bn_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    lib.nesie_blend_conv_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_blend_conv_runs.argtypes = [_I, _I]
     lib.nesie_blend_conv_runs.restype = _I
     lib.nesie_mlp_stream_partials.argtypes = [_I, ctypes.c_longlong]

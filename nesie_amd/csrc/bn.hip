@@ -100,8 +100,11 @@ __device__ __forceinline__ void bn_fwd_finalize(const BnFwdFin &f, int c, bool w
     s0 = wave_sum_f64(s0);
     s1 = wave_sum_f64(s1);
     if (threadIdx.x == 0) {
-      const double shift = (double)(f.x[(size_t)c * f.p] +
-                                    (f.row_bias ? f.row_bias[(size_t)c * (f.p / f.group)] : 0.f));
+      // sums are taken about the channel's first element (no shift when the producer of the
+      // partials had no such element at hand: f.x == NULL)
+      const double shift = f.x ? (double)(f.x[(size_t)c * f.p] +
+                                          (f.row_bias ? f.row_bias[(size_t)c * (f.p / f.group)] : 0.f))
+                               : 0.0;
       const double m = s0 / f.n;
       double var = s1 / f.n - m * m;
       if (var < 0.0) var = 0.0;
@@ -474,6 +477,27 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   return check_launch(W);
 }
 
+
+// For producers that compute the (sum, sum of squares) partials themselves
+// (partial[(c * nslice + i) * 2 + {0,1}], unshifted): interpolate.hip's blend + norm kernels.
+namespace nesie {
+int launch_bn_finalize(int c, int nslice, double count, const float *partial,
+                       const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float momentum, float eps, float *save_mean,
+                       float *save_invstd, float *coef, hipStream_t s) {
+  const BnFwdFin fin{nslice, count, nullptr, 0, nullptr, 1, partial, gamma, beta, running_mean,
+                     running_var, momentum, eps, save_mean, save_invstd, coef};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c);
+  return check_launch("bn_finalize");
+}
+int launch_bn_bwd_finalize(int c, int nslice, double count, const float *partial,
+                           const float *gamma, const float *save_invstd, float *dgamma,
+                           float *dbeta, float *coef, hipStream_t s) {
+  const BnBwdFin fin{nslice, count, partial, gamma, save_invstd, dgamma, dbeta};
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c, coef);
+  return check_launch("bn_bwd_finalize");
+}
+}  // namespace nesie
 
 static int bn_pool_dims(const char *W, int m, int ns) {
   if (m <= 0 || ns < 4 || ns > 64 || (ns & (ns - 1))) {

@@ -435,6 +435,270 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
   }
 }
 
+// ---- blend + BatchNorm + ReLU fused by RECOMPUTATION ------------------------------------------
+// The blended first conv is cheap to re-evaluate (three L2-resident row gathers per query and
+// 64 channels), its output c0 (B, segs, C, K*G) is not: 403 + 269 MB per step that the norm
+// layer behind it reads twice forward and once backward, plus the gradient dx of the same size
+// written by the norm backward and read by the scatter.  So c0 and dx are never stored:
+//   forward : blend -> per-channel (sum, sum^2) partials        [no tensor traffic]
+//             finalize; blend again -> relu(scale * c0 + bias) -> a0   [one write]
+//   backward: blend again + dy -> the two BatchNorm sums        [one read of dy]
+//             finalize; blend again + dy -> dx in LDS -> sorted-tap scatter (blend_bwd_rows)
+//                                                               [one read of dy, no dx]
+// 4 tensor passes instead of 11 (side_pooling_module.py:226-243, 346-348).
+__device__ __forceinline__ float blend_value(const float *f, int pitch, const int *j,
+                                             const float *w, const float *r, float x0, float x1,
+                                             float x2, bool has_wx) {
+  const float a0 = f[(size_t)j[0] * pitch], a1 = f[(size_t)j[1] * pitch],
+              a2 = f[(size_t)j[2] * pitch];
+  float v = __fadd_rn(__fadd_rn(__fmul_rn(w[0], a0), __fmul_rn(w[1], a1)), __fmul_rn(w[2], a2));
+  if (has_wx)
+    v = __fadd_rn(__fadd_rn(__fadd_rn(v, __fmul_rn(x0, r[0])), __fmul_rn(x1, r[1])),
+                  __fmul_rn(x2, r[2]));
+  return v;
+}
+
+__device__ __forceinline__ void load_taps(int tid, int bi, int n, int m, int segs, int seg_len,
+                                          int sg, int r0, const int *idx, const float *weight,
+                                          const float *rel, int (*sj)[3], float (*sw)[3],
+                                          float (*sr)[3]) {
+  if (tid < TS_Q) {
+    const int r = r0 + tid;
+    const int k = r / seg_len, g = r - k * seg_len;
+    const size_t p = (size_t)bi * n + (size_t)(k * segs + sg) * seg_len + g;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      int j = idx[p * 3 + t];
+      sj[tid][t] = j < 0 ? 0 : (j >= m ? m - 1 : j);
+      sw[tid][t] = weight[p * 3 + t];
+      sr[tid][t] = rel ? rel[p * 3 + t] : 0.f;
+    }
+  }
+}
+
+// MODE 0: statistics partials of c0.  MODE 1: a0 = relu(scale * c0 + bias) (coef = fwd_coef).
+// MODE 2: BatchNorm backward sums from (dy, recomputed c0).
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_bn_kernel(
+    int c, int m, int n, int segs, int seg_len, int pitch, int seg_off,
+    const float *__restrict__ table, const int *__restrict__ idx,
+    const float *__restrict__ weight, const float *__restrict__ rel,
+    const float *__restrict__ wx, const float *__restrict__ coef,
+    const float *__restrict__ dy, float *__restrict__ out, float *__restrict__ partial) {
+  __shared__ float tile[64][TS_Q + 1];
+  __shared__ float red[4][64][2];
+  __shared__ int sj[TS_Q][3];
+  __shared__ float sw[TS_Q][3];
+  __shared__ float sr[TS_Q][3];
+  const int bi = blockIdx.y;
+  const int q0 = blockIdx.x * TS_Q;
+  const int per_seg = n / segs;
+  const int sg = q0 / per_seg, r0 = q0 - sg * per_seg;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  load_taps(threadIdx.x, bi, n, m, segs, seg_len, sg, r0, idx, weight, rel, sj, sw, sr);
+  __syncthreads();
+  const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off;
+  const size_t row0 = ((size_t)bi * segs + sg) * c;       // first channel row of this (b, s)
+  const int nslice = gridDim.y * (per_seg / TS_Q);
+  const int slice = bi * (per_seg / TS_Q) + r0 / TS_Q;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int chan = sg * c + c0 + lane;                   // stacked channel of this lane
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (wx) {
+      const float *wr = wx + (size_t)chan * 3;
+      x0 = wr[0]; x1 = wr[1]; x2 = wr[2];
+    }
+    float sc = 1.f, bs = 0.f, mean = 0.f, invstd = 1.f;
+    if (MODE != 0) {
+      sc = coef[chan * 4 + 0]; bs = coef[chan * 4 + 1];
+      mean = coef[chan * 4 + 2]; invstd = coef[chan * 4 + 3];
+    }
+    if (MODE == 2) {  // dy tile of these 64 channels: dense rows, lane = query
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int ch = wv * 16 + i;
+        tile[ch][lane] = dy[(row0 + c0 + ch) * per_seg + r0 + lane];
+      }
+      __syncthreads();
+    }
+    float a_s = 0.f, a_q = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int qi = wv * 16 + i;
+      const float v = blend_value(feat + c0 + lane, pitch, sj[qi], sw[qi], sr[qi], x0, x1, x2,
+                                  wx != nullptr);
+      if (MODE == 0) {
+        a_s += v; a_q += v * v;
+      } else if (MODE == 1) {
+        tile[lane][qi] = fmaxf(v * sc + bs, 0.f);
+      } else {
+        const float g = v * sc + bs > 0.f ? tile[lane][qi] : 0.f;
+        a_s += g; a_q += g * ((v - mean) * invstd);
+      }
+    }
+    if (MODE == 1) {
+      __syncthreads();
+      float *dst = out + (row0 + c0) * per_seg + r0;
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int ch = wv * 16 + i;
+        dst[(size_t)ch * per_seg + lane] = tile[ch][lane];
+      }
+      __syncthreads();
+    } else {
+      red[wv][lane][0] = a_s; red[wv][lane][1] = a_q;
+      __syncthreads();
+      if (wv == 0) {
+        const float s = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
+        const float q = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+        float *dst = partial + ((size_t)chan * nslice + slice) * 2;
+        dst[0] = s; dst[1] = q;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Scatter half of the backward: blend_bwd_rows_kernel with dx rebuilt in the LDS tile from
+// (dy, recomputed c0, the forward's and the backward's per-channel coefficients).
+template <int CPT>
+__global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
+    int m, int n, int segs, int seg_len, int pitch, int seg_off,
+    const float *__restrict__ dy, const float *__restrict__ table,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    const float *__restrict__ rel, const float *__restrict__ wx,
+    const float *__restrict__ fwd_coef, const float *__restrict__ bwd_coef,
+    float *__restrict__ d_table, float *__restrict__ d_wx_part) {
+  constexpr int C = CPT * 64;
+  __shared__ float tile[C * (TS_Q + 1)];
+  __shared__ int sj[TS_Q][3];
+  __shared__ float sw[TS_Q][3];
+  __shared__ float sr[TS_Q][3];
+  const int bi = blockIdx.y, sg = blockIdx.z;
+  const int per_seg = n / segs;
+  const int run0 = blockIdx.x * BL_RUN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float *src = dy + ((size_t)bi * segs + sg) * C * per_seg;
+  const float *feat = table + (size_t)bi * m * pitch + (size_t)sg * seg_off;
+  float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
+  float dx[CPT][3];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) dx[e][0] = dx[e][1] = dx[e][2] = 0.f;
+  const int run_end = run0 + BL_RUN < per_seg ? run0 + BL_RUN : per_seg;
+  for (int r0 = run0; r0 < run_end; r0 += TS_Q) {
+    __syncthreads();
+    load_taps(threadIdx.x, bi, n, m, segs, seg_len, sg, r0, idx, weight, rel, sj, sw, sr);
+#pragma unroll
+    for (int rb = 0; rb < C / 4; rb += 16) {
+      float t16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        t16[u] = src[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) tile[((rb + u) * 4 + wv) * (TS_Q + 1) + lane] = t16[u];
+    }
+    __syncthreads();
+    const int q0 = wv * 16;
+    // dy -> dx for this wave's 16 queries (lane = channel): recompute c0, apply the norm
+    // backward.  All 48 row gathers of a channel block are issued before the first is used
+    // (two waves per SIMD cannot hide an L2 round trip per gather otherwise).
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const int chan = sg * C + e * 64 + lane;
+      const float sc = fwd_coef[chan * 4 + 0], bs = fwd_coef[chan * 4 + 1],
+                  mean = fwd_coef[chan * 4 + 2], invstd = fwd_coef[chan * 4 + 3];
+      const float a = bwd_coef[chan * 4 + 0], k1 = bwd_coef[chan * 4 + 1],
+                  k2 = bwd_coef[chan * 4 + 2];
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      if (wx) {
+        const float *wr = wx + (size_t)chan * 3;
+        x0 = wr[0]; x1 = wr[1]; x2 = wr[2];
+      }
+      const float *f = feat + e * 64 + lane;
+      float t0[16], t1[16], t2[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        t0[u] = f[(size_t)sj[q0 + u][0] * pitch];
+        t1[u] = f[(size_t)sj[q0 + u][1] * pitch];
+        t2[u] = f[(size_t)sj[q0 + u][2] * pitch];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int q = q0 + u;
+        float v = __fadd_rn(__fadd_rn(__fmul_rn(sw[q][0], t0[u]), __fmul_rn(sw[q][1], t1[u])),
+                            __fmul_rn(sw[q][2], t2[u]));
+        if (wx)
+          v = __fadd_rn(__fadd_rn(__fadd_rn(v, __fmul_rn(x0, sr[q][0])), __fmul_rn(x1, sr[q][1])),
+                        __fmul_rn(x2, sr[q][2]));
+        float *cell = &tile[(e * 64 + lane) * (TS_Q + 1) + q];
+        const float g = v * sc + bs > 0.f ? *cell : 0.f;
+        *cell = a * (g - k1 - (v - mean) * invstd * k2);
+      }
+    }
+    // (each wave only touches its own 16 columns from here on: no barrier needed)
+    if (d_wx_part) {
+#pragma unroll 4
+      for (int u = 0; u < 16; ++u) {
+        const float r0x = sr[q0 + u][0], r1x = sr[q0 + u][1], r2x = sr[q0 + u][2];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+          const float v = tile[(e * 64 + lane) * (TS_Q + 1) + q0 + u];
+          dx[e][0] += v * r0x; dx[e][1] += v * r1x; dx[e][2] += v * r2x;
+        }
+      }
+    }
+    unsigned key = 0xFFFFFFFFu;
+    if (lane < 48) key = ((unsigned)sj[q0 + lane / 3][lane % 3] << 6) | (unsigned)lane;
+    key = bitonic_sort64(key, lane);
+    int cur = -1;
+    float acc[CPT];
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+    for (int i0 = 0; i0 < 48; i0 += 8) {
+      int seeds[8];
+      float x[8][CPT];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned u = (unsigned)__builtin_amdgcn_readlane((int)key, i0 + i);
+        const int tap = (int)(u & 63u);
+        const int q = q0 + tap / 3, t = tap % 3;
+        seeds[i] = (int)(u >> 6);
+        const float w = sw[q][t];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) x[i][e] = tile[(e * 64 + lane) * (TS_Q + 1) + q] * w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (seeds[i] != cur) {
+          if (cur >= 0) {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+          }
+          cur = seeds[i];
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc[e] += x[i][e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+  }
+  if (d_wx_part) {
+    __syncthreads();
+    float *red = tile;  // [4][C][3]
+#pragma unroll
+    for (int e = 0; e < CPT; ++e)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) red[(wv * C + e * 64 + lane) * 3 + d] = dx[e][d];
+    __syncthreads();
+    float *dst = d_wx_part + ((((size_t)bi * gridDim.x + blockIdx.x) * segs + sg) * C) * 3;
+    for (int i = threadIdx.x; i < C * 3; i += 256)
+      dst[i] = (red[i] + red[C * 3 + i]) + (red[2 * C * 3 + i] + red[3 * C * 3 + i]);
+  }
+}
+
 // grad_out (B,C,N) -> grad_points (B,C,M) += w * g   (3 float atomics, .cu:81-83)
 __global__ __launch_bounds__(TI_BLOCK) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
@@ -583,5 +847,103 @@ extern "C" int nesie_three_interpolate_grad_wrapper(int b, int c, int n, int m,
   hipLaunchKernelGGL(three_interpolate_grad_kernel,
                      dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b), dim3(TI_BLOCK), 0,
                      (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+  return check_launch(W);
+}
+
+namespace nesie {
+int launch_bn_finalize(int c, int nslice, double count, const float *partial,
+                       const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float momentum, float eps, float *save_mean,
+                       float *save_invstd, float *coef, hipStream_t s);
+int launch_bn_bwd_finalize(int c, int nslice, double count, const float *partial,
+                           const float *gamma, const float *save_invstd, float *dgamma,
+                           float *dbeta, float *coef, hipStream_t s);
+}  // namespace nesie
+
+static int blend_bn_check(const char *W, int b, int c, int m, int n, int segs, int seg_len,
+                          int pitch, int seg_off) {
+  int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
+  if (st) return st;
+  if (c % 64 != 0 || c > 256 || (n / segs) % TS_Q != 0 || segs > 65535) {
+    set_error("%s: c %d (needs 64, 128, 192 or 256) / %d queries per face (needs a multiple "
+              "of %d)", W, c, n / segs, TS_Q);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  return NESIE_OK;
+}
+
+extern "C" size_t nesie_blend_conv_bn_workspace_bytes(int b, int c, int n, int segs) {
+  if (b <= 0 || c <= 0 || n <= 0 || segs <= 0) return 0;
+  // partials [segs*c][b * per_seg/64][2] + backward coefficients [segs*c][4]
+  return ((size_t)segs * c * ((size_t)b * (n / segs / TS_Q)) * 2 + (size_t)segs * c * 4) *
+         sizeof(float);
+}
+
+extern "C" int nesie_blend_conv_bn_forward(int b, int c, int m, int n, const float *table,
+                                           int pitch, int seg_off, const int *idx,
+                                           const float *weight, const float *rel,
+                                           const float *wx, const float *gamma,
+                                           const float *beta, float *running_mean,
+                                           float *running_var, float momentum, float eps,
+                                           float *out, float *save_mean, float *save_invstd,
+                                           float *fwd_coef, void *workspace,
+                                           size_t workspace_bytes, int segs, int seg_len,
+                                           void *stream) {
+  const char *W = "blend_conv_bn_forward";
+  int st = blend_bn_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
+  if (st) return st;
+  if (b == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 1 && table && idx && weight && out && save_mean && save_invstd && fwd_coef, W);
+  NESIE_REQUIRE((wx == nullptr) == (rel == nullptr), W);
+  NESIE_REQUIRE(workspace && workspace_bytes >= nesie_blend_conv_bn_workspace_bytes(b, c, n, segs), W);
+  hipStream_t s = (hipStream_t)stream;
+  float *partial = (float *)workspace;
+  const int per_seg = n / segs, nslice = b * (per_seg / TS_Q);
+  const dim3 grid(n / TS_Q, b);
+  hipLaunchKernelGGL(blend_bn_kernel<0>, grid, dim3(256), 0, s, c, m, n, segs, seg_len, pitch,
+                     seg_off, table, idx, weight, rel, wx, (const float *)nullptr,
+                     (const float *)nullptr, (float *)nullptr, partial);
+  st = launch_bn_finalize(segs * c, nslice, (double)b * per_seg, partial, gamma, beta,
+                          running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                          fwd_coef, s);
+  if (st) return st;
+  hipLaunchKernelGGL(blend_bn_kernel<1>, grid, dim3(256), 0, s, c, m, n, segs, seg_len, pitch,
+                     seg_off, table, idx, weight, rel, wx, fwd_coef, (const float *)nullptr, out,
+                     (float *)nullptr);
+  return check_launch(W);
+}
+
+extern "C" int nesie_blend_conv_bn_backward(int b, int c, int m, int n, const float *dy,
+                                            const float *table, int pitch, int seg_off,
+                                            const int *idx, const float *weight,
+                                            const float *rel, const float *wx,
+                                            const float *gamma, const float *save_invstd,
+                                            const float *fwd_coef, float *d_table,
+                                            float *d_wx_part, float *dgamma, float *dbeta,
+                                            void *workspace, size_t workspace_bytes, int segs,
+                                            int seg_len, void *stream) {
+  const char *W = "blend_conv_bn_backward";
+  int st = blend_bn_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
+  if (st) return st;
+  if (b == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(m >= 1 && dy && table && idx && weight && save_invstd && fwd_coef && d_table, W);
+  NESIE_REQUIRE((wx == nullptr) == (rel == nullptr) && (d_wx_part == nullptr || rel), W);
+  NESIE_REQUIRE(workspace && workspace_bytes >= nesie_blend_conv_bn_workspace_bytes(b, c, n, segs), W);
+  hipStream_t s = (hipStream_t)stream;
+  const int per_seg = n / segs, nslice = b * (per_seg / TS_Q);
+  float *partial = (float *)workspace;
+  float *bwd_coef = partial + (size_t)segs * c * nslice * 2;
+  hipLaunchKernelGGL(blend_bn_kernel<2>, dim3(n / TS_Q, b), dim3(256), 0, s, c, m, n, segs,
+                     seg_len, pitch, seg_off, table, idx, weight, rel, wx, fwd_coef, dy,
+                     (float *)nullptr, partial);
+  st = launch_bn_bwd_finalize(segs * c, nslice, (double)b * per_seg, partial, gamma, save_invstd,
+                              dgamma, dbeta, bwd_coef, s);
+  if (st) return st;
+  const dim3 grid(cdiv(per_seg, BL_RUN), b, segs);
+#define L(N) hipLaunchKernelGGL(blend_bn_bwd_rows_kernel<N>, grid, dim3(256), 0, s, m, n, segs,   \
+                                seg_len, pitch, seg_off, dy, table, idx, weight, rel, wx,        \
+                                fwd_coef, bwd_coef, d_table, d_wx_part)
+  if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
+#undef L
   return check_launch(W);
 }

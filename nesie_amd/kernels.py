@@ -290,6 +290,47 @@ class HipKernels(_BNPoolMixin):
             if part is not None:
                 d_wx += part.sum(0)
 
+    def blend_conv_bn_forward(self, table, idx, weight, rel, wx, gamma, beta, running_mean,
+                              running_var, momentum, eps, out, save_mean, save_invstd, fwd_coef,
+                              segs, seg_len):
+        """out (B, segs, c, n/segs) = relu(bn(blend conv)); table (B, M, segs*c)."""
+        _check(table, idx, weight, rel, wx, out, save_mean, save_invstd, fwd_coef)
+        _f32(table, weight, rel, wx, out); _i32(idx)
+        b, m, pitch = table.shape
+        n, c = idx.shape[1], pitch // segs
+        assert tuple(out.shape) == (b, segs, c, n // segs) and tuple(wx.shape) == (segs, c, 3)
+        lib = _lib.load()
+        need = lib.nesie_blend_conv_bn_workspace_bytes(b, c, n, segs)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(table.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=table.device)
+            _lib.call("nesie_blend_conv_bn_forward", b, c, m, n, _ptr(table), pitch, c, _ptr(idx),
+                      _ptr(weight), _ptr(rel), _ptr(wx), opt(gamma), opt(beta),
+                      opt(running_mean), opt(running_var), float(momentum), float(eps), _ptr(out),
+                      _ptr(save_mean), _ptr(save_invstd), _ptr(fwd_coef), _ptr(ws), need, segs,
+                      seg_len, _stream(table))
+
+    def blend_conv_bn_backward(self, dy, table, idx, weight, rel, wx, gamma, save_invstd,
+                               fwd_coef, d_table, d_wx, dgamma, dbeta, segs, seg_len):
+        """d_table (zeroed) += ..., d_wx (segs, c, 3) += ..., dgamma / dbeta [segs*c] written."""
+        _check(dy, table, idx, weight, rel, wx, d_table, d_wx, dgamma, dbeta)
+        _f32(dy, table, d_table); _i32(idx)
+        b, m, pitch = table.shape
+        n, c = idx.shape[1], pitch // segs
+        assert tuple(dy.shape) == (b, segs, c, n // segs) and d_table.shape == table.shape
+        lib = _lib.load()
+        need = lib.nesie_blend_conv_bn_workspace_bytes(b, c, n, segs)
+        runs = lib.nesie_blend_conv_runs(n, segs)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(dy.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
+            part = torch.empty(b * runs, segs, c, 3, dtype=torch.float32, device=dy.device)
+            _lib.call("nesie_blend_conv_bn_backward", b, c, m, n, _ptr(dy), _ptr(table), pitch, c,
+                      _ptr(idx), _ptr(weight), _ptr(rel), _ptr(wx), opt(gamma),
+                      _ptr(save_invstd), _ptr(fwd_coef), _ptr(d_table), _ptr(part), _ptr(dgamma),
+                      _ptr(dbeta), _ptr(ws), need, segs, seg_len, _stream(dy))
+            d_wx += part.sum(0)
+
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):
         _check(grad_out, idx, weight, grad_points); _f32(grad_out, weight, grad_points)

@@ -9,7 +9,7 @@ from .furthest_point_sample import (Points_Sampler, furthest_point_sample,
                                     furthest_point_sample_with_dist)
 from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup, group_points, grouping_operation
-from .interpolate import blend_conv, three_interpolate, three_interpolate_segmented, three_nn
+from .interpolate import blend_conv, blend_conv_bn, three_interpolate, three_interpolate_segmented, three_nn
 from .pointnet_modules import (ConvModule, PointFPModule, PointSAModule, PointSAModuleMSG,
                                PointwiseConv1d, PointwiseConv2d, build_sa_module,
                                pointwise_conv)

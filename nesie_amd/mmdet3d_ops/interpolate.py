@@ -120,3 +120,42 @@ class BlendConv(Function):
 
 
 blend_conv = BlendConv.apply
+
+
+class BlendConvBN(Function):
+    """``BlendConv`` followed by the training BatchNorm + ReLU behind it, fused by
+    recomputation: the conv output (and its gradient) is re-evaluated from the small table
+    wherever it is needed instead of being stored (side_pooling_module.py:226-243, 346-348).
+    gamma / beta / running statistics are over the segs*H stacked channels."""
+
+    @staticmethod
+    def forward(ctx, table, wx, gamma, beta, idx, weight, rel, running_mean, running_var,
+                momentum, eps, segs, seg_len):
+        table, wx = table.contiguous(), wx.contiguous()
+        b, m, pitch = table.shape
+        h = pitch // segs
+        n = idx.shape[1]
+        out = table.new_empty(b, segs, h, n // segs)
+        save_mean, save_invstd = table.new_empty(segs * h), table.new_empty(segs * h)
+        fwd_coef = table.new_empty(segs * h, 4)
+        backend_for(table).blend_conv_bn_forward(
+            table, idx, weight, rel, wx, gamma, beta, running_mean, running_var, momentum, eps,
+            out, save_mean, save_invstd, fwd_coef, segs, seg_len)
+        ctx.save_for_backward(table, wx, gamma, idx, weight, rel, save_invstd, fwd_coef)
+        ctx.dims = (segs, seg_len, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        table, wx, gamma, idx, weight, rel, save_invstd, fwd_coef = ctx.saved_tensors
+        segs, seg_len, h = ctx.dims
+        d_table = torch.zeros_like(table)
+        d_wx = dy.new_zeros(segs, h, 3)
+        dgamma, dbeta = dy.new_empty(segs * h), dy.new_empty(segs * h)
+        backend_for(dy).blend_conv_bn_backward(dy.contiguous(), table, idx, weight, rel, wx,
+                                               gamma, save_invstd, fwd_coef, d_table, d_wx,
+                                               dgamma, dbeta, segs, seg_len)
+        return (d_table, d_wx, dgamma, dbeta) + (None,) * 9
+
+
+blend_conv_bn = BlendConvBN.apply

@@ -71,19 +71,21 @@ class QualityEstimation(SidePooling):
         fused = backend_for(origin_xyz).name == 'hip'
         side_nets = list(self.mlps_before[:6])
         if fused:
-            side_c0 = self.first_conv_through_blend(
+            side_c0, side_normed = self.first_conv_through_blend(
                 side_nets, origin_xyz, origin_features, None, center,
-                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'))
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'), with_norm=self.fuse_first_norm)
         else:
             whole_grid = self.generate_grid(size)
             side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
         if fused and mini_pointnets_groupable(side_nets, side_c0):
-            pooled = grouped_mini_pointnets(side_nets, side_c0)
+            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed)
+        elif fused:
+            key = 'a0' if side_normed else 'conv0_out'
+            pooled = torch.stack([side_nets[i](**{key: side_c0[:, i]}) for i in range(6)], 1)
         else:
-            pooled = torch.stack([side_nets[i](conv0_out=side_c0[:, i]) if fused
-                                  else side_nets[i](side_feats[:, i]) for i in range(6)], 1)
+            pooled = torch.stack([side_nets[i](side_feats[:, i]) for i in range(6)], 1)
         heads = list(self.mlps_head[:6])
         x = torch.cat([pooled, dist_feature.transpose(0, 1)], dim=2)      # (B,6,166,2K)
         if heads_batchable(heads, x[:, 0]):

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..kernels import backend_for
-from ..mmdet3d_ops import blend_conv, three_interpolate_segmented, three_nn
+from ..mmdet3d_ops import blend_conv, blend_conv_bn, three_interpolate_segmented, three_nn
 from ..mmdet3d_ops.pool import group_max_pool, group_max_pool_shared
 from ..mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
 from ..mmdet3d_ops.pointnet_modules import PointwiseConv1d, PointwiseConv2d, pointwise_conv
@@ -41,9 +41,10 @@ class MiniPointNet(nn.Module):
             PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), FusedBNReLU2d(hide_dim),
             nn.Identity(), PointwiseConv2d(hide_dim, feature_dim, 1))
 
-    def forward(self, points=None, conv0_out=None):
+    def forward(self, points=None, conv0_out=None, a0=None):
         """``points`` (B,C,K,G) grid features, or ``conv0_out`` (B,H,K,G) = the first conv
-        already applied through the blend (SidePooling._first_conv_through_blend).
+        already applied through the blend (SidePooling.first_conv_through_blend), or ``a0`` =
+        that followed by the first norm + ReLU as well (``with_norm=True`` there).
 
         Same function as the reference's
             f = first_conv(x); g = max_G f; y = second_conv(cat[g expanded, f]); out = max_G y
@@ -55,9 +56,9 @@ class MiniPointNet(nn.Module):
         Differences from the concatenated form are summation-order rounding only."""
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
-        if conv0_out is None:
-            conv0_out = conv0(points)
-        c = pointwise_conv(bn0(conv0_out), conv3.weight)              # f without its bias
+        if a0 is None:
+            a0 = bn0(conv0(points) if conv0_out is None else conv0_out)
+        c = pointwise_conv(a0, conv3.weight)                           # f without its bias
         g, c = group_max_pool_shared(c)                                # (B, H, K): max_G f - b
         half = conv3.out_channels
         w = sconv0.weight.reshape(sconv0.out_channels, -1)
@@ -99,16 +100,18 @@ def _stackable_bn(layers):
                for l in layers)
 
 
-def grouped_mini_pointnets(nets, c0):
+def grouped_mini_pointnets(nets, c0, normed=False):
     """S structurally identical MiniPointNets on S inputs at once: ``c0`` (B, S, H, K, G) =
-    the outputs of their first convs -> (B, S, F, K).  Same function as calling
+    the outputs of their first convs (``normed``: already through the first norm + ReLU) ->
+    (B, S, F, K).  Same function as calling
     ``net(conv0_out=c0[:, i])`` for each net (see MiniPointNet.forward for the algebra); every
     1x1 conv is one broadcast batched GEMM over the stacked weights (48 instead of 8 matrices
     per launch at B = 8) and every norm layer one stacked BatchNorm."""
     B, S, H, K, G = c0.shape
     f, sc = [n.first_conv for n in nets], [n.second_conv for n in nets]
     stack = lambda ws: torch.stack([w.flatten(1) for w in ws]).unsqueeze(0)  # noqa: E731
-    a0 = _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G)).view(B, S, H, K * G)
+    a0 = c0.reshape(B, S, H, K * G) if normed else \
+        _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G)).view(B, S, H, K * G)
     c = torch.matmul(stack([x[3].weight for x in f]), a0)               # (B,S,half,K*G)
     half = c.shape[2]
     g, c5 = group_max_pool_shared(c.view(B, S, half, K, G))              # (B,S,half,K)
@@ -224,6 +227,12 @@ class SidePooling(nn.Module):
         self.mlps_before = nn.ModuleList(before)
         self.mlps_head = nn.ModuleList(head)
 
+    # BlendConvBN (first conv AND its norm + ReLU by recomputation, the conv output never
+    # stored) is exact and saves 1.3 GB of activations, but measured break-even on MI355X: the
+    # forward gains 0.23 ms, the backward loses 0.3 ms to the recomputed row gathers at the two
+    # waves per SIMD its LDS tile allows.  Off; flip to trade time for memory.
+    fuse_first_norm = False
+
     def _register_grid_tables(self, face_idx, plane=None):
         """Box-frame multipliers of the grid points of one proposal, in the order the grids are
         consumed: ``_mult_box`` (g^3,3) for the box grid, ``_mult_side`` for the six face groups
@@ -303,7 +312,7 @@ class SidePooling(nn.Module):
         return idx, weight, relative_grid.contiguous()
 
     def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center,
-                                 taps=None):
+                                 taps=None, with_norm=False):
         """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
         S consecutive point groups of every proposal: (B,S,H,K,G), evaluated as
         W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
@@ -316,8 +325,24 @@ class SidePooling(nn.Module):
         w = torch.stack([net.first_conv[0].weight.flatten(1) for net in nets])   # (S, H, 3+C)
         H = w.shape[1]
         table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
+        bns = [net.first_conv[1] for net in nets]
+        if with_norm and _stackable_bn(bns) and H % 64 == 0 and H <= 256 and (K * G) % 64 == 0 \
+                and origin_features.dtype == torch.float32:
+            # ... and the norm + ReLU behind it, the conv output never stored (BlendConvBN)
+            from ..mmdet3d_ops import norm as _norm
+            rm = torch.cat([l.running_mean for l in bns])
+            rv = torch.cat([l.running_var for l in bns])
+            out = blend_conv_bn(table, w[:, :, :3], torch.cat([l.weight for l in bns]),
+                                torch.cat([l.bias for l in bns]), idx, weight, rel, rm, rv,
+                                bns[0].momentum, bns[0].eps, segs, G)
+            with torch.no_grad():
+                torch._foreach_copy_([l.running_mean for l in bns], list(rm.split(H)))
+                torch._foreach_copy_([l.running_var for l in bns], list(rv.split(H)))
+                for l in bns:
+                    _norm.count_batch(l.num_batches_tracked)
+            return out.view(B, segs, H, K, G), True
         out = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G)    # (B, S, H, K*G)
-        return out.view(B, segs, H, K, G)
+        return out.view(B, segs, H, K, G), False
 
     def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
         """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
@@ -349,14 +374,15 @@ class SidePooling(nn.Module):
         origin_xyz, origin_features = self.extract_features(end_points)
         fused = backend_for(origin_xyz).name == 'hip'
         side_nets = list(self.mlps_before[:6])
-        if fused:   # grids + taps in one launch each, first convs through the blend; the
-            #         literal form below stays the CPU checker's
-            side_c0 = self.first_conv_through_blend(
+        if fused:   # grids + taps in one launch each, first convs (+ norm) through the blend;
+            #         the literal form below stays the CPU checker's
+            side_c0, side_normed = self.first_conv_through_blend(
                 side_nets, origin_xyz, origin_features, None, center,
-                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'))
-            bbox_c0 = self.first_conv_through_blend(
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'), with_norm=self.fuse_first_norm)
+            bbox_c0, bbox_normed = self.first_conv_through_blend(
                 self.mlps_before[6:7], origin_xyz, origin_features, None, center,
-                taps=self.fused_taps(origin_xyz, center, size, heading, 'box'))[:, 0]
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'box'), with_norm=self.fuse_first_norm)
+            bbox_c0 = bbox_c0[:, 0]
         else:
             whole_grid = self.generate_grid(size)
             side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
@@ -365,10 +391,12 @@ class SidePooling(nn.Module):
             bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
         dist_feature = self.dist_feature(end_points, prefix)
         if fused and mini_pointnets_groupable(side_nets, side_c0):
-            pooled = grouped_mini_pointnets(side_nets, side_c0)            # (B,6,128,2K)
+            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed)  # (B,6,128,2K)
+        elif fused:
+            key = 'a0' if side_normed else 'conv0_out'
+            pooled = torch.stack([side_nets[i](**{key: side_c0[:, i]}) for i in range(6)], 1)
         else:
-            pooled = torch.stack([side_nets[i](conv0_out=side_c0[:, i]) if fused
-                                  else side_nets[i](side_feats[:, i]) for i in range(6)], 1)
+            pooled = torch.stack([side_nets[i](side_feats[:, i]) for i in range(6)], 1)
         heads = list(self.mlps_head[:6])
         x = torch.cat([pooled, dist_feature.transpose(0, 1)], dim=2)      # (B,6,166,2K)
         if heads_batchable(heads, x[:, 0]):
@@ -376,7 +404,9 @@ class SidePooling(nn.Module):
         else:
             side_scores = torch.stack([self.mlps_head[i](x[:, i]) for i in range(6)], 0)
         end_points[f'{prefix}side_scores'] = side_scores
-        bbox_feats = self.mlps_before[6](conv0_out=bbox_c0) if fused \
-            else self.mlps_before[6](bbox_feats)
+        if fused:
+            bbox_feats = self.mlps_before[6](**{'a0' if bbox_normed else 'conv0_out': bbox_c0})
+        else:
+            bbox_feats = self.mlps_before[6](bbox_feats)
         end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)
         return end_points

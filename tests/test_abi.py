@@ -39,7 +39,8 @@ def test_binding_covers_every_compute_entry_point():
                if n not in ("nesie_abi_version", "nesie_last_error",
                             "nesie_fps_workspace_bytes", "nesie_bn_workspace_bytes",
                             "nesie_mlp_stat_partials", "nesie_blend_conv_runs",
-                            "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials")]
+                            "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials",
+                            "nesie_blend_conv_bn_workspace_bytes")]
     assert sorted(compute) == sorted(_lib.SIGNATURES)
     lib = _lib.load()
     assert lib.nesie_abi_version() >= 1

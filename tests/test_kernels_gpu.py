@@ -649,3 +649,43 @@ def test_three_interpolate_grad_through_inverted_index(oracle_kernels, hip_devic
     got.backward(go.to(hip_device))
     assert torch.equal(got.detach().cpu(), want.detach())
     torch.testing.assert_close(f1.grad.cpu(), f0.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,segs,g,h", [(64, 6, 16, 64), (32, 1, 64, 128), (64, 6, 27, 128),
+                                        (128, 6, 16, 256)])
+def test_blend_conv_bn_matches_blend_then_norm(hip_device, k, segs, g, h):
+    """BlendConvBN (conv output and its gradient recomputed, never stored) vs BlendConv followed
+    by the fused training BatchNorm + ReLU, both on the HIP kernels pinned above: activations,
+    running statistics, and the gradients of the table, the xyz columns, gamma and beta."""
+    from nesie_amd.mmdet3d_ops.norm import BNReLUTrain
+    gen, b, m, n, idx, w, rel = _blend_case(k, segs, g, h, k + 3 * h)
+    dev = hip_device
+    table = torch.randn(b, m, segs * h, generator=gen).to(dev)
+    wx = torch.randn(segs, h, 3, generator=gen).to(dev)
+    gamma = (torch.rand(segs * h, generator=gen) + 0.5).to(dev)
+    beta = (torch.randn(segs * h, generator=gen) * 0.3).to(dev)
+    go = torch.randn(b, segs, h, k * g, generator=gen).to(dev)
+    idx, w, rel = idx.to(dev), w.to(dev), rel.to(dev)
+
+    def run(fused):
+        t, x = table.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(segs * h, device=dev), torch.ones(segs * h, device=dev)
+        if fused:
+            out = ops.blend_conv_bn(t, x, ga, be, idx, w, rel, rm, rv, 0.1, 1e-5, segs, g)
+        else:
+            c0 = ops.blend_conv(t, x, idx, w, rel, segs, g)
+            out = BNReLUTrain.apply(c0.reshape(b, segs * h, k, g), ga, be, rm, rv, 0.1, 1e-5,
+                                    True).view(b, segs, h, k * g)
+        out.backward(go)
+        return out.detach(), t.grad, x.grad, ga.grad, be.grad, rm, rv
+
+    got, want = run(True), run(False)
+    torch.testing.assert_close(got[0], want[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[5], want[5], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(got[6], want[6], rtol=1e-4, atol=1e-6)
+    # a ReLU mask within rounding of zero may flip between the two evaluation orders and moves
+    # the per-channel sums of its channel: gradients are compared in norm
+    for i, name in ((1, 'table'), (2, 'wx'), (3, 'gamma'), (4, 'beta')):
+        err = (got[i] - want[i]).norm().item()
+        assert err <= 5e-3 * want[i].norm().item() + 1e-5, (name, err, want[i].norm().item())

@@ -148,7 +148,7 @@ def test_first_conv_through_blend_equals_conv_of_grid_features(oracle_kernels):
         grid = sp.grid_for_side(sp.generate_grid(size), center, heading).view(B, -1, 3).contiguous()
         nets = sp.mlps_before[:6]
         go = [torch.randn(B, 256, K, 16) for _ in range(6)]
-        got = sp.first_conv_through_blend(nets, xyz, feats_t, grid, center).unbind(1)
+        got = sp.first_conv_through_blend(nets, xyz, feats_t, grid, center)[0].unbind(1)
         sum((g * o).sum() for g, o in zip(go, got)).backward()
         g_fused = [n.first_conv[0].weight.grad.clone() for n in nets]
         for n in nets:
