@@ -177,7 +177,10 @@ int nesie_grid_taps(int b, int kprop, int gp, int m, const float *centre, const 
 int nesie_blend_conv_forward(int b, int c, int m, int n, const float *table, int pitch,
                              int seg_off, const int *idx, const float *weight,
                              const float *rel, const float *wx, float *out, int segs,
-                             int seg_len, int c_total, int c_offset, void *stream);
+                             int seg_len, int c_total, int c_offset,
+                             float *stat_partial /* NULL, or [segs*c][B*K*seg_len/64][2]: (sum,
+                             sum of squares) per 64-query tile for nesie_bn_relu_forward's
+                             pre_partial */, void *stream);
 int nesie_blend_conv_runs(int n, int segs);
 int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy, int pitch, int seg_off, const int *idx, const float *weight,
                               const float *rel, float *d_table, float *d_wx, int segs,
@@ -281,7 +284,10 @@ int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float
                           const float *beta, float *running_mean, float *running_var,
                           float momentum, float eps, int relu, float *y, float *save_mean,
                           float *save_invstd, float *fwd_coef /* [C,4] out */,
-                          const float *row_bias, int group, void *workspace,
+                          const float *row_bias, int group,
+                          const float *pre_partial /* NULL, or unshifted (sum, sum^2) partials
+                          [C][pre_nslice][2] left by the producer of x: the statistics pass over
+                          x is skipped */, int pre_nslice, void *workspace,
                           size_t workspace_bytes, void *stream);
 int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const float *x,
                            const float *y, const float *gamma, const float *beta,

@@ -34,7 +34,7 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
     "nesie_grid_taps": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
-                                 _P],
+                                 _P, _P],
     "nesie_blend_conv_backward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "nesie_mlp_stat_finalize": [_I, ctypes.c_longlong, ctypes.c_double, _P, _P, _P, _P, _P, _F,
                                 _F, _P, _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
-                              _P, _P, _P, _I, _P, ctypes.c_size_t, _P],
+                              _P, _P, _P, _I, _P, _I, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
                                _P, _P, _P, _I, _P, _P, ctypes.c_size_t, _P],
 }

@@ -416,6 +416,7 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
                                      float momentum, float eps, int relu, float *y,
                                      float *save_mean, float *save_invstd, float *fwd_coef,
                                      const float *row_bias, int group,
+                                     const float *pre_partial, int pre_nslice,
                                      void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "bn_relu_forward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
@@ -432,9 +433,14 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
   const int sp = bn_sp(p), nslice = b * sp;
   float *partial = (float *)workspace, *coef = fwd_coef;  // [C][4]: scale, bias, mean, invstd
   dim3 grid(sp, c, b);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, row_bias, group,
-                     partial);
-  const BnFwdFin fin{nslice, (double)b * (double)p, x, p, row_bias, group, partial, gamma, beta,
+  NESIE_REQUIRE(!pre_partial || (pre_nslice >= 1 && !row_bias), W);
+  if (!pre_partial)
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, row_bias, group,
+                       partial);
+  // the producer's partials are unshifted sums: no shift element (x = NULL in the finalize)
+  const BnFwdFin fin{pre_partial ? pre_nslice : nslice, (double)b * (double)p,
+                     pre_partial ? nullptr : x, p, row_bias, group,
+                     pre_partial ? pre_partial : partial, gamma, beta,
                      running_mean, running_var, momentum, eps, save_mean, save_invstd, coef};
   if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);
   else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);

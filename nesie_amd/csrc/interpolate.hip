@@ -188,8 +188,9 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     int c, int m, int n, int segs, int seg_len, int c_total, int c_offset, int pitch,
     int seg_off, const float *__restrict__ table, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
-    const float *__restrict__ wx, float *__restrict__ out) {
+    const float *__restrict__ wx, float *__restrict__ out, float *__restrict__ stat_partial) {
   __shared__ float tile[64][TS_Q + 1];
+  __shared__ float red[4][64][2];
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
   __shared__ float sr[TS_Q][3];
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
       x0 = wr[0]; x1 = wr[1]; x2 = wr[2];
     }
     // wave wv blends queries wv*16 .. wv*16+15 for channels c0 .. c0+63 (lane = channel)
+    float a_s = 0.f, a_q = 0.f;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int qi = wv * 16 + i;
@@ -233,13 +235,25 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
         v = __fadd_rn(__fadd_rn(__fadd_rn(v, __fmul_rn(x0, sr[qi][0])), __fmul_rn(x1, sr[qi][1])),
                       __fmul_rn(x2, sr[qi][2]));
       tile[lane][qi] = v;
+      a_s += v; a_q += v * v;
     }
+    if (stat_partial) { red[wv][lane][0] = a_s; red[wv][lane][1] = a_q; }
     __syncthreads();
     // wave wv stores channels c0 + wv*16 .. +15 (lane = query): dense 256-byte rows
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int ch = wv * 16 + i;
       dst[(size_t)(c0 + ch) * per_seg + lane] = tile[ch][lane];
+    }
+    if (stat_partial && wv == 0) {
+      // (sum, sum of squares) of this tile per stacked channel, for the norm layer that follows:
+      // partial[(chan * nslice + slice) * 2], nslice = B * per_seg / 64 (bn.hip's layout)
+      const float ss = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
+      const float qq = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+      const int nslice = gridDim.y * (per_seg / TS_Q);
+      const int slice = bi * (per_seg / TS_Q) + r0 / TS_Q;
+      float *pd = stat_partial + ((size_t)(sg * c + c0 + lane) * nslice + slice) * 2;
+      pd[0] = ss; pd[1] = qq;
     }
     __syncthreads();
   }
@@ -787,17 +801,21 @@ extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float 
                                         int pitch, int seg_off, const int *idx,
                                         const float *weight, const float *rel, const float *wx,
                                         float *out, int segs, int seg_len, int c_total,
-                                        int c_offset, void *stream) {
+                                        int c_offset, float *stat_partial, void *stream) {
   const char *W = "blend_conv_forward";
   int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
   if (st) return st;
   NESIE_REQUIRE(c_offset >= 0 && c_offset + c <= c_total && (wx == nullptr) == (rel == nullptr), W);
   if (b == 0 || c == 0 || n == 0) return NESIE_OK;
   NESIE_REQUIRE(m >= 1 && table && idx && weight && out, W);
+  if (stat_partial && !(c % 64 == 0 && (n / segs) % TS_Q == 0)) {
+    set_error("%s: stat_partial needs c %% 64 == 0 and %d-multiple faces", W, TS_Q);
+    return NESIE_ERR_UNSUPPORTED;
+  }
   if (c % 64 == 0 && (n / segs) % TS_Q == 0)
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(n / TS_Q, b), dim3(256), 0, (hipStream_t)stream, c,
                        m, n, segs, seg_len, c_total, c_offset, pitch, seg_off, table, idx, weight,
-                       rel, wx, out);
+                       rel, wx, out, stat_partial);
   else
     hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b),
                        dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, segs, seg_len, c_total,

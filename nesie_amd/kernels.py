@@ -249,7 +249,7 @@ class HipKernels(_BNPoolMixin):
         return idx, weight, rel
 
     def blend_conv_forward(self, table, seg_off, idx, weight, rel, wx, out, segs, seg_len,
-                           c, c_offset):
+                           c, c_offset, stat_partial=None):
         """table (B, M, pitch) point-major; out (B, segs, c_total, n/segs): query (k, s, g) ->
         out[b, s, c_offset+ch, k*seg_len+g] = blend(table[..., s*seg_off+ch]) (+ wx[s,ch].rel)."""
         _check(table, idx, weight, out); _f32(table, weight, out); _i32(idx)
@@ -264,9 +264,12 @@ class HipKernels(_BNPoolMixin):
             assert rel.numel() == b * n * 3 and tuple(wx.shape) == (segs, c, 3)
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
         with torch.cuda.device(table.device):
+            if stat_partial is not None:
+                _check(stat_partial); _f32(stat_partial)
+                assert stat_partial.numel() == segs * c * (b * (n // segs // 64)) * 2
             _lib.call("nesie_blend_conv_forward", b, c, m, n, _ptr(table), pitch, seg_off,
                       _ptr(idx), _ptr(weight), opt(rel), opt(wx), _ptr(out), segs, seg_len,
-                      int(out.shape[2]), c_offset, _stream(table))
+                      int(out.shape[2]), c_offset, opt(stat_partial), _stream(table))
 
     def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len):
         """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c)
@@ -433,7 +436,7 @@ class HipKernels(_BNPoolMixin):
                       int(bool(x_relu)), _ptr(dw), _ptr(ws), need, _stream(dy))
 
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                        y, save_mean, save_invstd, fwd_coef, row_bias=None):
+                        y, save_mean, save_invstd, fwd_coef, row_bias=None, pre_partial=None):
         """x, y (B, C, *) fp32; per-channel vectors [C]; running stats updated in place.
         row_bias (B, C, K): added to x broadcast over the last axis of x (B, C, K, G)."""
         _check(x, y, save_mean, save_invstd); _f32(x, y, save_mean, save_invstd)
@@ -447,7 +450,9 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_bn_relu_forward", b, c, p, _ptr(x), opt(gamma), opt(beta),
                       opt(running_mean), opt(running_var), float(momentum), float(eps),
                       int(bool(relu)), _ptr(y), _ptr(save_mean), _ptr(save_invstd),
-                      _ptr(fwd_coef), opt(row_bias), group, _ptr(ws), need, _stream(x))
+                      _ptr(fwd_coef), opt(row_bias), group, opt(pre_partial),
+                      0 if pre_partial is None else pre_partial.numel() // (2 * c),
+                      _ptr(ws), need, _stream(x))
 
     def bn_relu_backward(self, dy, x, y, gamma, beta, save_mean, save_invstd, fwd_coef, relu,
                          dx, dgamma, dbeta, row_bias=None, d_row_bias=None):

@@ -96,27 +96,41 @@ class BlendConv(Function):
     (B, n, 3) constants -> (B, segs, H, n/segs)."""
 
     @staticmethod
-    def forward(ctx, table, wx, idx, weight, rel, segs, seg_len):
+    def forward(ctx, table, wx, idx, weight, rel, segs, seg_len, with_stats=False):
+        """with_stats: also return the per-tile (sum, sum of squares) of the output per stacked
+        channel, (segs*H, B*K*G/64, 2), for the norm layer behind it (its statistics pass over
+        the output is then skipped)."""
         table, wx = table.contiguous(), wx.contiguous()
         b, m, pitch = table.shape
         h = pitch // segs
         n = idx.shape[1]
         out = table.new_empty(b, segs, h, n // segs)
-        backend_for(table).blend_conv_forward(table, h, idx, weight, rel, wx, out, segs,
-                                              seg_len, h, 0)
+        backend = backend_for(table)
+        partial = None
+        if with_stats and backend.name == 'hip' and h % 64 == 0 and (n // segs) % 64 == 0:
+            partial = table.new_empty(segs * h, b * (n // segs // 64), 2)
+            backend.blend_conv_forward(table, h, idx, weight, rel, wx, out, segs, seg_len, h, 0,
+                                       stat_partial=partial)
+        else:
+            backend.blend_conv_forward(table, h, idx, weight, rel, wx, out, segs, seg_len, h, 0)
         ctx.save_for_backward(idx, weight, rel)
         ctx.dims = (segs, seg_len, b, m, pitch, h)
+        if with_stats:
+            if partial is None:
+                partial = table.new_empty(0)
+            ctx.mark_non_differentiable(partial)
+            return out, partial
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         idx, weight, rel = ctx.saved_tensors
         segs, seg_len, b, m, pitch, h = ctx.dims
         d_table = dy.new_zeros(b, m, pitch)
         d_wx = dy.new_zeros(segs, h, 3)
         backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
                                             segs, seg_len)
-        return d_table, d_wx, None, None, None, None, None
+        return d_table, d_wx, None, None, None, None, None, None
 
 
 blend_conv = BlendConv.apply

@@ -51,7 +51,9 @@ def count_batch(counter):
 class BNReLUTrain(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu,
-                row_bias=None):
+                row_bias=None, pre_partial=None):
+        """pre_partial (C, nslice, 2): unshifted (sum, sum of squares) partials of x left by its
+        producer; the statistics pass over x is then skipped."""
         x = x.contiguous()
         if row_bias is not None:
             row_bias = row_bias.contiguous()
@@ -62,7 +64,7 @@ class BNReLUTrain(Function):
         fwd_coef = x.new_empty(c, 4)  # scale, bias, mean, invstd as the forward applied them
         backend_for(x).bn_relu_forward(x, weight, bias, running_mean, running_var, momentum,
                                        eps, relu, y, save_mean, save_invstd, fwd_coef,
-                                       row_bias=row_bias)
+                                       row_bias=row_bias, pre_partial=pre_partial)
         ctx.relu = relu
         ctx.has_row_bias = row_bias is not None
         saved = (x, y, weight, bias, save_mean, save_invstd, fwd_coef)
@@ -81,7 +83,7 @@ class BNReLUTrain(Function):
         backend_for(dy).bn_relu_backward(dy, x, y, weight, bias, save_mean, save_invstd, fwd_coef,
                                          ctx.relu, dx, dgamma, dbeta, row_bias=row_bias,
                                          d_row_bias=d_row_bias)
-        return dx, dgamma, dbeta, None, None, None, None, None, d_row_bias
+        return dx, dgamma, dbeta, None, None, None, None, None, d_row_bias, None
 
 
 class BNReLUMaxPoolTrain(Function):
@@ -121,9 +123,11 @@ class _FusedBNReLU:
     def _init_fused(self, relu):
         self.fuse_relu = bool(relu)
 
-    def forward(self, x, row_bias=None):
+    def forward(self, x, row_bias=None, pre_partial=None):
         """``row_bias`` (B, C, K), optional: normalise ``x + row_bias[..., None]`` for
-        ``x`` (B, C, K, G) without materialising the sum (G a power of two in 4..256)."""
+        ``x`` (B, C, K, G) without materialising the sum (G a power of two in 4..256).
+        ``pre_partial`` (C, nslice, 2), optional: (sum, sum of squares) partials of x left by
+        its producer (native training path only; ignored otherwise)."""
         backend = backend_for(x)  # raises for CPU tensors without an injected back end
         native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
                   and self.affine and self.track_running_stats and self.momentum is not None)
@@ -138,7 +142,7 @@ class _FusedBNReLU:
                 self.num_batches_tracked.add_(1)
             return BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean,
                                      self.running_var, self.momentum, self.eps, self.fuse_relu,
-                                     row_bias)
+                                     row_bias, pre_partial if row_bias is None else None)
         y = super().forward(x)
         return F.relu(y) if self.fuse_relu else y
 

@@ -71,7 +71,7 @@ class QualityEstimation(SidePooling):
         fused = backend_for(origin_xyz).name == 'hip'
         side_nets = list(self.mlps_before[:6])
         if fused:
-            side_c0, side_normed = self.first_conv_through_blend(
+            side_c0, side_normed, side_stats = self.first_conv_through_blend(
                 side_nets, origin_xyz, origin_features, None, center,
                 taps=self.fused_taps(origin_xyz, center, size, heading, 'side'), with_norm=self.fuse_first_norm)
         else:
@@ -80,7 +80,8 @@ class QualityEstimation(SidePooling):
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
         dist_feature = self.dist_feature(end_points, prefix)
         if fused and mini_pointnets_groupable(side_nets, side_c0):
-            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed)
+            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed,
+                                            c0_stats=side_stats)
         elif fused:
             key = 'a0' if side_normed else 'conv0_out'
             pooled = torch.stack([side_nets[i](**{key: side_c0[:, i]}) for i in range(6)], 1)

@@ -41,7 +41,7 @@ class MiniPointNet(nn.Module):
             PointwiseConv2d(hide_dim, hide_dim, 1, bias=False), FusedBNReLU2d(hide_dim),
             nn.Identity(), PointwiseConv2d(hide_dim, feature_dim, 1))
 
-    def forward(self, points=None, conv0_out=None, a0=None):
+    def forward(self, points=None, conv0_out=None, a0=None, c0_stats=None):
         """``points`` (B,C,K,G) grid features, or ``conv0_out`` (B,H,K,G) = the first conv
         already applied through the blend (SidePooling.first_conv_through_blend), or ``a0`` =
         that followed by the first norm + ReLU as well (``with_norm=True`` there).
@@ -56,8 +56,8 @@ class MiniPointNet(nn.Module):
         Differences from the concatenated form are summation-order rounding only."""
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
-        if a0 is None:
-            a0 = bn0(conv0(points) if conv0_out is None else conv0_out)
+        if a0 is None:   # c0_stats: (sum, sum^2) partials of conv0_out left by its producer
+            a0 = bn0(conv0(points)) if conv0_out is None else bn0(conv0_out, pre_partial=c0_stats)
         c = pointwise_conv(a0, conv3.weight)                           # f without its bias
         g, c = group_max_pool_shared(c)                                # (B, H, K): max_G f - b
         half = conv3.out_channels
@@ -72,7 +72,7 @@ class MiniPointNet(nn.Module):
         return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
 
-def _stacked_bn(layers, x, row_bias=None):
+def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     """ONE fused BatchNorm(+ReLU) over the S*C channels of x (B, S*C, ...) for the S norm
     layers ``layers`` (each C channels): statistics are per channel, so stacking the layers
     along the channel axis is the same arithmetic as calling them one by one.  Running
@@ -83,7 +83,7 @@ def _stacked_bn(layers, x, row_bias=None):
     rv = torch.cat([l.running_var for l in layers])
     y = _norm.BNReLUTrain.apply(x, torch.cat([l.weight for l in layers]),
                                 torch.cat([l.bias for l in layers]), rm, rv, first.momentum,
-                                first.eps, first.fuse_relu, row_bias)
+                                first.eps, first.fuse_relu, row_bias, pre_partial)
     with torch.no_grad():
         torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
         torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
@@ -100,7 +100,7 @@ def _stackable_bn(layers):
                for l in layers)
 
 
-def grouped_mini_pointnets(nets, c0, normed=False):
+def grouped_mini_pointnets(nets, c0, normed=False, c0_stats=None):
     """S structurally identical MiniPointNets on S inputs at once: ``c0`` (B, S, H, K, G) =
     the outputs of their first convs (``normed``: already through the first norm + ReLU) ->
     (B, S, F, K).  Same function as calling
@@ -111,7 +111,8 @@ def grouped_mini_pointnets(nets, c0, normed=False):
     f, sc = [n.first_conv for n in nets], [n.second_conv for n in nets]
     stack = lambda ws: torch.stack([w.flatten(1) for w in ws]).unsqueeze(0)  # noqa: E731
     a0 = c0.reshape(B, S, H, K * G) if normed else \
-        _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G)).view(B, S, H, K * G)
+        _stacked_bn([x[1] for x in f], c0.reshape(B, S * H, K, G),
+                    pre_partial=c0_stats).view(B, S, H, K * G)
     c = torch.matmul(stack([x[3].weight for x in f]), a0)               # (B,S,half,K*G)
     half = c.shape[2]
     g, c5 = group_max_pool_shared(c.view(B, S, half, K, G))              # (B,S,half,K)
@@ -314,7 +315,8 @@ class SidePooling(nn.Module):
     def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center,
                                  taps=None, with_norm=False):
         """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
-        S consecutive point groups of every proposal: (B,S,H,K,G), evaluated as
+        S consecutive point groups of every proposal: ((B,S,H,K,G), normed?, statistics partials
+        of the output for the first norm layer or None), evaluated as
         W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
         conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points."""
         B, K = center.shape[:2]
@@ -340,9 +342,10 @@ class SidePooling(nn.Module):
                 torch._foreach_copy_([l.running_var for l in bns], list(rv.split(H)))
                 for l in bns:
                     _norm.count_batch(l.num_batches_tracked)
-            return out.view(B, segs, H, K, G), True
-        out = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G)    # (B, S, H, K*G)
-        return out.view(B, segs, H, K, G), False
+            return out.view(B, segs, H, K, G), True, None
+        # (B, S, H, K*G) and the (sum, sum^2) partials of it for the first norm layer
+        out, stats = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G, True)
+        return out.view(B, segs, H, K, G), False, (stats if stats.numel() else None)
 
     def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
         """(B,N,3),(B,N,C),(B,K*S*G,3),(B,K,3) -> (B,S,3+C,K,G)  (:183-243).
@@ -376,12 +379,14 @@ class SidePooling(nn.Module):
         side_nets = list(self.mlps_before[:6])
         if fused:   # grids + taps in one launch each, first convs (+ norm) through the blend;
             #         the literal form below stays the CPU checker's
-            side_c0, side_normed = self.first_conv_through_blend(
+            side_c0, side_normed, side_stats = self.first_conv_through_blend(
                 side_nets, origin_xyz, origin_features, None, center,
-                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'), with_norm=self.fuse_first_norm)
-            bbox_c0, bbox_normed = self.first_conv_through_blend(
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'side'),
+                with_norm=self.fuse_first_norm)
+            bbox_c0, bbox_normed, bbox_stats = self.first_conv_through_blend(
                 self.mlps_before[6:7], origin_xyz, origin_features, None, center,
-                taps=self.fused_taps(origin_xyz, center, size, heading, 'box'), with_norm=self.fuse_first_norm)
+                taps=self.fused_taps(origin_xyz, center, size, heading, 'box'),
+                with_norm=self.fuse_first_norm)
             bbox_c0 = bbox_c0[:, 0]
         else:
             whole_grid = self.generate_grid(size)
@@ -391,7 +396,8 @@ class SidePooling(nn.Module):
             bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
         dist_feature = self.dist_feature(end_points, prefix)
         if fused and mini_pointnets_groupable(side_nets, side_c0):
-            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed)  # (B,6,128,2K)
+            pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed,
+                                            c0_stats=side_stats)               # (B,6,128,2K)
         elif fused:
             key = 'a0' if side_normed else 'conv0_out'
             pooled = torch.stack([side_nets[i](**{key: side_c0[:, i]}) for i in range(6)], 1)
@@ -405,7 +411,8 @@ class SidePooling(nn.Module):
             side_scores = torch.stack([self.mlps_head[i](x[:, i]) for i in range(6)], 0)
         end_points[f'{prefix}side_scores'] = side_scores
         if fused:
-            bbox_feats = self.mlps_before[6](**{'a0' if bbox_normed else 'conv0_out': bbox_c0})
+            bbox_feats = self.mlps_before[6](**{'a0' if bbox_normed else 'conv0_out': bbox_c0},
+                                             c0_stats=bbox_stats)
         else:
             bbox_feats = self.mlps_before[6](bbox_feats)
         end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)

@@ -674,9 +674,12 @@ def test_blend_conv_bn_matches_blend_then_norm(hip_device, k, segs, g, h):
         if fused:
             out = ops.blend_conv_bn(t, x, ga, be, idx, w, rel, rm, rv, 0.1, 1e-5, segs, g)
         else:
-            c0 = ops.blend_conv(t, x, idx, w, rel, segs, g)
+            # (with the statistics partials of the blend epilogue feeding the norm when the
+            # shape allows: the production path)
+            c0, stats = ops.blend_conv(t, x, idx, w, rel, segs, g, True)
             out = BNReLUTrain.apply(c0.reshape(b, segs * h, k, g), ga, be, rm, rv, 0.1, 1e-5,
-                                    True).view(b, segs, h, k * g)
+                                    True, None, stats if stats.numel() else None
+                                    ).view(b, segs, h, k * g)
         out.backward(go)
         return out.detach(), t.grad, x.grad, ga.grad, be.grad, rm, rv
 
@@ -689,3 +692,28 @@ def test_blend_conv_bn_matches_blend_then_norm(hip_device, k, segs, g, h):
     for i, name in ((1, 'table'), (2, 'wx'), (3, 'gamma'), (4, 'beta')):
         err = (got[i] - want[i]).norm().item()
         assert err <= 5e-3 * want[i].norm().item() + 1e-5, (name, err, want[i].norm().item())
+
+
+def test_blend_statistics_epilogue_feeds_the_norm(hip_device):
+    """The (sum, sum of squares) partials the blend kernel leaves per 64-query tile, handed to
+    nesie_bn_relu_forward as pre_partial, give the same normalisation and running statistics
+    as the norm's own statistics pass over the tensor."""
+    from nesie_amd.mmdet3d_ops.norm import BNReLUTrain
+    k, segs, g, h = 64, 6, 16, 128
+    gen, b, m, n, idx, w, rel = _blend_case(k, segs, g, h, 77)
+    dev = hip_device
+    table = (torch.randn(b, m, segs * h, generator=gen) + 0.7).to(dev)   # non-zero channel means
+    wx = torch.randn(segs, h, 3, generator=gen).to(dev)
+    gamma = (torch.rand(segs * h, generator=gen) + 0.5).to(dev)
+    beta = (torch.randn(segs * h, generator=gen) * 0.3).to(dev)
+    c0, stats = ops.blend_conv(table, wx, idx.to(dev), w.to(dev), rel.to(dev), segs, g, True)
+    assert tuple(stats.shape) == (segs * h, b * (k * g // 64), 2)
+    x = c0.reshape(b, segs * h, k, g)
+    outs = []
+    for pre in (stats, None):
+        rm, rv = torch.zeros(segs * h, device=dev), torch.ones(segs * h, device=dev)
+        y = BNReLUTrain.apply(x, gamma, beta, rm, rv, 0.1, 1e-5, True, None, pre)
+        outs.append((y, rm, rv))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)
