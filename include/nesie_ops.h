@@ -318,6 +318,21 @@ int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns, const float *gra
                                    float *dbeta, void *workspace, size_t workspace_bytes,
                                    void *stream);
 
+/* NesieHead.side2box + Integral + the bbox_probs softmax (dense_heads/nesie_head.py:19-52,
+ * 150-209, 255-257), one thread per proposal.  reg (B, 6*bins+2, K) channel-major = the
+ * regression branch's output (6 sides x bins logits, then the (sin, cos)-like heading pair);
+ * agg (B, K, 3) aggregated points; scale / sign [6].
+ *   forward : probs (B, 6, bins, K) = per-side softmax; surface (B, K, 6) = agg +- E[bin] * scale;
+ *             bbox (B, K, 7) = ((lo+hi)/2, hi-lo, atan2(h0/|h|, h1/|h|)).
+ *   backward: d_reg (B, 6*bins+2, K), d_agg (B, K, 3) from d_surface, d_bbox (either may be NULL).
+ * bins <= 33. */
+int nesie_side_decode_forward(int b, int k, int bins, const float *reg, const float *agg,
+                              const float *scale, const float *sign, float *probs,
+                              float *surface, float *bbox, void *stream);
+int nesie_side_decode_backward(int b, int k, int bins, const float *reg, const float *probs,
+                               const float *scale, const float *sign, const float *d_surface,
+                               const float *d_bbox, float *d_reg, float *d_agg, void *stream);
+
 /* One shared-MLP layer of a grouped MLP on the matrix cores.  No extension entry in the
  * reference: it evaluates mmcv ConvModule(Conv2d 1x1 -> BN2d -> ReLU) op by op
  * (point_sa_module.py:277-289, side_pooling_module.py:346-358).

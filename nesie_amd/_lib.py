@@ -32,6 +32,8 @@ SIGNATURES = {
                                     _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
     "nesie_blend_conv_bn_backward": [_I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
+    "nesie_side_decode_forward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nesie_side_decode_backward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_grid_taps": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                  _P, _P],

@@ -1,0 +1,135 @@
+// side2box: distribution-over-bins side offsets -> box planes -> (centre, size, yaw), forward
+// and backward, one thread per proposal.
+//
+// Stands in for NesieHead.side2box + Integral + the bbox_probs softmax (reference
+// mmdet3d/models/dense_heads/nesie_head.py:19-52, 150-209, 255-257): per proposal 6 softmaxes
+// over reg_max+1 bins, their expectations scaled to metres and added to / subtracted from the
+// aggregated point, the heading from a normalised (sin, cos) pair.  ~75 small ATen launches
+// (forward + autograd backward) become two.  reg is channel-major (B, 6*(R+1)+2, K), so the
+// threads of a wave read consecutive proposals of one channel: dense rows.
+#include "common.h"
+#include <math.h>
+
+namespace nesie {
+
+constexpr int DEC_MAXBINS = 33;
+
+__global__ __launch_bounds__(256) void side_decode_fwd_kernel(
+    int kprop, int bins, const float *__restrict__ reg, const float *__restrict__ agg,
+    const float *__restrict__ scale, const float *__restrict__ sign, float *__restrict__ probs,
+    float *__restrict__ surface, float *__restrict__ bbox) {
+  const int k = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+  if (k >= kprop) return;
+  const int cch = 6 * bins + 2;
+  const float *r = reg + (size_t)bi * cch * kprop + k;
+  float *pr = probs + (size_t)bi * 6 * bins * kprop + k;
+  const float *a = agg + ((size_t)bi * kprop + k) * 3;
+  float sf[6];
+  for (int s = 0; s < 6; ++s) {
+    float l[DEC_MAXBINS], mx = -INFINITY;
+    for (int j = 0; j < bins; ++j) {
+      l[j] = r[(size_t)(s * bins + j) * kprop];
+      mx = fmaxf(mx, l[j]);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < bins; ++j) { l[j] = expf(l[j] - mx); sum += l[j]; }
+    float res = 0.f;
+    for (int j = 0; j < bins; ++j) {
+      const float pj = l[j] / sum;
+      pr[(size_t)(s * bins + j) * kprop] = pj;
+      res += pj * ((float)j / (float)(bins - 1));
+    }
+    sf[s] = a[s % 3] + sign[s] * (res * scale[s]);
+  }
+  float *so = surface + ((size_t)bi * kprop + k) * 6;
+  for (int s = 0; s < 6; ++s) so[s] = sf[s];
+  const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
+  const float nrm = sqrtf(h0 * h0 + h1 * h1);
+  float *bo = bbox + ((size_t)bi * kprop + k) * 7;
+  for (int d = 0; d < 3; ++d) {
+    bo[d] = (sf[d] + sf[d + 3]) / 2.0f;
+    bo[3 + d] = sf[d + 3] - sf[d];
+  }
+  bo[6] = atan2f(h0 / nrm, h1 / nrm);
+}
+
+__global__ __launch_bounds__(256) void side_decode_bwd_kernel(
+    int kprop, int bins, const float *__restrict__ reg, const float *__restrict__ probs,
+    const float *__restrict__ scale, const float *__restrict__ sign,
+    const float *__restrict__ d_surface, const float *__restrict__ d_bbox,
+    float *__restrict__ d_reg, float *__restrict__ d_agg) {
+  const int k = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+  if (k >= kprop) return;
+  const int cch = 6 * bins + 2;
+  const float *r = reg + (size_t)bi * cch * kprop + k;
+  const float *pr = probs + (size_t)bi * 6 * bins * kprop + k;
+  float *dr = d_reg + (size_t)bi * cch * kprop + k;
+  const float *ds = d_surface ? d_surface + ((size_t)bi * kprop + k) * 6 : nullptr;
+  const float *db = d_bbox ? d_bbox + ((size_t)bi * kprop + k) * 7 : nullptr;
+  float g[6];  // gradient reaching each plane
+  for (int s = 0; s < 6; ++s) g[s] = ds ? ds[s] : 0.f;
+  if (db) {
+    for (int d = 0; d < 3; ++d) {
+      g[d] += db[d] * 0.5f - db[3 + d];        // lo: centre / 2, -size
+      g[d + 3] += db[d] * 0.5f + db[3 + d];    // hi: centre / 2, +size
+    }
+  }
+  float *da = d_agg + ((size_t)bi * kprop + k) * 3;
+  for (int d = 0; d < 3; ++d) da[d] = g[d] + g[d + 3];
+  for (int s = 0; s < 6; ++s) {
+    const float dres = g[s] * sign[s] * scale[s];
+    float res = 0.f;
+    for (int j = 0; j < bins; ++j)
+      res += pr[(size_t)(s * bins + j) * kprop] * ((float)j / (float)(bins - 1));
+    for (int j = 0; j < bins; ++j) {
+      const float pj = pr[(size_t)(s * bins + j) * kprop];
+      dr[(size_t)(s * bins + j) * kprop] = pj * dres * ((float)j / (float)(bins - 1) - res);
+    }
+  }
+  const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
+  const float n2 = h0 * h0 + h1 * h1;
+  const float dyaw = db ? db[6] : 0.f;
+  dr[(size_t)(6 * bins) * kprop] = dyaw * h1 / n2;
+  dr[(size_t)(6 * bins + 1) * kprop] = -dyaw * h0 / n2;
+}
+
+}  // namespace nesie
+
+using namespace nesie;
+
+static int dec_check(const char *W, int b, int k, int bins) {
+  NESIE_REQUIRE(b >= 0 && k >= 0 && bins >= 2 && b <= 65535, W);
+  if (bins > DEC_MAXBINS) {
+    set_error("%s: %d bins per side (built for <= %d)", W, bins, DEC_MAXBINS);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  return NESIE_OK;
+}
+
+extern "C" int nesie_side_decode_forward(int b, int k, int bins, const float *reg,
+                                         const float *agg, const float *scale, const float *sign,
+                                         float *probs, float *surface, float *bbox,
+                                         void *stream) {
+  const char *W = "side_decode_forward";
+  int st = dec_check(W, b, k, bins);
+  if (st || b == 0 || k == 0) return st;
+  NESIE_REQUIRE(reg && agg && scale && sign && probs && surface && bbox, W);
+  hipLaunchKernelGGL(side_decode_fwd_kernel, dim3(cdiv(k, 256), b), dim3(256), 0,
+                     (hipStream_t)stream, k, bins, reg, agg, scale, sign, probs, surface, bbox);
+  return check_launch(W);
+}
+
+extern "C" int nesie_side_decode_backward(int b, int k, int bins, const float *reg,
+                                          const float *probs, const float *scale,
+                                          const float *sign, const float *d_surface,
+                                          const float *d_bbox, float *d_reg, float *d_agg,
+                                          void *stream) {
+  const char *W = "side_decode_backward";
+  int st = dec_check(W, b, k, bins);
+  if (st || b == 0 || k == 0) return st;
+  NESIE_REQUIRE(reg && probs && scale && sign && d_reg && d_agg, W);
+  hipLaunchKernelGGL(side_decode_bwd_kernel, dim3(cdiv(k, 256), b), dim3(256), 0,
+                     (hipStream_t)stream, k, bins, reg, probs, scale, sign, d_surface, d_bbox,
+                     d_reg, d_agg);
+  return check_launch(W);
+}

@@ -231,6 +231,28 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_three_interpolate_wrapper", b, c, m, n, _ptr(points),
                       _ptr(idx), _ptr(weight), _ptr(out), _stream(points))
 
+    def side_decode_forward(self, reg, agg, scale, sign, probs, surface, bbox):
+        _check(reg, agg, scale, sign, probs, surface, bbox); _f32(reg, agg, probs, surface, bbox)
+        b, cch, k = reg.shape
+        bins = (cch - 2) // 6
+        assert tuple(probs.shape) == (b, 6, bins, k) and tuple(bbox.shape) == (b, k, 7)
+        with torch.cuda.device(reg.device):
+            _lib.call("nesie_side_decode_forward", b, k, bins, _ptr(reg), _ptr(agg), _ptr(scale),
+                      _ptr(sign), _ptr(probs), _ptr(surface), _ptr(bbox), _stream(reg))
+
+    def side_decode_backward(self, reg, probs, scale, sign, d_surface, d_bbox, d_reg, d_agg):
+        _check(reg, probs, scale, sign, d_reg, d_agg)
+        b, cch, k = reg.shape
+        bins = (cch - 2) // 6
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        for t in (d_surface, d_bbox):
+            if t is not None:
+                _check(t); _f32(t)
+        with torch.cuda.device(reg.device):
+            _lib.call("nesie_side_decode_backward", b, k, bins, _ptr(reg), _ptr(probs),
+                      _ptr(scale), _ptr(sign), opt(d_surface), opt(d_bbox), _ptr(d_reg),
+                      _ptr(d_agg), _stream(reg))
+
     def grid_taps(self, centre, size, heading, mult, plane, known):
         """-> idx (B,K*gp,3) int32, weight, rel (B,K*gp,3) for the gp grid points per proposal."""
         _check(centre, size, heading, mult, plane, known)

@@ -39,6 +39,36 @@ class Integral(nn.Module):
         return F.linear(x, self.project.type_as(x)).reshape(-1, 6)
 
 
+class SideDecode(torch.autograd.Function):
+    """side2box + Integral + the bbox_probs softmax in one kernel each way (HIP back end).
+    reg (B, 6*bins+2, K) channel-major, agg (B, K, 3) -> probs (B, 6, bins, K, no gradient: every
+    consumer detaches it), surface (B, K, 6), bbox (B, K, 7)."""
+
+    @staticmethod
+    def forward(ctx, reg, agg, scale, sign):
+        from ..kernels import backend_for
+        reg, agg = reg.contiguous(), agg.contiguous()
+        b, cch, k = reg.shape
+        bins = (cch - 2) // 6
+        probs = reg.new_empty(b, 6, bins, k)
+        surface, bbox = reg.new_empty(b, k, 6), reg.new_empty(b, k, 7)
+        backend_for(reg).side_decode_forward(reg, agg, scale, sign, probs, surface, bbox)
+        ctx.save_for_backward(reg, probs, scale, sign)
+        ctx.mark_non_differentiable(probs)
+        return probs, surface, bbox
+
+    @staticmethod
+    def backward(ctx, _d_probs, d_surface, d_bbox):
+        from ..kernels import backend_for
+        reg, probs, scale, sign = ctx.saved_tensors
+        d_reg = torch.empty_like(reg)
+        d_agg = reg.new_empty(reg.shape[0], reg.shape[2], 3)
+        backend_for(reg).side_decode_backward(
+            reg, probs, scale, sign, None if d_surface is None else d_surface.contiguous(),
+            None if d_bbox is None else d_bbox.contiguous(), d_reg, d_agg)
+        return d_reg, d_agg, None, None
+
+
 class GTBatch:
     """Ground truth of a batch padded to T_max boxes, resident on the device.
 
@@ -120,6 +150,14 @@ class NesieHead(nn.Module):
     def _extract_input(feat_dict):
         return feat_dict['fp_xyz'][-1], feat_dict['fp_features'][-1], feat_dict['fp_indices'][-1]
 
+    def _fused_decode(self, reg_predictions):
+        """One-kernel decode when this class's own side2box is in effect (SAQEHead overrides
+        it), on the HIP back end, fp32."""
+        from ..kernels import backend_for
+        return (type(self).side2box is NesieHead.side2box
+                and backend_for(reg_predictions).name == 'hip'
+                and reg_predictions.dtype == torch.float32 and self.reg_max + 1 <= 33)
+
     # ---- decode (:150-209) ------------------------------------------------------
     def side2box(self, aggregated_points, bbox_pred, results):
         B, proposal_num = bbox_pred.shape[:2]
@@ -190,10 +228,17 @@ class NesieHead(nn.Module):
         cls_preds_trans = cls_predictions.transpose(2, 1)
         results['obj_scores'] = cls_preds_trans[..., :2]
         results['sem_scores'] = cls_preds_trans[..., 2:]
-        results = self.side2box(aggregated_points, reg_predictions.transpose(2, 1), results)
         B = reg_predictions.shape[0]
-        probs = reg_predictions[:, :self.n_reg_outs, :]
-        results['bbox_probs'] = F.softmax(probs.reshape(B, 6, self.reg_max + 1, -1), dim=2)
+        if self._fused_decode(reg_predictions):
+            probs, surface, boxes = SideDecode.apply(
+                reg_predictions, aggregated_points, self._side_scale, self._side_sign)
+            results['surface_scale'] = self._side_scale.expand(B, origin_proposal_num, 6)
+            results['surface_pred'], results['bbox_preds'] = surface, boxes
+            results['bbox_probs'] = probs
+        else:
+            results = self.side2box(aggregated_points, reg_predictions.transpose(2, 1), results)
+            probs = reg_predictions[:, :self.n_reg_outs, :]
+            results['bbox_probs'] = F.softmax(probs.reshape(B, 6, self.reg_max + 1, -1), dim=2)
 
         center, size, heading, results = self.jitter_bbox_preds(results, dataset_name)
         results = self.grid_conv(center.detach(), size.detach(), heading.detach(), results)

@@ -295,3 +295,30 @@ def test_fused_grid_taps_match_the_literal_chain(hip_device, variant):
         same = (idx1 == idx0).all(-1)
         assert same.float().mean().item() > 0.995          # near-ties may order differently
         torch.testing.assert_close(w1[same], w0[same], rtol=1e-4, atol=1e-6)
+
+
+def test_fused_side_decode_matches_side2box(hip_device):
+    """nesie_side_decode_forward/backward vs NesieHead.side2box + Integral + the bbox_probs
+    softmax evaluated with ATen ops and autograd (nesie_head.py:19-52, 150-209, 255-257)."""
+    import torch.nn.functional as F
+    from nesie_amd.votenet.nesie_head import SideDecode
+    torch.manual_seed(31)
+    from nesie_amd.votenet import build_nesie_votenet
+    head = build_nesie_votenet().bbox_head.to(hip_device)
+    B, K = 3, 70
+    reg = torch.randn(B, head.n_reg_outs + 2, K, device=hip_device) * 2.0
+    agg = torch.rand(B, K, 3, device=hip_device) * 4
+    g_s = torch.randn(B, K, 6, device=hip_device)
+    g_b = torch.randn(B, K, 7, device=hip_device)
+    r1, a1 = reg.clone().requires_grad_(True), agg.clone().requires_grad_(True)
+    probs1, surf1, box1 = SideDecode.apply(r1, a1, head._side_scale, head._side_sign)
+    ((surf1 * g_s).sum() + (box1 * g_b).sum()).backward()
+    r2, a2 = reg.clone().requires_grad_(True), agg.clone().requires_grad_(True)
+    res = head.side2box(a2, r2.transpose(2, 1), {})
+    probs2 = F.softmax(r2[:, :head.n_reg_outs].reshape(B, 6, head.reg_max + 1, -1), dim=2)
+    ((res['surface_pred'] * g_s).sum() + (res['bbox_preds'] * g_b).sum()).backward()
+    torch.testing.assert_close(probs1, probs2.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(surf1, res['surface_pred'], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(box1, res['bbox_preds'], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a1.grad, a2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r1.grad, r2.grad, rtol=1e-4, atol=1e-5)
