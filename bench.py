@@ -289,7 +289,8 @@ def main():
 
     rank, world, local = dp.init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local)
+    # (several ranks may share a device only in the gloo rehearsal, see dp.init_distributed)
+    device = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     from nesie_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing

@@ -22,7 +22,10 @@ def init_distributed(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # NESIE_DIST_BACKEND=gloo: rehearse the N > 1 step with several ranks on ONE GPU
+            # (RCCL refuses two ranks on a device; gloo stages the all-reduce through the host)
+            backend = os.environ.get('NESIE_DIST_BACKEND') or \
+                ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

@@ -322,3 +322,26 @@ def test_fused_side_decode_matches_side2box(hip_device):
     torch.testing.assert_close(box1, res['bbox_preds'], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(a1.grad, a2.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(r1.grad, r2.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_two_rank_step_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path end to end (graphs, pipelined index chain, flat gradient
+    all-reduce between the two graphs, fused AdamW) with two ranks sharing this GPU; gloo stands
+    in for RCCL, which refuses two ranks on one device (NESIE_DIST_BACKEND, dp.init_distributed)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NESIE_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
+         '--gpus', '2', '--steps', '2', '--warmup', '1', '--cpu-baseline', '0'],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 16
+    assert res['scaling'] == 'weak' and res['value'] > 0 and 'cpu_baseline' not in res
