@@ -333,6 +333,33 @@ int nesie_side_decode_backward(int b, int k, int bins, const float *reg, const f
                                const float *scale, const float *sign, const float *d_surface,
                                const float *d_bbox, float *d_reg, float *d_agg, void *stream);
 
+/* ---- inference post-processing and evaluation geometry -------------- */
+
+/* aligned_3d_nms (core/post_processing/box3d_nms.py:129-176) for B scenes at once.
+ * boxes (B,K,6) f32 axis-aligned (x1,y1,z1,x2,y2,z2), scores (B,K) f32, classes (B,K) i32,
+ * valid (B,K) u8 or NULL: only boxes with valid != 0 take part (the reference indexes them
+ * out with a boolean mask first, nesie_head.py:752-755).  picks (B,K) i32 = input positions
+ * of the kept boxes in pick order (descending score), padded with -1; count (B) i32.
+ * fp32 arithmetic in the reference's order; equal scores order by index (the later one is
+ * picked first, as a stable ascending argsort read from its end).  K <= 512. */
+int nesie_aligned_3d_nms(int b, int k, const float *boxes, const float *scores,
+                         const int *classes, const uint8_t *valid, float thr, int *picks,
+                         int *count, void *stream);
+
+/* counts[b, t] = number of points of scene b inside box t: the column sums of
+ * points_in_boxes_batch (same test, same LiDAR-frame operands) that
+ * NesieHead.multiclass_nms_single takes for its non-empty mask
+ * (`box_indices.T.sum(1) > 5`, nesie_head.py:744-750), without the (M, T) table. */
+int nesie_points_in_boxes_count(int b, int boxes_num, int pts_num, const float *boxes,
+                                const float *pts, int *counts, void *stream);
+
+/* iou3d_cuda.boxes_overlap_bev_gpu (ops/iou3d/src/iou3d.cpp:66-90, iou3d_kernel.cu:127-264):
+ * overlap AREA of every pair of rotated BEV rectangles (x1, y1, x2, y2, angle);
+ * boxes_a (N,5), boxes_b (M,5) -> ans_overlap (N,M).  BaseInstance3DBoxes.overlaps
+ * (base_box3d.py:387-438) multiplies it by the height overlap for the 3-D IoU of indoor_eval. */
+int nesie_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                            float *ans_overlap, void *stream);
+
 /* One shared-MLP layer of a grouped MLP on the matrix cores.  No extension entry in the
  * reference: it evaluates mmcv ConvModule(Conv2d 1x1 -> BN2d -> ReLU) op by op
  * (point_sa_module.py:277-289, side_pooling_module.py:346-358).

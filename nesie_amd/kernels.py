@@ -253,6 +253,40 @@ class HipKernels(_BNPoolMixin):
                       _ptr(scale), _ptr(sign), opt(d_surface), opt(d_bbox), _ptr(d_reg),
                       _ptr(d_agg), _stream(reg))
 
+    def aligned_3d_nms(self, boxes, scores, classes, valid, thr, picks, count):
+        """boxes (B,K,6), scores (B,K), classes (B,K) i32, valid (B,K) u8 or None ->
+        picks (B,K) i32 (-1 padded, pick order), count (B) i32."""
+        _check(boxes, scores, classes, picks, count); _f32(boxes, scores); _i32(classes, picks, count)
+        b, k = scores.shape
+        assert tuple(boxes.shape) == (b, k, 6) and tuple(classes.shape) == (b, k)
+        assert tuple(picks.shape) == (b, k) and count.numel() == b
+        if valid is not None:
+            _check(valid)
+            assert valid.dtype == torch.uint8 and tuple(valid.shape) == (b, k)
+        with torch.cuda.device(boxes.device):
+            _lib.call("nesie_aligned_3d_nms", b, k, _ptr(boxes), _ptr(scores), _ptr(classes),
+                      0 if valid is None else _ptr(valid), float(thr), _ptr(picks), _ptr(count),
+                      _stream(boxes))
+
+    def points_in_boxes_count(self, boxes, pts, counts):
+        """boxes (B,T,7) LiDAR frame, pts (B,M,3) -> counts (B,T) i32."""
+        _check(boxes, pts, counts); _f32(boxes, pts); _i32(counts)
+        b, t, _ = boxes.shape
+        assert pts.shape[0] == b and pts.shape[2] == 3 and tuple(counts.shape) == (b, t)
+        with torch.cuda.device(boxes.device):
+            _lib.call("nesie_points_in_boxes_count", b, t, pts.shape[1], _ptr(boxes), _ptr(pts),
+                      _ptr(counts), _stream(boxes))
+
+    def boxes_overlap_bev(self, boxes_a, boxes_b, ans_overlap):
+        """(N,5), (M,5) rotated BEV rectangles (x1,y1,x2,y2,angle) -> overlap areas (N,M)."""
+        _check(boxes_a, boxes_b, ans_overlap); _f32(boxes_a, boxes_b, ans_overlap)
+        n, m = boxes_a.shape[0], boxes_b.shape[0]
+        assert boxes_a.shape[1] == 5 and boxes_b.shape[1] == 5
+        assert tuple(ans_overlap.shape) == (n, m)
+        with torch.cuda.device(boxes_a.device):
+            _lib.call("nesie_boxes_overlap_bev", n, _ptr(boxes_a), m, _ptr(boxes_b),
+                      _ptr(ans_overlap), _stream(boxes_a))
+
     def grid_taps(self, centre, size, heading, mult, plane, known):
         """-> idx (B,K*gp,3) int32, weight, rel (B,K*gp,3) for the gp grid points per proposal."""
         _check(centre, size, heading, mult, plane, known)
@@ -520,6 +554,10 @@ def backend_for(tensor):
         _lib.load()
         _hip = HipKernels()
     return _hip
+
+
+def injected_backend():
+    return _injected
 
 
 @contextlib.contextmanager

@@ -13,7 +13,8 @@ from .interpolate import blend_conv, blend_conv_bn, three_interpolate, three_int
 from .pointnet_modules import (ConvModule, PointFPModule, PointSAModule, PointSAModuleMSG,
                                PointwiseConv1d, PointwiseConv2d, build_sa_module,
                                pointwise_conv)
-from .roiaware_pool3d import points_in_boxes_batch
+from .iou3d import boxes_overlap_bev
+from .roiaware_pool3d import points_in_boxes_batch, points_in_boxes_count
 from .rotated_iou import cal_iou_3d, sort_v
 
 _HOT = [
@@ -21,7 +22,7 @@ _HOT = [
     'three_interpolate', 'three_nn', 'gather_points', 'grouping_operation', 'group_points',
     'GroupAll', 'QueryAndGroup', 'PointSAModule', 'PointSAModuleMSG', 'PointFPModule',
     'points_in_boxes_batch', 'Points_Sampler', 'build_sa_module', 'cal_iou_3d', 'sort_v',
-    'ConvModule',
+    'ConvModule', 'boxes_overlap_bev', 'points_in_boxes_count',
 ]
 _OUT_OF_SCOPE = [
     'nms', 'soft_nms', 'RoIAlign', 'roi_align', 'get_compiler_version',

@@ -18,3 +18,13 @@ def points_in_boxes_batch(points, boxes):
     backend_for(points).points_in_boxes_batch(boxes.contiguous(), points.contiguous(),
                                               box_idxs_of_pts)
     return box_idxs_of_pts
+
+
+def points_in_boxes_count(points, boxes):
+    """points (B,M,3) LiDAR frame, boxes (B,T,7) -> (B,T) int32: how many of the scene's points
+    lie in each box -- ``points_in_boxes_batch(points, boxes).sum(1)`` without the table (the
+    non-empty test of NesieHead.multiclass_nms_single, nesie_head.py:744-750)."""
+    assert boxes.shape[0] == points.shape[0] and boxes.shape[2] == 7 and points.shape[2] == 3
+    counts = points.new_empty((boxes.shape[0], boxes.shape[1]), dtype=torch.int)
+    backend_for(points).points_in_boxes_count(boxes.contiguous(), points.contiguous(), counts)
+    return counts

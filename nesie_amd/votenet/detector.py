@@ -66,6 +66,14 @@ def saqe_votenet_scannet_cfg():
     return cfg
 
 
+def bbox3d2result(bboxes, scores, labels, attrs=None):
+    """core/bbox/transforms.py:49-75: detection results as host tensors."""
+    result = dict(boxes_3d=bboxes.to('cpu'), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+    if attrs is not None:
+        result['attrs_3d'] = attrs.cpu()
+    return result
+
+
 class VoteNet(nn.Module):
     """backbone -> bbox head -> losses dict; total loss = sum of every entry whose key
     contains 'loss' (mmdet BaseDetector._parse_losses)."""
@@ -97,6 +105,19 @@ class VoteNet(nn.Module):
         return self.bbox_head.loss(bbox_preds, points_cat, gt_bboxes_3d, gt_labels_3d,
                                    pts_semantic_mask, pts_instance_mask, img_metas,
                                    gt_bboxes_ignore=gt_bboxes_ignore, vote_targets=votes)
+
+    def simple_test(self, points, img_metas, imgs=None, rescale=False):
+        """Test-time forward (detectors/votenet.py:62-83, votenet_nesie.py:326-348): head in
+        `test_cfg.sample_mod`, box decoding + NMS, results moved to the host."""
+        points_cat = torch.stack(points) if isinstance(points, (list, tuple)) else points
+        cfg = self.test_cfg if isinstance(self.test_cfg, dict) else vars(self.test_cfg)
+        with torch.no_grad():
+            x = self.extract_feat(points_cat)
+            bbox_preds = self.bbox_head(x, cfg['sample_mod'])
+            bbox_list = self.bbox_head.get_bboxes(
+                points_cat, bbox_preds, img_metas, rescale=rescale,
+                use_iou_for_nms=cfg.get('use_iou_for_nms', True))
+        return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
 
     @staticmethod
     def parse_losses(losses):

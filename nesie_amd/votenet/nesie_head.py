@@ -15,10 +15,12 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
-from ..mmdet3d_ops import build_sa_module, furthest_point_sample, points_in_boxes_batch
+from ..mmdet3d_ops import (build_sa_module, furthest_point_sample, points_in_boxes_batch,
+                           points_in_boxes_count)
+from ..post_processing import batched_aligned_3d_nms
 from ..mmdet3d_ops.rotated_iou import cal_iou_3d
 from .bbox_module import ReliableConvBboxHead
-from .boxes import depth_to_lidar_boxes, depth_to_lidar_points
+from .boxes import DepthInstance3DBoxes, depth_to_lidar_boxes, depth_to_lidar_points
 from .losses import build_loss
 from ..streams import fork_join
 from .side_pooling import SidePooling
@@ -250,6 +252,80 @@ class NesieHead(nn.Module):
         results['side_scores_jitter'] = side[:, origin_proposal_num:]
         results['side_scores'] = side[:, :origin_proposal_num]
         return results
+
+    # ---- test path (:681-788) ---------------------------------------------------
+    def _test_cfg(self, key, default=None):
+        cfg = self.test_cfg
+        if isinstance(cfg, dict):
+            return cfg.get(key, default)
+        return getattr(cfg, key, default)
+
+    def _nms_selection(self, obj_scores, sem_scores, bbox3d, points_xyz):
+        """The device half of multiclass_nms_single (:738-766) for a whole batch, without a
+        host synchronisation: bottom-origin boxes (B,K,7), classes (B,K), selected (B,K) bool.
+        Three launches stand in for the reference's per-scene (M, K) membership table, its
+        python NMS loop and the scatter: a per-box point count, one NMS workgroup per scene,
+        one scatter."""
+        B, K = obj_scores.shape
+        boxes = bbox3d.clone()                                 # origin (0.5,0.5,0.5) -> bottom
+        boxes[..., :3] += boxes[..., 3:6] * boxes.new_tensor((0.0, 0.0, -0.5))
+        counts = points_in_boxes_count(depth_to_lidar_points(points_xyz).contiguous(),
+                                       depth_to_lidar_boxes(boxes).contiguous())
+        nonempty = counts > 5
+        corners = DepthInstance3DBoxes.__new__(DepthInstance3DBoxes)
+        corners.tensor = boxes.reshape(B * K, 7)
+        corner3d = corners.corners.view(B, K, 8, 3)
+        minmax = torch.cat([corner3d.min(dim=2)[0], corner3d.max(dim=2)[0]], dim=-1)
+        classes = torch.argmax(sem_scores, -1)
+        picks, _ = batched_aligned_3d_nms(minmax, obj_scores, classes,
+                                          self._test_cfg('nms_thr'), valid=nonempty)
+        kept = torch.zeros(B, K + 1, dtype=torch.bool, device=boxes.device)
+        kept.scatter_(1, torch.where(picks < 0, picks.new_full((), K), picks).long(),
+                      torch.ones_like(picks, dtype=torch.bool))
+        selected = kept[:, :K] & (obj_scores > self._test_cfg('score_thr'))
+        return boxes, classes, selected
+
+    def _gather_selected(self, boxes, obj_scores, sem_scores, classes, selected):
+        """One scene: (K,7), (K), (K,C), (K), (K) bool -> the reference's return triple."""
+        box_sel, obj_sel = boxes[selected], obj_scores[selected]
+        if self._test_cfg('per_class_proposal'):
+            sem_sel = sem_scores[selected]                       # (n, C)
+            C = sem_sel.shape[-1]
+            labels = torch.arange(C, device=boxes.device, dtype=classes.dtype) \
+                .repeat_interleave(box_sel.shape[0])
+            return (box_sel.repeat(C, 1), (obj_sel.unsqueeze(1) * sem_sel).t().reshape(-1),
+                    labels)
+        return box_sel, obj_sel, classes[selected]
+
+    def get_bboxes(self, points, bbox_preds, input_metas, rescale=False, use_nms=True,
+                   use_iou_for_nms=True):
+        """Boxes, scores and labels per scene from the head's predictions (:681-729)."""
+        obj_scores = F.softmax(bbox_preds['obj_scores'], dim=-1)[..., -1]
+        sem_scores = F.softmax(bbox_preds['sem_scores'], dim=-1)
+        bbox3d = bbox_preds['bbox_preds']
+        if use_iou_for_nms:
+            indx = bbox_preds['sem_scores'].max(dim=-1)[1]
+            obj_scores = obj_scores * bbox_preds['iou_scores'].gather(2, indx.unsqueeze(-1)).squeeze(-1)
+        if not use_nms:
+            return bbox3d
+        boxes, classes, selected = self._nms_selection(obj_scores, sem_scores, bbox3d,
+                                                       points[..., :3])
+        results = []
+        for b in range(bbox3d.shape[0]):
+            box_sel, score_sel, labels = self._gather_selected(
+                boxes[b], obj_scores[b], sem_scores[b], classes[b], selected[b])
+            box_type = (input_metas[b] or {}).get('box_type_3d', DepthInstance3DBoxes) \
+                if input_metas is not None else DepthInstance3DBoxes
+            results.append((box_type(box_sel, box_dim=box_sel.shape[-1], with_yaw=True),
+                            score_sel, labels))
+        return results
+
+    def multiclass_nms_single(self, obj_scores, sem_scores, bbox, points, input_meta):
+        """Single-scene form with the reference's signature (:731-788)."""
+        boxes, classes, selected = self._nms_selection(
+            obj_scores.unsqueeze(0), sem_scores.unsqueeze(0), bbox.unsqueeze(0),
+            points[..., :3].unsqueeze(0))
+        return self._gather_selected(boxes[0], obj_scores, sem_scores, classes[0], selected[0])
 
     # ---- loss (:278-412) --------------------------------------------------------
     @staticmethod

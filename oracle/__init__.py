@@ -33,6 +33,9 @@ _SIGS = {
     "oracle_sort_vertices": [_I, _I, _I, _P, _P, _P, _P],
     "oracle_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P],
     "oracle_lhs_nms_samecls": [_I, _I, _P, _F, _P],
+    "oracle_aligned_3d_nms": [_I, _I, _P, _P, _P, _P, _F, _P, _P],
+    "oracle_points_in_boxes_count": [_I, _I, _I, _P, _P, _P],
+    "oracle_boxes_overlap_bev": [_I, _P, _I, _P, _P],
     "oracle_num_threads": [],
 }
 _lib = None
@@ -218,6 +221,26 @@ class OracleKernels:
         _cpu(boxes, keep)
         b, k, _ = boxes.shape
         lib().oracle_lhs_nms_samecls(b, k, boxes.data_ptr(), float(thr), keep.data_ptr())
+
+    def aligned_3d_nms(self, boxes, scores, classes, valid, thr, picks, count):
+        _cpu(boxes, scores, classes, picks, count)
+        b, k = scores.shape
+        if valid is not None:
+            _cpu(valid)
+        lib().oracle_aligned_3d_nms(b, k, boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(),
+                                    None if valid is None else valid.data_ptr(), float(thr),
+                                    picks.data_ptr(), count.data_ptr())
+
+    def points_in_boxes_count(self, boxes, pts, counts):
+        _cpu(boxes, pts, counts)
+        b, t, _ = boxes.shape
+        lib().oracle_points_in_boxes_count(b, t, pts.shape[1], boxes.data_ptr(), pts.data_ptr(),
+                                           counts.data_ptr())
+
+    def boxes_overlap_bev(self, boxes_a, boxes_b, ans_overlap):
+        _cpu(boxes_a, boxes_b, ans_overlap)
+        lib().oracle_boxes_overlap_bev(boxes_a.shape[0], boxes_a.data_ptr(), boxes_b.shape[0],
+                                       boxes_b.data_ptr(), ans_overlap.data_ptr())
 
     # dense-op stand-ins of the CPU path (PyTorch-CPU, first-index tie rule like ATen)
     def group_max_pool_forward(self, x, out, argmax):

@@ -528,3 +528,181 @@ int oracle_lhs_nms_samecls(int b, int k, const float *boxes, float thr, uint8_t 
   }
   return 1;
 }
+
+/* ------------------------------------------------------------------ */
+/* inference post-processing / evaluation geometry    */
+/* ------------------------------------------------------------------ */
+
+/* aligned_3d_nms (mmdet3d/core/post_processing/box3d_nms.py:129-176) as the python reads:
+ * a list of candidates in ascending score order; take the last, compute fp32 IoU with all
+ * the others (times the same-class flag), keep those with iou <= thr.  boxes (B,K,6),
+ * scores/classes (B,K), valid (B,K) u8 or NULL (the boolean-mask indexing of the caller,
+ * nesie_head.py:752-755); picks (B,K) = positions in pick order, -1 padded; count (B).
+ * PIN: tests/golden/inference_golden.pt holds the outputs of the reference function itself
+ * (imported by path) on seeded inputs without score ties.  torch.argsort leaves equal scores
+ * unordered; here they order by index (stable ascending sort; NaN scores sort last). */
+int oracle_aligned_3d_nms(int b, int k, const float *boxes, const float *scores,
+                          const int *classes, const uint8_t *valid, float thr, int *picks,
+                          int *count) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *bx = boxes + (size_t)bi * k * 6;
+    const float *sc = scores + (size_t)bi * k;
+    const int *cl = classes + (size_t)bi * k;
+    int *pk = picks + (size_t)bi * k;
+    int *list = (int *)malloc(sizeof(int) * (size_t)(k ? k : 1));
+    int n = 0, np = 0;
+    for (int i = 0; i < k; ++i) {
+      pk[i] = -1;
+      if (!valid || valid[(size_t)bi * k + i]) list[n++] = i;
+    }
+    for (int i = 1; i < n; ++i) { /* stable insertion sort, ascending; NaN = largest */
+      int v = list[i], j = i - 1;
+      float sv = sc[v];
+      while (j >= 0) {
+        float sj = sc[list[j]];
+        int greater = (sj != sj) ? (sv == sv) : (sv == sv && sj > sv);
+        if (!greater) break;
+        list[j + 1] = list[j];
+        --j;
+      }
+      list[j + 1] = v;
+    }
+    while (n > 0) {
+      const int i = list[n - 1];
+      pk[np++] = i;
+      const float ai = (bx[i*6+3] - bx[i*6+0]) * (bx[i*6+4] - bx[i*6+1]) * (bx[i*6+5] - bx[i*6+2]);
+      int w = 0;
+      for (int p = 0; p < n - 1; ++p) {
+        const int j = list[p];
+        float xx1 = fmaxf(bx[i*6+0], bx[j*6+0]), yy1 = fmaxf(bx[i*6+1], bx[j*6+1]);
+        float zz1 = fmaxf(bx[i*6+2], bx[j*6+2]), xx2 = fminf(bx[i*6+3], bx[j*6+3]);
+        float yy2 = fminf(bx[i*6+4], bx[j*6+4]), zz2 = fminf(bx[i*6+5], bx[j*6+5]);
+        float l = fmaxf(0.f, xx2 - xx1), wd = fmaxf(0.f, yy2 - yy1), h = fmaxf(0.f, zz2 - zz1);
+        float aj = (bx[j*6+3] - bx[j*6+0]) * (bx[j*6+4] - bx[j*6+1]) * (bx[j*6+5] - bx[j*6+2]);
+        float inter = l * wd * h;
+        float iou = inter / (ai + aj - inter);
+        iou = iou * (cl[i] == cl[j] ? 1.f : 0.f);
+        if (iou <= thr) list[w++] = j;
+      }
+      n = w;
+    }
+    count[bi] = np;
+    free(list);
+  }
+  return 1;
+}
+
+/* Column sums of points_in_boxes_batch: counts (B,T) (nesie_head.py:744-750). */
+int oracle_points_in_boxes_count(int b, int boxes_num, int pts_num, const float *boxes,
+                                 const float *pts, int *counts) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int k = 0; k < boxes_num; ++k) {
+      const float *bx = boxes + ((size_t)bi * boxes_num + k) * 7;
+      int c = 0;
+      for (int pi = 0; pi < pts_num; ++pi) c += pib_check(pts + ((size_t)bi * pts_num + pi) * 3, bx);
+      counts[(size_t)bi * boxes_num + k] = c;
+    }
+  return 1;
+}
+
+/* Rotated BEV overlap area, iou3d_kernel.cu:127-238 (box_overlap) with its helpers
+ * (:36-125).  The CUDA source cannot be built here (no nvcc; UNBUILDABLE), and the reference
+ * ships no vectors for it: PIN = analytic cases only (tests/test_postprocess_cpu.py:
+ * axis-aligned rectangles, identical boxes, a square turned by 45 degrees, symmetry).
+ * cos / sin / atan2 in double rounded to float (canonical form shared with the HIP kernel). */
+typedef struct { float x, y; } op2;
+
+static float ov_cross3(op2 p1, op2 p2, op2 p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+static int ov_crossing(op2 p1, op2 p0, op2 q1, op2 q0, op2 *ans) {
+  if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+        fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+    return 0;
+  float s1 = ov_cross3(q0, p1, p0), s2 = ov_cross3(p1, q1, p0);
+  float s3 = ov_cross3(p0, q1, q0), s4 = ov_cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  float s5 = ov_cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+static op2 ov_turn(float px, float py, float cx, float cy, float c, float s) {
+  op2 r;
+  r.x = (px - cx) * c + (py - cy) * s + cx;
+  r.y = -(px - cx) * s + (py - cy) * c + cy;
+  return r;
+}
+
+static void ov_corners(const float *b, op2 *c, float *cx, float *cy, float *ca, float *sa) {
+  *cx = (b[0] + b[2]) / 2; *cy = (b[1] + b[3]) / 2;
+  *ca = (float)cos((double)b[4]); *sa = (float)sin((double)b[4]);
+  c[0] = ov_turn(b[0], b[1], *cx, *cy, *ca, *sa);
+  c[1] = ov_turn(b[2], b[1], *cx, *cy, *ca, *sa);
+  c[2] = ov_turn(b[2], b[3], *cx, *cy, *ca, *sa);
+  c[3] = ov_turn(b[0], b[3], *cx, *cy, *ca, *sa);
+  c[4] = c[0];
+}
+
+static int ov_inside(const float *b, float cx, float cy, float ca, float sa, op2 p) {
+  const float M = 1e-5f;
+  op2 q = ov_turn(p.x, p.y, cx, cy, ca, -sa); /* cos(-a), sin(-a) */
+  return q.x > b[0] - M && q.x < b[2] + M && q.y > b[1] - M && q.y < b[3] + M;
+}
+
+static float ov_box_overlap(const float *a, const float *b) {
+  op2 ca[5], cb[5], pts[16];
+  float ang[16];
+  float acx, acy, aco, asi, bcx, bcy, bco, bsi;
+  ov_corners(a, ca, &acx, &acy, &aco, &asi);
+  ov_corners(b, cb, &bcx, &bcy, &bco, &bsi);
+  int cnt = 0;
+  float sx = 0.f, sy = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      op2 hit;
+      if (ov_crossing(ca[i + 1], ca[i], cb[j + 1], cb[j], &hit)) {
+        sx = sx + hit.x; sy = sy + hit.y; pts[cnt++] = hit;
+      }
+    }
+  for (int k = 0; k < 4; ++k) {
+    if (ov_inside(a, acx, acy, aco, asi, cb[k])) { sx = sx + cb[k].x; sy = sy + cb[k].y; pts[cnt++] = cb[k]; }
+    if (ov_inside(b, bcx, bcy, bco, bsi, ca[k])) { sx = sx + ca[k].x; sy = sy + ca[k].y; pts[cnt++] = ca[k]; }
+  }
+  if (cnt == 0) return 0.f;
+  float mx = sx / cnt, my = sy / cnt;
+  for (int i = 0; i < cnt; ++i) ang[i] = (float)atan2((double)(pts[i].y - my), (double)(pts[i].x - mx));
+  /* the reference's bubble passes: swap neighbours while angle[i] > angle[i+1] */
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (ang[i] > ang[i + 1]) {
+        op2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+        float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y;
+    float bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+    area += ax * by - ay * bx;
+  }
+  return (float)(fabsf(area) / 2.0);
+}
+
+int oracle_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                             float *out) {
+  for (int i = 0; i < num_a; ++i)
+    for (int j = 0; j < num_b; ++j)
+      out[(size_t)i * num_b + j] = ov_box_overlap(boxes_a + (size_t)i * 5, boxes_b + (size_t)j * 5);
+  return 1;
+}

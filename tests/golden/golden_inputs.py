@@ -151,3 +151,84 @@ def aug_metas():
                         rot_mat=rot, scale=0.9 + 0.2 * torch.rand(3, generator=g),
                         trans=torch.randn(3, 3, generator=g) * 0.1))
     return out  # [teacher, student]
+
+
+# ---- test path: NMS, corners, get_bboxes, indoor_eval ---------------------------------------
+def aligned_nms_cases():
+    """boxes (3,96,6) in clusters (heavy same-class overlap), scores without ties, classes."""
+    g = torch.Generator().manual_seed(31)
+    c = torch.rand(3, 10, 3, generator=g) * 5
+    centre = c[:, torch.arange(96) % 10] + (torch.rand(3, 96, 3, generator=g) - 0.5) * 0.5
+    half = 0.25 + torch.rand(3, 96, 3, generator=g) * 0.5
+    boxes = torch.cat([centre - half, centre + half], -1)
+    boxes[2, 90:] = boxes[2, 90:91]               # identical boxes
+    boxes[1, 7, 3:] = boxes[1, 7, :3]             # a degenerate (zero-volume) box
+    scores = torch.rand(3, 96, generator=g)
+    classes = torch.randint(0, 4, (3, 96), generator=g)
+    return boxes, scores, classes
+
+
+def corner_boxes():
+    g = torch.Generator().manual_seed(32)
+    b = torch.cat([torch.randn(40, 3, generator=g) * 2, 0.2 + torch.rand(40, 3, generator=g) * 2,
+                   (torch.rand(40, 1, generator=g) - 0.5) * 6.2], -1)
+    b[:5, 6] = 0
+    return b
+
+
+def detect_inputs():
+    """points (3,4096,4) and a prediction dict (K = 64 proposals): gravity-centre boxes around
+    the scene's GT boxes (some far away = empty), peaked class scores, random objectness and
+    per-class IoU scores."""
+    pts, gts, _ = make_batch(78, 3, num_points=4096)
+    g = torch.Generator().manual_seed(33)
+    B, K, C = 3, 64, 18
+    boxes = []
+    for b in range(B):
+        gt = gts[b]
+        pick = torch.arange(K) % gt.shape[0]
+        centre = gt[pick, :3].clone()
+        centre[:, 2] += gt[pick, 5] * 0.5
+        centre += torch.randn(K, 3, generator=g) * 0.08
+        size = gt[pick, 3:6] * (0.7 + 0.6 * torch.rand(K, 3, generator=g))
+        yaw = gt[pick, 6:7] + (torch.rand(K, 1, generator=g) - 0.5) * 0.3
+        centre[K - 6:] += 40.0                                    # off-scene proposals: empty
+        boxes.append(torch.cat([centre, size, yaw], -1))
+    sem = torch.randn(B, K, C, generator=g)
+    sem.scatter_(2, torch.randint(0, 3, (B, K, 1), generator=g), 4.0)
+    obj = torch.randn(B, K, 2, generator=g) * 2
+    iou = torch.rand(B, K, C, generator=g)
+    return pts, dict(bbox_preds=torch.stack(boxes), sem_scores=sem, obj_scores=obj,
+                     iou_scores=iou)
+
+
+def eval_annos():
+    """6 scenes, 5 classes (class 4 is predicted but has no ground truth; scene 3 has no GT):
+    gt_annos in the dataset's form, detections as (boxes (n,7) bottom-origin, scores, labels)."""
+    g = torch.Generator().manual_seed(34)
+    gt_annos, dets = [], []
+    for s in range(6):
+        n = 0 if s == 3 else 3 + s
+        centre = torch.rand(n, 3, generator=g) * torch.tensor([5.0, 5.0, 1.0])
+        size = 0.4 + torch.rand(n, 3, generator=g)
+        yaw = (torch.rand(n, 1, generator=g) - 0.5) * 2.0
+        cls = torch.randint(0, 4, (n,), generator=g)
+        gt = torch.cat([centre, size, yaw], -1)
+        gt_annos.append(dict(gt_num=n, gt_boxes_upright_depth=gt.numpy().copy(),
+                             **{'class': cls.numpy().copy()}))
+        m = 2 * n + 4
+        src = torch.arange(m) % max(n, 1)
+        if n:
+            dc = centre[src] + torch.randn(m, 3, generator=g) * 0.12
+            ds = size[src] * (0.8 + 0.4 * torch.rand(m, 3, generator=g))
+            dy = yaw[src] + torch.randn(m, 1, generator=g) * 0.15
+            dl = cls[src].clone()
+        else:
+            dc = torch.rand(m, 3, generator=g) * 5
+            ds = 0.4 + torch.rand(m, 3, generator=g)
+            dy = torch.zeros(m, 1)
+            dl = torch.randint(0, 4, (m,), generator=g)
+        dl[-2:] = torch.tensor([4, (s % 4)])
+        dc[:, 2] -= ds[:, 2] * 0.5                                 # detections are bottom-origin
+        dets.append((torch.cat([dc, ds, dy], -1), torch.rand(m, generator=g), dl))
+    return gt_annos, dets

@@ -313,6 +313,99 @@ def semi_goldens():
     return out
 
 
+def inference_goldens():
+    """The reference's test path, run from its own files (call after semi_goldens(), which
+    installs the reference's DepthInstance3DBoxes):
+      * core/post_processing/box3d_nms.py::aligned_3d_nms (numba / iou3d imports stubbed:
+        the function itself is plain torch);
+      * DepthInstance3DBoxes.corners / .overlaps (base_box3d.py, depth_box3d.py) -- the CUDA op
+        behind overlaps (`iou3d_cuda.boxes_overlap_bev_gpu`, not buildable here) is served by
+        the oracle's restatement, so the overlap AREAS are ours and everything around them is
+        the reference's;
+      * NesieHead.get_bboxes / multiclass_nms_single (nesie_head.py:681-788);
+      * core/evaluation/indoor_eval.py::indoor_eval, with the same stand-in for the BEV op.
+    Writes tests/golden/inference_golden.pt."""
+    r = os.path.join(REF, 'mmdet3d')
+    core = sys.modules['mmdet3d.core']
+    RefBoxes = core.DepthInstance3DBoxes
+    assert RefBoxes.__module__.startswith('mmdet3d.core.bbox.structures')
+
+    class _Iou3dCuda:
+        @staticmethod
+        def boxes_overlap_bev_gpu(a, b, out):
+            oracle.OracleKernels().boxes_overlap_bev(a.contiguous().float(), b.contiguous().float(), out)
+    sys.modules['mmdet3d.ops.iou3d'].iou3d_cuda = _Iou3dCuda
+    sys.modules['mmdet3d.core.bbox.structures.base_box3d'].iou3d_cuda = _Iou3dCuda
+    _mod('numba', jit=lambda *a, **k: (lambda f: f))
+    _mod('mmdet3d.ops.roiaware_pool3d', points_in_boxes_gpu=None, points_in_boxes_cpu=None,
+         points_in_boxes_batch=my_ops.points_in_boxes_batch)
+    _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=None, nms_normal_gpu=None)
+    sys.modules['mmdet3d.core.post_processing'].__path__ = [os.path.join(r, 'core', 'post_processing')]
+    nms_mod = importlib.import_module('mmdet3d.core.post_processing.box3d_nms')
+    out = {}
+    # (a) aligned_3d_nms
+    boxes, scores, classes = golden_inputs.aligned_nms_cases()
+    for i in range(boxes.shape[0]):
+        out[f'nms/picks/{i}'] = nms_mod.aligned_3d_nms(boxes[i], scores[i], classes[i], 0.25).clone()
+    # the masked form of the head: only a subset takes part
+    sub = torch.arange(96) % 3 != 0
+    out['nms/picks_masked'] = nms_mod.aligned_3d_nms(boxes[0][sub], scores[0][sub],
+                                                     classes[0][sub], 0.25).clone()
+    # (b) corners
+    out['boxes/corners'] = RefBoxes(golden_inputs.corner_boxes()).corners.clone()
+    # (c) get_bboxes through the reference head class (no weights involved)
+    head_mod = sys.modules['mmdet3d.models.dense_heads.nesie_head']
+    head_mod.aligned_3d_nms = nms_mod.aligned_3d_nms
+    head = head_mod.NesieHead.__new__(head_mod.NesieHead)
+    nn.Module.__init__(head)
+    head.num_classes = 18
+    pts, preds = golden_inputs.detect_inputs()
+    metas = [dict(box_type_3d=RefBoxes) for _ in range(pts.shape[0])]
+    for per_class in (True, False):
+        head.test_cfg = types.SimpleNamespace(nms_thr=0.25, score_thr=0.05,
+                                              per_class_proposal=per_class)
+        res = head.get_bboxes(pts, {k: v.clone() for k, v in preds.items()}, metas)
+        tag = 'per_class' if per_class else 'single'
+        for b, (bx, sc, lb) in enumerate(res):
+            out[f'det/{tag}/boxes/{b}'] = bx.tensor.clone()
+            out[f'det/{tag}/scores/{b}'] = sc.clone()
+            out[f'det/{tag}/labels/{b}'] = lb.clone()
+    # (d) overlaps + indoor_eval
+    _mod('terminaltables', AsciiTable=type('AsciiTable', (), {
+        '__init__': lambda self, data: setattr(self, 'table', ''), }))
+    sys.modules['mmcv.utils'].print_log = lambda *a, **k: None
+    sys.modules['mmdet3d.core'].__path__ = [os.path.join(r, 'core')]
+    _pkg('mmdet3d.core.evaluation', os.path.join(r, 'core', 'evaluation'))
+    ev = importlib.import_module('mmdet3d.core.evaluation.indoor_eval')
+    gt_annos, dets = golden_inputs.eval_annos()
+    dt_annos = [dict(boxes_3d=RefBoxes(b.clone()), scores_3d=s.clone(), labels_3d=l.clone())
+                for b, s, l in dets]
+    gt0 = RefBoxes(torch.from_numpy(gt_annos[5]['gt_boxes_upright_depth']), origin=(0.5, 0.5, 0.5))
+    out['eval/overlaps_scene5'] = RefBoxes.overlaps(dt_annos[5]['boxes_3d'], gt0).clone()
+    label2cat = {i: f'cat{i}' for i in range(5)}
+    ret = ev.indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat, box_type_3d=RefBoxes,
+                         box_mode_3d=2)
+    out['eval/keys'] = sorted(ret.keys())
+    out['eval/values'] = torch.tensor([ret[k] for k in sorted(ret.keys())], dtype=torch.float64)
+    # the same detections with the GT-less class 4 relabelled: finite means
+    for d in dt_annos:
+        d['labels_3d'] = torch.where(d['labels_3d'] == 4, torch.zeros_like(d['labels_3d']), d['labels_3d'])
+    ret = ev.indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat, box_type_3d=RefBoxes,
+                         box_mode_3d=2)
+    out['eval4/keys'] = sorted(ret.keys())
+    out['eval4/values'] = torch.tensor([ret[k] for k in sorted(ret.keys())], dtype=torch.float64)
+    ap = ev.average_precision(np.array([[0.1, 0.4, 0.4, 0.9], [0.2, 0.2, 0.5, 1.0]]),
+                              np.array([[1.0, 0.5, 0.66, 0.3], [0.9, 0.95, 0.4, 0.2]]))
+    out['eval/ap_area'] = torch.from_numpy(ap.copy())
+    path = os.path.join(ROOT, 'tests', 'golden', 'inference_golden.pt')
+    torch.save(out, path)
+    print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'entries')
+    for k in sorted(ret):
+        if k.startswith('m'):
+            print(k, ret[k])
+    return out
+
+
 def main():
     ref_head_mod = install_reference_sandbox()
     out = {}
@@ -411,6 +504,10 @@ def main():
         vm = out.pop('head/target/vote_target_masks')
         out['head/target/vote_target_masks_sum'] = vm.sum()
         out.update(semi_goldens())
+        if '--keep-head' not in sys.argv:
+            inference_goldens()
+    if '--inference-only' in sys.argv:
+        return
     path = os.path.join(ROOT, 'tests', 'golden', 'nesie_head_golden.pt')
     torch.save(out, path)
     print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'entries')

@@ -1,0 +1,176 @@
+"""Test path on the MI355X: the HIP kernels behind aligned_3d_nms, the
+per-box point count and the rotated BEV overlap against the CPU oracle through the C ABI, the
+head's get_bboxes against the reference's golden outputs, and simple_test end to end."""
+import copy
+import os
+
+import pytest
+import torch
+
+from nesie_amd import evaluation, kernels, post_processing
+from nesie_amd.mmdet3d_ops import boxes_overlap_bev, points_in_boxes_count
+from nesie_amd.votenet.boxes import DepthInstance3DBoxes
+from tests import _small
+from tests.golden import golden_inputs
+from tests.test_postprocess_cpu import _bare_head, _dt_annos
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "inference_golden.pt")
+
+
+def _nms_case(seed, b, k, classes=3, ties=False, nan=False):
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.rand(b, max(k // 6, 1), 3, generator=g) * 4
+    c = centres[:, torch.arange(k) % centres.shape[1]] + (torch.rand(b, k, 3, generator=g) - 0.5) * 0.5
+    h = 0.2 + torch.rand(b, k, 3, generator=g) * 0.5
+    boxes = torch.cat([c - h, c + h], -1)
+    scores = torch.rand(b, k, generator=g)
+    if ties:
+        scores = (scores * 8).floor() / 8          # many equal scores
+    if nan:
+        scores[:, 3] = float("nan")
+        boxes[:, 5, 3:] = boxes[:, 5, :3]          # zero-volume boxes
+        boxes[:, 6] = boxes[:, 5]
+    cls = torch.randint(0, classes, (b, k), generator=g)
+    valid = torch.rand(b, k, generator=g) > 0.3
+    return boxes, scores, cls, valid
+
+
+@pytest.mark.parametrize("k,ties,nan", [(1, False, False), (64, False, False), (63, True, False),
+                                        (256, False, True), (300, True, False), (512, False, False)])
+def test_aligned_nms_bit_exact_vs_oracle(oracle_kernels, hip_device, k, ties, nan):
+    boxes, scores, cls, valid = _nms_case(100 + k, 5, k, ties=ties, nan=nan)
+    for mask in (None, valid):
+        with kernels.use_backend(oracle_kernels):
+            want_p, want_c = post_processing.batched_aligned_3d_nms(boxes, scores, cls, 0.25, valid=mask)
+        got_p, got_c = post_processing.batched_aligned_3d_nms(
+            boxes.to(hip_device), scores.to(hip_device), cls.to(hip_device), 0.25,
+            valid=None if mask is None else mask.to(hip_device))
+        assert torch.equal(got_c.cpu(), want_c)
+        assert torch.equal(got_p.cpu(), want_p)
+        assert int(want_c.min()) >= (1 if mask is None else 0) and int(want_c.max()) <= k
+
+
+def test_aligned_nms_reference_outputs_and_limits(hip_device):
+    gold = torch.load(GOLD)
+    boxes, scores, classes = golden_inputs.aligned_nms_cases()
+    for i in range(3):
+        got = post_processing.aligned_3d_nms(boxes[i].to(hip_device), scores[i].to(hip_device),
+                                             classes[i].to(hip_device), 0.25)
+        assert got.dtype == torch.long and got.is_cuda
+        assert torch.equal(got.cpu(), gold[f"nms/picks/{i}"])
+    with pytest.raises(RuntimeError, match="built for <= 512"):
+        post_processing.batched_aligned_3d_nms(torch.zeros(1, 513, 6, device=hip_device),
+                                               torch.zeros(1, 513, device=hip_device),
+                                               torch.zeros(1, 513, dtype=torch.long, device=hip_device), 0.25)
+    with pytest.raises(RuntimeError, match="HIP"):
+        post_processing.aligned_3d_nms(boxes[0], scores[0], classes[0], 0.25)   # CPU tensors
+
+
+@pytest.mark.parametrize("b,m,t", [(1, 100, 1), (3, 5000, 37), (2, 40000, 256), (2, 777, 300)])
+def test_points_in_boxes_count_bit_exact_vs_oracle(oracle_kernels, hip_device, b, m, t):
+    g = torch.Generator().manual_seed(b * 1000 + t)
+    pts = torch.randn(b, m, 3, generator=g) * 1.5
+    boxes = torch.cat([torch.randn(b, t, 3, generator=g), 0.3 + 1.5 * torch.rand(b, t, 3, generator=g),
+                       (torch.rand(b, t, 1, generator=g) - 0.5) * 6], -1)
+    with kernels.use_backend(oracle_kernels):
+        want = points_in_boxes_count(pts, boxes)
+    got = points_in_boxes_count(pts.to(hip_device), boxes.to(hip_device))
+    assert torch.equal(got.cpu(), want)
+    assert int(want.sum()) > 0
+
+
+def test_boxes_overlap_bev_vs_oracle(oracle_kernels, hip_device):
+    g = torch.Generator().manual_seed(77)
+
+    def rects(n, aligned=False):
+        c = torch.rand(n, 2, generator=g) * 4
+        h = 0.2 + torch.rand(n, 2, generator=g)
+        ang = torch.zeros(n, 1) if aligned else (torch.rand(n, 1, generator=g) - 0.5) * 6.3
+        return torch.cat([c - h, c + h, ang], -1)
+    for a, b in [(rects(150), rects(130)), (rects(64, True), rects(64, True)), (rects(1), rects(1))]:
+        b[0] = a[0]                                  # an identical pair
+        with kernels.use_backend(oracle_kernels):
+            want = boxes_overlap_bev(a, b)
+        got = boxes_overlap_bev(a.to(hip_device), b.to(hip_device)).cpu()
+        # the same fp32 formulas on both sides; libm vs device cos/sin/atan2 (double, rounded
+        # to float) may differ in the last place
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+        assert (got == want).float().mean().item() > 0.99
+    assert boxes_overlap_bev(torch.zeros(0, 5, device=hip_device), rects(3).to(hip_device)).shape == (0, 3)
+
+
+@pytest.mark.parametrize("per_class", [True, False])
+def test_get_bboxes_matches_reference_on_gpu(hip_device, per_class):
+    gold = torch.load(GOLD)
+    pts, preds = golden_inputs.detect_inputs()
+    head = _bare_head(per_class)
+    res = head.get_bboxes(pts.to(hip_device), {k: v.to(hip_device) for k, v in preds.items()},
+                          [dict(box_type_3d=DepthInstance3DBoxes)] * 3)
+    tag = "per_class" if per_class else "single"
+    for b, (bx, sc, lb) in enumerate(res):
+        assert bx.tensor.is_cuda
+        torch.testing.assert_close(bx.tensor.cpu(), gold[f"det/{tag}/boxes/{b}"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(sc.cpu(), gold[f"det/{tag}/scores/{b}"], rtol=1e-5, atol=1e-7)
+        assert torch.equal(lb.cpu(), gold[f"det/{tag}/labels/{b}"])
+
+
+@pytest.mark.parametrize("relabel", [False, True])
+def test_indoor_eval_matches_reference_on_gpu(hip_device, relabel):
+    """Host-resident annotations; `overlaps` takes them to the GPU for the BEV op."""
+    gold = torch.load(GOLD)
+    gt_annos, dt = _dt_annos(relabel)
+    ret = evaluation.indoor_eval(gt_annos, dt, (0.25, 0.5), {i: f"cat{i}" for i in range(5)},
+                                 logger="silent")
+    tag = "eval4" if relabel else "eval"
+    assert sorted(ret.keys()) == gold[f"{tag}/keys"]
+    got = torch.tensor([ret[k] for k in sorted(ret.keys())], dtype=torch.float64)
+    torch.testing.assert_close(got, gold[f"{tag}/values"], rtol=1e-6, atol=1e-7, equal_nan=True)
+
+
+def test_simple_test_end_to_end(oracle_kernels, hip_device):
+    """Eval-mode forward on the GPU against the CPU oracle path (running BatchNorm statistics,
+    un-grouped MiniPointNets), then NMS on both sides from the SAME predictions."""
+    model = _small.small_model()
+    model.test_cfg['sample_mod'] = 'seed'
+    pts, boxes, labels = _small.small_batch()
+    # a few training-mode forwards so that the running statistics are not the initial ones
+    gmodel = copy.deepcopy(model).to(hip_device)
+    gmodel.train()
+    gmodel.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
+    with torch.no_grad():
+        for _ in range(2):
+            x = gmodel.extract_feat(pts.to(hip_device))
+            gmodel.bbox_head(x, 'vote')
+    gmodel.eval()
+    cmodel = copy.deepcopy(gmodel).cpu()
+    cmodel.bbox_head.jitter_noise = gmodel.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
+    with torch.no_grad():
+        got = gmodel.bbox_head(gmodel.extract_feat(pts.to(hip_device)), 'seed')
+        with kernels.use_backend(oracle_kernels):
+            want = cmodel.bbox_head(cmodel.extract_feat(pts), 'seed')
+    for k in ['bbox_preds', 'obj_scores', 'sem_scores', 'iou_scores', 'side_scores']:
+        torch.testing.assert_close(got[k].cpu(), want[k], rtol=1e-3, atol=2e-4, msg=k)
+    # decisions (NMS, thresholds) from identical numbers: the GPU predictions on both sides
+    host = {k: v.cpu() for k, v in got.items() if torch.is_tensor(v)}
+    res_g = gmodel.bbox_head.get_bboxes(pts.to(hip_device), got, None)
+    with kernels.use_backend(oracle_kernels):
+        res_c = cmodel.bbox_head.get_bboxes(pts, host, None)
+    for (bg, sg, lg), (bc, sc, lc) in zip(res_g, res_c):
+        assert bg.tensor.shape == bc.tensor.shape and bg.tensor.shape[0] > 0
+        torch.testing.assert_close(bg.tensor.cpu(), bc.tensor, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(sg.cpu(), sc, rtol=1e-5, atol=1e-7)
+        assert torch.equal(lg.cpu(), lc)
+    out = gmodel.simple_test([p for p in pts.to(hip_device)], [dict(), dict()])
+    assert len(out) == 2
+    for r in out:
+        assert set(r) == {'boxes_3d', 'scores_3d', 'labels_3d'}
+        assert not r['scores_3d'].is_cuda and not r['boxes_3d'].tensor.is_cuda
+        assert r['boxes_3d'].tensor.shape[0] == r['scores_3d'].shape[0] == r['labels_3d'].shape[0]
+    # and the metric runs on what simple_test returns
+    gt_annos = [dict(gt_num=len(b), gt_boxes_upright_depth=torch.cat(
+        [b[:, :2], b[:, 2:3] + b[:, 5:6] / 2, b[:, 3:]], 1).numpy(), **{'class': l.numpy()})
+        for b, l in zip(boxes, labels)]
+    ret = evaluation.indoor_eval(gt_annos, out, (0.25, 0.5), {i: str(i) for i in range(18)},
+                                 logger="silent")
+    assert 'mAP_0.25' in ret and 'mAR_0.50' in ret
