@@ -1,0 +1,74 @@
+"""Test-path timing at the full config (8 scenes x 40 000 points): eval-mode forward,
+get_bboxes (point count + NMS + selection), and the reference-style per-scene python NMS
+(the literal loop of box3d_nms.py:129-176 written with torch ops on the device) beside it."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from nesie_amd.scenes import make_batch
+from nesie_amd.votenet import build_nesie_votenet
+from nesie_amd import post_processing
+
+
+def loop_nms(boxes, scores, classes, thresh):
+    area = (boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2])
+    order = torch.argsort(scores)
+    zero = boxes.new_zeros(1)
+    pick = []
+    while order.shape[0] != 0:
+        i = order[-1]
+        pick.append(i)
+        rest = order[:-1]
+        lo = torch.max(boxes[i, :3], boxes[rest, :3])
+        hi = torch.min(boxes[i, 3:], boxes[rest, 3:])
+        d = torch.max(zero, hi - lo)
+        inter = d[:, 0] * d[:, 1] * d[:, 2]
+        iou = inter / (area[i] + area[rest] - inter) * (classes[i] == classes[rest]).float()
+        order = rest[torch.nonzero(iou <= thresh, as_tuple=False).flatten()]
+    return torch.stack(pick)
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+def main():
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = build_nesie_votenet().to(dev)
+    pts, _, _ = make_batch(1, 8)
+    pts = pts.to(dev)
+    model.train()
+    with torch.no_grad():
+        model.bbox_head(model.extract_feat(pts), 'vote')   # move the running statistics
+    model.eval()
+    with torch.no_grad():
+        preds = model.bbox_head(model.extract_feat(pts), 'seed')
+        fwd = timed(lambda: model.bbox_head(model.extract_feat(pts), 'seed'))
+        post = timed(lambda: model.bbox_head.get_bboxes(pts, preds, None))
+        whole = timed(lambda: model.simple_test(pts, None))
+    g = torch.Generator().manual_seed(1)
+    c = torch.rand(8, 256, 3, generator=g) * 4
+    h = 0.2 + torch.rand(8, 256, 3, generator=g) * 0.5
+    boxes = torch.cat([c - h, c + h], -1).to(dev)
+    scores, classes = torch.rand(8, 256, generator=g).to(dev), torch.randint(0, 18, (8, 256), generator=g).to(dev)
+    ours = timed(lambda: post_processing.batched_aligned_3d_nms(boxes, scores, classes, 0.25), 50)
+    loop = timed(lambda: [loop_nms(boxes[b], scores[b], classes[b], 0.25) for b in range(8)], 3)
+    print(f'eval forward (8 x 40k)      {fwd:8.2f} ms')
+    print(f'get_bboxes                   {post:8.2f} ms')
+    print(f'simple_test                  {whole:8.2f} ms  = {8e3 / whole:.0f} scenes/s')
+    print(f'aligned_3d_nms, 8 x 256      {ours:8.3f} ms (one launch)  vs  {loop:8.1f} ms python loop of torch ops')
+
+
+if __name__ == '__main__':
+    main()
