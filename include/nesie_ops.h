@@ -360,6 +360,23 @@ int nesie_points_in_boxes_count(int b, int boxes_num, int pts_num, const float *
 int nesie_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                             float *ans_overlap, void *stream);
 
+/* ---- input side ---------------------------------------------------------- */
+
+/* One training batch from HBM-resident scenes: the reference's per-sample CPU pipeline
+ * IndoorPointSample -> RandomFlip3D -> GlobalRotScaleTrans after GlobalAlignment
+ * (datasets/pipelines/transforms_3d.py:821-891, 59-162, 497-648, 410-488) in one gather pass.
+ *   pool    (pool_rows, 3) f32  raw xyz of all resident scenes, back to back
+ *   height  (pool_rows)    f32  shifted height z - percentile(z, 0.99) (loading.py:424-430)
+ *   choices (B, n)         i32  sampled rows of the pool (np.random.choice + scene offset)
+ *   xform   (B, 20)        f32  per scene: axis-align R[9] row-major, t[3]; flip_x, flip_y
+ *                               (-1 = flipped, +1 = not); cos, sin of the rotation noise;
+ *                               scale; trans[3]
+ *   out     (B, n, 4)      f32  (x, y, z, height) as DefaultFormatBundle3D hands them on
+ * out = ((flip(p R^T + t)) [[c, s, 0], [-s, c, 0], [0, 0, 1]]) * scale + trans; height * scale. */
+int nesie_scene_assemble(int b, int n, long long pool_rows, const float *pool,
+                         const float *height, const int *choices, const float *xform,
+                         float *out, void *stream);
+
 /* One shared-MLP layer of a grouped MLP on the matrix cores.  No extension entry in the
  * reference: it evaluates mmcv ConvModule(Conv2d 1x1 -> BN2d -> ReLU) op by op
  * (point_sa_module.py:277-289, side_pooling_module.py:346-358).

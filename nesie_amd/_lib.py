@@ -37,6 +37,7 @@ SIGNATURES = {
     "nesie_aligned_3d_nms": [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P],
     "nesie_points_in_boxes_count": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],
+    "nesie_scene_assemble": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P],
     "nesie_grid_taps": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                  _P, _P],

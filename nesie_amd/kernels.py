@@ -287,6 +287,16 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_boxes_overlap_bev", n, _ptr(boxes_a), m, _ptr(boxes_b),
                       _ptr(ans_overlap), _stream(boxes_a))
 
+    def scene_assemble(self, pool, height, choices, xform, out):
+        """pool (R,3), height (R), choices (B,n) i32 rows of the pool, xform (B,20) -> out (B,n,4)."""
+        _check(pool, height, choices, xform, out); _f32(pool, height, xform, out); _i32(choices)
+        b, n = choices.shape
+        assert pool.dim() == 2 and pool.shape[1] == 3 and height.numel() == pool.shape[0]
+        assert tuple(xform.shape) == (b, 20) and tuple(out.shape) == (b, n, 4)
+        with torch.cuda.device(pool.device):
+            _lib.call("nesie_scene_assemble", b, n, pool.shape[0], _ptr(pool), _ptr(height),
+                      _ptr(choices), _ptr(xform), _ptr(out), _stream(pool))
+
     def grid_taps(self, centre, size, heading, mult, plane, known):
         """-> idx (B,K*gp,3) int32, weight, rel (B,K*gp,3) for the gp grid points per proposal."""
         _check(centre, size, heading, mult, plane, known)

@@ -36,6 +36,7 @@ _SIGS = {
     "oracle_aligned_3d_nms": [_I, _I, _P, _P, _P, _P, _F, _P, _P],
     "oracle_points_in_boxes_count": [_I, _I, _I, _P, _P, _P],
     "oracle_boxes_overlap_bev": [_I, _P, _I, _P, _P],
+    "oracle_scene_assemble": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "oracle_num_threads": [],
 }
 _lib = None
@@ -241,6 +242,12 @@ class OracleKernels:
         _cpu(boxes_a, boxes_b, ans_overlap)
         lib().oracle_boxes_overlap_bev(boxes_a.shape[0], boxes_a.data_ptr(), boxes_b.shape[0],
                                        boxes_b.data_ptr(), ans_overlap.data_ptr())
+
+    def scene_assemble(self, pool, height, choices, xform, out):
+        _cpu(pool, height, choices, xform, out)
+        b, n = choices.shape
+        lib().oracle_scene_assemble(b, n, pool.shape[0], pool.data_ptr(), height.data_ptr(),
+                                    choices.data_ptr(), xform.data_ptr(), out.data_ptr())
 
     # dense-op stand-ins of the CPU path (PyTorch-CPU, first-index tie rule like ATen)
     def group_max_pool_forward(self, x, out, argmax):

@@ -706,3 +706,47 @@ int oracle_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const f
       out[(size_t)i * num_b + j] = ov_box_overlap(boxes_a + (size_t)i * 5, boxes_b + (size_t)j * 5);
   return 1;
 }
+
+/* ------------------------------------------------------------------ */
+/* input side: batch assembly                         */
+/* ------------------------------------------------------------------ */
+
+/* The reference's per-sample pipeline on the points of one batch, in its order
+ * (configs/Nesie/nesie-votenet-scannet-pretrain-010.py:151-196):
+ *   GlobalAlignment   transforms_3d.py:465-488 -> points.rotate(R^T): p @ R^T, then + t
+ *                     (base_points.py:173-177, 186-205); the height column is left alone
+ *   IndoorPointSample :865-891   rows `choices`
+ *   RandomFlip3D      :143-161   x = -x (horizontal), y = -y (vertical) (depth_points.py:28-33)
+ *   GlobalRotScaleTrans :560-648 p @ [[c,-s,0],[s,c,0],[0,0,1]]^T, xyz and height * scale,
+ *                     xyz + trans
+ * xform (B,20) = R[9] t[3] | flip_x flip_y (-1/+1) | cos sin | scale | trans[3].
+ * PIN: tests/golden/input_golden.pt = outputs of the reference's own transform classes
+ * (loaded by path) on seeded scenes; agreement to float rounding (the reference multiplies
+ * (N,3) by (3,3) through torch's matmul, whose summation order / FMA use is the BLAS's). */
+int oracle_scene_assemble(int b, int n, long long pool_rows, const float *pool,
+                          const float *height, const int *choices, const float *xform,
+                          float *out) {
+  for (int bi = 0; bi < b; ++bi) {
+    const float *xf = xform + (size_t)bi * 20;
+    for (int i = 0; i < n; ++i) {
+      long long src = choices[(size_t)bi * n + i];
+      if (src < 0) src = 0;
+      if (src >= pool_rows) src = pool_rows - 1;
+      const float x = pool[src * 3], y = pool[src * 3 + 1], z = pool[src * 3 + 2];
+      float ax = ((x * xf[0] + y * xf[1]) + z * xf[2]) + xf[9];
+      float ay = ((x * xf[3] + y * xf[4]) + z * xf[5]) + xf[10];
+      float az = ((x * xf[6] + y * xf[7]) + z * xf[8]) + xf[11];
+      if (xf[12] < 0.f) ax = -ax;
+      if (xf[13] < 0.f) ay = -ay;
+      const float c = xf[14], s = xf[15], sc = xf[16];
+      const float rx = ax * c + ay * (-s);
+      const float ry = ax * s + ay * c;
+      float *o = out + ((size_t)bi * n + i) * 4;
+      o[0] = rx * sc + xf[17];
+      o[1] = ry * sc + xf[18];
+      o[2] = az * sc + xf[19];
+      o[3] = height[src] * sc;
+    }
+  }
+  return 1;
+}

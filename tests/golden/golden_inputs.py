@@ -232,3 +232,37 @@ def eval_annos():
         dc[:, 2] -= ds[:, 2] * 0.5                                 # detections are bottom-origin
         dets.append((torch.cat([dc, ds, dy], -1), torch.rand(m, generator=g), dl))
     return gt_annos, dets
+
+
+# ---- input side: raw scenes for the loading / augmentation pipeline ------------------------
+INPUT_CASES = [
+    # name, seed, raw points, sampled, with_yaw, rot_range, scale_range, translation_std
+    ('scannet_big', 41, 60000, 40000, False, (-0.087266, 0.087266), (1.0, 1.0), (0, 0, 0)),
+    ('scannet_small', 42, 30000, 40000, False, (-0.087266, 0.087266), (1.0, 1.0), (0, 0, 0)),
+    ('sunrgbd_like', 43, 50000, 20000, True, (-0.523599, 0.523599), (0.85, 1.15), (0.1, 0.1, 0.05)),
+]
+
+
+def raw_scene(seed, n, with_yaw):
+    """An un-aligned raw scan: (n,6) xyz+rgb float32, its axis-align matrix (4,4) float64 (as
+    the info files store it), gravity-centre GT boxes (T,6|7) and labels."""
+    from nesie_amd.scenes import make_scene
+    pts, boxes, labels = make_scene(seed, n)
+    g = torch.Generator().manual_seed(seed)
+    ang = float(torch.rand(1, generator=g)) * 1.2 - 0.6
+    c, s = np.cos(ang), np.sin(ang)
+    align = np.eye(4)
+    align[:3, :3] = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    align[:3, 3] = (torch.rand(3, generator=g).numpy() - 0.5) * 4
+    # raw = R^-1 (aligned - t), so that GlobalAlignment lands near the synthetic room
+    xyz = pts[:, :3].double().numpy()
+    raw = (xyz - align[:3, 3]) @ align[:3, :3]          # (R^T (p - t))^T = (p - t) R
+    rgb = torch.rand(n, 3, generator=g).numpy() * 255
+    raw6 = np.concatenate([raw, rgb], 1).astype(np.float32)
+    gt = boxes.clone()
+    gt[:, 2] += gt[:, 5] * 0.5                            # bottom -> gravity centre
+    if with_yaw:
+        gt[:, 6] = (torch.rand(gt.shape[0], generator=g) - 0.5) * 2
+    else:
+        gt = gt[:, :6]
+    return raw6, align, gt.numpy().astype(np.float32), labels.numpy()

@@ -21,6 +21,7 @@ under torch.manual_seed and its state_dict is loaded into the reference head), s
 fixtures hold only OUTPUTS: tests/golden/nesie_head_golden.pt (< 100 KB).
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -406,6 +407,125 @@ def inference_goldens():
     return out
 
 
+def input_goldens():
+    """The reference's input pipeline run from its own files on seeded raw scans:
+    loading.py::LoadPointsFromFile (on a temporary .bin), transforms_3d.py::GlobalAlignment,
+    IndoorPointSample, RandomFlip3D, GlobalRotScaleTrans, with the reference's DepthPoints and
+    DepthInstance3DBoxes.  Third-party stand-ins: mmcv.FileClient (reads the file), mmdet's
+    RandomFlip base class (restated from mmdet 2.19: one np.random.choice over
+    [direction, None] when 'flip' is absent; no image fields here).  The numpy draws are taped
+    so that the fixture also pins the ORDER of the random decisions.
+    Writes tests/golden/input_golden.pt (sub-sampled rows + checksums)."""
+    import tempfile
+    r = os.path.join(REF, 'mmdet3d')
+    core = sys.modules['mmdet3d.core']
+    RefBoxes = core.DepthInstance3DBoxes
+    pp = _pkg('mmdet3d.core.points', os.path.join(r, 'core', 'points'))
+    for f in ['base_points', 'cam_points', 'depth_points', 'lidar_points']:
+        importlib.import_module(f'mmdet3d.core.points.{f}')
+    pts_init = importlib.util.spec_from_file_location(
+        'mmdet3d.core.points', os.path.join(r, 'core', 'points', '__init__.py'),
+        submodule_search_locations=[os.path.join(r, 'core', 'points')])
+    pts_mod = importlib.util.module_from_spec(pts_init)
+    sys.modules['mmdet3d.core.points'] = pts_mod
+    pts_init.loader.exec_module(pts_mod)
+    # depth_box3d.py bound the placeholder BasePoints of semi_goldens(); hand it the real class
+    sys.modules['mmdet3d.core.bbox.structures.depth_box3d'].BasePoints = pts_mod.BasePoints
+    core.VoxelGenerator = None
+    sys.modules['mmdet3d.core.bbox'].box_np_ops = None
+    PIPE = Registry('pipeline')
+
+    class RandomFlip:   # mmdet/datasets/pipelines/transforms.py (2.19), image-free subset
+        def __init__(self, flip_ratio=None, direction='horizontal'):
+            self.flip_ratio, self.direction = flip_ratio, direction
+
+        def __call__(self, results):
+            if 'flip' not in results:
+                direction_list = [self.direction, None]
+                non_flip_ratio = 1 - self.flip_ratio
+                single_ratio = self.flip_ratio / (len(direction_list) - 1)
+                flip_ratio_list = [single_ratio] * (len(direction_list) - 1) + [non_flip_ratio]
+                cur_dir = np.random.choice(direction_list, p=flip_ratio_list)
+                results['flip'] = cur_dir is not None
+            if 'flip_direction' not in results:
+                results['flip_direction'] = cur_dir
+            return results
+
+    class FileClient:
+        def __init__(self, backend='disk'):
+            pass
+
+        def get(self, path):
+            with open(path, 'rb') as f:
+                return f.read()
+    sys.modules['mmcv'].FileClient = FileClient
+    sys.modules['mmcv.utils'].build_from_cfg = None
+    _mod('mmdet.datasets')
+    _mod('mmdet.datasets.builder', PIPELINES=PIPE)
+    _mod('mmdet.datasets.pipelines', RandomFlip=RandomFlip, LoadAnnotations=object,
+         LoadImageFromFile=object)
+    _pkg('mmdet3d.datasets', os.path.join(r, 'datasets'))
+    _mod('mmdet3d.datasets.builder', OBJECTSAMPLERS=Registry('sampler'))
+    _pkg('mmdet3d.datasets.pipelines', os.path.join(r, 'datasets', 'pipelines'))
+    _mod('mmdet3d.datasets.pipelines.data_augment_utils', noise_per_object_v3_=None)
+    T = importlib.import_module('mmdet3d.datasets.pipelines.transforms_3d')
+    Ld = importlib.import_module('mmdet3d.datasets.pipelines.loading')
+
+    out = {}
+    for name, seed, n_raw, n_pts, with_yaw, rot, scl, tstd in golden_inputs.INPUT_CASES:
+        raw6, align, gt, labels = golden_inputs.raw_scene(seed, n_raw, with_yaw)
+        rs = np.random.RandomState(1000 + seed)
+        tape = []
+        saved = {k: getattr(np.random, k) for k in ('choice', 'rand', 'uniform', 'normal')}
+
+        def taped(k):
+            def f(*a, **kw):
+                v = getattr(rs, k)(*a, **kw)
+                tape.append((k, np.array(v, dtype=object if k == 'choice' and np.ndim(v) == 0 else None)))
+                return v
+            return f
+        for k in saved:
+            setattr(np.random, k, taped(k))
+        try:
+            with tempfile.NamedTemporaryFile(suffix='.bin') as tf:
+                raw6.tofile(tf.name)
+                res = dict(pts_filename=tf.name, bbox3d_fields=['gt_bboxes_3d'],
+                           box_type_3d=RefBoxes, ann_info=dict(axis_align_matrix=align),
+                           gt_bboxes_3d=RefBoxes(gt, box_dim=gt.shape[-1], with_yaw=with_yaw,
+                                                 origin=(0.5, 0.5, 0.5)))
+                res = Ld.LoadPointsFromFile(coord_type='DEPTH', shift_height=True, load_dim=6,
+                                            use_dim=[0, 1, 2])(res)
+            res = T.GlobalAlignment(rotation_axis=2)(res)
+            res = T.IndoorPointSample(num_points=n_pts)(res)
+            res = T.RandomFlip3D(sync_2d=False, flip_ratio_bev_horizontal=0.5,
+                                 flip_ratio_bev_vertical=0.5)(res)
+            res = T.GlobalRotScaleTrans(rot_range=list(rot), scale_ratio_range=list(scl),
+                                        translation_std=list(tstd), shift_height=True)(res)
+        finally:
+            for k, v in saved.items():
+                setattr(np.random, k, v)
+        pts = res['points'].tensor
+        assert pts.shape == (n_pts, 4)
+        kinds = [k for k, _ in tape]
+        assert kinds == ['choice', 'choice', 'rand', 'rand', 'uniform', 'uniform', 'normal'], kinds
+        out[f'input/{name}/rows'] = pts[::64].clone()
+        out[f'input/{name}/sum'] = pts.double().sum(0)
+        out[f'input/{name}/abs_sum'] = pts.double().abs().sum(0)
+        out[f'input/{name}/boxes'] = res['gt_bboxes_3d'].tensor.clone()
+        out[f'input/{name}/choices_head'] = torch.from_numpy(np.asarray(tape[0][1][:256], dtype=np.int64))
+        out[f'input/{name}/choices_sum'] = torch.tensor(int(np.asarray(tape[0][1], dtype=np.int64).sum()))
+        out[f'input/{name}/flips'] = torch.tensor([bool(res['pcd_horizontal_flip']),
+                                                   bool(res['pcd_vertical_flip'])])
+        out[f'input/{name}/angle_scale'] = torch.tensor([float(tape[4][1]), float(tape[5][1])],
+                                                        dtype=torch.float64)
+        out[f'input/{name}/trans'] = torch.from_numpy(np.asarray(tape[6][1], dtype=np.float64))
+        out[f'input/{name}/flow'] = list(res['transformation_3d_flow'])
+    path = os.path.join(ROOT, 'tests', 'golden', 'input_golden.pt')
+    torch.save(out, path)
+    print('wrote', path, os.path.getsize(path), 'bytes;', len(out), 'entries')
+    return out
+
+
 def main():
     ref_head_mod = install_reference_sandbox()
     out = {}
@@ -506,6 +626,7 @@ def main():
         out.update(semi_goldens())
         if '--keep-head' not in sys.argv:
             inference_goldens()
+            input_goldens()
     if '--inference-only' in sys.argv:
         return
     path = os.path.join(ROOT, 'tests', 'golden', 'nesie_head_golden.pt')
