@@ -85,7 +85,7 @@ def transform_gt(boxes, meta, i):
     return semi.transform_boxes(boxes.unsqueeze(0).to(meta.trans.device), one)[0].cpu()
 
 
-def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
+def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', resident=0):
     """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
     all-reduce (world > 1), clip, AdamW.  With graph=True the device work of a step is
     captured once into hipGraphs and replayed (the step has no host synchronisation);
@@ -119,6 +119,23 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     else:
         model = build_nesie_votenet().to(device)
         gt = GTBatch.collate(boxes, labels, device)
+    scenes = None
+    if resident and graph and on_gpu and workload == 'pretrain':
+        # --resident-input: a data set of `resident` synthetic raw scans (50 000 points each)
+        # lives in HBM; every step trains on a freshly sampled + augmented batch assembled on
+        # the side stream (nesie_amd/input_pipeline.py) instead of one fixed batch
+        from nesie_amd.input_pipeline import ResidentScenes
+        from nesie_amd.scenes import make_scene
+        scenes = ResidentScenes(device)
+        for i in range(resident):
+            p_, b_, l_ = make_scene(seed + 7 * i, 50000)
+            centre = torch.cat([b_[:, :2], b_[:, 2:3] + b_[:, 5:6] * 0.5, b_[:, 3:6]], 1)
+            scenes.add_scene(p_[:, :3].numpy(), None, centre.numpy(), l_.numpy())
+        scenes.finalize()
+        ids_next = torch.arange(batch, device=device) % resident
+        pts, gt = scenes.assemble_batch(ids_next, num_points=NUM_POINTS)
+        pts_next = pts.clone()
+        gt_next = GTBatch(gt.boxes.clone(), gt.labels.clone(), gt.count.clone(), gt.valid.clone())
     model.train()
     # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
     # all-reduce, the clip and AdamW each see ONE tensor
@@ -185,14 +202,36 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
     semi_like = workload in ('semi', 'saqe')
     # weight-independent work of a step: the backbone's index chain(s) and, for the supervised
     # step, the per-point vote targets (points-in-boxes over 40 000 x T)
+    def gt_parts(g_):
+        return [g_.boxes, g_.labels, g_.count, g_.valid]
+
+    noise = scenes.new_noise(batch, NUM_POINTS) if scenes is not None else None
+
+    def assemble_next():
+        ids_next.copy_((ids_next + batch) % resident)
+        p_, g_ = scenes.assemble_batch(ids_next, num_points=NUM_POINTS, noise=noise)
+        torch._foreach_copy_([pts_next] + gt_parts(gt_next), [p_] + gt_parts(g_))
+
     def input_only_work():
+        if scenes is not None:
+            assemble_next()
+            return (model.backbone.sample_and_group_indices(pts_next),
+                    list(model.bbox_head.vote_targets_of(pts_next, gt_next)))
         if semi_like:
             return (model.backbone.sample_and_group_indices(pts_s)
                     + model.backbone.sample_and_group_indices(pts_t), [])
         return (model.backbone.sample_and_group_indices(pts),
                 list(model.bbox_head.vote_targets_of(pts, gt)))
+    def stage(msg):   # NESIE_DIAG_STAGES=1: synchronise and report where the build is
+        if os.environ.get('NESIE_DIAG_STAGES'):
+            torch.cuda.synchronize(device)
+            print('[stage]', msg, file=sys.stderr, flush=True)
+    stage('model + optimiser built')
+    if scenes is not None:
+        scenes.refresh_noise(noise)
     idx_next, votes_next = input_only_work()
     idx_cur, votes_cur = clone_tree(idx_next), [t.clone() for t in votes_next]
+    stage('first input-only pass (eager)')
     nlev = len(idx_cur) // 2 if semi_like else len(idx_cur)
 
     def fwd_bwd_pre():
@@ -218,34 +257,45 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain'):
             update()
     main.wait_stream(side)
     torch.cuda.synchronize(device)
+    stage('eager warm-up steps')
     g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(g1):
         fwd_bwd_pre()
     with torch.cuda.graph(g2, pool=g1.pool()):
         update()
+    stage('step graphs captured')
     if pipelined:
         g_idx = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_idx, stream=side):
             fresh, fresh_votes = input_only_work()
             torch._foreach_copy_(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
         ready, copied = torch.cuda.Event(), torch.cuda.Event()
+        stage('input graph captured')
         with torch.cuda.stream(side):
             g_idx.replay()
             ready.record(side)
+        stage('input graph replayed once')
 
     def graph_step():
         if pipelined:
             main.wait_event(ready)                       # this step's indices are complete
             torch._foreach_copy_(flat(idx_cur) + votes_cur, flat(idx_next) + votes_next)
+            if scenes is not None:                       # ... and so is this step's batch
+                torch._foreach_copy_([pts] + gt_parts(gt), [pts_next] + gt_parts(gt_next))
             copied.record(main)
             side.wait_event(copied)
             with torch.cuda.stream(side):                # next step's index chain, overlapped
+                if scenes is not None:   # this batch's random variates: 4 in-place launches
+                    scenes.refresh_noise(noise)
                 if not os.environ.get('NESIE_DIAG_SKIP_CHAIN'):  # diagnostic only
                     g_idx.replay()
                 ready.record(side)
+        stage('input graph launched for the next step')
         g1.replay()
+        stage('forward/backward graph replayed')
         bucket.all_reduce_mean()
         g2.replay()
+        stage('update graph replayed')
         return loss_out
     graph_step.eager = eager_step
     return model, graph_step, bucket
@@ -282,6 +332,9 @@ def main():
     ap.add_argument('--workload', default='pretrain', choices=['pretrain', 'semi', 'saqe'],
                     help='pretrain = BASELINE configs[2] (the metric); semi = configs[3]; '
                          'saqe = configs[4] (use --batch 16)')
+    ap.add_argument('--resident-input', type=int, default=0,
+                    help='N > 0: keep N synthetic raw scans in HBM and assemble a fresh sampled + '
+                         'augmented batch per step on the side stream (input_pipeline.py)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=10)
@@ -298,7 +351,8 @@ def main():
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
                                      cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
-                                     graph=bool(args.graph), workload=args.workload)
+                                     graph=bool(args.graph), workload=args.workload,
+                                     resident=args.resident_input)
     hip = kernels.backend_for(torch.empty(1, device=device))
     # longest single launch: D-FPS over the 40 000-point scene (latency-bound; in graph mode it
     # runs on a side stream under the previous step, off the critical path)
@@ -370,7 +424,8 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'hip_graph': bool(args.graph),
                        'index_chain_pipelined': bool(args.graph),
-                       'grad_allreduce_bytes': bucket.nbytes()},
+                       'grad_allreduce_bytes': bucket.nbytes(),
+                       'resident_input_scenes': args.resident_input},
         }
         # HBM-streaming kernels, priced on their largest launches (537 MB / 268 MB tensors at
         # B = 8, beyond the 256 MB Infinity Cache).  Algorithmic bytes:

@@ -99,10 +99,26 @@ class ResidentScenes:
         self.pool = torch.cat(self._xyz).to(self.device).contiguous()
         self.height = torch.cat(self._height).to(self.device).contiguous()
         self.align = torch.stack(self._align).to(self.device)
-        self._boxes = [b.to(self.device) for b in self._boxes]
-        self._labels = [l.to(self.device) for l in self._labels]
+        # ground truth padded to the widest scene, in the head's GTBatch form: padding columns
+        # are zero-size boxes far away; an empty scene keeps the reference's all-zero fake box
+        S, T = len(self._boxes), max(1, max(b.shape[0] for b in self._boxes))
+        box_pad = torch.zeros(S, T, 7)
+        box_pad[:, :, :3] = 1e6
+        label_pad = torch.zeros(S, T, dtype=torch.long)
+        valid = torch.zeros(S, T)
+        for i, (b, l) in enumerate(zip(self._boxes, self._labels)):
+            n = b.shape[0]
+            if n == 0:
+                box_pad[i, 0] = 0.0
+            else:
+                box_pad[i, :n], label_pad[i, :n], valid[i, :n] = b, l, 1.0
+        self.box_counts = [b.shape[0] for b in self._boxes]
+        self.box_pad, self.label_pad = box_pad.to(self.device), label_pad.to(self.device)
+        self.box_valid = valid.to(self.device)
+        self.box_count_dev = torch.tensor([max(n, 1) for n in self.box_counts], device=self.device)
         self._counts_dev = counts.to(self.device)
         self._offsets_dev = self.offsets.to(self.device)
+        self._max_count = int(counts.max())
         return self
 
     def __len__(self):
@@ -112,35 +128,54 @@ class ResidentScenes:
         return self.pool.numel() * 4 + self.height.numel() * 4
 
     # ---- random decisions ---------------------------------------------------------------
+    def new_noise(self, batch, num_points=40000):
+        """Static buffers for the uniform / normal variates one batch consumes: refresh them
+        with ``refresh_noise`` (a few in-place launches, outside any captured graph) and pass
+        them to ``draw_on_device`` / ``assemble_batch`` -- the rest of the assembly is then
+        free of random-number calls and can be replayed as a hipGraph next to other graphs
+        that use the default generator."""
+        dev = self.device
+        return dict(keys=torch.empty(batch, self._max_count, device=dev),
+                    refill=torch.empty(batch, num_points, device=dev),
+                    u=torch.empty(batch, 4, device=dev), normal=torch.empty(batch, 3, device=dev))
+
+    @staticmethod
+    def refresh_noise(noise, generator=None):
+        for k in ('keys', 'refill', 'u'):
+            noise[k].uniform_(generator=generator)
+        noise['normal'].normal_(generator=generator)
+        return noise
+
     def draw_on_device(self, scene_ids, num_points=40000, generator=None, flip_ratio_h=0.5,
                        flip_ratio_v=0.5, rot_range=(-0.087266, 0.087266),
-                       scale_range=(1.0, 1.0), translation_std=(0, 0, 0)):
+                       scale_range=(1.0, 1.0), translation_std=(0, 0, 0), noise=None):
         """Same distributions as the reference, drawn with the device generator:
         -> choices (B,n) int32 pool rows, xform (B,20), and the (B,) flip / angle / scale /
         (B,3) trans tensors the boxes need.  Without replacement when the scene has at least
-        ``num_points`` points (random keys, smallest n), with replacement otherwise."""
+        ``num_points`` points (random keys, smallest n), with replacement otherwise.
+        ``noise``: pre-drawn variates (``new_noise``) instead of drawing here."""
         ids = torch.as_tensor(scene_ids, device=self.device)
         B = ids.numel()
         cnt, off = self._counts_dev[ids], self._offsets_dev[ids]
-        nmax = int(self.counts[torch.as_tensor(scene_ids)].max())
-        rand = lambda *s: torch.rand(*s, device=self.device, generator=generator)  # noqa: E731
-        keys = rand(B, nmax)
+        nmax = self._max_count            # static: the draw is capturable in a hipGraph
+        if noise is None:
+            noise = self.refresh_noise(self.new_noise(B, num_points), generator)
+        keys, u = noise['keys'], noise['u']
         keys = torch.where(torch.arange(nmax, device=self.device)[None] < cnt[:, None], keys,
                            keys.new_full((), 2.0))
         if nmax >= num_points:
-            local = keys.topk(num_points, dim=1, largest=False, sorted=False)[1]
+            local = torch.argsort(keys, dim=1)[:, :num_points]   # the n smallest random keys
         else:
             local = torch.zeros(B, num_points, dtype=torch.int64, device=self.device)
         short = cnt < num_points                              # with replacement
-        refill = (rand(B, num_points) * cnt[:, None]).long().clamp_(max=int(self.counts.max()) - 1)
-        refill = torch.minimum(refill, cnt[:, None] - 1)
+        refill = torch.minimum((noise['refill'] * cnt[:, None]).long(), cnt[:, None] - 1)
         local = torch.where(short[:, None], refill, local)
         choices = (local + off[:, None]).to(torch.int32)
-        flip_h, flip_v = rand(B) < flip_ratio_h, rand(B) < flip_ratio_v
-        angle = rot_range[0] + (rot_range[1] - rot_range[0]) * rand(B)
-        scale = scale_range[0] + (scale_range[1] - scale_range[0]) * rand(B)
-        trans = torch.randn(B, 3, device=self.device, generator=generator) \
-            * torch.tensor(translation_std, dtype=torch.float32, device=self.device)
+        flip_h, flip_v = u[:, 0] < flip_ratio_h, u[:, 1] < flip_ratio_v
+        angle = rot_range[0] + (rot_range[1] - rot_range[0]) * u[:, 2]
+        scale = scale_range[0] + (scale_range[1] - scale_range[0]) * u[:, 3]
+        trans = torch.stack([noise['normal'][:, k] * float(translation_std[k]) for k in range(3)],
+                            dim=1)
         return choices, self._xform(ids, flip_h, flip_v, angle, scale, trans), \
             (flip_h, flip_v, angle, scale, trans)
 
@@ -165,50 +200,64 @@ class ResidentScenes:
             (flip_h, flip_v, angle, scale, trans)
 
     # ---- batch assembly -----------------------------------------------------------------
-    def assemble(self, scene_ids, draws=None, num_points=40000, generator=None, **ranges):
-        """-> points (B, n, 4) = (x, y, z, height), list of (T_i, 7) bottom-origin boxes, list
-        of (T_i,) labels, all on the device.  ``draws``: list of ``AugmentDraws`` (reference
-        order); None = draw on the device."""
+    def assemble_batch(self, scene_ids, draws=None, num_points=40000, generator=None,
+                       noise=None, **ranges):
+        """-> points (B, n, 4) = (x, y, z, height) and the ground truth as the head's GTBatch
+        (boxes (B,T,7) bottom-origin, labels, count, valid), all on the device, no host
+        synchronisation.  ``scene_ids``: list or device tensor; ``draws``: list of
+        ``AugmentDraws`` (reference order) or None = draw on the device; with ``noise``
+        (``new_noise``) and ``scene_ids`` a static device tensor the call makes no random-number
+        and no host-side call and is capturable in a hipGraph."""
+        from .votenet.nesie_head import GTBatch
         if draws is None:
-            choices, xform, dec = self.draw_on_device(scene_ids, num_points, generator, **ranges)
+            choices, xform, dec = self.draw_on_device(scene_ids, num_points, generator,
+                                                      noise=noise, **ranges)
         else:
             choices, xform, dec = self._from_draws(scene_ids, draws)
+        ids = torch.as_tensor(scene_ids, device=self.device)
         out = torch.empty(choices.shape[0], choices.shape[1], 4, dtype=torch.float32,
                           device=self.device)
         backend_for(self.pool).scene_assemble(self.pool, self.height, choices.contiguous(),
                                               xform, out)
-        boxes = [self._augment_boxes(self._boxes[s], *(t[i] for t in dec))
-                 for i, s in enumerate(scene_ids)]
-        return out, boxes, [self._labels[s] for s in scene_ids]
+        valid = self.box_valid[ids]
+        boxes = self._augment_boxes(self.box_pad[ids], valid, *dec)
+        return out, GTBatch(boxes, self.label_pad[ids], self.box_count_dev[ids], valid)
 
-    def _augment_boxes(self, boxes, flip_h, flip_v, angle, scale, trans):
-        """RandomFlip3D + GlobalRotScaleTrans on the boxes of one scene
-        (depth_box3d.py:118-214, base_box3d.py:149-157, 215-222); tensor ops only, no host
-        synchronisation (the flips are applied as signs)."""
+    def assemble(self, scene_ids, draws=None, num_points=40000, generator=None, **ranges):
+        """List form: points, [(T_i,7) boxes], [(T_i,) labels] (host-known box counts)."""
+        pts, gt = self.assemble_batch(list(scene_ids), draws, num_points, generator, **ranges)
+        n = [self.box_counts[s] for s in scene_ids]
+        return pts, [gt.boxes[i, :k] for i, k in enumerate(n)], \
+            [gt.labels[i, :k] for i, k in enumerate(n)]
+
+    def _augment_boxes(self, boxes, valid, flip_h, flip_v, angle, scale, trans):
+        """RandomFlip3D + GlobalRotScaleTrans on the padded boxes of a batch (B,T,7)
+        (depth_box3d.py:118-214, base_box3d.py:149-157, 215-222): tensor ops only, the flips
+        applied as signs; padding and fake boxes pass through unchanged."""
         b = boxes.clone()
-        if b.shape[0] == 0:
-            return b
-        sx = torch.where(flip_h, -1.0, 1.0).to(b.dtype)
-        sy = torch.where(flip_v, -1.0, 1.0).to(b.dtype)
-        b[:, 0] = b[:, 0] * sx
-        b[:, 1] = b[:, 1] * sy
+        B, T = b.shape[:2]
+        sx = torch.where(flip_h, -1.0, 1.0).to(b.dtype).view(B, 1)
+        sy = torch.where(flip_v, -1.0, 1.0).to(b.dtype).view(B, 1)
+        b[..., 0] = b[..., 0] * sx
+        b[..., 1] = b[..., 1] * sy
         if self.with_yaw:
             # horizontal: yaw = -yaw + pi; vertical: yaw = -yaw
-            yaw = torch.where(flip_h, -b[:, 6] + math.pi, b[:, 6])
-            b[:, 6] = torch.where(flip_v, -yaw, yaw)
+            yaw = torch.where(flip_h.view(B, 1), -b[..., 6] + math.pi, b[..., 6])
+            b[..., 6] = torch.where(flip_v.view(B, 1), -yaw, yaw)
         sin, cos = torch.sin(angle), torch.cos(angle)
         zero, one = torch.zeros_like(sin), torch.ones_like(sin)
-        rot_t = torch.stack([torch.stack([cos, sin, zero]), torch.stack([-sin, cos, zero]),
-                             torch.stack([zero, zero, one])])          # [[c,-s,0],[s,c,0],[0,0,1]].T
-        b[:, 0:3] = b[:, 0:3] @ rot_t
+        rot_t = torch.stack([torch.stack([cos, sin, zero], -1), torch.stack([-sin, cos, zero], -1),
+                             torch.stack([zero, zero, one], -1)], 1)   # (B,3,3) = [[c,-s,0],[s,c,0],[0,0,1]].T
+        b[..., 0:3] = b[..., 0:3] @ rot_t
         if self.with_yaw:
-            b[:, 6] -= angle
+            b[..., 6] -= angle.view(B, 1)
         else:
             holder = DepthInstance3DBoxes.__new__(DepthInstance3DBoxes)
-            holder.tensor = b
-            corners = holder.corners @ rot_t
-            b[:, 3] = corners[..., 0].max(dim=1)[0] - corners[..., 0].min(dim=1)[0]
-            b[:, 4] = corners[..., 1].max(dim=1)[0] - corners[..., 1].min(dim=1)[0]
-        b[:, :6] *= scale
-        b[:, :3] += trans
-        return b
+            holder.tensor = b.reshape(B * T, 7)
+            corners = holder.corners.view(B, T * 8, 3) @ rot_t
+            corners = corners.view(B, T, 8, 3)
+            b[..., 3] = corners[..., 0].max(dim=2)[0] - corners[..., 0].min(dim=2)[0]
+            b[..., 4] = corners[..., 1].max(dim=2)[0] - corners[..., 1].min(dim=2)[0]
+        b[..., :6] *= scale.view(B, 1, 1)
+        b[..., :3] += trans.view(B, 1, 3)
+        return torch.where(valid.unsqueeze(-1) > 0, b, boxes)

@@ -86,8 +86,12 @@ class DepthInstance3DBoxes:
         to the bottom centre (depth_box3d.py:50-89)."""
         assert len(self.tensor) != 0
         t = self.tensor
-        norm = t.new_tensor([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0],
-                             [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]]) - t.new_tensor([0.5, 0.5, 0])
+        # corner i = (x, y, z) bits (i>>2, (i>>1)&1, (i&1)^y): the order above; built with device
+        # arithmetic (no host-to-device copy, so the property can run under graph capture)
+        i = torch.arange(8, device=t.device)
+        yb = (i >> 1) & 1
+        norm = torch.stack([(i >> 2).to(t.dtype) - 0.5, yb.to(t.dtype) - 0.5,
+                            ((i & 1) ^ yb).to(t.dtype)], dim=1)
         c = t[:, 3:6].view(-1, 1, 3) * norm.view(1, 8, 3)
         sin, cos = torch.sin(t[:, 6]).view(-1, 1), torch.cos(t[:, 6]).view(-1, 1)
         x, y = c[..., 0], c[..., 1]

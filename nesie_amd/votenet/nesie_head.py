@@ -268,7 +268,7 @@ class NesieHead(nn.Module):
         one scatter."""
         B, K = obj_scores.shape
         boxes = bbox3d.clone()                                 # origin (0.5,0.5,0.5) -> bottom
-        boxes[..., :3] += boxes[..., 3:6] * boxes.new_tensor((0.0, 0.0, -0.5))
+        boxes[..., 2] += boxes[..., 5] * -0.5                  # (x, y get + 0.0 * size)
         counts = points_in_boxes_count(depth_to_lidar_points(points_xyz).contiguous(),
                                        depth_to_lidar_boxes(boxes).contiguous())
         nonempty = counts > 5
