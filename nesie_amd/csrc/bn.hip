@@ -14,11 +14,15 @@
 // sums need it), the apply re-derives the mask from x with the forward's own scale/bias.  Sums are taken about a per-channel shift (the channel's first
 // element) so E[x^2]-E[x]^2 does not cancel; partials are combined in double.
 #include "common.h"
+#include <stdlib.h>
 
 namespace nesie {
 
 constexpr int BN_BLOCK = 256;
 constexpr int BN_SPAN = 8192;  // floats of one (b, c) row handled by a stats/reduce block
+
+// log2 of the row-bias group (a power of two; 1 when there is no row bias)
+__device__ __forceinline__ int group_shift(int group) { return __ffs(group) - 1; }
 
 __device__ __forceinline__ float block_sum(float v, float *sh) {
 #pragma unroll
@@ -46,11 +50,12 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
   const float shift = x[(size_t)c * p] + (row_bias ? row_bias[(size_t)c * (p / group)] : 0.f);
   const long long lo = (long long)s * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  const int gs = group_shift(group);
   float a0 = 0.f, a1 = 0.f;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       const float4 v = *(const float4 *)(row + i);
-      const float r = rb ? rb[i / group] : 0.f;  // group % 4 == 0: one term per float4
+      const float r = rb ? rb[i >> gs] : 0.f;  // group % 4 == 0: one term per float4
       const float d0 = v.x + r - shift, d1 = v.y + r - shift, d2 = v.z + r - shift,
                   d3 = v.w + r - shift;
       a0 += (d0 + d1) + (d2 + d3);
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
-      const float d = row[i] + (rb ? rb[i / group] : 0.f) - shift;
+      const float d = row[i] + (rb ? rb[i >> gs] : 0.f) - shift;
       a0 += d; a1 += d * d;
     }
   }
@@ -137,7 +142,7 @@ __global__ void bn_finalize_kernel(BnFwdFin f, int c_total) {
   if ((int)blockIdx.x < c_total) bn_fwd_finalize(f, blockIdx.x, true, sh);
 }
 
-template <bool RELU>
+template <bool RELU, bool NT>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
     int c_total, long long p, const float *__restrict__ x, const float *__restrict__ row_bias,
     int group, BnFwdFin fin, float *__restrict__ y) {
@@ -149,26 +154,27 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
   const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  const int gs = group_shift(group);
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
-      float4 v = *(const float4 *)(x + base + i);
-      if (rb) { const float r = rb[i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
+      float4 v = ld4<NT>(x + base + i);
+      if (rb) { const float r = rb[i >> gs]; v.x += r; v.y += r; v.z += r; v.w += r; }
       float4 o = make_float4(v.x * sc + bi, v.y * sc + bi, v.z * sc + bi, v.w * sc + bi);
       if (RELU) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
-      *(float4 *)(y + base + i) = o;
+      st4<NT>(y + base + i, o);
     }
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
-      float o = (x[base + i] + (rb ? rb[i / group] : 0.f)) * sc + bi;
+      float o = (x[base + i] + (rb ? rb[i >> gs] : 0.f)) * sc + bi;
       y[base + i] = RELU ? fmaxf(o, 0.f) : o;
     }
   }
 }
 
 // backward partials: sum(g), sum(g * xhat), g = RELU ? dy * [y > 0] : dy
-template <bool RELU>
+template <bool RELU, bool NT>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     int c_total, long long p, int sp, const float *__restrict__ dy,
     const float *__restrict__ x, const float *__restrict__ y,
@@ -189,17 +195,18 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   if (from_y) { mean = bt; invstd = 1.f / gm; }
   const long long lo = (long long)s * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  const int gs = group_shift(group);
   float a0 = 0.f, a1 = 0.f;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
-      float4 g = *(const float4 *)(dy + base + i);
-      float4 v = *(const float4 *)(src + base + i);
+      float4 g = *(const float4 *)(dy + base + i);      // read again by the apply pass
+      float4 v = from_y ? ld4<NT>(src + base + i) : *(const float4 *)(src + base + i);
       if (RELU) {
-        const float4 o = from_y ? v : *(const float4 *)(y + base + i);
+        const float4 o = from_y ? v : ld4<NT>(y + base + i);
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
-      if (rb && !from_y) { const float r = rb[i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
+      if (rb && !from_y) { const float r = rb[i >> gs]; v.x += r; v.y += r; v.z += r; v.w += r; }
       a0 += (g.x + g.y) + (g.z + g.w);
       a1 += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) +
             (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
       float g = dy[base + i];
       float v = src[base + i];
       if (RELU) g = (from_y ? v : y[base + i]) > 0.f ? g : 0.f;
-      if (rb && !from_y) v += rb[i / group];
+      if (rb && !from_y) v += rb[i >> gs];
       a0 += g; a1 += g * ((v - mean) * invstd);
     }
   }
@@ -260,7 +267,7 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFin f, int c_total, float *coef) {
   if (threadIdx.x == 0) { coef[c * 4 + 0] = sh[0]; coef[c * 4 + 1] = sh[1]; coef[c * 4 + 2] = sh[2]; }
 }
 
-template <bool RELU>
+template <bool RELU, bool NT>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
     const float *__restrict__ fwd_coef, BnBwdFin fin,
@@ -279,11 +286,12 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   const size_t rbase = row_bias ? ((size_t)b * c_total + c) * (p / group) : 0;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  const int gs = group_shift(group);
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
-      float4 g = *(const float4 *)(dy + base + i);
-      float4 v = *(const float4 *)(x + base + i);
-      if (row_bias) { const float r = row_bias[rbase + i / group]; v.x += r; v.y += r; v.z += r; v.w += r; }
+      float4 g = ld4<NT>(dy + base + i);
+      float4 v = ld4<NT>(x + base + i);
+      if (row_bias) { const float r = row_bias[rbase + (i >> gs)]; v.x += r; v.y += r; v.z += r; v.w += r; }
       if (RELU) {
         g.x = v.x * sc + bi > 0.f ? g.x : 0.f; g.y = v.y * sc + bi > 0.f ? g.y : 0.f;
         g.z = v.z * sc + bi > 0.f ? g.z : 0.f; g.w = v.w * sc + bi > 0.f ? g.w : 0.f;
@@ -293,13 +301,13 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
       r.y = a * (g.y - k1 - (v.y - mean) * invstd * k2);
       r.z = a * (g.z - k1 - (v.z - mean) * invstd * k2);
       r.w = a * (g.w - k1 - (v.w - mean) * invstd * k2);
-      *(float4 *)(dx + base + i) = r;
+      st4<NT>(dx + base + i, r);
       if (d_row_bias) {
         // gradient of the broadcast term = sum of dx over its `group` positions = the
         // group/4 consecutive lanes that hold them (group in {4..256}, power of two)
         float t = (r.x + r.y) + (r.z + r.w);
         for (int off = 1; off < group / 4; off <<= 1) t += __shfl_xor(t, off, 64);
-        if (((threadIdx.x & 63) & (group / 4 - 1)) == 0) d_row_bias[rbase + i / group] = t;
+        if (((threadIdx.x & 63) & (group / 4 - 1)) == 0) d_row_bias[rbase + (i >> gs)] = t;
       }
     }
   } else {
@@ -320,14 +328,14 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(
     long long rows, int m, int c_total, const float4 *__restrict__ x,
-    const float *__restrict__ coef, float *__restrict__ out, uint8_t *__restrict__ arg) {
+    const float *__restrict__ coef, float *__restrict__ out, uint8_t *__restrict__ arg, int nt) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 each
   const long long row = t / LPR;
   const int part = (int)(t % LPR);
   const bool live = row < rows;
   const int c = live ? (int)((row / m) % c_total) : 0;
   const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
-  float4 q = live ? x[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 q = live ? (nt ? ld4<true>((const float *)(x + t)) : x[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
   q.x = fmaxf(q.x * sc + bi, 0.f); q.y = fmaxf(q.y * sc + bi, 0.f);
   q.z = fmaxf(q.z * sc + bi, 0.f); q.w = fmaxf(q.w * sc + bi, 0.f);
   float v; int i;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
     long long rows, int m, int c_total, const float4 *__restrict__ x,
     const float *__restrict__ gpool, const float *__restrict__ pooled,
     const uint8_t *__restrict__ arg, const float *__restrict__ fwd_coef,
-    const float *__restrict__ coef, float4 *__restrict__ dx) {
+    const float *__restrict__ coef, float4 *__restrict__ dx, int nt) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long row = t / LPR;
   const int part = (int)(t % LPR);
@@ -381,13 +389,13 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const float g = pooled[row] > 0.f ? gpool[row] : 0.f;
   const int ai = (int)arg[row] - part * 4;
-  const float4 v = x[t];
+  const float4 v = nt ? ld4<true>((const float *)(x + t)) : x[t];
   float4 r;
   r.x = a * ((ai == 0 ? g : 0.f) - k1 - (v.x - mean) * invstd * k2);
   r.y = a * ((ai == 1 ? g : 0.f) - k1 - (v.y - mean) * invstd * k2);
   r.z = a * ((ai == 2 ? g : 0.f) - k1 - (v.z - mean) * invstd * k2);
   r.w = a * ((ai == 3 ? g : 0.f) - k1 - (v.w - mean) * invstd * k2);
-  dx[t] = r;
+  if (nt) st4<true>((float *)(dx + t), r); else dx[t] = r;
 }
 
 static inline int bn_sp(long long p) { return (int)((p + BN_SPAN - 1) / BN_SPAN); }
@@ -409,6 +417,17 @@ static int bn_check(const char *W, int b, int c, long long p, const void *ws, si
   NESIE_REQUIRE(b <= 65535 && c <= 65535 && bn_sp(p) < (1 << 30), W);
   return NESIE_OK;
 }
+
+// Non-temporal accesses for tensors that cannot stay in the 256 MB Infinity Cache anyway.
+// NESIE_NT_MB=<n>: threshold in MB (0 = never), a measurement aid.
+namespace nesie {
+bool stream_nt(long long bytes, int family) {
+  static const long long mb = [] { const char *e = getenv("NESIE_NT_MB"); return e ? atoll(e) : 192ll; }();
+  static const int mask = [] { const char *e = getenv("NESIE_NT_MASK"); return e ? atoi(e) : 3; }();
+  return mb > 0 && (mask & family) && bytes >= (mb << 20);
+}
+}  // namespace nesie
+static bool bn_use_nt(long long elements) { return nesie::stream_nt(elements * 4, 1); }
 
 extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
                                      const float *gamma, const float *beta,
@@ -442,8 +461,11 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
                      pre_partial ? nullptr : x, p, row_bias, group,
                      pre_partial ? pre_partial : partial, gamma, beta,
                      running_mean, running_var, momentum, eps, save_mean, save_invstd, coef};
-  if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);
-  else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y);
+  const bool nt = bn_use_nt((long long)b * c * p);
+#define L(R, N) hipLaunchKernelGGL((bn_apply_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, fin, y)
+  if (relu) { if (nt) L(true, true); else L(true, false); }
+  else { if (nt) L(false, true); else L(false, false); }
+#undef L
   return check_launch(W);
 }
 
@@ -466,20 +488,19 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   const int sp = bn_sp(p), nslice = b * sp;
   float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
   dim3 grid(sp, c, b);
-  if (relu)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x, y,
-                       save_mean, save_invstd, gamma, beta, row_bias, group, partial);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, x,
-                       y, save_mean, save_invstd, gamma, beta, row_bias, group, partial);
+  const bool nt = bn_use_nt((long long)b * c * p);
+#define LR(R, N) hipLaunchKernelGGL((bn_bwd_reduce_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, \
+                                    x, y, save_mean, save_invstd, gamma, beta, row_bias, group, partial)
+  if (relu) { if (nt) LR(true, true); else LR(true, false); }
+  else { if (nt) LR(false, true); else LR(false, false); }
+#undef LR
   const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
   (void)coef;
-  if (relu)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       fin, row_bias, group, d_row_bias, dx);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, fwd_coef,
-                       fin, row_bias, group, d_row_bias, dx);
+#define LA(R, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, \
+                                    fwd_coef, fin, row_bias, group, d_row_bias, dx)
+  if (relu) { if (nt) LA(true, true); else LA(true, false); }
+  else { if (nt) LA(false, true); else LA(false, false); }
+#undef LA
   return check_launch(W);
 }
 
@@ -543,7 +564,8 @@ extern "C" int nesie_bn_relu_maxpool_forward(int b, int c, int m, int ns, const 
   const int lpr = ns / 4;
   const dim3 grid((unsigned)cdiv(rows * lpr, 256));
 #define L(N) hipLaunchKernelGGL(bn_pool_fwd_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
-                                (const float4 *)x, fwd_coef, pooled, argmax)
+                                (const float4 *)x, fwd_coef, pooled, argmax, nt)
+  const int nt = stream_nt(rows * ns * 4, 2) ? 1 : 0;
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L
@@ -579,7 +601,8 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
   const dim3 grid((unsigned)cdiv(rows * lpr, 256));
 #define L(N) hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
                                 (const float4 *)x, grad_pooled, pooled, argmax, fwd_coef, coef, \
-                                (float4 *)dx)
+                                (float4 *)dx, nt)
+  const int nt = stream_nt(rows * ns * 4, 2) ? 1 : 0;
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L

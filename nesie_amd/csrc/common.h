@@ -29,6 +29,10 @@ inline int check_launch(const char *what) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// true when a tensor of this size should be streamed with non-temporal accesses (bn.hip)
+// family: 1 = norm passes, 2 = pooling passes, 4 = blend (NESIE_NT_MASK selects; default 3: same-box A/B showed the blend stores neutral)
+bool stream_nt(long long bytes, int family);
+
 // Squared distance in the canonical, contraction-free form
 // ((dx*dx) + (dy*dy)) + (dz*dz)   (SURVEY.md appendix A.0).
 __device__ __forceinline__ float sqdist_nofma(float dx, float dy, float dz) {
@@ -76,4 +80,26 @@ __device__ __forceinline__ void row_argmax4(const float4 q, int part, float &v, 
   if (LPR >= 16) argmax_step<0x140>(v, i);  // row_mirror: 15 - lane (within 16)
 }
 
+
+// Streaming accesses.  NT = non-temporal: a tensor larger than the 256 MB Infinity Cache that is
+// not read again soon should not displace what is (tools/clk/stream.hip: 6.65 vs 6.0 TB/s for a
+// read + write pass over 268 MB).  The launchers choose NT by tensor size (stream_nt).
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float *p) {
+  if (NT) {
+    const f4v t = __builtin_nontemporal_load((const f4v *)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return *(const float4 *)p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float *p, const float4 v) {
+  if (NT) {
+    const f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (f4v *)p);
+  } else {
+    *(float4 *)p = v;
+  }
+}
 }  // namespace nesie

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     int c, int m, int n, int segs, int seg_len, int c_total, int c_offset, int pitch,
     int seg_off, const float *__restrict__ table, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
-    const float *__restrict__ wx, float *__restrict__ out, float *__restrict__ stat_partial) {
+    const float *__restrict__ wx, float *__restrict__ out, float *__restrict__ stat_partial,
+    int nt) {
   __shared__ float tile[64][TS_Q + 1];
   __shared__ float red[4][64][2];
   __shared__ int sj[TS_Q][3];
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int ch = wv * 16 + i;
-      dst[(size_t)(c0 + ch) * per_seg + lane] = tile[ch][lane];
+      float *o = dst + (size_t)(c0 + ch) * per_seg + lane;
+      if (nt) __builtin_nontemporal_store(tile[ch][lane], o); else *o = tile[ch][lane];
     }
     if (stat_partial && wv == 0) {
       // (sum, sum of squares) of this tile per stacked channel, for the norm layer that follows:
@@ -815,7 +817,8 @@ extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float 
   if (c % 64 == 0 && (n / segs) % TS_Q == 0)
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(n / TS_Q, b), dim3(256), 0, (hipStream_t)stream, c,
                        m, n, segs, seg_len, c_total, c_offset, pitch, seg_off, table, idx, weight,
-                       rel, wx, out, stat_partial);
+                       rel, wx, out, stat_partial,
+                       stream_nt((long long)b * segs * c_total * (n / segs) * 4, 4) ? 1 : 0);
   else
     hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b),
                        dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, segs, seg_len, c_total,

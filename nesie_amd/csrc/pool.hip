@@ -17,12 +17,13 @@ namespace nesie {
 template <int LPR>
 __global__ __launch_bounds__(256) void group_max_fwd_kernel(
     long long rows, const float4 *__restrict__ x, float *__restrict__ out,
-    uint8_t *__restrict__ arg) {
+    uint8_t *__restrict__ arg, int nt) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 each
   const long long row = t / LPR;
   const int part = (int)(t % LPR);
   const bool live = row < rows;
-  const float4 q = live ? x[t] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const float4 q = live ? (nt ? ld4<true>((const float *)(x + t)) : x[t])
+                        : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   float v; int i;
   row_argmax4<LPR>(q, part, v, i);
   if (live && part == 0) { out[row] = v; arg[row] = (uint8_t)i; }
@@ -31,15 +32,16 @@ __global__ __launch_bounds__(256) void group_max_fwd_kernel(
 template <int LPR>
 __global__ __launch_bounds__(256) void group_max_bwd_kernel(
     long long rows, const float *__restrict__ grad_out, const uint8_t *__restrict__ arg,
-    float4 *__restrict__ grad_x) {
+    float4 *__restrict__ grad_x, int nt) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long row = t / LPR;
   const int part = (int)(t % LPR);
   if (row >= rows) return;
   const float g = grad_out[row];
   const int a = (int)arg[row] - part * 4;
-  grad_x[t] = make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f,
-                          a == 3 ? g : 0.f);
+  const float4 r = make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f,
+                               a == 3 ? g : 0.f);
+  if (nt) st4<true>((float *)(grad_x + t), r); else grad_x[t] = r;
 }
 
 // grad_x[row, argmax[row]] += grad_out[row]: the pooled gradient added into a dense gradient
@@ -132,7 +134,8 @@ extern "C" int nesie_group_max_pool_forward(long long rows, int nsample, const f
   dim3 grid((unsigned)cdiv(threads, 256));
   hipStream_t s = (hipStream_t)stream;
 #define L(N) hipLaunchKernelGGL(group_max_fwd_kernel<N>, grid, dim3(256), 0, s, rows, \
-                                (const float4 *)x, out, argmax)
+                                (const float4 *)x, out, argmax, nt)
+  const int nt = stream_nt(rows * nsample * 4, 2) ? 1 : 0;
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L
@@ -153,7 +156,8 @@ extern "C" int nesie_group_max_pool_backward(long long rows, int nsample,
   dim3 grid((unsigned)cdiv(threads, 256));
   hipStream_t s = (hipStream_t)stream;
 #define L(N) hipLaunchKernelGGL(group_max_bwd_kernel<N>, grid, dim3(256), 0, s, rows, \
-                                grad_out, argmax, (float4 *)grad_x)
+                                grad_out, argmax, (float4 *)grad_x, nt)
+  const int nt = stream_nt(rows * nsample * 4, 2) ? 1 : 0;
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L
