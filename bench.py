@@ -442,10 +442,10 @@ def main():
                     'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'traffic': None,
                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes}
         pooled_bytes = args.batch * 128 * 2048 * 4
-        # PMC figure for the same pair at B = 8 (profiles/r01b_pmc_hbm_traffic.txt: FETCH_SIZE
+        # PMC figure for the same pair at B = 8 (profiles/r01e_pmc_hbm_traffic.txt: FETCH_SIZE
         # and WRITE_SIZE collected in separate rocprofv3 passes, streaming reads doubled per
-        # the gfx950 note of MI355X_MICROARCH.md): reduce 132 340 KB + apply 573 741 + 524 288
-        measured_traffic = 1230369 * 1024 if args.batch == 8 else None
+        # the gfx950 note of MI355X_MICROARCH.md): reduce 16 438 + 512 KB, apply 573 529 + 524 289 KB
+        measured_traffic = 1114768 * 1024 if args.batch == 8 else None
         out['roofline'] = _stream(
             'nesie::bn_pool_bwd_reduce_kernel + bn_pool_bwd_apply_kernel<16> (SA1 MLP tail, '
             'x (B,128,2048,64)): largest launch on the critical path', pool_bwd_timer.mean_ms(),

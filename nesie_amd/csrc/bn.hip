@@ -354,13 +354,21 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_pool_bwd_reduce_kernel(
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
+  const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
+  // Where the pooled activation is positive it IS the normalised arg-max element,
+  // pooled = sc * x + bi, so x comes back from it without touching the dense tensor (one
+  // 4-byte gather per 64-byte line otherwise: 0.16 GB of the pair's traffic at SA1).  Channels
+  // whose scale is ~0 keep the gather.
+  const bool from_pooled = fabsf(sc) > 1e-4f * invstd;
+  const float rsc = from_pooled ? 1.f / sc : 0.f;
   const size_t base = ((size_t)b * c_total + c) * m;
   const int lo = s * rows_per, hi = lo + rows_per < m ? lo + rows_per : m;
   float a0 = 0.f, a1 = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
-    if (pooled[base + i] > 0.f) {
+    const float pv = pooled[base + i];
+    if (pv > 0.f) {
       const float g = gpool[base + i];
-      const float xa = x[(base + i) * ns + arg[base + i]];
+      const float xa = from_pooled ? (pv - bi) * rsc : x[(base + i) * ns + arg[base + i]];
       a0 += g;
       a1 += g * ((xa - mean) * invstd);
     }
