@@ -40,7 +40,7 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {
 // partial[(c * nslice + b * sp + s) * 2 + {0,1}] = sum(x - shift), sum((x - shift)^2)
 __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
     int c_total, long long p, int sp, const float *__restrict__ x,
-    const float *__restrict__ row_bias, int group, float *__restrict__ partial) {
+    const float *__restrict__ row_bias, int group, float *__restrict__ partial, int nt) {
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const float *row = x + ((size_t)b * c_total + c) * p;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
   float a0 = 0.f, a1 = 0.f;
   if ((p & 3) == 0) {
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
-      const float4 v = *(const float4 *)(row + i);
+      const float4 v = nt ? ld4<true>(row + i) : *(const float4 *)(row + i);
       const float r = rb ? rb[i >> gs] : 0.f;  // group % 4 == 0: one term per float4
       const float d0 = v.x + r - shift, d1 = v.y + r - shift, d2 = v.z + r - shift,
                   d3 = v.w + r - shift;
@@ -329,11 +329,15 @@ template <int LPR>
 __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(
     long long rows, int m, int c_total, const float4 *__restrict__ x,
     const float *__restrict__ coef, float *__restrict__ out, uint8_t *__restrict__ arg, int nt) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 each
-  const long long row = t / LPR;
-  const int part = (int)(t % LPR);
-  const bool live = row < rows;
-  const int c = live ? (int)((row / m) % c_total) : 0;
+  // grid.y = (b, c) slab of m rows, grid.x covers its m * LPR float4s: the channel is a scalar
+  // per workgroup (no per-thread 64-bit division)
+  const int slab = blockIdx.y;
+  const int tl = blockIdx.x * 256 + threadIdx.x;          // float4 index inside the slab
+  const bool live = tl < m * LPR;
+  const int c = slab % c_total;
+  const long long t = (long long)slab * m * LPR + tl;
+  const long long row = (long long)slab * m + tl / LPR;
+  const int part = tl % LPR;
   const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
   float4 q = live ? (nt ? ld4<true>((const float *)(x + t)) : x[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
   q.x = fmaxf(q.x * sc + bi, 0.f); q.y = fmaxf(q.y * sc + bi, 0.f);
@@ -388,11 +392,13 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
     const float *__restrict__ gpool, const float *__restrict__ pooled,
     const uint8_t *__restrict__ arg, const float *__restrict__ fwd_coef,
     const float *__restrict__ coef, float4 *__restrict__ dx, int nt) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long row = t / LPR;
-  const int part = (int)(t % LPR);
-  if (row >= rows) return;
-  const int c = (int)((row / m) % c_total);
+  const int slab = blockIdx.y;                              // (b, c): scalar channel
+  const int tl = blockIdx.x * 256 + threadIdx.x;
+  if (tl >= m * LPR) return;
+  const int c = slab % c_total;
+  const long long t = (long long)slab * m * LPR + tl;
+  const long long row = (long long)slab * m + tl / LPR;
+  const int part = tl % LPR;
   const float a = coef[c * 4 + 0], k1 = coef[c * 4 + 1], k2 = coef[c * 4 + 2];
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const float g = pooled[row] > 0.f ? gpool[row] : 0.f;
@@ -463,7 +469,7 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
   NESIE_REQUIRE(!pre_partial || (pre_nslice >= 1 && !row_bias), W);
   if (!pre_partial)
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_BLOCK), 0, s, c, p, sp, x, row_bias, group,
-                       partial);
+                       partial, nesie::stream_nt((long long)b * c * p * 4, 8) ? 1 : 0);
   // the producer's partials are unshifted sums: no shift element (x = NULL in the finalize)
   const BnFwdFin fin{pre_partial ? pre_nslice : nslice, (double)b * (double)p,
                      pre_partial ? nullptr : x, p, row_bias, group,
@@ -564,13 +570,15 @@ extern "C" int nesie_bn_relu_maxpool_forward(int b, int c, int m, int ns, const 
   const int sp = bn_sp(p), nslice = b * sp;
   float *partial = (float *)workspace;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, p, sp, x,
-                     (const float *)nullptr, 1, partial);
+                     (const float *)nullptr, 1, partial,
+                     nesie::stream_nt((long long)b * c * p * 4, 8) ? 1 : 0);
   const BnFwdFin fin{nslice, (double)b * (double)p, x, p, nullptr, 1, partial, gamma, beta,
                      running_mean, running_var, momentum, eps, save_mean, save_invstd, fwd_coef};
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c);
   const long long rows = (long long)b * c * m;
   const int lpr = ns / 4;
-  const dim3 grid((unsigned)cdiv(rows * lpr, 256));
+  NESIE_REQUIRE((long long)b * c <= 65535 && (long long)m * lpr < (1ll << 30), W);
+  const dim3 grid((unsigned)cdiv((long long)m * lpr, 256), (unsigned)(b * c));
 #define L(N) hipLaunchKernelGGL(bn_pool_fwd_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
                                 (const float4 *)x, fwd_coef, pooled, argmax, nt)
   const int nt = stream_nt(rows * ns * 4, 2) ? 1 : 0;
@@ -606,7 +614,8 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c, coef);
   const long long rows = (long long)b * c * m;
   const int lpr = ns / 4;
-  const dim3 grid((unsigned)cdiv(rows * lpr, 256));
+  NESIE_REQUIRE((long long)b * c <= 65535 && (long long)m * lpr < (1ll << 30), W);
+  const dim3 grid((unsigned)cdiv((long long)m * lpr, 256), (unsigned)(b * c));
 #define L(N) hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
                                 (const float4 *)x, grad_pooled, pooled, argmax, fwd_coef, coef, \
                                 (float4 *)dx, nt)

@@ -55,21 +55,24 @@ __global__ __launch_bounds__(256) void sum_kernel(long long n4, int span4, const
 
 int main() {
   const long long n = 67108864;  // 268 MB
-  float *x, *y, *o;
-  hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&o, 4096);
-  hipMemset(x, 0, n * 4); hipMemset(o, 0, 4096);
+  const int NB = 6;                       // 6 x 268 MB inputs + 6 outputs: every pass is cold
+  float *xs[NB], *ys[NB], *o;
+  for (int i = 0; i < NB; ++i) { hipMalloc(&xs[i], n * 4); hipMalloc(&ys[i], n * 4); hipMemset(xs[i], 0x3c, n * 4); }
+  hipMalloc(&o, 4096); hipMemset(o, 0, 4096);
+  int turn = 0;
+  float *x = xs[0], *y = ys[0];
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const long long n4 = n / 4;
 #define RUN(label, bytes, launch)                                            \
   do {                                                                       \
-    for (int w = 0; w < 3; ++w) { launch; }                                  \
+    for (int w = 0; w < 3; ++w) { x = xs[turn % NB]; y = ys[turn % NB]; ++turn; launch; }  \
     hipEventRecord(e0);                                                      \
-    for (int r = 0; r < 20; ++r) { launch; }                                 \
+    for (int r = 0; r < 20; ++r) { x = xs[turn % NB]; y = ys[turn % NB]; ++turn; launch; } \
     hipEventRecord(e1); hipEventSynchronize(e1);                             \
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;                    \
     printf("%-44s %7.1f us  %6.2f TB/s\n", label, ms * 1e3, (bytes) / ms / 1e9); \
   } while (0)
-  const int spans[] = {2048, 8192, 32768, 131072};
+  const int spans[] = {2048, 8192, 32768, 131072};  // floats per workgroup
   char label[128];
   for (int si = 0; si < 4; ++si) {
     const int span4 = spans[si] / 4;
