@@ -119,9 +119,52 @@ class VoteNet(nn.Module):
                 use_iou_for_nms=cfg.get('use_iou_for_nms', True))
         return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
 
+    def graphed_simple_test(self, batch, num_points, feat_dim=4, device=None):
+        """-> callable(points, img_metas=None) with ``simple_test``'s results, the device half
+        (backbone, head, score fusion, point counts, NMS) captured once as a hipGraph for a fixed
+        (batch, num_points) and replayed per call; only the per-scene boolean selection and the
+        copy to the host stay eager."""
+        return GraphedSimpleTest(self, batch, num_points, feat_dim, device)
+
     @staticmethod
     def parse_losses(losses):
         return sum(v for k, v in losses.items() if 'loss' in k)
+
+
+class GraphedSimpleTest:
+    def __init__(self, model, batch, num_points, feat_dim=4, device=None):
+        self.model = model.eval()
+        device = device or next(model.parameters()).device
+        cfg = model.test_cfg if isinstance(model.test_cfg, dict) else vars(model.test_cfg)
+        self.pts = torch.zeros(batch, num_points, feat_dim, device=device)
+        # plausible coordinates for the warm-up passes (degenerate all-zero clouds are legal
+        # but exercise nothing)
+        self.pts[..., :3].uniform_(-3.0, 3.0)
+
+        def device_half():
+            x = model.extract_feat(self.pts)
+            preds = model.bbox_head(x, cfg['sample_mod'])
+            return model.bbox_head.detect_tensors(self.pts, preds,
+                                                  cfg.get('use_iou_for_nms', True))
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(2):
+                device_half()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.tensors = device_half()
+
+    def __call__(self, points, img_metas=None):
+        pts = torch.stack(points) if isinstance(points, (list, tuple)) else points
+        assert pts.shape == self.pts.shape, (tuple(pts.shape), tuple(self.pts.shape))
+        self.pts.copy_(pts, non_blocking=True)
+        self.graph.replay()
+        with torch.no_grad():
+            out = self.model.bbox_head.boxes_from_tensors(self.tensors, img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in out]
 
 
 def build_nesie_votenet(cfg=None):

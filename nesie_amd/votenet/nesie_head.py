@@ -297,21 +297,25 @@ class NesieHead(nn.Module):
                     labels)
         return box_sel, obj_sel, classes[selected]
 
-    def get_bboxes(self, points, bbox_preds, input_metas, rescale=False, use_nms=True,
-                   use_iou_for_nms=True):
-        """Boxes, scores and labels per scene from the head's predictions (:681-729)."""
+    def detect_tensors(self, points, bbox_preds, use_iou_for_nms=True):
+        """The device half of get_bboxes (:696-718): scores, bottom-origin boxes, classes and
+        the per-proposal `selected` mask for the whole batch -- fixed shapes, no host
+        synchronisation (capturable in a hipGraph)."""
         obj_scores = F.softmax(bbox_preds['obj_scores'], dim=-1)[..., -1]
         sem_scores = F.softmax(bbox_preds['sem_scores'], dim=-1)
-        bbox3d = bbox_preds['bbox_preds']
         if use_iou_for_nms:
             indx = bbox_preds['sem_scores'].max(dim=-1)[1]
             obj_scores = obj_scores * bbox_preds['iou_scores'].gather(2, indx.unsqueeze(-1)).squeeze(-1)
-        if not use_nms:
-            return bbox3d
-        boxes, classes, selected = self._nms_selection(obj_scores, sem_scores, bbox3d,
-                                                       points[..., :3])
+        boxes, classes, selected = self._nms_selection(obj_scores, sem_scores,
+                                                       bbox_preds['bbox_preds'], points[..., :3])
+        return boxes, obj_scores, sem_scores, classes, selected
+
+    def boxes_from_tensors(self, tensors, input_metas=None):
+        """The host-shaped half: per scene, the boolean selection and the reference's
+        (boxes, scores, labels) triple (:719-729, 768-788)."""
+        boxes, obj_scores, sem_scores, classes, selected = tensors
         results = []
-        for b in range(bbox3d.shape[0]):
+        for b in range(boxes.shape[0]):
             box_sel, score_sel, labels = self._gather_selected(
                 boxes[b], obj_scores[b], sem_scores[b], classes[b], selected[b])
             box_type = (input_metas[b] or {}).get('box_type_3d', DepthInstance3DBoxes) \
@@ -319,6 +323,14 @@ class NesieHead(nn.Module):
             results.append((box_type(box_sel, box_dim=box_sel.shape[-1], with_yaw=True),
                             score_sel, labels))
         return results
+
+    def get_bboxes(self, points, bbox_preds, input_metas, rescale=False, use_nms=True,
+                   use_iou_for_nms=True):
+        """Boxes, scores and labels per scene from the head's predictions (:681-729)."""
+        if not use_nms:
+            return bbox_preds['bbox_preds']
+        return self.boxes_from_tensors(self.detect_tensors(points, bbox_preds, use_iou_for_nms),
+                                       input_metas)
 
     def multiclass_nms_single(self, obj_scores, sem_scores, bbox, points, input_meta):
         """Single-scene form with the reference's signature (:731-788)."""

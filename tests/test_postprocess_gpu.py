@@ -174,3 +174,25 @@ def test_simple_test_end_to_end(oracle_kernels, hip_device):
     ret = evaluation.indoor_eval(gt_annos, out, (0.25, 0.5), {i: str(i) for i in range(18)},
                                  logger="silent")
     assert 'mAP_0.25' in ret and 'mAR_0.50' in ret
+
+
+def test_graphed_simple_test_equals_eager(hip_device):
+    model = _small.small_model().to(hip_device)
+    model.test_cfg['sample_mod'] = 'seed'
+    pts, _, _ = _small.small_batch()
+    pts = pts.to(hip_device)
+    model.train()
+    with torch.no_grad():
+        model.bbox_head(model.extract_feat(pts), 'vote')      # move the running statistics
+    model.eval()
+    # injected noise must already live on the device: a host->device copy cannot be captured
+    model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(2, 32))
+    graphed = model.graphed_simple_test(2, pts.shape[1])
+    for rep in range(2):                                        # two replays, fresh inputs
+        p = pts if rep == 0 else pts.flip(1).contiguous()
+        want = model.simple_test(p, None)
+        got = graphed([q for q in p])
+        for a, b in zip(want, got):
+            assert torch.equal(a['labels_3d'], b['labels_3d'])
+            torch.testing.assert_close(a['scores_3d'], b['scores_3d'], rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(a['boxes_3d'].tensor, b['boxes_3d'].tensor, rtol=1e-5, atol=1e-6)
