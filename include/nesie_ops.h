@@ -333,6 +333,18 @@ int nesie_side_decode_backward(int b, int k, int bins, const float *reg, const f
                                const float *scale, const float *sign, const float *d_surface,
                                const float *d_bbox, float *d_reg, float *d_agg, void *stream);
 
+/* Evaluation-mode BatchNorm (+ ReLU) (+ max over the neighbourhood axis): the running statistics
+ * are folded by the caller into coef [C,4] = (scale, bias, -, -), scale = gamma / sqrt(var + eps),
+ * bias = beta - mean * scale (what torch.nn.BatchNorm{1,2}d.eval() + nn.ReLU compute for the
+ * ConvModules of point_sa_module.py:277-289 / side_pooling_module.py:346-358 at test time).
+ * row_bias / group as in nesie_bn_relu_forward. */
+int nesie_affine_relu_forward(int b, int c, long long p, const float *x, const float *coef,
+                              int relu, const float *row_bias, int group, float *y,
+                              void *stream);
+int nesie_affine_relu_maxpool_forward(int b, int c, int m, int ns, const float *x,
+                                      const float *coef, float *pooled, uint8_t *argmax,
+                                      void *stream);
+
 /* ---- inference post-processing and evaluation geometry -------------- */
 
 /* aligned_3d_nms (core/post_processing/box3d_nms.py:129-176) for B scenes at once.

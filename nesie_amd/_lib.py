@@ -34,6 +34,8 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
     "nesie_side_decode_forward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_side_decode_backward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nesie_affine_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _I, _P, _I, _P, _P],
+    "nesie_affine_relu_maxpool_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_aligned_3d_nms": [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P],
     "nesie_points_in_boxes_count": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],

@@ -173,6 +173,37 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
   }
 }
 
+// Evaluation mode: y = relu?(scale[c] * (x + row_bias) + bias[c]) with the coefficients given
+// (running statistics folded on the host side of the C ABI): one read + one write.
+template <bool RELU, bool NT>
+__global__ __launch_bounds__(BN_BLOCK) void affine_apply_kernel(
+    int c_total, long long p, const float *__restrict__ x, const float *__restrict__ row_bias,
+    int group, const float *__restrict__ coef, float *__restrict__ y) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
+  const size_t base = ((size_t)b * c_total + c) * p;
+  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
+  const long long lo = (long long)blockIdx.x * BN_SPAN;
+  const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
+  const int gs = group_shift(group);
+  if ((p & 3) == 0) {
+    for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
+      float4 v = ld4<NT>(x + base + i);
+      if (rb) { const float r = rb[i >> gs]; v.x += r; v.y += r; v.z += r; v.w += r; }
+      float4 o = make_float4(v.x * sc + bi, v.y * sc + bi, v.z * sc + bi, v.w * sc + bi);
+      if (RELU) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      st4<NT>(y + base + i, o);
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
+      float o = (x[base + i] + (rb ? rb[i >> gs] : 0.f)) * sc + bi;
+      y[base + i] = RELU ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
 // backward partials: sum(g), sum(g * xhat), g = RELU ? dy * [y > 0] : dy
 template <bool RELU, bool NT>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
@@ -620,6 +651,53 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
                                 (const float4 *)x, grad_pooled, pooled, argmax, fwd_coef, coef, \
                                 (float4 *)dx, nt)
   const int nt = stream_nt(rows * ns * 4, 2) ? 1 : 0;
+  if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
+  else if (lpr == 8) L(8); else L(16);
+#undef L
+  return check_launch(W);
+}
+
+// ---- evaluation mode -----------------------------------------------------------------------
+extern "C" int nesie_affine_relu_forward(int b, int c, long long p, const float *x,
+                                         const float *coef, int relu, const float *row_bias,
+                                         int group, float *y, void *stream) {
+  const char *W = "affine_relu_forward";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && p >= 0, W);
+  if (b == 0 || c == 0 || p == 0) return NESIE_OK;
+  NESIE_REQUIRE(x && coef && y && b <= 65535 && c <= 65535, W);
+  if (!row_bias) group = 1;
+  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
+  NESIE_REQUIRE(!row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
+  NESIE_REQUIRE((p & 3) != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
+  const dim3 grid(bn_sp(p), c, b);
+  hipStream_t s = (hipStream_t)stream;
+  const bool nt = bn_use_nt((long long)b * c * p);
+#define L(R, N) hipLaunchKernelGGL((affine_apply_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, x, row_bias, group, coef, y)
+  if (relu) { if (nt) L(true, true); else L(true, false); }
+  else { if (nt) L(false, true); else L(false, false); }
+#undef L
+  return check_launch(W);
+}
+
+extern "C" int nesie_affine_relu_maxpool_forward(int b, int c, int m, int ns, const float *x,
+                                                 const float *coef, float *pooled,
+                                                 uint8_t *argmax, void *stream) {
+  const char *W = "affine_relu_maxpool_forward";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && m >= 0 && ns >= 1, W);
+  if (b == 0 || c == 0 || m == 0) return NESIE_OK;
+  if (ns < 4 || ns > 64 || (ns & (ns - 1))) {
+    set_error("%s: nsample %d (needs a power of two in 4..64)", W, ns);
+    return NESIE_ERR_UNSUPPORTED;
+  }
+  NESIE_REQUIRE(x && coef && pooled && argmax && ((uintptr_t)x & 15) == 0, W);
+  const long long rows = (long long)b * c * m;
+  const int lpr = ns / 4;
+  NESIE_REQUIRE((long long)b * c <= 65535 && (long long)m * lpr < (1ll << 30), W);
+  const dim3 grid((unsigned)cdiv((long long)m * lpr, 256), (unsigned)(b * c));
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = stream_nt(rows * ns * 4, 2) ? 1 : 0;
+#define L(N) hipLaunchKernelGGL(bn_pool_fwd_kernel<N>, grid, dim3(256), 0, s, rows, m, c, \
+                                (const float4 *)x, coef, pooled, argmax, nt)
   if (lpr == 1) L(1); else if (lpr == 2) L(2); else if (lpr == 4) L(4);
   else if (lpr == 8) L(8); else L(16);
 #undef L

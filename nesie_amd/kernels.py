@@ -253,6 +253,27 @@ class HipKernels(_BNPoolMixin):
                       _ptr(scale), _ptr(sign), opt(d_surface), opt(d_bbox), _ptr(d_reg),
                       _ptr(d_agg), _stream(reg))
 
+    def affine_relu_forward(self, x, coef, relu, y, row_bias=None):
+        """Evaluation-mode norm: y = relu?(coef[c,0] * (x + row_bias) + coef[c,1]); x, y (B,C,*)."""
+        _check(x, coef, y); _f32(x, coef, y)
+        b, c = x.shape[:2]
+        p = x.numel() // (b * c) if b * c else 0
+        assert tuple(coef.shape) == (c, 4) and y.shape == x.shape
+        group = _row_bias_group(x, row_bias)
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_affine_relu_forward", b, c, p, _ptr(x), _ptr(coef), int(bool(relu)),
+                      0 if row_bias is None else _ptr(row_bias), group, _ptr(y), _stream(x))
+
+    def affine_relu_maxpool_forward(self, x, coef, pooled, argmax):
+        """x (B,C,M,ns) -> pooled (B,C,M) = max_ns relu(coef[c,0] * x + coef[c,1]), argmax u8."""
+        _check(x, coef, pooled, argmax); _f32(x, coef, pooled)
+        b, c, m, ns = x.shape
+        assert tuple(coef.shape) == (c, 4) and tuple(pooled.shape) == (b, c, m)
+        assert argmax.dtype == torch.uint8 and tuple(argmax.shape) == (b, c, m)
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_affine_relu_maxpool_forward", b, c, m, ns, _ptr(x), _ptr(coef),
+                      _ptr(pooled), _ptr(argmax), _stream(x))
+
     def aligned_3d_nms(self, boxes, scores, classes, valid, thr, picks, count):
         """boxes (B,K,6), scores (B,K), classes (B,K) i32, valid (B,K) u8 or None ->
         picks (B,K) i32 (-1 padded, pick order), count (B) i32."""

@@ -5,8 +5,10 @@ The reference builds conv -> BN -> ReLU from mmcv ``ConvModule`` and from
 side_pooling_module.py:55-78, 346-358); these classes ARE ``nn.BatchNorm{1,2}d`` (same
 parameters, buffers and state-dict keys) whose training forward runs
 ``nesie_bn_relu_forward`` (3 streaming passes) instead of batch_norm + relu (5), and whose
-backward runs ``nesie_bn_relu_backward`` (5 passes instead of 10).  Evaluation mode and the
-injected CPU back end use the ATen path.
+backward runs ``nesie_bn_relu_backward`` (5 passes instead of 10).  In evaluation mode (no
+autograd) the running statistics are folded into one scale / bias pair per channel and the layer
+is a single read + write pass (``nesie_affine_relu_forward``); with autograd enabled, and on the
+injected CPU back end, evaluation uses the ATen path.
 """
 import torch
 import torch.nn.functional as F
@@ -117,6 +119,27 @@ class BNReLUMaxPoolTrain(Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+def eval_coefficients(weight, bias, running_mean, running_var, eps):
+    """(C,4) = (scale, bias, 0, 0) of an evaluation-mode BatchNorm: scale = gamma / sqrt(var +
+    eps), bias = beta - mean * scale."""
+    scale = torch.rsqrt(running_var + eps)
+    if weight is not None:
+        scale = scale * weight
+    shift = -running_mean * scale
+    if bias is not None:
+        shift = shift + bias
+    zero = torch.zeros_like(scale)
+    return torch.stack([scale, shift, zero, zero], dim=1).contiguous()
+
+
+def affine_relu_eval(x, coef, relu, row_bias=None):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    backend_for(x).affine_relu_forward(x, coef, relu, y,
+                                       None if row_bias is None else row_bias.contiguous())
+    return y
+
+
 class _FusedBNReLU:
     """Mixin over nn.BatchNorm{1,2}d: ``relu=True`` folds the activation into the norm."""
 
@@ -131,10 +154,15 @@ class _FusedBNReLU:
         backend = backend_for(x)  # raises for CPU tensors without an injected back end
         native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
                   and self.affine and self.track_running_stats and self.momentum is not None)
+        native_eval = self._native_eval(x, backend)
         if row_bias is not None:
             g = x.shape[-1]
-            if not (native and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
+            if not ((native or native_eval) and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
                 x, row_bias = x + row_bias.unsqueeze(-1), None
+        if native_eval:
+            return affine_relu_eval(x, eval_coefficients(self.weight, self.bias, self.running_mean,
+                                                         self.running_var, self.eps),
+                                    self.fuse_relu, row_bias)
         if native:
             if _counter_sink is not None:
                 _counter_sink.append(self.num_batches_tracked)
@@ -147,6 +175,11 @@ class _FusedBNReLU:
         return F.relu(y) if self.fuse_relu else y
 
 
+    def _native_eval(self, x, backend):
+        return (backend.name == 'hip' and not self.training and self.track_running_stats
+                and self.running_mean is not None and x.dtype == torch.float32
+                and not torch.is_grad_enabled())
+
     def forward_max_pool(self, x):
         """relu(bn(x)) followed by the max over the last axis of x (B, C, M, ns) -> (B, C, M),
         in one fused pass when the native training path applies; else the two-step form."""
@@ -155,6 +188,15 @@ class _FusedBNReLU:
         native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
                   and self.affine and self.track_running_stats and self.momentum is not None
                   and self.fuse_relu and x.dim() == 4 and 4 <= ns <= 64 and ns & (ns - 1) == 0)
+        if (self._native_eval(x, backend) and self.fuse_relu and x.dim() == 4
+                and 4 <= ns <= 64 and ns & (ns - 1) == 0):
+            x = x.contiguous()
+            pooled = x.new_empty(x.shape[:3])
+            argmax = torch.empty(x.shape[:3], dtype=torch.uint8, device=x.device)
+            backend.affine_relu_maxpool_forward(
+                x, eval_coefficients(self.weight, self.bias, self.running_mean, self.running_var,
+                                     self.eps), pooled, argmax)
+            return pooled
         if not native:
             from .pool import group_max_pool
             return group_max_pool(self.forward(x))

@@ -81,6 +81,10 @@ def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     first, C = layers[0], layers[0].num_features
     rm = torch.cat([l.running_mean for l in layers])
     rv = torch.cat([l.running_var for l in layers])
+    if not first.training:   # evaluation: one scale / bias pass over the stacked channels
+        coef = _norm.eval_coefficients(torch.cat([l.weight for l in layers]),
+                                       torch.cat([l.bias for l in layers]), rm, rv, first.eps)
+        return _norm.affine_relu_eval(x, coef, first.fuse_relu, row_bias)
     y = _norm.BNReLUTrain.apply(x, torch.cat([l.weight for l in layers]),
                                 torch.cat([l.bias for l in layers]), rm, rv, first.momentum,
                                 first.eps, first.fuse_relu, row_bias, pre_partial)
@@ -94,7 +98,9 @@ def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
 
 def _stackable_bn(layers):
     f = layers[0]
-    return all(type(l) is type(f) and l.training and l.affine and l.track_running_stats
+    mode_ok = all(l.training for l in layers) or \
+        (not any(l.training for l in layers) and not torch.is_grad_enabled())
+    return mode_ok and all(type(l) is type(f) and l.affine and l.track_running_stats
                and l.momentum is not None and l.momentum == f.momentum and l.eps == f.eps
                and l.fuse_relu == f.fuse_relu and l.num_features == f.num_features
                for l in layers)
