@@ -307,6 +307,10 @@ extern "C" int nesie_mlp_stat_finalize(int c, long long nparts, double count,
 namespace nesie {
 
 constexpr int WG_Q = 64;  // positions per LDS tile
+// row pitch 68 floats: rows stay 16-byte aligned (one ds_write_b128 per staged float4, one
+// ds_read_b128 per four positions of an MFMA operand row) and the 8 rows a quarter-wave reads
+// start 4 banks apart, i.e. cover the 32 banks exactly
+constexpr int WG_P = WG_Q + 4;
 
 template <int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float *__restrict__ dy, const float *__restrict__ x,
     const float *__restrict__ x_coef, int x_relu, float *__restrict__ partial) {
   constexpr int MT = WM * MB * 32, NT = WN * NB * 32;  // padded Cout, Cin covered
-  extern __shared__ float lds[];                      // [MT + NT][WG_Q + 1]
-  float *sa = lds, *sb = lds + MT * (WG_Q + 1);
+  extern __shared__ float lds[];                      // [MT + NT][WG_P]
+  float *sa = lds, *sb = lds + MT * WG_P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int bi = blockIdx.y;
@@ -338,6 +342,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   float4 v[PASSES];
   auto load_tile = [&](long long q0) {
     const long long q = q0 + (tid & 15) * 4;
+    if (vec && q0 + WG_Q <= p1) {
+      // interior tile (a wave-uniform test): PASSES unconditional 16-byte loads issued back to
+      // back -- rows past Cout / Cin read a valid row and are zeroed by a select, so that no
+      // branch (and no wait) separates the loads
+#pragma unroll
+      for (int u = 0; u < PASSES; ++u) {
+        const bool is_a = u * 16 < MT;                      // compile-time per pass
+        const int row = u * 16 + (tid >> 4) - (is_a ? 0 : MT);
+        const int lim = is_a ? cout : cin;
+        const int rr = row < lim ? row : lim - 1;
+        const float4 t = *(const float4 *)((is_a ? dyb : xb) + (size_t)rr * p + q);
+        v[u] = row < lim ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (x_coef) {
+#pragma unroll
+        for (int u = MT / 16; u < PASSES; ++u) {
+          const int row = u * 16 + (tid >> 4) - MT;
+          if (row < cin) {
+            const float sc = x_coef[row * 4 + 0], bs = x_coef[row * 4 + 1];
+            v[u].x = v[u].x * sc + bs; v[u].y = v[u].y * sc + bs;
+            v[u].z = v[u].z * sc + bs; v[u].w = v[u].w * sc + bs;
+            if (x_relu) {
+              v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f);
+              v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < PASSES; ++u) {
       const int r = u * 16 + (tid >> 4);
@@ -376,25 +410,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
     for (int u = 0; u < PASSES; ++u) {
       const int r = u * 16 + (tid >> 4);
-      float *dst = (r < MT ? sa + r * (WG_Q + 1) : sb + (r - MT) * (WG_Q + 1)) + (tid & 15) * 4;
-      dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+      float *dst = (r < MT ? sa + r * WG_P : sb + (r - MT) * WG_P) + (tid & 15) * 4;
+      *(float4 *)dst = v[u];
     }
     __syncthreads();
     if (q0 + WG_Q < p1) load_tile(q0 + WG_Q);
-    const float *pa = sa + (wm * MB * 32 + l32) * (WG_Q + 1) + half;
-    const float *pb = sb + (wn * NB * 32 + l32) * (WG_Q + 1) + half;
-#pragma unroll 8
-    for (int k2 = 0; k2 < WG_Q / 2; ++k2) {
-      float a[MB], b[NB];
+    const float *pa = sa + (wm * MB * 32 + l32) * WG_P;
+    const float *pb = sb + (wn * NB * 32 + l32) * WG_P;
+    // four positions per LDS read: lanes 0-31 feed k = 4j, 4j+2, lanes 32-63 k = 4j+1, 4j+3
+#pragma unroll 4
+    for (int k4 = 0; k4 < WG_Q / 4; ++k4) {
+      float4 a[MB], b[NB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) a[i] = pa[i * 32 * (WG_Q + 1) + k2 * 2];
+      for (int i = 0; i < MB; ++i) a[i] = *(const float4 *)(pa + i * 32 * WG_P + k4 * 4);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) b[j] = pb[j * 32 * (WG_Q + 1) + k2 * 2];
+      for (int j = 0; j < NB; ++j) b[j] = *(const float4 *)(pb + j * 32 * WG_P + k4 * 4);
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a[i].y : a[i].x,
+                                                           half ? b[j].y : b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a[i].w : a[i].z,
+                                                           half ? b[j].w : b[j].z, acc[i][j], 0, 0, 0);
+        }
     }
   }
   // partial[(b * runs + run)][cout][cin]
@@ -484,7 +523,7 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
   const dim3 grid(runs, b);
 #define L(WM, WN, MB, NB)                                                                        \
   do {                                                                                           \
-    const size_t lds = (size_t)(WM * MB + WN * NB) * 32 * (WG_Q + 1) * sizeof(float);            \
+    const size_t lds = (size_t)(WM * MB + WN * NB) * 32 * WG_P * sizeof(float);            \
     hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MB, NB>), grid, dim3(256), lds, s, cout, cin, \
                        p, x_bstride, run, vec_ok, dy, x, x_coef, x_relu, partial);                       \
   } while (0)
