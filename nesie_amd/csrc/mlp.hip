@@ -77,6 +77,29 @@ __global__ __launch_bounds__(WM * WN * 64) void mlp_fwd_kernel(
   float wr[WPT];
 
   auto load_tiles = [&](int k0) {
+    if (inside && k0 + MLP_BK <= cin && XV % NT == 0) {
+      // interior K step of an interior column block (wave-uniform): unconditional 16-byte
+      // loads issued back to back (no branch, hence no wait, between them)
+#pragma unroll
+      for (int t = 0; t < XPT; ++t) {
+        const int v = tid + t * NT;
+        const int kk = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
+        xr[t] = *(const float4 *)(xb + (size_t)(k0 + kk) * p + n0 + c4);
+      }
+      if (in_coef) {
+#pragma unroll
+        for (int t = 0; t < XPT; ++t) {
+          const int k = k0 + (tid + t * NT) / (BN / 4);
+          const float sc = in_coef[k * 4 + 0], bs = in_coef[k * 4 + 1];
+          float4 q = xr[t];
+          q.x = q.x * sc + bs; q.y = q.y * sc + bs; q.z = q.z * sc + bs; q.w = q.w * sc + bs;
+          if (in_relu) {
+            q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
+          }
+          xr[t] = q;
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < XPT; ++t) {
       const int v = tid + t * NT;
@@ -110,13 +133,17 @@ __global__ __launch_bounds__(WM * WN * 64) void mlp_fwd_kernel(
       }
       xr[t] = q;
     }
+    }
+    // W tile: clamped, unconditional loads; out-of-range entries zeroed by a select
 #pragma unroll
     for (int t = 0; t < WPT; ++t) {
       const int e = tid + t * NT;       // kk fastest: 16 consecutive k of one output channel
       const int m = e / MLP_BK, kk = e % MLP_BK;
       const int k = k0 + kk;
-      wr[t] = ((WE % NT == 0 || e < WE) && k < cin && m0 + m < cout)
-                  ? w[(size_t)(m0 + m) * cin + k] : 0.f;
+      const bool ok = (WE % NT == 0 || e < WE) && k < cin && m0 + m < cout;
+      const int mm = m0 + m < cout ? m0 + m : cout - 1, kc = k < cin ? k : cin - 1;
+      const float t0 = w[(size_t)mm * cin + kc];
+      wr[t] = ok ? t0 : 0.f;
     }
   };
   auto store_tiles = [&](int buf) {
