@@ -1,5 +1,5 @@
 // side2box: distribution-over-bins side offsets -> box planes -> (centre, size, yaw), forward
-// and backward, one thread per proposal.
+// and backward, one thread per (proposal, side).
 //
 // Stands in for NesieHead.side2box + Integral + the bbox_probs softmax (reference
 // mmdet3d/models/dense_heads/nesie_head.py:19-52, 150-209, 255-257): per proposal 6 softmaxes
@@ -14,83 +14,95 @@ namespace nesie {
 
 constexpr int DEC_MAXBINS = 33;
 
-__global__ __launch_bounds__(256) void side_decode_fwd_kernel(
+// One thread per (proposal, side): a workgroup = 64 proposals x 6 sides, wave s owns side s (its
+// lanes read consecutive proposals of one channel row); the six planes of a proposal meet in LDS.
+constexpr int DEC_KB = 64;
+
+__global__ __launch_bounds__(6 * DEC_KB) void side_decode_fwd_kernel(
     int kprop, int bins, const float *__restrict__ reg, const float *__restrict__ agg,
     const float *__restrict__ scale, const float *__restrict__ sign, float *__restrict__ probs,
     float *__restrict__ surface, float *__restrict__ bbox) {
-  const int k = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
-  if (k >= kprop) return;
+  __shared__ float sfs[6][DEC_KB];
+  const int kl = threadIdx.x & (DEC_KB - 1), s = threadIdx.x / DEC_KB;
+  const int k = blockIdx.x * DEC_KB + kl, bi = blockIdx.y;
+  const bool live = k < kprop;
+  const int kc = live ? k : kprop - 1;
   const int cch = 6 * bins + 2;
-  const float *r = reg + (size_t)bi * cch * kprop + k;
-  float *pr = probs + (size_t)bi * 6 * bins * kprop + k;
-  const float *a = agg + ((size_t)bi * kprop + k) * 3;
-  float sf[6];
-  for (int s = 0; s < 6; ++s) {
-    float l[DEC_MAXBINS], mx = -INFINITY;
-    for (int j = 0; j < bins; ++j) {
-      l[j] = r[(size_t)(s * bins + j) * kprop];
-      mx = fmaxf(mx, l[j]);
-    }
-    float sum = 0.f;
-    for (int j = 0; j < bins; ++j) { l[j] = expf(l[j] - mx); sum += l[j]; }
-    float res = 0.f;
-    for (int j = 0; j < bins; ++j) {
-      const float pj = l[j] / sum;
-      pr[(size_t)(s * bins + j) * kprop] = pj;
-      res += pj * ((float)j / (float)(bins - 1));
-    }
-    sf[s] = a[s % 3] + sign[s] * (res * scale[s]);
+  const float *r = reg + (size_t)bi * cch * kprop + kc;
+  const float *rs = r + (size_t)(s * bins) * kprop;
+  float mx = -INFINITY;
+  for (int j = 0; j < bins; ++j) mx = fmaxf(mx, rs[(size_t)j * kprop]);
+  float sum = 0.f;
+  for (int j = 0; j < bins; ++j) sum += expf(rs[(size_t)j * kprop] - mx);
+  float res = 0.f;
+  float *pr = probs + (size_t)bi * 6 * bins * kprop + (size_t)(s * bins) * kprop + kc;
+  for (int j = 0; j < bins; ++j) {
+    const float pj = expf(rs[(size_t)j * kprop] - mx) / sum;
+    if (live) pr[(size_t)j * kprop] = pj;
+    res += pj * ((float)j / (float)(bins - 1));
   }
-  float *so = surface + ((size_t)bi * kprop + k) * 6;
-  for (int s = 0; s < 6; ++s) so[s] = sf[s];
-  const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
-  const float nrm = sqrtf(h0 * h0 + h1 * h1);
+  const float *a = agg + ((size_t)bi * kprop + kc) * 3;
+  const float sf = a[s % 3] + sign[s] * (res * scale[s]);
+  sfs[s][kl] = sf;
+  if (live) surface[((size_t)bi * kprop + k) * 6 + s] = sf;
+  __syncthreads();
+  if (!live) return;
   float *bo = bbox + ((size_t)bi * kprop + k) * 7;
-  for (int d = 0; d < 3; ++d) {
-    bo[d] = (sf[d] + sf[d + 3]) / 2.0f;
-    bo[3 + d] = sf[d + 3] - sf[d];
+  if (s < 3) {
+    bo[s] = (sfs[s][kl] + sfs[s + 3][kl]) / 2.0f;
+  } else {
+    const int d = s - 3;
+    bo[3 + d] = sfs[d + 3][kl] - sfs[d][kl];
+    if (d == 0) {
+      const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
+      const float nrm = sqrtf(h0 * h0 + h1 * h1);
+      bo[6] = atan2f(h0 / nrm, h1 / nrm);
+    }
   }
-  bo[6] = atan2f(h0 / nrm, h1 / nrm);
 }
 
-__global__ __launch_bounds__(256) void side_decode_bwd_kernel(
+__global__ __launch_bounds__(6 * DEC_KB) void side_decode_bwd_kernel(
     int kprop, int bins, const float *__restrict__ reg, const float *__restrict__ probs,
     const float *__restrict__ scale, const float *__restrict__ sign,
     const float *__restrict__ d_surface, const float *__restrict__ d_bbox,
     float *__restrict__ d_reg, float *__restrict__ d_agg) {
-  const int k = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
-  if (k >= kprop) return;
+  __shared__ float gs[6][DEC_KB];
+  const int kl = threadIdx.x & (DEC_KB - 1), s = threadIdx.x / DEC_KB;
+  const int k = blockIdx.x * DEC_KB + kl, bi = blockIdx.y;
+  const bool live = k < kprop;
+  const int kc = live ? k : kprop - 1;
   const int cch = 6 * bins + 2;
-  const float *r = reg + (size_t)bi * cch * kprop + k;
-  const float *pr = probs + (size_t)bi * 6 * bins * kprop + k;
-  float *dr = d_reg + (size_t)bi * cch * kprop + k;
-  const float *ds = d_surface ? d_surface + ((size_t)bi * kprop + k) * 6 : nullptr;
-  const float *db = d_bbox ? d_bbox + ((size_t)bi * kprop + k) * 7 : nullptr;
-  float g[6];  // gradient reaching each plane
-  for (int s = 0; s < 6; ++s) g[s] = ds ? ds[s] : 0.f;
+  const float *ds = d_surface ? d_surface + ((size_t)bi * kprop + kc) * 6 : nullptr;
+  const float *db = d_bbox ? d_bbox + ((size_t)bi * kprop + kc) * 7 : nullptr;
+  // gradient reaching plane s: lo planes (s < 3) take centre / 2 - size, hi planes centre / 2 + size
+  float g = ds ? ds[s] : 0.f;
   if (db) {
-    for (int d = 0; d < 3; ++d) {
-      g[d] += db[d] * 0.5f - db[3 + d];        // lo: centre / 2, -size
-      g[d + 3] += db[d] * 0.5f + db[3 + d];    // hi: centre / 2, +size
-    }
+    const int d = s % 3;
+    g += s < 3 ? db[d] * 0.5f - db[3 + d] : db[d] * 0.5f + db[3 + d];
   }
-  float *da = d_agg + ((size_t)bi * kprop + k) * 3;
-  for (int d = 0; d < 3; ++d) da[d] = g[d] + g[d + 3];
-  for (int s = 0; s < 6; ++s) {
-    const float dres = g[s] * sign[s] * scale[s];
-    float res = 0.f;
-    for (int j = 0; j < bins; ++j)
-      res += pr[(size_t)(s * bins + j) * kprop] * ((float)j / (float)(bins - 1));
+  gs[s][kl] = g;
+  const float *pr = probs + (size_t)bi * 6 * bins * kprop + (size_t)(s * bins) * kprop + kc;
+  float *dr = d_reg + (size_t)bi * cch * kprop + kc;
+  const float dres = g * sign[s] * scale[s];
+  float res = 0.f;
+  for (int j = 0; j < bins; ++j) res += pr[(size_t)j * kprop] * ((float)j / (float)(bins - 1));
+  if (live)
     for (int j = 0; j < bins; ++j) {
-      const float pj = pr[(size_t)(s * bins + j) * kprop];
+      const float pj = pr[(size_t)j * kprop];
       dr[(size_t)(s * bins + j) * kprop] = pj * dres * ((float)j / (float)(bins - 1) - res);
     }
+  __syncthreads();
+  if (!live) return;
+  if (s < 3) {
+    d_agg[((size_t)bi * kprop + k) * 3 + s] = gs[s][kl] + gs[s + 3][kl];
+  } else if (s == 3) {
+    const float *r = reg + (size_t)bi * cch * kprop + k;
+    const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
+    const float n2 = h0 * h0 + h1 * h1;
+    const float dyaw = db ? db[6] : 0.f;
+    dr[(size_t)(6 * bins) * kprop] = dyaw * h1 / n2;
+    dr[(size_t)(6 * bins + 1) * kprop] = -dyaw * h0 / n2;
   }
-  const float h0 = r[(size_t)(6 * bins) * kprop], h1 = r[(size_t)(6 * bins + 1) * kprop];
-  const float n2 = h0 * h0 + h1 * h1;
-  const float dyaw = db ? db[6] : 0.f;
-  dr[(size_t)(6 * bins) * kprop] = dyaw * h1 / n2;
-  dr[(size_t)(6 * bins + 1) * kprop] = -dyaw * h0 / n2;
 }
 
 }  // namespace nesie
@@ -114,7 +126,7 @@ extern "C" int nesie_side_decode_forward(int b, int k, int bins, const float *re
   int st = dec_check(W, b, k, bins);
   if (st || b == 0 || k == 0) return st;
   NESIE_REQUIRE(reg && agg && scale && sign && probs && surface && bbox, W);
-  hipLaunchKernelGGL(side_decode_fwd_kernel, dim3(cdiv(k, 256), b), dim3(256), 0,
+  hipLaunchKernelGGL(side_decode_fwd_kernel, dim3(cdiv(k, DEC_KB), b), dim3(6 * DEC_KB), 0,
                      (hipStream_t)stream, k, bins, reg, agg, scale, sign, probs, surface, bbox);
   return check_launch(W);
 }
@@ -128,7 +140,7 @@ extern "C" int nesie_side_decode_backward(int b, int k, int bins, const float *r
   int st = dec_check(W, b, k, bins);
   if (st || b == 0 || k == 0) return st;
   NESIE_REQUIRE(reg && probs && scale && sign && d_reg && d_agg, W);
-  hipLaunchKernelGGL(side_decode_bwd_kernel, dim3(cdiv(k, 256), b), dim3(256), 0,
+  hipLaunchKernelGGL(side_decode_bwd_kernel, dim3(cdiv(k, DEC_KB), b), dim3(6 * DEC_KB), 0,
                      (hipStream_t)stream, k, bins, reg, probs, scale, sign, d_surface, d_bbox,
                      d_reg, d_agg);
   return check_launch(W);
