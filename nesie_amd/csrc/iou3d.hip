@@ -102,18 +102,28 @@ __device__ __forceinline__ void corners_of(const Dual<ND> &x, const Dual<ND> &y,
   }
 }
 
-template <int ND>
+// SPLIT (with ND = 1): eight threads per pair, thread `comp` carries the derivative with respect
+// to parameter `comp` only (the components of a dual number never mix, so every derivative is
+// the same chain of operations as in the 7-wide form: identical bits) -- a quarter of the serial
+// work per thread and eight times the threads for a kernel that is pure latency at 2 048 pairs.
+template <int ND, bool SPLIT>
 __global__ __launch_bounds__(64) void iou3d_kernel(int n, const float *__restrict__ box1,
                                                    const float *__restrict__ box2,
                                                    float *__restrict__ iou,
                                                    float *__restrict__ jac) {
   typedef Dual<ND> D;
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
+  const int gid = blockIdx.x * 64 + threadIdx.x;
+  const int i = SPLIT ? gid >> 3 : gid;
+  const int comp = gid & 7;
+  if (i >= n || (SPLIT && comp == 7)) return;
   const float *p = box1 + (size_t)i * 7, *q = box2 + (size_t)i * 7;
   D b1[7], b2[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) { b1[k] = D::var(p[k], k); b2[k] = D(q[k]); }
+  for (int k = 0; k < 7; ++k) {
+    if (SPLIT) { b1[k] = D(p[k]); if (k == comp) b1[k].d[0] = 1.f; }
+    else b1[k] = D::var(p[k], k);
+    b2[k] = D(q[k]);
+  }
 
   // ---- BEV corners -----------------------------------------------------------------
   D c1x[4], c1y[4], c2x[4], c2y[4];
@@ -206,6 +216,11 @@ __global__ __launch_bounds__(64) void iou3d_kernel(int n, const float *__restric
   const D inter3 = iou2d * uni * zov;
   const D v1 = b1[3] * b1[4] * b1[5], v2 = b2[3] * b2[4] * b2[5];
   const D out = inter3 / (v1 + v2 - inter3);
+  if (SPLIT) {
+    if (comp == 0) iou[i] = out.v;
+    jac[(size_t)i * 7 + comp] = out.d[0];
+    return;
+  }
   iou[i] = out.v;
   if (ND > 0) {
 #pragma unroll
@@ -223,10 +238,11 @@ extern "C" int nesie_iou3d_forward(int n, const float *box1, const float *box2, 
   NESIE_REQUIRE(n >= 0, W);
   if (n == 0) return NESIE_OK;
   NESIE_REQUIRE(box1 && box2 && iou, W);
-  dim3 grid(cdiv(n, 64));
   if (jac)
-    hipLaunchKernelGGL(iou3d_kernel<7>, grid, dim3(64), 0, (hipStream_t)stream, n, box1, box2, iou, jac);
+    hipLaunchKernelGGL((iou3d_kernel<1, true>), dim3(cdiv((long long)n * 8, 64)), dim3(64), 0,
+                       (hipStream_t)stream, n, box1, box2, iou, jac);
   else
-    hipLaunchKernelGGL(iou3d_kernel<0>, grid, dim3(64), 0, (hipStream_t)stream, n, box1, box2, iou, jac);
+    hipLaunchKernelGGL((iou3d_kernel<0, false>), dim3(cdiv(n, 64)), dim3(64), 0,
+                       (hipStream_t)stream, n, box1, box2, iou, jac);
   return check_launch(W);
 }
