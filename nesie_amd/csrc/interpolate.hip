@@ -240,12 +240,14 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     }
     if (stat_partial) { red[wv][lane][0] = a_s; red[wv][lane][1] = a_q; }
     __syncthreads();
-    // wave wv stores channels c0 + wv*16 .. +15 (lane = query): dense 256-byte rows
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int ch = wv * 16 + i;
-      float *o = dst + (size_t)(c0 + ch) * per_seg + lane;
-      if (nt) __builtin_nontemporal_store(tile[ch][lane], o); else *o = tile[ch][lane];
+    // wave wv stores channels c0 + wv*16 .. +15: four 256-byte rows per instruction (16 lanes x
+    // 16 bytes each) instead of one -- a quarter of the store instructions for the same bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = wv * 16 + i * 4 + (lane >> 4), q4 = (lane & 15) * 4;
+      const float4 v = make_float4(tile[ch][q4], tile[ch][q4 + 1], tile[ch][q4 + 2], tile[ch][q4 + 3]);
+      float *o = dst + (size_t)(c0 + ch) * per_seg + q4;
+      if (nt) st4<true>(o, v); else st4<false>(o, v);
     }
     if (stat_partial && wv == 0) {
       // (sum, sum of squares) of this tile per stacked channel, for the norm layer that follows:
