@@ -179,25 +179,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
     main = torch.cuda.current_stream(device)
 
-    def flat(tree):
-        out = []
-        for d in tree:
-            out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
-            for csr in d.get('group_csr', ()):
-                out += list(csr or ())
-            for idx_, w_, csr in d.get('fp_taps', ()):
-                out += [idx_, w_] + list(csr or ())
-        return out
-
-    def clone_tree(tree):
-        return [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
-                     group_idx=[t.clone() for t in d['group_idx']],
-                     group_csr=[None if csr is None else tuple(t.clone() for t in csr)
-                                for csr in d.get('group_csr', ())],
-                     **({'fp_taps': [(i_.clone(), w_.clone(),
-                                      None if c_ is None else tuple(t.clone() for t in c_))
-                                     for i_, w_, c_ in d['fp_taps']]} if 'fp_taps' in d else {}))
-                for d in tree]
+    from nesie_amd.votenet.backbone import clone_index_tree as clone_tree, index_tree_tensors as flat
 
     semi_like = workload in ('semi', 'saqe')
     # weight-independent work of a step: the backbone's index chain(s) and, for the supervised

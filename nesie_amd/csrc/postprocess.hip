@@ -102,6 +102,14 @@ __global__ __launch_bounds__(NMS_BLOCK) void aligned_nms_kernel(
   }
 }
 
+// zero-fill as a kernel: a hipMemsetAsync captured into a hipGraph next to the kernel that adds
+// into the same buffer replayed WITHOUT the ordering between the two on this stack (counts came
+// back partly zeroed on later replays), so the clears below are ordinary launches
+__global__ __launch_bounds__(256) void zero_i32_kernel(int n, int *__restrict__ p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 // ---- points_in_boxes_count ------------------------------------------------------------
 // Same inside-test as points_in_boxes.hip (points_in_boxes_cuda.cu:24-49), LiDAR-frame boxes;
 // counts[b, t] = number of the scene's points inside box t.
@@ -302,8 +310,10 @@ extern "C" int nesie_aligned_3d_nms(int b, int k, const float *boxes, const floa
     set_error("%s: k = %d boxes per scene, built for <= %d", W, k, NMS_MAX_K);
     return NESIE_ERR_UNSUPPORTED;
   }
-  if (k == 0) return hipMemsetAsync(count, 0, sizeof(int) * (size_t)b, (hipStream_t)stream) ==
-                             hipSuccess ? NESIE_OK : NESIE_ERR_LAUNCH;
+  if (k == 0) {
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(b, 256)), dim3(256), 0, (hipStream_t)stream, b, count);
+    return check_launch(W);
+  }
   NESIE_REQUIRE(boxes && scores && classes && picks, W);
   hipLaunchKernelGGL(aligned_nms_kernel, dim3(b), dim3(NMS_BLOCK), 0, (hipStream_t)stream, k,
                      boxes, scores, classes, valid, thr, picks, count);
@@ -317,9 +327,8 @@ extern "C" int nesie_points_in_boxes_count(int b, int boxes_num, int pts_num,
   NESIE_REQUIRE(b >= 0 && boxes_num >= 0 && pts_num >= 0, W);
   if (b == 0 || boxes_num == 0) return NESIE_OK;
   NESIE_REQUIRE(counts, W);
-  if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)b * boxes_num, (hipStream_t)stream) !=
-      hipSuccess)
-    return NESIE_ERR_LAUNCH;
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv((long long)b * boxes_num, 256)), dim3(256), 0,
+                     (hipStream_t)stream, b * boxes_num, counts);
   if (pts_num == 0) return NESIE_OK;
   NESIE_REQUIRE(boxes && pts && b <= 65535, W);
   hipLaunchKernelGGL(points_in_boxes_count_kernel, dim3(cdiv(pts_num, PIC_BLOCK), b),

@@ -87,3 +87,28 @@ class PointNet2SASSG(nn.Module):
             fp_indices.append(sa_indices[self.num_sa - i - 1])
         return dict(fp_xyz=fp_xyz, fp_features=fp_features, fp_indices=fp_indices,
                     sa_xyz=sa_xyz, sa_features=sa_features, sa_indices=sa_indices)
+
+
+def index_tree_tensors(tree):
+    """Every tensor of a ``sample_and_group_indices`` result, in a fixed order (for copying one
+    such result into the static buffers of another: the pipelined loops of bench.py and of
+    ``GraphedSimpleTest``)."""
+    out = []
+    for d in tree:
+        out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
+        for csr in d.get('group_csr', ()):
+            out += list(csr or ())
+        for idx_, w_, csr in d.get('fp_taps', ()):
+            out += [idx_, w_] + list(csr or ())
+    return out
+
+
+def clone_index_tree(tree):
+    return [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
+                 group_idx=[t.clone() for t in d['group_idx']],
+                 group_csr=[None if csr is None else tuple(t.clone() for t in csr)
+                            for csr in d.get('group_csr', ())],
+                 **({'fp_taps': [(i_.clone(), w_.clone(),
+                                  None if c_ is None else tuple(t.clone() for t in c_))
+                                 for i_, w_, c_ in d['fp_taps']]} if 'fp_taps' in d else {}))
+            for d in tree]

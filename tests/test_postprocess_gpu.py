@@ -188,11 +188,18 @@ def test_graphed_simple_test_equals_eager(hip_device):
     # injected noise must already live on the device: a host->device copy cannot be captured
     model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(2, 32))
     graphed = model.graphed_simple_test(2, pts.shape[1])
-    for rep in range(2):                                        # two replays, fresh inputs
-        p = pts if rep == 0 else pts.flip(1).contiguous()
-        want = model.simple_test(p, None)
-        got = graphed([q for q in p])
+    def same(want, got):
         for a, b in zip(want, got):
             assert torch.equal(a['labels_3d'], b['labels_3d'])
             torch.testing.assert_close(a['scores_3d'], b['scores_3d'], rtol=1e-5, atol=1e-7)
             torch.testing.assert_close(a['boxes_3d'].tensor, b['boxes_3d'].tensor, rtol=1e-5, atol=1e-6)
+    batches = [pts, pts.flip(1).contiguous(), pts.roll(1, 0).contiguous(), pts * 0.9]
+    wants = [model.simple_test(p, None) for p in batches]
+    for p, want in zip(batches[:2], wants):                     # one batch at a time
+        same(want, graphed([q for q in p]))
+    # throughput mode: the index chain of batch t+1 runs under the network of batch t
+    outs = list(graphed.stream(batches))
+    assert len(outs) == len(batches)
+    for want, got in zip(wants, outs):
+        same(want, got)
+    assert list(graphed.stream([])) == []

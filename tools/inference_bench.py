@@ -64,6 +64,16 @@ def main():
                torch.allclose(a['scores_3d'], b['scores_3d'], rtol=1e-4, atol=1e-6)
                for a, b in zip(ref, got))
     gwhole = timed(lambda: graphed(pts))
+    batches = [pts.roll(i, 0) for i in range(12)]
+    for _ in graphed.stream(batches[:3]):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_out = sum(1 for _ in graphed.stream(batches))
+    torch.cuda.synchronize()
+    piped = (time.perf_counter() - t0) / n_out * 1e3
+    first = next(iter(graphed.stream([pts])))
+    same_stream = all(torch.equal(a['labels_3d'], b['labels_3d']) for a, b in zip(ref, first))
     g = torch.Generator().manual_seed(1)
     c = torch.rand(8, 256, 3, generator=g) * 4
     h = 0.2 + torch.rand(8, 256, 3, generator=g) * 0.5
@@ -75,6 +85,7 @@ def main():
     print(f'get_bboxes                   {post:8.2f} ms')
     print(f'simple_test                  {whole:8.2f} ms  = {8e3 / whole:.0f} scenes/s')
     print(f'simple_test, hipGraph        {gwhole:8.2f} ms  = {8e3 / gwhole:.0f} scenes/s  (same detections as eager: {same})')
+    print(f'simple_test, pipelined graphs{piped:8.2f} ms  = {8e3 / piped:.0f} scenes/s  (index chain of batch t+1 under the network of batch t; same detections: {same_stream})')
     print(f'aligned_3d_nms, 8 x 256      {ours:8.3f} ms (one launch)  vs  {loop:8.1f} ms python loop of torch ops')
 
 
