@@ -673,28 +673,33 @@ __global__ __launch_bounds__(256) void mlp_stream_kernel(
     if (n0 + 4 * 32 < c1) load_cols(n0 + 4 * 32);
   }
   if (stat_partial) {
+    // per-wave slots, then a fixed-order sum over the four waves: the statistics (and with
+    // them the whole forward pass) are bitwise reproducible from run to run
+    __shared__ float sq_w[4][MB * 32];
+    __shared__ float cs_w[4][2 * KP];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const float q = half_wave_sum(qrow[i][r]);
-        if (l32 == 0) atomicAdd(&sstat[m][1], q);
+        if (l32 == 0) sq_w[wave][m] = q;
       }
     // column sums of the operand per k, then sum(y)[m] = sum_k W[m][k] * colsum[k]
     __shared__ float colsum[2 * KP];
-    if (tid < 2 * KP) colsum[tid] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
       const float t = half_wave_sum(ax[kp]);
-      if (l32 == 0) atomicAdd(&colsum[kp * 2 + half], t);
+      if (l32 == 0) cs_w[wave][kp * 2 + half] = t;
     }
+    __syncthreads();
+    if (tid < 2 * KP) colsum[tid] = (cs_w[0][tid] + cs_w[1][tid]) + (cs_w[2][tid] + cs_w[3][tid]);
     __syncthreads();
     for (int m = tid; m < cout; m += 256) {
       float t = 0.f;
       for (int k = 0; k < cin; ++k) t += ws[k * LDW + m] * colsum[k];
       sstat[m][0] = t;
+      sstat[m][1] = (sq_w[0][m] + sq_w[1][m]) + (sq_w[2][m] + sq_w[3][m]);
     }
     __syncthreads();
     float *dst = stat_partial + (((size_t)bi * gridDim.x + blockIdx.x) * cout) * 2;

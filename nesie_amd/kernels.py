@@ -274,6 +274,26 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_affine_relu_maxpool_forward", b, c, m, ns, _ptr(x), _ptr(coef),
                       _ptr(pooled), _ptr(argmax), _stream(x))
 
+    def mlp_stream_forward(self, x, w, y, stat_partial=None, in_coef=None, in_relu=False):
+        """y[b] = W . act(x[b]) on the matrix cores, streaming form (Cin <= 64, Cout <= 128):
+        x (B,Cin,P), w (Cout,Cin), y (B,Cout,P); stat_partial (parts, Cout, 2) receives the
+        per-workgroup (sum, sum of squares) of y, parts = mlp_stream_parts(B, P)."""
+        _check(x, w, y); _f32(x, w, y)
+        b, cin, p = x.shape
+        cout = w.shape[0]
+        assert tuple(w.shape) == (cout, cin) and tuple(y.shape) == (b, cout, p)
+        if stat_partial is not None:
+            _check(stat_partial); _f32(stat_partial)
+            assert tuple(stat_partial.shape) == (self.mlp_stream_parts(b, p), cout, 2)
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_mlp_layer_forward_stream", b, cin, cout, p, _ptr(x), cin * p,
+                      _ptr(w), 0 if in_coef is None else _ptr(in_coef), int(bool(in_relu)),
+                      _ptr(y), 0 if stat_partial is None else _ptr(stat_partial), _stream(x))
+
+    @staticmethod
+    def mlp_stream_parts(b, p):
+        return int(_lib.load().nesie_mlp_stream_partials(b, p))
+
     def aligned_3d_nms(self, boxes, scores, classes, valid, thr, picks, count):
         """boxes (B,K,6), scores (B,K), classes (B,K) i32, valid (B,K) u8 or None ->
         picks (B,K) i32 (-1 padded, pick order), count (B) i32."""

@@ -345,3 +345,30 @@ def test_two_rank_step_rehearsal_on_one_gpu():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 16
     assert res['scaling'] == 'weak' and res['value'] > 0 and 'cpu_baseline' not in res
+
+
+def test_stream_first_layer_equals_the_gemm_path(hip_device):
+    """ConvModule's skinny-first-layer path (streaming MFMA kernel + statistics epilogue feeding
+    the norm) against the plain conv -> norm path: outputs, running statistics, gradients."""
+    from nesie_amd.mmdet3d_ops import pointnet_modules as pm
+    torch.manual_seed(3)
+    a = pm.ConvModule(4, 64, 1, conv_cfg=dict(type='Conv2d'), norm_cfg=dict(type='BN2d')).to(hip_device)
+    b = copy.deepcopy(a)
+    x = torch.randn(2, 4, 1024, 32, device=hip_device)          # P = 32768 per scene
+    assert pm.stream_conv_eligible(x, a.conv, a.norm)
+    g = torch.randn(2, 64, 1024, 32, device=hip_device)
+    ya = a(x)
+    (ya * g).sum().backward()
+    real = pm.stream_conv_eligible
+    pm.stream_conv_eligible = lambda *_: False
+    try:
+        yb = b(x)
+        (yb * g).sum().backward()
+    finally:
+        pm.stream_conv_eligible = real
+    torch.testing.assert_close(ya, yb, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.norm.running_mean, b.norm.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.norm.running_var, b.norm.running_var, rtol=1e-5, atol=1e-6)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        scale = max(float(pb.grad.abs().max()), 1e-3)
+        assert float((pa.grad - pb.grad).abs().max()) / scale < 1e-3
