@@ -717,3 +717,30 @@ def test_blend_statistics_epilogue_feeds_the_norm(hip_device):
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,dups", [(1024, False), (1024, True), (300, True), (2048, False), (3000, False)])
+def test_grid_taps_equal_three_nn_on_the_same_points(hip_device, m, dups):
+    """The fused grid + tap kernel against three_nn on the grid points it reports: same indices
+    (duplicated seeds: equal distances, the smaller index keeps the better slot), same weights."""
+    from nesie_amd.mmdet3d_ops import three_nn
+    g = torch.Generator().manual_seed(m + dups)
+    B, K, gp = 3, 70, 96
+    known = torch.rand(B, m, 3, generator=g) * torch.tensor([8.0, 6.0, 2.5])
+    if dups:                                   # exact duplicates: equal distances, index decides
+        known[:, m // 2:] = known[:, :m - m // 2]
+    centre = torch.rand(B, K, 3, generator=g) * torch.tensor([8.0, 6.0, 2.5])
+    centre[:, :5] = known[:, :5]               # zero distances
+    centre[:, 5] += 30.0                       # a proposal far outside the seed cloud
+    size = 0.2 + torch.rand(B, K, 3, generator=g) * 2
+    heading = (torch.rand(B, K, generator=g) - 0.5) * 6
+    mult = torch.rand(gp, 3, generator=g) * 2 - 1
+    plane = torch.zeros(gp, 3)
+    dev = lambda t: t.to(hip_device).contiguous()   # noqa: E731
+    hip = kernels.backend_for(dev(known))
+    idx, weight, rel = hip.grid_taps(dev(centre), dev(size), dev(heading), dev(mult), dev(plane), dev(known))
+    world = rel + dev(centre).repeat_interleave(gp, 1)
+    d, ref_idx = three_nn(world.contiguous(), dev(known))
+    assert torch.equal(idx, ref_idx)
+    w = 1.0 / (d + 1e-8)
+    torch.testing.assert_close(weight, w / w.sum(-1, keepdim=True), rtol=1e-6, atol=1e-7)
