@@ -114,9 +114,13 @@ class VoteNet(nn.Module):
         with torch.no_grad():
             x = self.extract_feat(points_cat)
             bbox_preds = self.bbox_head(x, cfg['sample_mod'])
-            bbox_list = self.bbox_head.get_bboxes(
-                points_cat, bbox_preds, img_metas, rescale=rescale,
-                use_iou_for_nms=cfg.get('use_iou_for_nms', True))
+            tensors = self.bbox_head.detect_tensors(points_cat, bbox_preds,
+                                                    cfg.get('use_iou_for_nms', True))
+            # the results go to the host anyway (bbox3d2result): one transfer of the five small
+            # per-proposal tensors, then the per-scene selection there -- instead of a boolean
+            # indexing (a device->host synchronisation) per scene
+            bbox_list = self.bbox_head.boxes_from_tensors(tuple(t.cpu() for t in tensors),
+                                                          img_metas)
         return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
 
     def graphed_simple_test(self, batch, num_points, feat_dim=4, device=None):
@@ -202,8 +206,9 @@ class GraphedSimpleTest:
         self.taken.record(self.main)
 
     def _results(self, img_metas):
-        with torch.no_grad():
-            out = self.model.bbox_head.boxes_from_tensors(self.tensors, img_metas)
+        with torch.no_grad():   # one device->host transfer, selection on the host
+            out = self.model.bbox_head.boxes_from_tensors(tuple(t.cpu() for t in self.tensors),
+                                                          img_metas)
         return [bbox3d2result(b, s, l) for b, s, l in out]
 
     def __call__(self, points, img_metas=None):
@@ -212,22 +217,51 @@ class GraphedSimpleTest:
         self.graph.replay()
         return self._results(img_metas)
 
+    def _launch(self):
+        """Replay the network graph and start the device->host copy of its five small output
+        tensors into pinned buffers (two sets, alternating); -> (host tensors, event)."""
+        if getattr(self, '_host', None) is None:
+            self._host = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self.tensors]
+                          for _ in range(2)]
+            self._done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._flip = 0
+        self.graph.replay()
+        host, ev = self._host[self._flip], self._done[self._flip]
+        for h, t in zip(host, self.tensors):
+            h.copy_(t, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self._flip ^= 1
+        return host, ev
+
+    def _host_results(self, launched, img_metas):
+        host, ev = launched
+        ev.synchronize()            # waits for THIS batch's outputs only, not for the next graph
+        with torch.no_grad():
+            out = self.model.bbox_head.boxes_from_tensors(tuple(host), img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in out]
+
     def stream(self, batches, img_metas=None):
-        """Generator over the results of consecutive batches; the index chain of the next batch
-        runs under the network of the current one."""
+        """Generator over the results of consecutive batches.  Three things overlap: the index
+        chain of batch t+1 (side-stream graph), the network of batch t (main graph) and the
+        host-side selection of batch t-1 (its outputs were copied to pinned memory before the
+        next graph was queued)."""
         it = iter(batches)
         cur = next(it, None)
         if cur is None:
             return
         self._load_next(cur)
+        pending = None
         while cur is not None:
             nxt = next(it, None)
             self._rotate()
             if nxt is not None:
                 self._load_next(nxt)
-            self.graph.replay()
-            yield self._results(img_metas)
+            launched = self._launch()
+            if pending is not None:
+                yield self._host_results(pending, img_metas)
+            pending = launched
             cur = nxt
+        yield self._host_results(pending, img_metas)
 
 
 def build_nesie_votenet(cfg=None):
