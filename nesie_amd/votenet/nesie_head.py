@@ -242,7 +242,18 @@ class NesieHead(nn.Module):
             probs = reg_predictions[:, :self.n_reg_outs, :]
             results['bbox_probs'] = F.softmax(probs.reshape(B, 6, self.reg_max + 1, -1), dim=2)
 
-        center, size, heading, results = self.jitter_bbox_preds(results, dataset_name)
+        if not self.training and self._test_cfg('skip_jitter', False):
+            # Opt-in, test time only: get_bboxes reads the ORIGINAL proposals' scores alone, and
+            # with evaluation-mode norms every proposal is scored independently of the others, so
+            # leaving the jittered copies out (half of the quality head's work) changes no
+            # detection.  The reference always scores both halves (:240-262); the `*_jitter`
+            # entries are then simply empty.
+            bp = results['bbox_preds']
+            center, size, heading = bp[..., :3], bp[..., 3:6], bp[..., -1]
+            if dataset_name == 'ScanNet':
+                heading = torch.zeros_like(heading)
+        else:
+            center, size, heading, results = self.jitter_bbox_preds(results, dataset_name)
         results = self.grid_conv(center.detach(), size.detach(), heading.detach(), results)
 
         iou = results['iou_scores'].sigmoid()

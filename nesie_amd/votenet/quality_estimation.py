@@ -78,7 +78,8 @@ class QualityEstimation(SidePooling):
             whole_grid = self.generate_grid(size)
             side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
-        dist_feature = self.dist_feature(end_points, prefix)
+        dist_feature = self.dist_feature(end_points, prefix,
+                                         copies=K // end_points[f'{prefix}bbox_probs'].shape[-1])
         if fused and mini_pointnets_groupable(side_nets, side_c0):
             pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed,
                                             c0_stats=side_stats)

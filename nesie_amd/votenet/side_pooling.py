@@ -370,13 +370,13 @@ class SidePooling(nn.Module):
         three_interpolate_segmented(origin_features, idx, weight, out, segs, G, 3)
         return out.view(B, segs, 3 + C, K, G)
 
-    def dist_feature(self, end_points, prefix=''):
+    def dist_feature(self, end_points, prefix='', copies=2):
         """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
         for the jittered half -> (6, B, 38, 2K)  (:245-264)."""
         prob = end_points[f'{prefix}bbox_probs'].detach()
         stat = torch.cat([prob, prob.topk(self.reg_topk, dim=2)[0],
                           prob.var(dim=2, keepdim=True)], dim=2)
-        return stat.permute(1, 0, 2, 3).repeat(1, 1, 1, 2)
+        return stat.permute(1, 0, 2, 3).repeat(1, 1, 1, copies)   # copies = 1: no jittered half
 
     def forward(self, center, size, heading, end_points, prefix=''):
         B, K = size.shape[:2]
@@ -400,7 +400,8 @@ class SidePooling(nn.Module):
             bbox_grid = self.grid_for_bbox(whole_grid, center, heading).view(B, -1, 3).contiguous()
             side_feats = self.grid_features(origin_xyz, origin_features, side_grid, center, segs=6)
             bbox_feats = self.grid_features(origin_xyz, origin_features, bbox_grid, center)[:, 0]
-        dist_feature = self.dist_feature(end_points, prefix)
+        dist_feature = self.dist_feature(end_points, prefix,
+                                         copies=K // end_points[f'{prefix}bbox_probs'].shape[-1])
         if fused and mini_pointnets_groupable(side_nets, side_c0):
             pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed,
                                             c0_stats=side_stats)               # (B,6,128,2K)

@@ -203,3 +203,10 @@ def test_graphed_simple_test_equals_eager(hip_device):
     for want, got in zip(wants, outs):
         same(want, got)
     assert list(graphed.stream([])) == []
+    # test_cfg.skip_jitter: the quality head scores the original proposals only -- same detections
+    model.test_cfg['skip_jitter'] = True
+    try:
+        lean = model.simple_test(pts, None)
+    finally:
+        model.test_cfg['skip_jitter'] = False
+    same(wants[0], lean)
