@@ -34,6 +34,13 @@ __global__ __launch_bounds__(GG_BLOCK) void group_fwd_kernel(
   float *o = out + (size_t)bi * gstride + (size_t)c0 * e_total + e;  // gstride: scene pitch
   const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
   float v[GG_CH];
+  if (cend == GG_CH) {   // whole channel block (uniform): the eight gathers issue back to back
+#pragma unroll
+    for (int i = 0; i < GG_CH; ++i) v[i] = p[(size_t)i * n];
+#pragma unroll
+    for (int i = 0; i < GG_CH; ++i) o[(size_t)i * e_total] = v[i];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < GG_CH; ++i)
     if (i < cend) v[i] = p[(size_t)i * n];
