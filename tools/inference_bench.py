@@ -81,6 +81,11 @@ def main():
     scores, classes = torch.rand(8, 256, generator=g).to(dev), torch.randint(0, 18, (8, 256), generator=g).to(dev)
     ours = timed(lambda: post_processing.batched_aligned_3d_nms(boxes, scores, classes, 0.25), 50)
     loop = timed(lambda: [loop_nms(boxes[b], scores[b], classes[b], 0.25) for b in range(8)], 3)
+    with torch.no_grad():
+        one = pts[:1].contiguous()
+        f1 = timed(lambda: model.bbox_head(model.extract_feat(one), 'seed'))
+        s1 = timed(lambda: model.simple_test(one, None))
+    print(f'BASELINE configs[1] (batch 1, forward only): backbone + head {f1:6.2f} ms, simple_test {s1:6.2f} ms')
     print(f'eval forward (8 x 40k)      {fwd:8.2f} ms')
     print(f'get_bboxes                   {post:8.2f} ms')
     print(f'simple_test                  {whole:8.2f} ms  = {8e3 / whole:.0f} scenes/s')
