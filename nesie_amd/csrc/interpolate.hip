@@ -189,14 +189,16 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     int seg_off, const float *__restrict__ table, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
     const float *__restrict__ wx, float *__restrict__ out, float *__restrict__ stat_partial,
-    int nt) {
+    int nt, int nb) {
   __shared__ float tile[64][TS_Q + 1];
   __shared__ float red[4][64][2];
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
   __shared__ float sr[TS_Q][3];
-  const int bi = blockIdx.y;
-  const int q0 = blockIdx.x * TS_Q;  // output order: s * per_seg + k * seg_len + g
+  // 1-D grid with the scene fastest: workgroup i runs on XCD i % 8, so with B = 8 every scene's
+  // table rows are gathered through ONE XCD's L2 instead of all eight
+  const int bi = blockIdx.x % nb;
+  const int q0 = (blockIdx.x / nb) * TS_Q;  // output order: s * per_seg + k * seg_len + g
   const int per_seg = n / segs;
   const int sg = q0 / per_seg, r0 = q0 - sg * per_seg;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
       // partial[(chan * nslice + slice) * 2], nslice = B * per_seg / 64 (bn.hip's layout)
       const float ss = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
       const float qq = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
-      const int nslice = gridDim.y * (per_seg / TS_Q);
+      const int nslice = nb * (per_seg / TS_Q);
       const int slice = bi * (per_seg / TS_Q) + r0 / TS_Q;
       float *pd = stat_partial + ((size_t)(sg * c + c0 + lane) * nslice + slice) * 2;
       pd[0] = ss; pd[1] = qq;
@@ -342,15 +344,17 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
     const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
-    float *__restrict__ d_table, float *__restrict__ d_wx_part) {
+    float *__restrict__ d_table, float *__restrict__ d_wx_part, int nb, int nruns) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
   __shared__ float sr[TS_Q][3];
-  const int bi = blockIdx.y, sg = blockIdx.z;
+  // 1-D grid, scene fastest (workgroup i -> XCD i % 8): a scene's d_table rows take the atomic
+  // adds of one XCD's L2
+  const int bi = blockIdx.x % nb, run_i = (blockIdx.x / nb) % nruns, sg = blockIdx.x / (nb * nruns);
   const int per_seg = n / segs;
-  const int run0 = blockIdx.x * BL_RUN;
+  const int run0 = run_i * BL_RUN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float *src = dy + ((size_t)bi * segs + sg) * C * per_seg;
   float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
 #pragma unroll
       for (int d = 0; d < 3; ++d) red[(wv * C + e * 64 + lane) * 3 + d] = dx[e][d];
     __syncthreads();
-    float *dst = d_wx_part + ((((size_t)bi * gridDim.x + blockIdx.x) * segs + sg) * C) * 3;
+    float *dst = d_wx_part + ((((size_t)bi * nruns + run_i) * segs + sg) * C) * 3;
     for (int i = threadIdx.x; i < C * 3; i += 256)
       dst[i] = (red[i] + red[C * 3 + i]) + (red[2 * C * 3 + i] + red[3 * C * 3 + i]);
   }
@@ -817,10 +821,10 @@ extern "C" int nesie_blend_conv_forward(int b, int c, int m, int n, const float 
     return NESIE_ERR_UNSUPPORTED;
   }
   if (c % 64 == 0 && (n / segs) % TS_Q == 0)
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(n / TS_Q, b), dim3(256), 0, (hipStream_t)stream, c,
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3((n / TS_Q) * b), dim3(256), 0, (hipStream_t)stream, c,
                        m, n, segs, seg_len, c_total, c_offset, pitch, seg_off, table, idx, weight,
                        rel, wx, out, stat_partial,
-                       stream_nt((long long)b * segs * c_total * (n / segs) * 4, 4) ? 1 : 0);
+                       stream_nt((long long)b * segs * c_total * (n / segs) * 4, 4) ? 1 : 0, b);
   else
     hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(cdiv(n, TI_BLOCK), cdiv(c, TI_CH), b),
                        dim3(TI_BLOCK), 0, (hipStream_t)stream, c, m, n, segs, seg_len, c_total,
@@ -849,10 +853,12 @@ extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float
               "of %d)", W, c, per_seg, TS_Q);
     return NESIE_ERR_UNSUPPORTED;
   }
-  const dim3 grid(cdiv(per_seg, BL_RUN), b, segs);
+  const int nruns = cdiv(per_seg, BL_RUN);
+  NESIE_REQUIRE((long long)nruns * b * segs < (1ll << 31), W);
+  const dim3 grid((unsigned)(nruns * b * segs));
 #define L(N) hipLaunchKernelGGL(blend_bwd_rows_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, \
                                 m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel,        \
-                                d_table, d_wx)
+                                d_table, d_wx, b, nruns)
   if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
 #undef L
   return check_launch(W);
