@@ -8,30 +8,41 @@
 //                                         contiguous (NCHW as it stands: no transposes)
 //     act(v) = max(scale[k] * v + bias[k], lo)   the PREVIOUS layer's folded BatchNorm + ReLU
 //
-// Design (weight-stationary, operand streamed by DMA through a 3-deep LDS ring):
-//   * a workgroup is persistent and owns a run of (n, position-tile) tiles of ONE weight group;
-//     wave (wr, wc) keeps its 16 output rows of W in registers for the whole launch as the A
-//     operand of v_mfma_f32_16x16x4_f32 (lane l: W[16 wr + (l & 15)][4 kk + (l >> 4)], K/4
-//     registers: 64 at K = 256, so 8-16 waves per CU fit without spilling);
-//   * an X tile is K rows x PT positions ~ 32 KB.  Iteration t: tile t+2 is being copied
-//     HBM -> LDS by global_load_lds (16 bytes per lane, no VGPR staging), tile t+1 (landed) gets
-//     the previous layer's BatchNorm + ReLU applied IN PLACE, once per element, by all threads
-//     (2-4 float4 each), tile t feeds the MFMAs.  One barrier per tile.
-//   * B operand fetch (lane l: X[4 kk + (l >> 4)][pos + (l & 15)]) = 4 rows x 16 consecutive
-//     words; odd rows are stored with their 64-byte halves swapped (the swap is applied to the
-//     per-lane SOURCE address of the copy, LDS stays lane-linear) so rows r and r+1 sit on
-//     disjoint bank halves: conflict-free ds_read2st64_b32, issued a group ahead with counted
-//     lgkmcnt waits (explicit instructions: left to itself hipcc sinks the reads to their uses).
-//   * >= 2 accumulator chains per wave (position blocks of 16) cover the 40-cycle dependent
-//     latency of the 32-cycle instruction.
-//   * epilogue straight from the 4-register accumulators: optional output-side row bias /
-//     channel bias, the raw conv output, this layer's own BatchNorm statistics as per-wave
-//     SHIFTED sums (count, shift, sum(y - shift), sum((y - shift)^2): no E[x^2] - E[x]^2
-//     cancellation; merged in fp64 by pw_stats_finalize_kernel with Chan's formula), and the
-//     max / min over each group of 16 or 32 consecutive positions with the position of each
-//     (the pooling tail: a 16-position block is exactly one DPP row).
-// The K x P operand is read once, Y written once (or never, for a pooled tail): 2 tensor
-// passes per layer where conv + statistics + normalise cost 5.
+// What shapes the kernel: on gfx950 an fp32 MFMA holds its SIMD's instruction issue for its whole
+// duration -- no instruction of the same wave or of the SIMD's other waves overlaps it
+// (tools/pwbench modes 10 / 11: an MFMA stream starves its partner wave of VALU, SALU, LDS and
+// VMEM issue alike, s_setprio or not; k extra instructions behind an MFMA of the same wave cost
+// their full issue time).  Matrix-pipe utilisation is therefore
+//     MFMA cycles / (MFMA cycles + issue cycles of EVERYTHING else on the SIMD)
+// and the design minimises the instruction count per MFMA rather than trying to hide it:
+//   * weight-stationary: a persistent workgroup owns a run of (n, position-tile) tiles of one
+//     weight group; wave wr keeps 16 rows of W in registers for the whole launch (K/4 VGPRs);
+//   * v_mfma_f32_16x16x4_f32 computes the TRANSPOSED block D[position][channel] (A = X^T
+//     fragment, B = W^T fragment: the same register contents, swapped operands), so a lane ends
+//     with 4 CONSECUTIVE positions of one output channel: the block is stored with ONE
+//     global_store_dwordx4 per lane on a scalar tile base + a per-lane 32-bit offset computed
+//     once per launch (a lane of the untransposed block holds 4 channels x 1 position: 4 dword
+//     stores and 4x the statistics state);
+//   * X tiles are K rows x PT positions = 64 KB, two LDS buffers.  Tile t+1 is loaded
+//     HBM -> registers (global_load_dwordx4 on scalar base + constant per-lane offsets, no
+//     address arithmetic) at the top of iteration t, rides out the MFMAs of tile t, gets the
+//     previous layer's BatchNorm + ReLU applied IN REGISTERS (packed fma, once per element,
+//     coefficients of the thread's fixed rows held in registers) and is written to the other
+//     buffer: one barrier per tile, no LDS round trip for the transform;
+//   * operand fetch (lane l: X[4 kk + (l >> 4)][pos + (l & 15)]) = 4 rows x 16 consecutive
+//     words; odd rows are stored with their 64-byte halves swapped so rows r and r+1 sit on
+//     disjoint bank halves: conflict-free ds_read2st64_b32 (two k-steps per instruction),
+//     issued a group ahead with counted lgkmcnt waits (explicit instructions: left to itself
+//     hipcc sinks the reads to their uses and every MFMA pair waits out an LDS round trip);
+//   * Cout = 256 runs as two workgroups of 128 rows (the operand tile is fetched twice, the
+//     second time from L2 / Infinity Cache) so every geometry is 8 waves of 16 rows;
+//   * epilogue straight from the accumulators: optional output-side row bias / channel bias,
+//     the raw conv output, this layer's own BatchNorm statistics as per-wave SHIFTED sums
+//     (count, shift, sum(y - shift), sum((y - shift)^2): no E[x^2] - E[x]^2 cancellation;
+//     merged in fp64 by pw_stats_finalize_kernel with Chan's formula), and the max / min over
+//     each group of 16 or 32 consecutive positions with the position of each (pooling tail).
+// The K x P operand is read once (twice at Cout = 256), Y written once (or never, for a pooled
+// tail): 2 tensor passes per layer where conv + statistics + normalise cost 5.
 #include "common.h"
 #include <string.h>
 #include <type_traits>
@@ -40,8 +51,6 @@ namespace nesie {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -62,6 +71,26 @@ __device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
   f32x2 v;
   asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(U0), "n"(U1));
   return v;
+}
+
+// 16 bytes per lane from sbase (wave-uniform) + voff (per-lane byte offset).  A plain load: the
+// compiler places the vmcnt wait at the first use (an asm load + a separate asm wait let the
+// register allocator copy the destination before the wait: stale words in the first tile).
+__device__ __forceinline__ f32x4 load16_saddr(unsigned voff, const void *sbase) {
+  return *(const f32x4 *)((const char *)sbase + voff);
+}
+
+// *(float4 *)(sbase + voff + IMM) = v
+template <int IMM>
+__device__ __forceinline__ void store16_saddr(unsigned voff, f32x4 v, const void *sbase) {
+  // the trailing s_nop: a store of more than 64 bits needs wait states before its data VGPRs
+  // are overwritten, and the hazard recognizer does not look inside asm
+  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int N>
@@ -88,31 +117,22 @@ struct PwFwd {
   const float *bias;                       // [ng * cout]
   float *stat_part; int nslots;            // [ng][nslots][cout][4]
   float *pool_max, *pool_min; uint8_t *arg_max, *arg_min;  // (nb, cout, p / PG)
-  int tiles_per_batch, nwg_g;
+  int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout (128 rows each)
+  long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
-
-// max / min over the 16 lanes of a DPP row, result in every lane of the row
-template <bool MAX>
-__device__ __forceinline__ float row16_reduce(float v) {
-#define STEP(CTRL)                                                                            \
-  {                                                                                           \
-    const float o = __builtin_bit_cast(                                                       \
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); \
-    v = MAX ? fmaxf(v, o) : fminf(v, o);                                                      \
+#ifdef PW_STAMP
+#define STAMP(slot)                                                                      \
+  if (a.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && iter < 24) \
+    a.stamps[((wave >> 2) * 24 + iter) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+#define STAMP_CLK(which)                                                     \
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                      \
+    a.stamps[2 * 24 * 8 + 2 * (which)] = __builtin_amdgcn_s_memtime();       \
+    a.stamps[2 * 24 * 8 + 2 * (which) + 1] = __builtin_amdgcn_s_memrealtime(); \
   }
-  STEP(0xB1) STEP(0x4E) STEP(0x141) STEP(0x140)
-#undef STEP
-  return v;
-}
-
-__device__ __forceinline__ float row16_sum(float v) {
-#define STEP(CTRL)                                                                            \
-  v += __builtin_bit_cast(                                                                    \
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-  STEP(0xB1) STEP(0x4E) STEP(0x141) STEP(0x140)
-#undef STEP
-  return v;
-}
+#else
+#define STAMP(slot)
+#define STAMP_CLK(which)
+#endif
 
 // KQ = padded K / 4; WR x WC waves (16 output rows each x PT / WC positions); PT positions
 // per tile; EPI = epilogue / prologue flags; PG = pooling granule (16 or 32)
@@ -120,109 +140,210 @@ template <int KQ, int WR, int WC, int PT, int EPI, int PG>
 __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
   constexpr int NW = WR * WC, NT = NW * 64, KPAD = 4 * KQ, NBLK = PT / 16 / WC;
   constexpr int TILE = KPAD * PT, CPR = PT / 4;          // floats per buffer, 16-byte chunks per row
-  constexpr int NI = (KPAD * CPR + 64 * NW - 1) / (64 * NW);  // copy instructions per wave and tile
-  constexpr int NX = (KPAD * CPR + NT - 1) / NT;              // transform chunks per thread and tile
-  static_assert(NBLK >= 1 && PT % (16 * WC) == 0 && PT >= 32, "tile");
+  constexpr int NX = (KPAD * CPR + NT - 1) / NT;         // staged chunks per thread and tile
+  constexpr bool EVEN = KPAD * CPR == NX * NT;           // every staging slot is a real chunk
+  constexpr int CROWS = WR * 16;                         // output rows per workgroup
+  static_assert(NBLK >= 1 && PT % (16 * WC) == 0 && PT >= 32 && CPR % 8 == 0, "tile");
   static_assert(!(EPI & PW_POOL) || PG == 16 || NBLK % 2 == 0, "a 32-position pool needs block pairs");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2 *const sb = (float2 *)(lds + 3 * TILE);  // [KPAD] (scale, bias) of the operand rows
 
   const int tid = threadIdx.x, lane = tid & 63, quad = lane >> 4, l16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
-  const int g = blockIdx.x % a.ng, rank = blockIdx.x / a.ng;
-  const int k = a.k, cout = a.cout;
+  // block -> (weight group g, row half, rank inside the group)
+  const int half = blockIdx.x % a.nhalf;
+  const int g = (blockIdx.x / a.nhalf) % a.ng, rank = blockIdx.x / (a.nhalf * a.ng);
+  const int k = a.k;
+  const int c0 = half * CROWS;                           // first output row of this workgroup
+  const int cout = a.cout, crows = cout - c0 < CROWS ? cout - c0 : CROWS;
   const long long p = a.p;
 
-  // the rows K..KPAD-1 of the three buffers are never copied into and must read as 0
-  if (k < KPAD) {
-    const int pad = (KPAD - k) * PT;
-    for (int i = tid; i < 3 * pad; i += NT) lds[(i / pad) * TILE + k * PT + i % pad] = 0.f;
+  // staging slots of this thread: chunk c = i * NT + tid -> row c / CPR, 16-byte column c % CPR.
+  // goff: byte offset from the tile's first word; lw: LDS byte offset inside a buffer (odd rows
+  // carry their 64-byte halves swapped); (sc, bi): the row's BatchNorm coefficients.
+  unsigned goff[NX], lw[NX];
+  bool okslot[NX];
+  f32x2 sc[(EPI & PW_AFFINE) ? NX : 1], bi[(EPI & PW_AFFINE) ? NX : 1];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int c = i * NT + tid;
+    const int row = c / CPR, cp = c % CPR;
+    const bool ok = (EVEN || c < KPAD * CPR) && row < k;
+    okslot[i] = ok;
+    goff[i] = ok ? (unsigned)(((size_t)row * p + cp * 4) * 4) : 0u;   // invalid slots re-read word 0
+    lw[i] = (unsigned)((row * PT + ((cp ^ ((row & 1) << 2)) * 4)) * 4);
+    if (EPI & PW_AFFINE) {
+      const float s0 = ok ? a.in_coef[((size_t)g * k + row) * 4] : 0.f;
+      const float b0 = ok ? a.in_coef[((size_t)g * k + row) * 4 + 1] : 0.f;
+      sc[i] = (f32x2){s0, s0};
+      bi[i] = (f32x2){b0, b0};
+    }
   }
-  if (EPI & PW_AFFINE)
-    for (int i = tid; i < KPAD; i += NT)
-      sb[i] = i < k ? make_float2(a.in_coef[((size_t)g * k + i) * 4], a.in_coef[((size_t)g * k + i) * 4 + 1])
-                    : make_float2(0.f, 0.f);
-  // this wave's 16 rows of W, for the whole launch
+  // this wave's 16 rows of W, for the whole launch (lane: row l16, k = 4 kk + quad)
   float wreg[KQ];
   {
     const int m = wr * 16 + l16;
-    const float *wg = a.w + (size_t)g * a.w_gs + (size_t)m * a.w_rs;
+    const float *wg = a.w + (size_t)g * a.w_gs + (size_t)(c0 + m) * a.w_rs;
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk) {
       const int kx = 4 * kk + quad;
-      wreg[kk] = (m < cout && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
+      wreg[kk] = (m < crows && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
     }
   }
-  // per-lane source offsets of the NI copy instructions of a tile (tile-independent).  LDS
-  // chunk position cp of row r receives source chunk cp ^ ((r & 1) << 2): odd rows carry their
-  // 64-byte halves swapped.
-  unsigned coff[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c = (i * NW + wave) * 64 + lane;
-    const int row = c / CPR, cp = c % CPR;
-    const int col = (cp ^ ((row & 1) << 2)) * 4;
-    coff[i] = row < k ? (unsigned)((size_t)row * p + col) : 0xFFFFFFFFu;
-  }
+  const bool all_k = __builtin_amdgcn_readfirstlane(k == KPAD ? 1 : 0) != 0;
   const int tpb = a.tiles_per_batch, nwg = a.nwg_g;
   const int ntiles = (a.nb / a.ng) * tpb;
-  auto issue = [&](int t, float *buf) {
-    const int n = g + a.ng * (t / tpb);
-    const long long p0 = (long long)(t % tpb) * PT;
-    const float *xb = a.x + (size_t)n * a.x_bs + p0;
-    const int left = (int)(p - p0 < PT ? p - p0 : PT);  // positions of this tile that exist
+
+  // The launch-time loads (W, coefficients) are waited for HERE: left alone, the compiler puts
+  // their vmcnt(0) in front of the first use inside the tile loop, where it also drains the
+  // operand loads that were just issued for the next tile.
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c0 = (i * NW + wave) * 64;
-      const int row = (c0 + lane) / CPR;
-      const int col = (((c0 + lane) % CPR) ^ ((row & 1) << 2)) * 4;
-      if (coff[i] != 0xFFFFFFFFu && col < left)
-        __builtin_amdgcn_global_load_lds((gptr_t *)(xb + coff[i]), (lptr_t *)(buf + c0 * 4), 16, 0, 0);
-    }
+  for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(wreg[kk]));
+  if (EPI & PW_AFFINE) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(sc[i]), "+v"(bi[i]));
+  }
+
+  // Tiles are whole (the host requires p % PT == 0): the loads of a tile are a straight line of
+  // NX instructions with no branch between issue and first use.
+  f32x4 stg[NX];
+  auto load_tile = [&](int n, long long p0) {
+    const float *xb = a.x + (size_t)n * a.x_bs + p0;                  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NX; ++i) stg[i] = load16_saddr(goff[i], xb);
   };
-  // previous layer's BatchNorm + ReLU, in place, once per element
-  auto transform = [&](float *buf) {
+  // previous layer's BatchNorm + ReLU in registers (packed fma; the backward's mask test uses
+  // the same fused form), then into the LDS buffer
+  auto write_tile = [&](float *buf) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int c = i * NT + tid;
-      if (NX * NT == KPAD * CPR || c < KPAD * CPR) {
-        const float2 co = sb[c / CPR];
-        float4 v = *(float4 *)(buf + c * 4);
-        v.x = fmaxf(v.x * co.x + co.y, a.in_lo); v.y = fmaxf(v.y * co.x + co.y, a.in_lo);
-        v.z = fmaxf(v.z * co.x + co.y, a.in_lo); v.w = fmaxf(v.w * co.x + co.y, a.in_lo);
-        *(float4 *)(buf + c * 4) = v;
+      f32x4 q = stg[i];
+      if (!(EVEN && all_k)) q = okslot[i] ? q : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (EPI & PW_AFFINE) {
+        const f32x2 lo = __builtin_elementwise_fma((f32x2){q[0], q[1]}, sc[i], bi[i]);
+        const f32x2 hi = __builtin_elementwise_fma((f32x2){q[2], q[3]}, sc[i], bi[i]);
+        q[0] = fmaxf(lo[0], a.in_lo); q[1] = fmaxf(lo[1], a.in_lo);
+        q[2] = fmaxf(hi[0], a.in_lo); q[3] = fmaxf(hi[1], a.in_lo);
       }
+      if (EVEN || (i * NT + tid) < KPAD * CPR) *(f32x4 *)((char *)buf + lw[i]) = q;
     }
   };
 
-  // statistics state: a lane holds 4 channels (rows 4 quad + r) of its position column
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, shift[4] = {0.f, 0.f, 0.f, 0.f};
+  // statistics state: a lane holds ONE channel (row c0 + 16 wr + l16) x 4 positions per block
+  float s1 = 0.f, s2 = 0.f, shift = 0.f;
   int nblk_done = 0;
+  const int q0 = wc * NBLK * 16;              // this wave's first position inside a tile
+  const int m = c0 + wr * 16 + l16;           // this lane's output channel
+  // byte offset of (row m, position q0 + 4 quad) from the tile's first output word
+  const unsigned roff = (unsigned)(((size_t)m * p + q0 + 4 * quad) * 4);
 
-  float *b0 = lds, *b1 = lds + TILE, *b2 = lds + 2 * TILE;
-  int t = rank;
-  if (t < ntiles) issue(t, b0);
-  if (t + nwg < ntiles) issue(t + nwg, b1);
-  __syncthreads();          // pads, coefficients (and, with it, the first two copies: vmcnt(0))
-  if (EPI & PW_AFFINE) {
-    if (t < ntiles) transform(b0);
-  }
-  for (; t < ntiles; t += nwg) {
-    // b0: tile t (transformed), b1: tile t + nwg (copy issued one iteration ago), b2: free
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 * nwg < ntiles) issue(t + 2 * nwg, b2);
-    if (EPI & PW_AFFINE) {
-      if (t + nwg < ntiles) transform(b1);
+  f32x4 acc[NBLK];
+  auto epilogue = [&](int n, long long p0) {
+    constexpr bool full = true;   // p % PT == 0
+    float *ytile = a.y + (size_t)n * a.y_bs + p0;        // wave-uniform
+    static_for<0, NBLK>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (full || p0 + q0 + 16 * j < p) {
+        if (EPI & PW_ROWBIAS) {
+          if (m < cout) {
+            const float rb = a.row_bias[((size_t)n * cout + m) * (size_t)(p >> a.rb_shift) +
+                                        ((p0 + q0 + 16 * j) >> a.rb_shift)];
+            acc[j] += (f32x4){rb, rb, rb, rb};
+          }
+        }
+        if (EPI & PW_BIAS) {
+          if (m < cout) { const float bs = a.bias[g * cout + m]; acc[j] += (f32x4){bs, bs, bs, bs}; }
+        }
+        if (EPI & PW_STORE) {
+          if (m < cout) store16_saddr<64 * j>(roff, acc[j], ytile);
+        }
+        if (EPI & PW_STATS) {
+          if (nblk_done == 0) shift = __shfl(acc[j][0], l16, 64);   // first value of the channel
+          ++nblk_done;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = acc[j][r] - shift;
+            s1 += d;
+            s2 += d * d;
+          }
+        }
+      }
+    });
+    if (EPI & PW_POOL) {
+      // a group = PG consecutive positions = PG / 16 blocks x (4 quads x 4 registers)
+      const size_t prow = (size_t)(p / PG);
+      static_for<0, NBLK / (PG / 16)>([&](auto jc) {
+        constexpr int j = decltype(jc)::value * (PG / 16);
+        if (full || p0 + q0 + 16 * j < p) {
+          const size_t pcol = (size_t)((p0 + q0 + 16 * j) / PG);
+#pragma unroll
+          for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
+            // per lane: best of its 4 (8) values, smallest position on ties
+            float e = acc[j][0];
+            int at = 4 * quad;
+#pragma unroll
+            for (int u = 1; u < 4 * (PG / 16); ++u) {
+              const float v = acc[j + u / 4][u % 4];
+              const bool better = mm ? v < e : v > e;
+              at = better ? 16 * (u / 4) + 4 * quad + u % 4 : at;
+              e = better ? v : e;
+            }
+            // across the 4 quads (lanes l16, l16 + 16, + 32, + 48)
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+              const float oe = __shfl_xor(e, off, 64);
+              const int oa = __shfl_xor(at, off, 64);
+              const bool take = (mm ? oe < e : oe > e) || (oe == e && oa < at);
+              e = take ? oe : e;
+              at = take ? oa : at;
+            }
+            if (quad == 0 && m < cout) {
+              const size_t o = ((size_t)n * cout + m) * prow + pcol;
+              (mm ? a.pool_min : a.pool_max)[o] = e;
+              (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)at;
+            }
+          }
+        }
+      });
     }
-    const int n = g + a.ng * (t / tpb);
-    const long long p0 = (long long)(t % tpb) * PT;
-    const int q0 = wc * NBLK * 16;              // this wave's first position inside the tile
-    if (p0 + q0 < p) {
-      // ---- MFMA loop: NBLK blocks of 16 positions, K in groups of GK quads
+  };
+
+  // ---- main loop: one barrier per tile; b0 holds tile t, tile t+1 is staged through registers
+  // into b1 behind the MFMAs of tile t
+  float *b0 = lds, *b1 = lds + TILE;
+  // tile coordinates advance incrementally: tile t = (batch tq of the group, tile tr of the batch)
+  const int dq = nwg / tpb, dr = nwg % tpb;
+  auto advance = [&](int &q, int &r) {
+    q += dq; r += dr;
+    if (r >= tpb) { r -= tpb; ++q; }
+  };
+  int t = rank;
+  int tq = rank / tpb, tr = rank % tpb;          // tile t
+  int nq = tq, nr = tr;                          // tile t + 1
+  advance(nq, nr);
+  __syncthreads();                               // LDS zero fill
+  if (t < ntiles) {
+    load_tile(g + a.ng * tq, (long long)tr * PT);
+    write_tile(b0);
+  }
+  int iter = 0;
+  (void)iter;
+  STAMP_CLK(0)
+  for (; t < ntiles; t += nwg, ++iter) {
+    STAMP(0)
+    lgkm_wait<0>();          // this thread's ds_writes of tile t
+    __builtin_amdgcn_s_barrier();
+    STAMP(1)
+    const bool more = t + nwg < ntiles;
+    if (more) load_tile(g + a.ng * nq, (long long)nr * PT);
+    STAMP(2)
+    const int n = g + a.ng * tq;
+    const long long p0 = (long long)tr * PT;
+    constexpr bool do_mfma = true;
+    if (do_mfma) {
+      // ---- MFMA loop: NBLK blocks of 16 positions, K in groups of GK quads; the LDS reads of
+      // group gi + 1 are issued before the MFMAs of group gi, counted lgkmcnt waits
       constexpr int GK = NBLK >= 8 ? 2 : 4, NGRP = (KQ + GK - 1) / GK, UPK = PT / 16;   // 256-byte units per kk
-      f32x4 acc[NBLK];
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // lane address: row quad (odd rows: halves swapped), position q0 + 16 j + l16
@@ -261,103 +382,36 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
           if constexpr (kk < KQ) {
             static_for<0, NBLK>([&](auto jc) {
               constexpr int j = decltype(jc)::value;
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[kk], bq[gi & 1][j][i / 2][i & 1], acc[j], 0, 0, 0);
+              // D[position][channel] += X^T[position][k] . W^T[k][channel]
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[gi & 1][j][i / 2][i & 1], wreg[kk], acc[j], 0, 0, 0);
             });
           }
         });
         __builtin_amdgcn_sched_barrier(0);
       });
-
-      // ---- epilogue: lane holds rows mb + r (r = 0..3) of position p0 + q0 + 16 j + l16
-      const int mb = wr * 16 + 4 * quad;
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) {
-        const long long pos = p0 + q0 + 16 * j + l16;
-        if (p0 + q0 + 16 * j >= p) break;
-        if (EPI & (PW_ROWBIAS | PW_BIAS)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mb + r;
-            if (m < cout) {
-              if (EPI & PW_ROWBIAS)
-                acc[j][r] += a.row_bias[((size_t)n * cout + m) * (size_t)(p >> a.rb_shift) + (pos >> a.rb_shift)];
-              if (EPI & PW_BIAS) acc[j][r] += a.bias[g * cout + m];
-            }
-          }
-        }
-        if (EPI & PW_STORE) {
-          float *yb = a.y + (size_t)n * a.y_bs + pos;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (mb + r < cout) yb[(size_t)(mb + r) * p] = acc[j][r];
-        }
-        if (EPI & PW_STATS) {
-          if (nblk_done == 0) {
-            // shift = the first value this wave sees of each channel (lane 0 of the row)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) shift[r] = __shfl(acc[j][r], lane & 48, 64);
-          }
-          ++nblk_done;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float d = acc[j][r] - shift[r];
-            s1[r] += d;
-            s2[r] += d * d;
-          }
-        }
-      }
-      if (EPI & PW_POOL) {
-        // PG = 16: a position block is one DPP row; PG = 32: blocks (j, j + 1) of the same lane
-        const size_t prow = (size_t)(p / PG);
-#pragma unroll
-        for (int j = 0; j < NBLK; j += PG / 16) {
-          if (p0 + q0 + 16 * j >= p) break;
-          const size_t pcol = (size_t)((p0 + q0 + 16 * j) / PG);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
-              const float v0 = acc[j][r];
-              float e = mm ? row16_reduce<false>(v0) : row16_reduce<true>(v0);
-              int first;
-              if (PG == 32) {
-                const float v1 = acc[j + PG / 16 - 1][r];
-                const float e1 = mm ? row16_reduce<false>(v1) : row16_reduce<true>(v1);
-                e = mm ? fminf(e, e1) : fmaxf(e, e1);
-                const unsigned h0 = (unsigned)(__ballot(v0 == e) >> (lane & 48)) & 0xFFFFu;
-                const unsigned h1 = (unsigned)(__ballot(v1 == e) >> (lane & 48)) & 0xFFFFu;
-                first = h0 ? __ffs(h0) - 1 : 15 + __ffs(h1);
-              } else {
-                const unsigned h0 = (unsigned)(__ballot(v0 == e) >> (lane & 48)) & 0xFFFFu;
-                first = __ffs(h0) - 1;
-              }
-              if (l16 == 0 && mb + r < cout) {
-                const size_t o = ((size_t)n * cout + mb + r) * prow + pcol;
-                (mm ? a.pool_min : a.pool_max)[o] = e;
-                (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)first;
-              }
-            }
-          }
-        }
-      }
     }
-    float *const tb = b0; b0 = b1; b1 = b2; b2 = tb;
+    STAMP(3)
+    if (more) write_tile(b1);   // waits for the loads of tile t + 1 (issued before the MFMAs)
+    STAMP(4)
+    if (do_mfma) epilogue(n, p0);
+    STAMP(5)
+    tq = nq; tr = nr;
+    advance(nq, nr);
+    float *const tb = b0; b0 = b1; b1 = tb;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP_CLK(1)
   if (EPI & PW_STATS) {
-    // one partial per wave: (count, shift, sum, sum of squares) of its 16 channels
+    // one partial per wave: (count, shift, sum, sum of squares) of its 16 channels; the four
+    // quads hold different positions of the same channel
     const int slot = rank * WC + wc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float u = row16_sum(s1[r]), v = row16_sum(s2[r]);
-      const int m = wr * 16 + 4 * quad + r;
-      if (l16 == 0 && m < cout) {
-        float4 o;
-        o.x = (float)nblk_done * 16.f;
-        o.y = shift[r];
-        o.z = u; o.w = v;
-        *(float4 *)(a.stat_part + (((size_t)g * a.nslots + slot) * cout + m) * 4) = o;
-      }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (quad == 0 && m < cout) {
+      float4 o;
+      o.x = (float)nblk_done * 16.f;
+      o.y = shift;
+      o.z = s1; o.w = s2;
+      *(float4 *)(a.stat_part + (((size_t)g * a.nslots + slot) * cout + m) * 4) = o;
     }
   }
 }
@@ -411,30 +465,33 @@ __global__ __launch_bounds__(64) void pw_stats_finalize_kernel(
 }
 
 // tile geometry of a (K, Cout) layer
-struct PwGeom { int kq, wr, wc, pt; };
+struct PwGeom { int kq, wr, wc, pt, nhalf; };
 
 static bool pw_geometry(int k, int cout, PwGeom *o) {
   const int kq = k <= 64 ? 16 : k <= 128 ? 32 : k <= 132 ? 33 : k <= 256 ? 64 : k <= 260 ? 65 : 0;
-  const int wr = cout <= 64 ? 4 : cout <= 128 ? 8 : cout <= 256 ? 16 : 0;
-  if (!kq || !wr) return false;
-  o->kq = kq; o->wr = wr;
-  o->pt = kq == 16 ? 128 : kq <= 33 ? 64 : 32;
-  // >= 8 waves per workgroup, >= 2 position blocks per wave
-  o->wc = wr == 4 ? 2 : 1;
+  if (!kq || cout < 1 || cout > 256) return false;
+  o->kq = kq;
+  o->nhalf = cout > 128 ? 2 : 1;                 // 128-row workgroups
+  o->wr = cout <= 64 ? 4 : 8;
+  o->wc = o->wr == 4 ? 2 : 1;                    // 8 waves
+  // 64 KB operand tiles (32 KB at K <= 64): PT x padded K x 4 bytes
+  o->pt = kq == 16 ? (o->wc == 2 ? 256 : 128) : kq <= 33 ? 128 : 64;
   return true;
 }
 
-static size_t pw_lds_bytes(const PwGeom &g) {
-  return ((size_t)3 * 4 * g.kq * g.pt + 2 * 4 * g.kq) * sizeof(float);
-}
+static size_t pw_lds_bytes(const PwGeom &g) { return (size_t)2 * 4 * g.kq * g.pt * sizeof(float); }
 
 }  // namespace nesie
 
 using namespace nesie;
 
+#ifdef PW_STAMP
+long long *g_pw_stamps = nullptr;
+#endif
+
 extern "C" int nesie_pw_supported(int k, int cout, long long p) {
   PwGeom g;
-  return pw_geometry(k, cout, &g) && p % 32 == 0 && (long long)k * p < (1ll << 32) ? 1 : 0;
+  return pw_geometry(k, cout, &g) && p % g.pt == 0 && (long long)(k > cout ? k : cout) * p < (1ll << 30) ? 1 : 0;
 }
 
 // number of statistic slots per weight group a forward launch writes
@@ -442,7 +499,7 @@ extern "C" int nesie_pw_stat_slots(int nb, int ng, int k, int cout, long long p)
   PwGeom g;
   if (!pw_geometry(k, cout, &g) || ng < 1) return 0;
   const long long tiles = (long long)(nb / ng) * cdiv(p, g.pt);
-  long long nwg = 256 / ng;
+  long long nwg = 256 / (ng * g.nhalf);
   if (nwg < 1) nwg = 1;
   if (nwg > tiles) nwg = tiles;
   return (int)nwg * g.wc;
@@ -462,9 +519,18 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WR *WC * 64), lds, s, a);                       \
     return NESIE_OK;                                                                          \
   } while (0)
+#ifdef PW_DEV   // tools/pwbench development build: three instantiations per geometry
+  if (epi == PW_STORE) GO(PW_STORE, 16);
+  if (epi == (PW_AFFINE | PW_STORE | PW_STATS)) GO(PW_AFFINE | PW_STORE | PW_STATS, 16);
+  if (epi == (PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
+    GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
+  if (epi == (PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
+    GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
+  set_error("dev build");
+  return NESIE_ERR_UNSUPPORTED;
+#else
   const int aff = epi & PW_AFFINE;
   const int base = epi & ~PW_AFFINE;
-  constexpr bool P32 = (PT / 16 / WC) % 2 == 0;   // block pairs exist
   // the prologue / epilogue combinations the step uses
   if (aff) {
     if (base == PW_STORE) GO(PW_AFFINE | PW_STORE, 16);
@@ -473,20 +539,19 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
     if (base == PW_POOL && pg == 16) GO(PW_AFFINE | PW_POOL, 16);
     if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
       GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
-    if constexpr (P32) {
-      if (base == (PW_STORE | PW_POOL) && pg == 32) GO(PW_AFFINE | PW_STORE | PW_POOL, 32);
-      if (base == PW_POOL && pg == 32) GO(PW_AFFINE | PW_POOL, 32);
-      if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
-        GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
-    }
+    if (base == (PW_STORE | PW_POOL) && pg == 32) GO(PW_AFFINE | PW_STORE | PW_POOL, 32);
+    if (base == PW_POOL && pg == 32) GO(PW_AFFINE | PW_POOL, 32);
+    if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
+      GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
   } else {
     if (base == PW_STORE) GO(PW_STORE, 16);
     if (base == (PW_STORE | PW_STATS)) GO(PW_STORE | PW_STATS, 16);
     if (base == (PW_STORE | PW_STATS | PW_ROWBIAS)) GO(PW_STORE | PW_STATS | PW_ROWBIAS, 16);
   }
-#undef GO
   set_error("pw_layer_forward: epilogue combination 0x%x (pool group %d) is not built", epi, pg);
   return NESIE_ERR_UNSUPPORTED;
+#endif
+#undef GO
 }
 
 extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p,
@@ -502,11 +567,12 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
   if (nb == 0 || p == 0) return NESIE_OK;
   NESIE_REQUIRE(nb % ng == 0 && x && w, W);
   PwGeom g;
-  if (!pw_geometry(k, cout, &g) || p % 32 != 0 || (long long)k * p >= (1ll << 32)) {
+  if (!pw_geometry(k, cout, &g) || p % g.pt != 0 || (long long)(k > cout ? k : cout) * p >= (1ll << 30)) {
     set_error("%s: %d -> %d over %lld positions is outside the built tiles", W, k, cout, p);
     return NESIE_ERR_UNSUPPORTED;
   }
   NESIE_REQUIRE(((uintptr_t)x & 15) == 0 && (x_bstride & 3) == 0, W);
+  NESIE_REQUIRE(!y || (((uintptr_t)y & 15) == 0 && (y_bstride & 3) == 0), W);
   int epi = 0, pg = 16;
   if (in_coef) epi |= PW_AFFINE;
   if (y) epi |= PW_STORE;
@@ -518,7 +584,7 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
   if (bias) epi |= PW_BIAS;
   if (pool_group) {
     NESIE_REQUIRE(pool_group == 16 || pool_group == 32, W);
-    NESIE_REQUIRE(pool_max_out && arg_max_out, W);
+    NESIE_REQUIRE(pool_max_out && arg_max_out && p % pool_group == 0, W);
     NESIE_REQUIRE(!pool_min || (pool_min_out && arg_min_out), W);
     epi |= PW_POOL | (pool_min ? PW_POOLMIN : 0);
     pg = pool_group;
@@ -532,20 +598,29 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
   a.bias = bias;
   a.stat_part = stat_part;
   a.pool_max = pool_max_out; a.pool_min = pool_min_out; a.arg_max = arg_max_out; a.arg_min = arg_min_out;
+  a.stamps = nullptr;
+#ifdef PW_STAMP
+  a.stamps = g_pw_stamps;
+#endif
   a.tiles_per_batch = cdiv(p, g.pt);
   a.nslots = nesie_pw_stat_slots(nb, ng, k, cout, p);
   a.nwg_g = a.nslots / g.wc;
-  const int grid = a.nwg_g * ng;
+  a.nhalf = g.nhalf;
+  const int grid = a.nwg_g * ng * g.nhalf;
   const size_t lds = pw_lds_bytes(g);
   hipStream_t s = (hipStream_t)stream;
   int st = NESIE_ERR_UNSUPPORTED;
 #define G(KQ, WR, WC, PT) \
   if (g.kq == KQ && g.wr == WR) st = pw_launch_epi<KQ, WR, WC, PT>(a, epi, pg, grid, lds, s)
-  G(16, 4, 2, 128); G(16, 8, 1, 128); G(16, 16, 1, 128);
-  G(32, 4, 2, 64); G(32, 8, 1, 64); G(32, 16, 1, 64);
-  G(33, 8, 1, 64);
-  G(64, 8, 1, 32); G(64, 16, 1, 32);
-  G(65, 8, 1, 32);
+#ifdef PW_DEV
+  G(64, 8, 1, 64); G(32, 8, 1, 128);
+#else
+  G(16, 4, 2, 256); G(16, 8, 1, 128);
+  G(32, 4, 2, 128); G(32, 8, 1, 128);
+  G(33, 4, 2, 128); G(33, 8, 1, 128);
+  G(64, 4, 2, 64); G(64, 8, 1, 64);
+  G(65, 4, 2, 64); G(65, 8, 1, 64);
+#endif
 #undef G
   if (st != NESIE_OK) {
     if (st == NESIE_ERR_UNSUPPORTED && !strstr(nesie_last_error(), "epilogue"))

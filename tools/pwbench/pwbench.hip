@@ -23,6 +23,180 @@ int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *sta
                             float *running_var, float momentum, float eps, float *coef, void *stream);
 const char *nesie_last_error(void);
 }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+// matrix-pipe ceiling at the clock the chip holds under an fp32-MFMA load: register operands only
+template <int SHAPE, int CHAINS>
+__global__ __launch_bounds__(512) void mfma_peak_kernel(float *out, int iters, float a0, float b0) {
+  float a = a0 + threadIdx.x * 1e-6f, b = b0 + threadIdx.x * 1e-6f;
+  if constexpr (SHAPE == 16) {
+    f32x4_t acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) acc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  } else {
+    f32x16_t acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int c = 0; c < CHAINS; ++c) for (int r = 0; r < 16; ++r) s += acc[c][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  }
+}
+
+// Co-issue probe: waves 0-3 (one per SIMD) stream fp32 MFMAs; waves 4-7 (their SIMD partners)
+// run `what` (0 nothing, 1 v_fma chain-free VALU, 2 global loads, 3 SALU, 4 LDS reads,
+// 5 global stores).  Durations by s_memtime.
+template <int MF>
+__global__ __launch_bounds__(512) void coissue_kernel(float *buf, long long *times, int what, int iters, int prio) {
+  __shared__ float sh[4096];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  sh[threadIdx.x] = threadIdx.x; sh[threadIdx.x + 512] = 1.f;
+  __syncthreads();
+  long long t0 = 0, t1 = 0;
+  float sink = 0.f;
+  if (wave < 4) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    f32x16_t c0; for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+    float a = 1.f + lane, b = 2.f;
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (MF == 16) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a1, 0, 0, 0); }
+        else { c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0); }
+      }
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    sink = a0[0] + a1[0] + c0[0];
+  } else if (what) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    float x0 = lane, x1 = 1.f, x2 = 2.f, x3 = 3.f;
+    int si = blockIdx.x;
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+      if (what == 1) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { x0 = x0 * 1.0001f + 0.5f; x1 = x1 * 1.0001f + 0.5f; x2 = x2 * 1.0001f + 0.5f; x3 = x3 * 1.0001f + 0.5f; }
+      } else if (what == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x0 += buf[((size_t)(i * 4 + u) * 4096 + blockIdx.x * 64 + lane) & 0xFFFFFF];
+      } else if (what == 3) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) { si = si * 3 + 1; asm volatile("" : "+s"(si)); }
+      } else if (what == 4) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x0 += sh[(lane + u * 64 + i) & 1023];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) buf[(size_t)(1 << 24) + ((size_t)(i * 4 + u) * 4096 + blockIdx.x * 64 + lane)] = x0;
+      }
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    sink = x0 + x1 + x2 + x3 + si;
+  }
+  if (lane == 0) { times[(blockIdx.x * 8 + wave) * 2] = t0; times[(blockIdx.x * 8 + wave) * 2 + 1] = t1; }
+  if (sink == 123.456f) buf[0] = sink;
+}
+
+// Own-stream probe: ONE wave per SIMD; per MFMA, NV independent v_fma's + NS SALU + NL LDS reads
+// + NG global stores are issued behind it.  cycles per MFMA by s_memtime.
+template <int MF, int NV, int NS, int NL, int NG>
+__global__ __launch_bounds__(256) void ownstream_kernel(float *buf, long long *times, int iters) {
+  __shared__ float sh[4096];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4096; i += 256) sh[i] = i;
+  __syncthreads();
+  f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  f32x16_t c0; for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+  float a = 1.f + lane, b = 2.f, x[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  int si = blockIdx.x;
+  float *dst = buf + ((size_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MF == 16) { if (u & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a1, 0, 0, 0); else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a0, 0, 0, 0); }
+      else c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) x[v & 7] = x[v & 7] * 1.0001f + 0.5f;
+#pragma unroll
+      for (int v = 0; v < NS; ++v) { si = si * 3 + 1; asm volatile("" : "+s"(si)); }
+#pragma unroll
+      for (int v = 0; v < NL; ++v) x[v & 7] += sh[(lane + (u * 4 + v) * 64 + i) & 4095];
+#pragma unroll
+      for (int v = 0; v < NG; ++v) dst[(size_t)((i * 8 + u) * NG + v) * 65536 & 0xFFFFFF] = x[v & 7];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float sink = a0[0] + a1[0] + c0[0] + si;
+  for (int v = 0; v < 8; ++v) sink += x[v];
+  if (lane == 0) { times[(blockIdx.x * 4 + wave) * 2] = t0; times[(blockIdx.x * 4 + wave) * 2 + 1] = t1; }
+  if (sink == 123.456f) buf[0] = sink;
+}
+
+// Issue-cost probe: one wave per SIMD, per MFMA one extra instruction of kind WHAT whose result is
+// not waited for inside the loop (pure issue cost).  1 global_load_dwordx4, 2 ds_write_b128,
+// 3 global_load_lds_dwordx4, 4 global_store_dwordx4, 5 global_store_dword, 6 ds_read2st64_b32,
+// 7 ds_read_b128, 8 v_pk_fma_f32 x2, 9 s_waitcnt lgkmcnt(15)
+template <int WHAT>
+__global__ __launch_bounds__(256) void issue_kernel(float *buf, long long *times, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float shd[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 8192; i += 256) shd[i] = i;
+  __syncthreads();
+  f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  float a = 1.f + lane, b = 2.f;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v4 ld[8]; v2 r2 = {1.f, 2.f}, pk = {1.f, 1.f};
+  for (int u = 0; u < 8; ++u) ld[u] = (v4){1.f, 2.f, 3.f, 4.f};
+  const float *src = buf + ((size_t)blockIdx.x * 4 + wave) * 4096;
+  float *dst = buf + (size_t)(1 << 24) + ((size_t)blockIdx.x * 4 + wave) * 4096;
+  const unsigned lw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)shd + wave * 4096;
+  const unsigned la = lw + lane * 16;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a1, 0, 0, 0); else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned go = (unsigned)(((i * 8 + u) & 7) * 1024 + lane * 16);
+      if (WHAT == 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ld[u]) : "v"(go), "s"(src) : "memory");
+      if (WHAT == 2) asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(ld[u]) : "memory");
+      if (WHAT == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(go), "s"(src), "s"(lw) : "memory", "m0");
+      if (WHAT == 4) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(go), "v"(ld[u]), "s"(dst) : "memory");
+      if (WHAT == 5) asm volatile("global_store_dword %0, %1, %2" :: "v"(go), "v"(a), "s"(dst) : "memory");
+      if (WHAT == 6) asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:4" : "=v"(r2) : "v"(la));
+      if (WHAT == 7) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[u]) : "v"(la));
+      if (WHAT == 8) { pk = __builtin_elementwise_fma(pk, r2, r2); r2 = __builtin_elementwise_fma(r2, pk, pk); }
+      if (WHAT == 9) asm volatile("s_waitcnt lgkmcnt(15)");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (WHAT == 1 || WHAT == 3 || WHAT == 4 || WHAT == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (WHAT == 2 || WHAT == 6 || WHAT == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float sink = a0[0] + a1[0] + r2[0] + pk[0];
+  for (int u = 0; u < 8; ++u) sink += ld[u][0];
+  if (lane == 0) { times[(blockIdx.x * 4 + wave) * 2] = t0; times[(blockIdx.x * 4 + wave) * 2 + 1] = t1; }
+  if (sink == 123.456f) buf[0] = sink;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static uint32_t rng = 12345;
@@ -32,6 +206,8 @@ struct Shape { int nb, ng, k, cout; long long p; int g; const char *what; };
 
 int main(int argc, char **argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
+  const int only = argc > 2 ? atoi(argv[2]) : -1;   // shape index, -1 = all
+  const int mode = argc > 3 ? atoi(argv[3]) : 0;    // 1: plain kernel only, 2: fused only, 3: rocBLAS only (profiling)
   rocblas_handle h; rocblas_create_handle(&h);
   std::vector<Shape> shapes = {
       {48, 6, 256, 128, 8192, 16, "MiniPointNet side 256->128 (+pool16)"},
@@ -48,8 +224,107 @@ int main(int argc, char **argv) {
       {8, 1, 128, 256, 4096, 16, "SA4 128->256"},
       {8, 1, 256, 256, 1024, 16, "FP 256->256"},
   };
+  if (mode == 12) {
+    float *buf; long long *tm; CK(hipMalloc(&buf, (size_t)(1 << 24) * 4 * 2)); CK(hipMalloc(&tm, 256 * 8 * 8));
+    CK(hipMemset(buf, 0, (size_t)(1 << 24) * 4 * 2));
+    const int it = 64;
+    auto run = [&](auto kern, const char *nm) {
+      for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 65536, 0, buf, tm, it);
+      CK(hipDeviceSynchronize());
+      std::vector<long long> h(256 * 8);
+      CK(hipMemcpy(h.data(), tm, h.size() * 8, hipMemcpyDeviceToHost));
+      printf("16x16x4 + %-40s %.1f cycles per MFMA (incl. one drain per 8)\n", nm, (double)(h[7 * 8 + 1] - h[7 * 8]) / (it * 8));
+    };
+    run(issue_kernel<0>, "nothing");
+    run(issue_kernel<1>, "global_load_dwordx4 (saddr)");
+    run(issue_kernel<2>, "ds_write_b128");
+    run(issue_kernel<3>, "s_mov m0 + global_load_lds_dwordx4");
+    run(issue_kernel<4>, "global_store_dwordx4 (saddr)");
+    run(issue_kernel<5>, "global_store_dword (saddr)");
+    run(issue_kernel<6>, "ds_read2st64_b32");
+    run(issue_kernel<7>, "ds_read_b128");
+    run(issue_kernel<8>, "2 x v_pk_fma_f32");
+    run(issue_kernel<9>, "s_waitcnt lgkmcnt(15)");
+    return 0;
+  }
+  if (mode == 11) {
+    float *buf; long long *tm; CK(hipMalloc(&buf, (size_t)(1 << 24) * 4 * 2)); CK(hipMalloc(&tm, 256 * 8 * 8));
+    const int it = 128;
+    auto run = [&](auto kern, const char *nm) {
+      hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, buf, tm, it);
+      CK(hipDeviceSynchronize());
+      std::vector<long long> h(256 * 8);
+      CK(hipMemcpy(h.data(), tm, h.size() * 8, hipMemcpyDeviceToHost));
+      printf("%-44s %.1f cycles per MFMA\n", nm, (double)(h[7 * 8 + 1] - h[7 * 8]) / (it * 8));
+    };
+    run(ownstream_kernel<16, 0, 0, 0, 0>, "16x16x4 alone");
+    run(ownstream_kernel<16, 2, 0, 0, 0>, "16x16x4 + 2 VALU (v_mul, v_add)");
+    run(ownstream_kernel<16, 4, 0, 0, 0>, "16x16x4 + 4 VALU");
+    run(ownstream_kernel<16, 8, 0, 0, 0>, "16x16x4 + 8 VALU");
+    run(ownstream_kernel<16, 16, 0, 0, 0>, "16x16x4 + 16 VALU");
+    run(ownstream_kernel<16, 0, 8, 0, 0>, "16x16x4 + 8 SALU");
+    run(ownstream_kernel<16, 0, 0, 1, 0>, "16x16x4 + 1 LDS read");
+    run(ownstream_kernel<16, 0, 0, 2, 0>, "16x16x4 + 2 LDS read");
+    run(ownstream_kernel<16, 0, 0, 0, 1>, "16x16x4 + 1 global store");
+    run(ownstream_kernel<16, 4, 4, 1, 1>, "16x16x4 + 4 VALU 4 SALU 1 LDS 1 store");
+    run(ownstream_kernel<32, 0, 0, 0, 0>, "32x32x2 alone");
+    run(ownstream_kernel<32, 4, 0, 0, 0>, "32x32x2 + 4 VALU");
+    run(ownstream_kernel<32, 8, 0, 0, 0>, "32x32x2 + 8 VALU");
+    run(ownstream_kernel<32, 16, 0, 0, 0>, "32x32x2 + 16 VALU");
+    run(ownstream_kernel<32, 32, 0, 0, 0>, "32x32x2 + 32 VALU");
+    run(ownstream_kernel<32, 0, 16, 0, 0>, "32x32x2 + 16 SALU");
+    run(ownstream_kernel<32, 0, 0, 2, 0>, "32x32x2 + 2 LDS read");
+    run(ownstream_kernel<32, 0, 0, 0, 2>, "32x32x2 + 2 global store");
+    run(ownstream_kernel<32, 8, 8, 2, 2>, "32x32x2 + 8 VALU 8 SALU 2 LDS 2 store");
+    return 0;
+  }
+  if (mode == 10) {
+    float *buf; long long *tm; CK(hipMalloc(&buf, (size_t)(1 << 24) * 4 * 3)); CK(hipMalloc(&tm, 256 * 16 * 8));
+    CK(hipMemset(buf, 0, (size_t)(1 << 24) * 4));
+    const char *nm[6] = {"nothing", "VALU (64 v_mul+v_add / iter)", "global loads (4 / iter)", "SALU (64 / iter)", "LDS reads (8 / iter)", "global stores (4 / iter)"};
+    for (int mf = 16; mf <= 32; mf += 16)
+      for (int what = 0; what < 6; ++what)
+        for (int prio = 0; prio < (what ? 2 : 1); ++prio) {
+          const int it = 256;
+          if (mf == 16) hipLaunchKernelGGL(coissue_kernel<16>, dim3(256), dim3(512), 0, 0, buf, tm, what, it, prio);
+          else hipLaunchKernelGGL(coissue_kernel<32>, dim3(256), dim3(512), 0, 0, buf, tm, what, it, prio);
+          CK(hipDeviceSynchronize());
+          std::vector<long long> h(256 * 16);
+          CK(hipMemcpy(h.data(), tm, h.size() * 8, hipMemcpyDeviceToHost));
+          // workgroup 7: MFMA wave 0 and its partner wave 4
+          const long long *q = &h[7 * 16];
+          printf("mfma %dx: partner runs %-30s prio %d: MFMA wave %7lld cyc (%.1f per MFMA)  partner %7lld cyc  overlap: partner starts %+lld, ends %+lld vs MFMA end\n",
+                 mf, nm[what], prio, q[1] - q[0], (double)(q[1] - q[0]) / (it * (mf == 16 ? 16 : 8)), q[9] - q[8], q[8] - q[0], q[9] - q[1]);
+        }
+    return 0;
+  }
+  if (mode == 9) {
+    float *o; CK(hipMalloc(&o, 1024 * 512 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int it = 2000;
+    auto run = [&](auto kern, int threads, int chains, double flop_per_mfma, const char *nm) {
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, o, it, 0.5f, 0.25f);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double fl = 256.0 * (threads / 64) * it * 16.0 * chains * flop_per_mfma;
+        if (rep) printf("%-28s %d waves/CU: %.3f ms  %.1f TFLOP/s\n", nm, threads / 64, ms, fl / ms / 1e9);
+      }
+    };
+    run(mfma_peak_kernel<16, 2>, 256, 2, 2048.0, "16x16x4 f32, 2 chains");
+    run(mfma_peak_kernel<16, 2>, 512, 2, 2048.0, "16x16x4 f32, 2 chains");
+    run(mfma_peak_kernel<16, 1>, 512, 1, 2048.0, "16x16x4 f32, 1 chain");
+    run(mfma_peak_kernel<16, 4>, 256, 4, 2048.0, "16x16x4 f32, 4 chains");
+    run(mfma_peak_kernel<32, 1>, 256, 1, 4096.0, "32x32x2 f32, 1 chain");
+    run(mfma_peak_kernel<32, 1>, 512, 1, 4096.0, "32x32x2 f32, 1 chain");
+    run(mfma_peak_kernel<32, 2>, 256, 2, 4096.0, "32x32x2 f32, 2 chains");
+    return 0;
+  }
   printf("%-40s %9s %9s %8s %8s %9s %9s %9s\n", "layer", "rocblas", "nesie", "TF(roc)", "TF(own)", "fused ms", "maxerr", "staterr");
-  for (const Shape &s : shapes) {
+  for (size_t si = 0; si < shapes.size(); ++si) {
+    const Shape &s = shapes[si];
+    if (only >= 0 && (int)si != only) continue;
     const size_t xe = (size_t)s.nb * s.k * s.p, ye = (size_t)s.nb * s.cout * s.p, we = (size_t)s.ng * s.cout * s.k;
     std::vector<float> hx(xe), hw(we), hcoef((size_t)s.ng * s.k * 4);
     for (auto &v : hx) v = frand();
@@ -82,6 +357,36 @@ int main(int argc, char **argv) {
                                       dpmax, dpmin, damax, damin, 0);
       if (st) { printf("nesie error %d: %s\n", st, nesie_last_error()); exit(1); }
     };
+#ifdef PW_STAMP
+    if (mode == 7 || mode == 8) {
+      extern long long *g_pw_stamps;
+      long long *dst; CK(hipMalloc(&dst, (2 * 24 * 8 + 4) * 8)); CK(hipMemset(dst, 0, (2 * 24 * 8 + 4) * 8));
+      for (int rep = 0; rep < 400; ++rep) own(mode == 8 ? dcoef : nullptr, 1, dy, mode == 8 ? dpart : nullptr, 0, 0);
+      g_pw_stamps = dst;
+      own(mode == 8 ? dcoef : nullptr, 1, dy, mode == 8 ? dpart : nullptr, 0, 0);
+      CK(hipDeviceSynchronize());
+      g_pw_stamps = nullptr;
+      std::vector<long long> hs(2 * 24 * 8 + 4);
+      CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+      printf("in-kernel clock: %lld shader cycles over %lld ticks of the 100 MHz counter = %.3f GHz\n", hs[2 * 24 * 8 + 2] - hs[2 * 24 * 8],
+             hs[2 * 24 * 8 + 3] - hs[2 * 24 * 8 + 1], 0.1 * (double)(hs[2 * 24 * 8 + 2] - hs[2 * 24 * 8]) / (double)(hs[2 * 24 * 8 + 3] - hs[2 * 24 * 8 + 1]));
+      const char *nm[8] = {"top", "waited", "barrier", "issued", "xform", "late-epi", "mfma", "epi"};
+      for (int h = 0; h < 2; ++h) {
+        printf("%s wave %d: per-iteration phase durations (cycles): wait barrier issue xform late-epi mfma epi | total\n", s.what, h * 4);
+        for (int it = 0; it < 23; ++it) {
+          const long long *q = &hs[(h * 24 + it) * 8], *qn = &hs[(h * 24 + it + 1) * 8];
+          if (!q[0] || !qn[0]) break;
+          printf("  it %2d:", it);
+          for (int k = 1; k < 8; ++k) printf(" %6lld", q[k] - q[k - 1]);
+          printf(" | %6lld  (%s)\n", qn[0] - q[0], nm[0]);
+        }
+      }
+      continue;
+    }
+#endif
+    if (mode == 1) { printf("%s plain %.4f ms\n", s.what, timeit([&]() { own(nullptr, 0, dy, nullptr, 0, 0); })); continue; }
+    if (mode == 2) { printf("%s fused %.4f ms\n", s.what, timeit([&]() { own(dcoef, 1, dy, dpart, 0, 0); })); continue; }
+    if (mode == 3) { printf("%s rocblas %.4f ms\n", s.what, timeit(roc)); continue; }
     const float t_roc = timeit(roc);
     const float t_own = timeit([&]() { own(nullptr, 0, dy, nullptr, 0, 0); });
     // correctness of the plain product vs rocBLAS and fp64 samples
@@ -100,6 +405,17 @@ int main(int argc, char **argv) {
     }
     double maxd = 0.0;
     for (size_t i = 0; i < ye; ++i) { const double d = fabs((double)hy[i] - hy2[i]); if (d > maxd) maxd = d; }
+    if (maxd > 1e-3) {
+      size_t bad = 0, hp[16] = {0}, hm[16] = {0}, hn[64] = {0}; int shown = 0;
+      for (size_t i = 0; i < ye; ++i) if (fabs((double)hy[i] - hy2[i]) > 1e-3) {
+        const long long q = i % s.p; const int mm = (i / s.p) % s.cout, n = i / s.p / s.cout;
+        ++bad; ++hp[(q / 16) % 16]; ++hm[mm % 16]; ++hn[n % 64];
+        if (shown++ < 6) printf("   mismatch n %d m %d pos %lld: %g vs %g\n", n, mm, q, hy[i], hy2[i]);
+      }
+      printf("   %zu of %zu differ; by (pos/16)%%16:", bad, ye); for (int i = 0; i < 16; ++i) printf(" %zu", hp[i]);
+      printf("\n   by m%%16:"); for (int i = 0; i < 16; ++i) printf(" %zu", hm[i]);
+      printf("\n   by n:"); for (int i = 0; i < 16; ++i) printf(" %zu", hn[i]); printf("\n");
+    }
     // fused: affine + relu prologue, store + stats epilogue
     const float t_fused = timeit([&]() { own(dcoef, 1, dy, dpart, 0, 0); });
     nesie_pw_stats_finalize(s.ng * s.cout, s.cout, slots, dpart, nullptr, nullptr, nullptr, nullptr, 0.1f, 1e-5f, dcoef_out, 0);
