@@ -289,6 +289,9 @@ int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float
                           [C][pre_nslice][2] left by the producer of x: the statistics pass over
                           x is skipped */, int pre_nslice, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* y == NULL with relu != 0: the normalised tensor was never stored (nesie_pw_layer_forward applied
+ * it on its operand load); the mask is fma(x, scale, bias) > 0 from fwd_coef.  d_row_bias without
+ * row_bias: the per-group sums of dx (the producer had added the row term to x itself). */
 int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const float *x,
                            const float *y, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_invstd,
@@ -389,47 +392,77 @@ int nesie_scene_assemble(int b, int n, long long pool_rows, const float *pool,
                          const float *height, const int *choices, const float *xform,
                          float *out, void *stream);
 
-/* One shared-MLP layer of a grouped MLP on the matrix cores.  No extension entry in the
- * reference: it evaluates mmcv ConvModule(Conv2d 1x1 -> BN2d -> ReLU) op by op
- * (point_sa_module.py:277-289, side_pooling_module.py:346-358).
- *   y[b] = W . act(x[b]),  x[b] (cin, p) at x + b*x_bstride, W (cout, cin), y (B, cout, p)
- *   act(v) = in_coef ? relu?(in_coef[k][0] * v + in_coef[k][1]) : v   per input channel k --
- *            the previous layer's folded BatchNorm (scale, bias, -, -) and ReLU, applied while
- *            the tile is staged (the normalised activation is never stored);
- *   stat_partial (NULL = skip): nesie_mlp_stat_partials(b, cout, p) x cout x 2 floats, the
- *            per-workgroup (sum, sum of squares) of y for this layer's own batch statistics.
- * nesie_mlp_stat_finalize folds them (fp64) into coef[c][4] = (scale, bias, mean, invstd) with
- * scale = gamma * invstd, bias = beta - mean * scale, and updates the running statistics
- * like torch.nn.BatchNorm2d in training mode (biased variance to normalise, unbiased into
- * running_var). */
-long long nesie_mlp_stat_partials(int b, int cout, long long p);
-int nesie_mlp_layer_forward(int b, int cin, int cout, long long p, const float *x,
-                            long long x_bstride, const float *w, const float *in_coef,
-                            int in_relu, float *y, float *stat_partial, void *stream);
-int nesie_mlp_stat_finalize(int c, long long nparts, double count, const float *stat_partial,
+/* One pointwise (1x1) convolution layer of a grouped MLP on the fp32 matrix cores, with the
+ * previous layer's BatchNorm + ReLU folded into the operand load and this layer's statistics /
+ * pooling tail folded into the epilogue.  No extension entry in the reference: it evaluates mmcv
+ * ConvModule(Conv2d 1x1 -> BN2d -> ReLU) and the pooling op by op (point_sa_module.py:277-289,
+ * 136-158; side_pooling_module.py:343-370).
+ *   y[n] = W[n % ng] . act(x[n]) (+ row_bias) (+ bias)       n < nb, nb % ng == 0
+ *   x[n] (k, p) at x + n*x_bstride; y[n] (cout, p) at y + n*y_bstride (y NULL: not stored)
+ *   W[g][m][kk] = w[g*w_gstride + m*w_rstride + kk*w_cstride]  (strides: W or its transpose)
+ *   act(v) = in_coef ? max(fma(v, in_coef[g*k+kk][0], in_coef[g*k+kk][1]), in_relu ? 0 : -inf) : v
+ *   row_bias (nb, cout, p / rb_group) or NULL; bias [ng*cout] or NULL
+ *   stat_part (NULL = skip): [ng][nesie_pw_stat_slots(...)][cout][4] = (count, shift,
+ *            sum(y - shift), sum((y - shift)^2)) per wave, merged by nesie_pw_stats_finalize
+ *   pool_group 0 / 16 / 32: max (and, pool_min != 0, min) over each pool_group consecutive
+ *            positions -> pool_*_out (nb, cout, p / pool_group), arg_*_out the position inside it.
+ * Built for k <= 260, cout <= 256, p a multiple of the tile (nesie_pw_supported). */
+int nesie_pw_supported(int k, int cout, long long p);
+int nesie_pw_stat_slots(int nb, int ng, int k, int cout, long long p);
+int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p, const float *x,
+                           long long x_bstride, const float *w, long long w_gstride,
+                           int w_rstride, int w_cstride, const float *in_coef, int in_relu,
+                           const float *row_bias, int rb_group, const float *bias, float *y,
+                           long long y_bstride, float *stat_part, int pool_group, int pool_min,
+                           float *pool_max_out, float *pool_min_out, uint8_t *arg_max_out,
+                           uint8_t *arg_min_out, void *stream);
+/* stat_part -> coef[ch][4] = (scale, bias, mean, invstd), scale = gamma * invstd, bias = beta -
+ * mean * scale (fp64, Chan's merge of the shifted partials), running statistics updated like
+ * torch.nn.BatchNorm2d in training mode.  channels = ng * cout (stacked layers). */
+int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,
                             const float *gamma, const float *beta, float *running_mean,
                             float *running_var, float momentum, float eps, float *coef,
                             void *stream);
+/* Pooling tail: combine the group / pool_group partial extrema of every group of `group`
+ * positions; with coef (this layer's BatchNorm) the value is relu?(scale * ext + bias) of the
+ * extremum the sign of the scale selects (= max over the group of the normalised activation).
+ * pooled (nb, channels, p / group), argmax the position inside the group (first on ties). */
+int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, int pool_group,
+                         const float *pmax, const float *pmin, const uint8_t *amax,
+                         const uint8_t *amin, const float *coef, int relu, float *pooled,
+                         uint8_t *argmax, void *stream);
 
-/* nesie_mlp_layer_forward for skinny HBM-bound layers (cin <= 64, cout <= 128): W stays in
+/* The layer kernel for skinny HBM-bound first layers (cin <= 64, cout <= 128): W stays in
  * LDS / registers and every wave streams its own 32-position columns straight from global
  * memory into the MFMA operand registers (no LDS tile, no barrier in the main loop).
- * stat_partial: nesie_mlp_stream_partials(b, p) x cout x 2 floats. */
+ *   y[b] = W . act(x[b]),  x[b] (cin, p) at x + b*x_bstride, W (cout, cin), y (B, cout, p);
+ *   act(v) = in_coef ? relu?(in_coef[k][0] * v + in_coef[k][1]) : v;
+ *   stat_partial (NULL = skip): nesie_mlp_stream_partials(b, p) x cout x 2 floats, the
+ *   per-workgroup (sum, sum of squares) of y. */
 long long nesie_mlp_stream_partials(int b, long long p);
+/* (sum, sum of squares) partials -> coef[c][4] = (scale, bias, mean, invstd) (fp64), running
+ * statistics updated like torch.nn.BatchNorm2d in training mode.  stat_partial is [nparts][c][2]
+ * (the streaming kernel) or, channel_major != 0, [c][nparts][2] (nesie_blend_conv_forward). */
+int nesie_mlp_stat_finalize(int c, long long nparts, double count, const float *stat_partial,
+                            const float *gamma, const float *beta, float *running_mean,
+                            float *running_var, float momentum, float eps, float *coef,
+                            int channel_major, void *stream);
 int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p, const float *x,
                                    long long x_bstride, const float *w, const float *in_coef,
                                    int in_relu, float *y, float *stat_partial, void *stream);
 
 /* Weight gradient of a 1x1 conv on the matrix cores: dw[cout][cin] = sum over scenes and
  * positions of dy[b][m][p] * act(x[b][k][p]); dy (B, cout, p), x[b] (cin, p) at x + b*x_bstride,
- * act as in nesie_mlp_layer_forward (x_coef NULL = identity).  Reference: the conv2d backward
+ * act as in nesie_mlp_layer_forward_stream (x_coef NULL = identity).  Reference: the conv2d backward
  * that autograd runs for ConvModule's Conv2d (point_sa_module.py:277-289).  Partials are added in
- * a fixed order (bitwise reproducible).  cout <= 256, cin <= 160 (128 when cout > 128);
+ * a fixed order (bitwise reproducible).  dy[b] (cout, p) at dy + b*dy_bstride.  cout <= 128 with
+ * cin <= 288, or cout <= 256 with cin <= 128;
  * workspace = nesie_conv_wgrad_workspace_bytes(b, cout, cin, p). */
 size_t nesie_conv_wgrad_workspace_bytes(int b, int cout, int cin, long long p);
-int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy, const float *x,
-                     long long x_bstride, const float *x_coef, int x_relu, float *dw,
-                     void *workspace, size_t workspace_bytes, void *stream);
+int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
+                     long long dy_bstride, const float *x, long long x_bstride,
+                     const float *x_coef, int x_relu, float *dw, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

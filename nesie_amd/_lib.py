@@ -60,14 +60,18 @@ SIGNATURES = {
                                       _P, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_maxpool_backward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _P, ctypes.c_size_t, _P],
-    "nesie_mlp_layer_forward": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _I,
-                                _P, _P, _P],
-    "nesie_conv_wgrad": [_I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _I, _P, _P,
-                         ctypes.c_size_t, _P],
+    "nesie_conv_wgrad": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
+                         _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_mlp_layer_forward_stream": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P,
                                        _I, _P, _P, _P],
     "nesie_mlp_stat_finalize": [_I, ctypes.c_longlong, ctypes.c_double, _P, _P, _P, _P, _P, _F,
-                                _F, _P, _P],
+                                _F, _P, _I, _P],
+    "nesie_pw_layer_forward": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                               ctypes.c_longlong, _I, _I, _P, _I, _P, _I, _P, _P, ctypes.c_longlong,
+                               _P, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P],
+    "nesie_pw_pool_finish": [_I, _I, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P,
+                             _P],
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
                               _P, _P, _P, _I, _P, _I, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
@@ -106,8 +110,10 @@ def load():
     lib.nesie_blend_conv_runs.restype = _I
     lib.nesie_mlp_stream_partials.argtypes = [_I, ctypes.c_longlong]
     lib.nesie_mlp_stream_partials.restype = ctypes.c_longlong
-    lib.nesie_mlp_stat_partials.argtypes = [_I, _I, ctypes.c_longlong]
-    lib.nesie_mlp_stat_partials.restype = ctypes.c_longlong
+    lib.nesie_pw_supported.argtypes = [_I, _I, ctypes.c_longlong]
+    lib.nesie_pw_supported.restype = _I
+    lib.nesie_pw_stat_slots.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
+    lib.nesie_pw_stat_slots.restype = _I
     lib.nesie_abi_version.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib

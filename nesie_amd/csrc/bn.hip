@@ -211,17 +211,22 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     const float *__restrict__ x, const float *__restrict__ y,
     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta,
-    const float *__restrict__ row_bias, int group, float *__restrict__ partial) {
+    const float *__restrict__ row_bias, int group, float *__restrict__ partial,
+    const float *__restrict__ raw_coef) {
+  // raw_coef != NULL: the normalised tensor y was never stored (the next layer applied the
+  // norm + ReLU on its operand load, pwconv.hip): the ReLU mask is fma(x, scale, bias) > 0,
+  // the fused form that kernel used
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c_total + c) * p;
   const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
   float mean = save_mean[c], invstd = save_invstd[c];
+  const float rsc = raw_coef ? raw_coef[c * 4 + 0] : 0.f, rbi = raw_coef ? raw_coef[c * 4 + 1] : 0.f;
   // With the ReLU fused, xhat is only needed where y > 0, and there y = gamma*xhat + beta:
   // xhat = (y - beta) / gamma needs no read of x (one tensor pass less).  Channels whose
   // gamma is ~0 keep the x path.  `src` is the tensor xhat is rebuilt from.
   const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-  const bool from_y = RELU && fabsf(gm) > 1e-4f;
+  const bool from_y = RELU && !raw_coef && fabsf(gm) > 1e-4f;
   const float *__restrict__ src = from_y ? y : x;
   if (from_y) { mean = bt; invstd = 1.f / gm; }
   const long long lo = (long long)s * BN_SPAN;
@@ -232,12 +237,15 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     for (long long i = lo + threadIdx.x * 4; i < hi; i += BN_BLOCK * 4) {
       float4 g = *(const float4 *)(dy + base + i);      // read again by the apply pass
       float4 v = from_y ? ld4<NT>(src + base + i) : *(const float4 *)(src + base + i);
+      if (rb && !from_y) { const float r = rb[i >> gs]; v.x += r; v.y += r; v.z += r; v.w += r; }
       if (RELU) {
-        const float4 o = from_y ? v : ld4<NT>(y + base + i);
+        float4 o;
+        if (raw_coef) o = make_float4(__builtin_fmaf(v.x, rsc, rbi), __builtin_fmaf(v.y, rsc, rbi),
+                                      __builtin_fmaf(v.z, rsc, rbi), __builtin_fmaf(v.w, rsc, rbi));
+        else o = from_y ? v : ld4<NT>(y + base + i);
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
-      if (rb && !from_y) { const float r = rb[i >> gs]; v.x += r; v.y += r; v.z += r; v.w += r; }
       a0 += (g.x + g.y) + (g.z + g.w);
       a1 += (g.x * ((v.x - mean) * invstd) + g.y * ((v.y - mean) * invstd)) +
             (g.z * ((v.z - mean) * invstd) + g.w * ((v.w - mean) * invstd));
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
       float v = src[base + i];
-      if (RELU) g = (from_y ? v : y[base + i]) > 0.f ? g : 0.f;
       if (rb && !from_y) v += rb[i >> gs];
+      if (RELU) g = (raw_coef ? __builtin_fmaf(v, rsc, rbi) : from_y ? v : y[base + i]) > 0.f ? g : 0.f;
       a0 += g; a1 += g * ((v - mean) * invstd);
     }
   }
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     int c_total, long long p, const float *__restrict__ dy, const float *__restrict__ x,
     const float *__restrict__ fwd_coef, BnBwdFin fin,
     const float *__restrict__ row_bias, int group, float *__restrict__ d_row_bias,
-    float *__restrict__ dx) {
+    float *__restrict__ dx, int fused_mask) {
   // dx = a * (g - k1 - xhat * k2) for EVERY position, masked ones included, so x is needed
   // everywhere; the ReLU mask is re-derived from x with the forward's own scale/bias
   // (same two fp32 operations as bn_apply_kernel, hence the same bits) instead of reading y.
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const size_t base = ((size_t)b * c_total + c) * p;
-  const size_t rbase = row_bias ? ((size_t)b * c_total + c) * (p / group) : 0;
+  const size_t rbase = (row_bias || d_row_bias) ? ((size_t)b * c_total + c) * (p / group) : 0;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   const int gs = group_shift(group);
@@ -324,8 +332,13 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
       float4 v = ld4<NT>(x + base + i);
       if (row_bias) { const float r = row_bias[rbase + (i >> gs)]; v.x += r; v.y += r; v.z += r; v.w += r; }
       if (RELU) {
-        g.x = v.x * sc + bi > 0.f ? g.x : 0.f; g.y = v.y * sc + bi > 0.f ? g.y : 0.f;
-        g.z = v.z * sc + bi > 0.f ? g.z : 0.f; g.w = v.w * sc + bi > 0.f ? g.w : 0.f;
+        if (fused_mask) {   // the forward applied fma(x, scale, bias) (pwconv.hip operand load)
+          g.x = __builtin_fmaf(v.x, sc, bi) > 0.f ? g.x : 0.f; g.y = __builtin_fmaf(v.y, sc, bi) > 0.f ? g.y : 0.f;
+          g.z = __builtin_fmaf(v.z, sc, bi) > 0.f ? g.z : 0.f; g.w = __builtin_fmaf(v.w, sc, bi) > 0.f ? g.w : 0.f;
+        } else {
+          g.x = v.x * sc + bi > 0.f ? g.x : 0.f; g.y = v.y * sc + bi > 0.f ? g.y : 0.f;
+          g.z = v.z * sc + bi > 0.f ? g.z : 0.f; g.w = v.w * sc + bi > 0.f ? g.w : 0.f;
+        }
       }
       float4 r;
       r.x = a * (g.x - k1 - (v.x - mean) * invstd * k2);
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
       const float v = x[base + i];  // the row-bias form requires p % 4 == 0 (checked on the host)
-      if (RELU) g = v * sc + bi > 0.f ? g : 0.f;
+      if (RELU) g = (fused_mask ? __builtin_fmaf(v, sc, bi) : v * sc + bi) > 0.f ? g : 0.f;
       dx[base + i] = a * (g - k1 - (v - mean) * invstd * k2);
     }
   }
@@ -524,10 +537,14 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   const char *W = "bn_relu_backward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
-  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && fwd_coef && (!relu || y), W);
-  if (!row_bias) { group = 1; d_row_bias = nullptr; }
+  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && fwd_coef, W);
+  // y == NULL with relu: the normalised tensor was never stored (fused forward): the mask is
+  // re-derived from x with the forward's fused scale / bias.  d_row_bias without row_bias: only
+  // the per-group sums of dx are wanted (the producer had added the row term itself).
+  const int raw = relu && !y;
+  if (!row_bias && !d_row_bias) group = 1;
   NESIE_REQUIRE(group >= 1 && p % group == 0, W);
-  NESIE_REQUIRE(!row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
+  NESIE_REQUIRE(!(row_bias || d_row_bias) || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
@@ -535,14 +552,15 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   dim3 grid(sp, c, b);
   const bool nt = bn_use_nt((long long)b * c * p);
 #define LR(R, N) hipLaunchKernelGGL((bn_bwd_reduce_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, \
-                                    x, y, save_mean, save_invstd, gamma, beta, row_bias, group, partial)
+                                    x, y, save_mean, save_invstd, gamma, beta, row_bias, group, partial, \
+                                    raw ? fwd_coef : (const float *)nullptr)
   if (relu) { if (nt) LR(true, true); else LR(true, false); }
   else { if (nt) LR(false, true); else LR(false, false); }
 #undef LR
   const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
   (void)coef;
 #define LA(R, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, \
-                                    fwd_coef, fin, row_bias, group, d_row_bias, dx)
+                                    fwd_coef, fin, row_bias, group, d_row_bias, dx, raw)
   if (relu) { if (nt) LA(true, true); else LA(true, false); }
   else { if (nt) LA(false, true); else LA(false, false); }
 #undef LA

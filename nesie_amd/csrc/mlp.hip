@@ -1,27 +1,7 @@
-// Shared-MLP layer (1x1 conv -> BatchNorm -> ReLU) of the PointNet++ set-abstraction stack and
-// of the quality head's MiniPointNets as fp32 MFMA kernels for gfx950.
-//
-// The reference builds every grouped MLP from mmcv ConvModule(Conv2d 1x1, BN2d, ReLU)
-// (mmdet3d/ops/pointnet_modules/point_sa_module.py:277-289; dense_heads/
-// side_pooling_module.py:346-358).  Evaluated op by op, a layer moves its (B, C, P) tensor
-// through HBM five times in the forward pass (conv write, stats read, normalise read+write,
-// next conv read).  Here a layer is ONE kernel
-//
-//     x_l[b] = W_l . act(x_{l-1}[b]),   act(v) = relu?(scale_{l-1} * v + bias_{l-1})  per channel
-//
-// that applies the PREVIOUS layer's folded BatchNorm + ReLU while staging its input tile into
-// LDS (the normalised activation is never written), multiplies on the matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain), writes the raw conv output once
-// and leaves per-workgroup (sum, sum of squares) partials of it for this layer's own BatchNorm
-// statistics -- two tensor passes per layer instead of five.
-//
-// Tiling.  X[b] is (Cin x P) row-major with the positions contiguous and W is (Cout x Cin); a
-// workgroup owns BM output channels x BN positions and walks K = Cin in steps of 16.  Both LDS
-// tiles are k-major ([k][m] and [k][n]) so that an MFMA operand fetch is one ds_read_b32 of 32
-// consecutive words per half-wave; the row pitch is (tile + 32) words so the two half-waves
-// (k and k+1) fall on disjoint bank halves.  BM covers all of Cout where it can (64, 128 or
-// 256), so X streams from HBM exactly once.  Global loads of tile t+1 are issued before the
-// MFMAs of tile t and land in the other LDS buffer after them (one barrier per K step).
+// Weight gradient and the streaming (skinny) forward of the 1x1 convolutions of the grouped
+// MLPs on the fp32 matrix cores of gfx950 (mmcv ConvModule(Conv2d 1x1, BN2d, ReLU):
+// mmdet3d/ops/pointnet_modules/point_sa_module.py:277-289; dense_heads/
+// side_pooling_module.py:346-358).  The layer kernel proper is pwconv.hip.
 #include "common.h"
 #include <stdlib.h>
 
@@ -40,205 +20,27 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
-// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA blocks.
-template <int BM, int BN, int WM, int WN, int MLP_BK>
-__global__ __launch_bounds__(WM * WN * 64) void mlp_fwd_kernel(
-    int cin, int cout, long long p, long long x_bstride, const float *__restrict__ w,
-    const float *__restrict__ x, const float *__restrict__ in_coef, int in_relu,
-    float *__restrict__ y, float *__restrict__ stat_partial) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
-  constexpr int LDW = BM + 32, LDX = BN + 32;
-  constexpr int XV = MLP_BK * BN / 4;       // float4s in an X tile
-  constexpr int XPT = (XV + NT - 1) / NT;   // per thread
-  constexpr int WE = MLP_BK * BM;           // scalars in a W tile
-  constexpr int WPT = (WE + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) float ws[2][MLP_BK * LDW];
-  __shared__ __attribute__((aligned(16))) float xs[2][MLP_BK * LDX];
-  __shared__ float sstat[BM][2];
+}  // namespace nesie
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const long long n0 = (long long)blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-  const int bi = blockIdx.z;
-  const float *xb = x + (size_t)bi * x_bstride;
-  const bool inside = (p & 3) == 0 && (x_bstride & 3) == 0 && n0 + BN <= p;
+using namespace nesie;
 
-  f32x16 acc[MB][NB];
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 xr[XPT];
-  float wr[WPT];
-
-  auto load_tiles = [&](int k0) {
-    if (inside && k0 + MLP_BK <= cin && XV % NT == 0) {
-      // interior K step of an interior column block (wave-uniform): unconditional 16-byte
-      // loads issued back to back (no branch, hence no wait, between them)
-#pragma unroll
-      for (int t = 0; t < XPT; ++t) {
-        const int v = tid + t * NT;
-        const int kk = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
-        xr[t] = *(const float4 *)(xb + (size_t)(k0 + kk) * p + n0 + c4);
-      }
-      if (in_coef) {
-#pragma unroll
-        for (int t = 0; t < XPT; ++t) {
-          const int k = k0 + (tid + t * NT) / (BN / 4);
-          const float sc = in_coef[k * 4 + 0], bs = in_coef[k * 4 + 1];
-          float4 q = xr[t];
-          q.x = q.x * sc + bs; q.y = q.y * sc + bs; q.z = q.z * sc + bs; q.w = q.w * sc + bs;
-          if (in_relu) {
-            q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
-          }
-          xr[t] = q;
-        }
-      }
-    } else {
-#pragma unroll
-    for (int t = 0; t < XPT; ++t) {
-      const int v = tid + t * NT;
-      const int kk = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
-      const int k = k0 + kk;
-      const long long n = n0 + c4;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((XV % NT == 0 || v < XV) && k < cin) {
-        const float *src = xb + (size_t)k * p + n;
-        if (inside) {
-          q = *(const float4 *)src;
-        } else {
-          if (n < p) q.x = src[0];
-          if (n + 1 < p) q.y = src[1];
-          if (n + 2 < p) q.z = src[2];
-          if (n + 3 < p) q.w = src[3];
-        }
-        if (in_coef) {  // previous layer's folded BatchNorm (+ ReLU), per input channel
-          const float sc = in_coef[k * 4 + 0], bs = in_coef[k * 4 + 1];
-          q.x = q.x * sc + bs; q.y = q.y * sc + bs; q.z = q.z * sc + bs; q.w = q.w * sc + bs;
-          if (in_relu) {
-            q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
-          }
-          if (!inside) {  // columns past the end of the row stay zero (they feed the statistics)
-            if (n >= p) q.x = 0.f;
-            if (n + 1 >= p) q.y = 0.f;
-            if (n + 2 >= p) q.z = 0.f;
-            if (n + 3 >= p) q.w = 0.f;
-          }
-        }
-      }
-      xr[t] = q;
-    }
-    }
-    // W tile: clamped, unconditional loads; out-of-range entries zeroed by a select
-#pragma unroll
-    for (int t = 0; t < WPT; ++t) {
-      const int e = tid + t * NT;       // kk fastest: 16 consecutive k of one output channel
-      const int m = e / MLP_BK, kk = e % MLP_BK;
-      const int k = k0 + kk;
-      const bool ok = (WE % NT == 0 || e < WE) && k < cin && m0 + m < cout;
-      const int mm = m0 + m < cout ? m0 + m : cout - 1, kc = k < cin ? k : cin - 1;
-      const float t0 = w[(size_t)mm * cin + kc];
-      wr[t] = ok ? t0 : 0.f;
-    }
-  };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int t = 0; t < XPT; ++t) {
-      const int v = tid + t * NT;
-      if (XV % NT == 0 || v < XV) {
-        const int kk = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
-        *(float4 *)&xs[buf][kk * LDX + c4] = xr[t];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < WPT; ++t) {
-      const int e = tid + t * NT;
-      if (WE % NT == 0 || e < WE) ws[buf][(e % MLP_BK) * LDW + e / MLP_BK] = wr[t];
-    }
-  };
-
-  const int nk = (cin + MLP_BK - 1) / MLP_BK;
-  load_tiles(0);
-  if (stat_partial)
-    for (int i = tid; i < BM * 2; i += NT) (&sstat[0][0])[i] = 0.f;
-  store_tiles(0);
-  __syncthreads();
-  const int half = lane >> 5, l32 = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * MLP_BK);
-    const float *wsb = ws[buf] + wm * TM + l32;
-    const float *xsb = xs[buf] + wn * TN + l32;
-#pragma unroll
-    for (int k2 = 0; k2 < MLP_BK / 2; ++k2) {
-      float a[MB], b[NB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) a[i] = wsb[(k2 * 2 + half) * LDW + i * 32];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) b[j] = xsb[(k2 * 2 + half) * LDX + j * 32];
-#pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: raw conv output + per-channel (sum, sum of squares) of this tile
-  float *yb = y + ((size_t)bi * cout + m0) * p + n0;
-  const bool full = n0 + BN <= p && m0 + BM <= cout;
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const float v = acc[i][j][r];
-        const int nn = wn * TN + j * 32 + l32;
-        if (full || (m0 + m < cout && n0 + nn < p)) yb[(size_t)m * p + nn] = v;
-        s += v;
-        q += v * v;
-      }
-      if (stat_partial) {
-        s = half_wave_sum(s);
-        q = half_wave_sum(q);
-        if (l32 == 0) {
-          if (WN == 1) { sstat[m][0] = s; sstat[m][1] = q; }
-          else { atomicAdd(&sstat[m][0], s); atomicAdd(&sstat[m][1], q); }
-        }
-      }
-    }
-  }
-  if (stat_partial) {
-    __syncthreads();
-    // partial[(b * tiles_n + tile)][c][2]
-    float *dst = stat_partial + (((size_t)bi * gridDim.x + blockIdx.x) * cout + m0) * 2;
-    for (int i = tid; i < BM * 2; i += NT)
-      if (m0 + i / 2 < cout) dst[i] = (&sstat[0][0])[i];
-  }
-}
-
-// (sum, sumsq) partials -> mean / invstd, running statistics, folded (scale, bias)
+// (sum, sum of squares) partials of the streaming layer kernel -> mean / invstd, running
+// statistics, folded (scale, bias).  The streaming kernel serves first layers only (their input
+// is centred geometry), which keeps the unshifted sums harmless; the layer kernel proper
+// (pwconv.hip) carries shifted sums.
+namespace nesie {
 __global__ void mlp_stat_finalize_kernel(int c_total, int nparts, double n,
                                          const float *__restrict__ partial,
                                          const float *gamma, const float *beta,
                                          float *running_mean, float *running_var, float momentum,
-                                         float eps, float *coef) {
+                                         float eps, float *coef, int channel_major) {
   __shared__ double sh[2][256];
   const int c = blockIdx.x;
   double s0 = 0.0, s1 = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) {
-    s0 += (double)partial[((size_t)i * c_total + c) * 2];
-    s1 += (double)partial[((size_t)i * c_total + c) * 2 + 1];
+    const size_t o = channel_major ? ((size_t)c * nparts + i) * 2 : ((size_t)i * c_total + c) * 2;
+    s0 += (double)partial[o];
+    s1 += (double)partial[o + 1];
   }
   sh[0][threadIdx.x] = s0;
   sh[1][threadIdx.x] = s1;
@@ -266,58 +68,19 @@ __global__ void mlp_stat_finalize_kernel(int c_total, int nparts, double n,
   coef[c * 4 + 2] = (float)mean;
   coef[c * 4 + 3] = (float)invstd;
 }
-
-static void mlp_fwd_tile(int cout, int *bm, int *bn) {
-  if (cout <= 64) { *bm = 64; *bn = 256; }
-  else if (cout <= 128) { *bm = 128; *bn = 128; }
-  else { *bm = 256; *bn = 128; }
-}
-
 }  // namespace nesie
-
-using namespace nesie;
-
-extern "C" long long nesie_mlp_stat_partials(int b, int cout, long long p) {
-  int bm, bn;
-  mlp_fwd_tile(cout, &bm, &bn);
-  return (long long)b * cdiv(p, bn);
-}
-
-extern "C" int nesie_mlp_layer_forward(int b, int cin, int cout, long long p, const float *x,
-                                       long long x_bstride, const float *w,
-                                       const float *in_coef, int in_relu, float *y,
-                                       float *stat_partial, void *stream) {
-  const char *W = "mlp_layer_forward";
-  NESIE_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && p >= 0, W);
-  if (b == 0 || p == 0) return NESIE_OK;
-  NESIE_REQUIRE(x && w && y && x_bstride >= (long long)cin * p, W);
-  NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
-  int bm, bn;
-  mlp_fwd_tile(cout, &bm, &bn);
-  NESIE_REQUIRE(b <= 65535, W);
-  const dim3 grid(cdiv(p, bn), cdiv(cout, bm), b);
-  hipStream_t s = (hipStream_t)stream;
-#define L(BM, BN, WM, WN, BK)                                                                   \
-  hipLaunchKernelGGL((mlp_fwd_kernel<BM, BN, WM, WN, BK>), grid, dim3(WM * WN * 64), 0, s, cin, \
-                     cout, p, x_bstride, w, x, in_coef, in_relu, y, stat_partial)
-  if (bm == 64) L(64, 256, 1, 4, 16);
-  else if (bm == 128) L(128, 128, 2, 2, 16);
-  else L(256, 128, 4, 2, 16);
-#undef L
-  return check_launch(W);
-}
 
 extern "C" int nesie_mlp_stat_finalize(int c, long long nparts, double count,
                                        const float *stat_partial, const float *gamma,
                                        const float *beta, float *running_mean,
                                        float *running_var, float momentum, float eps,
-                                       float *coef, void *stream) {
+                                       float *coef, int channel_major, void *stream) {
   const char *W = "mlp_stat_finalize";
   NESIE_REQUIRE(c >= 1 && nparts >= 1 && count >= 1.0 && stat_partial && coef, W);
   NESIE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), W);
-  hipLaunchKernelGGL(mlp_stat_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, c,
+  hipLaunchKernelGGL(nesie::mlp_stat_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, c,
                      (int)nparts, count, stat_partial, gamma, beta, running_mean, running_var,
-                     momentum, eps, coef);
+                     momentum, eps, coef, channel_major);
   return check_launch(W);
 }
 
@@ -341,7 +104,7 @@ constexpr int WG_P = WG_Q + 4;
 
 template <int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    int cout, int cin, long long p, long long x_bstride, int run, int vec_ok,
+    int cout, int cin, long long p, long long x_bstride, long long dy_bstride, int run, int vec_ok,
     const float *__restrict__ dy, const float *__restrict__ x,
     const float *__restrict__ x_coef, int x_relu, float *__restrict__ partial) {
   constexpr int MT = WM * MB * 32, NT = WN * NB * 32;  // padded Cout, Cin covered
@@ -352,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const int bi = blockIdx.y;
   const long long p0 = (long long)blockIdx.x * run;
   const long long p1 = p0 + run < p ? p0 + run : p;
-  const float *dyb = dy + (size_t)bi * cout * p;
+  const float *dyb = dy + (size_t)bi * dy_bstride;
   const float *xb = x + (size_t)bi * x_bstride;
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -529,7 +292,8 @@ extern "C" size_t nesie_conv_wgrad_workspace_bytes(int b, int cout, int cin, lon
 }
 
 extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
-                                const float *x, long long x_bstride, const float *x_coef,
+                                long long dy_bstride, const float *x, long long x_bstride,
+                                const float *x_coef,
                                 int x_relu, float *dw, void *workspace, size_t workspace_bytes,
                                 void *stream) {
   const char *W = "conv_wgrad";
@@ -541,8 +305,10 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
     return NESIE_OK;
   }
   NESIE_REQUIRE(dy && x && workspace && x_bstride >= (long long)cin * p && b <= 65535, W);
+  NESIE_REQUIRE(dy_bstride >= (long long)cout * p, W);
   NESIE_REQUIRE(workspace_bytes >= nesie_conv_wgrad_workspace_bytes(b, cout, cin, p), W);
-  const int vec_ok = (((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (p & 3) == 0 && (x_bstride & 3) == 0;
+  const int vec_ok = (((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (p & 3) == 0 && (x_bstride & 3) == 0 &&
+                     (dy_bstride & 3) == 0;
   const int mb32 = cdiv(cout, 32), nb32 = cdiv(cin, 32);
   int run;
   const int runs = wgrad_runs(b, cout, cin, p, &run);
@@ -550,9 +316,16 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
   const dim3 grid(runs, b);
 #define L(WM, WN, MB, NB)                                                                        \
   do {                                                                                           \
-    const size_t lds = (size_t)(WM * MB + WN * NB) * 32 * WG_P * sizeof(float);            \
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MB, NB>), grid, dim3(256), lds, s, cout, cin, \
-                       p, x_bstride, run, vec_ok, dy, x, x_coef, x_relu, partial);                       \
+    const size_t lds = (size_t)(WM * MB + WN * NB) * 32 * WG_P * sizeof(float);                  \
+    auto kern = conv_wgrad_kernel<WM, WN, MB, NB>;                                               \
+    static bool attr = false;                                                                    \
+    if (!attr && lds > 65536) {                                                                  \
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds);                                                       \
+      attr = true;                                                                               \
+    }                                                                                            \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, cout, cin, p, x_bstride, dy_bstride, run,  \
+                       vec_ok, dy, x, x_coef, x_relu, partial);                                  \
   } while (0)
   // (Cout/32) x (Cin/32) output blocks over 4 waves
   if (mb32 <= 2 && nb32 <= 2) L(2, 2, 1, 1);
@@ -561,10 +334,12 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
   else if (mb32 <= 4 && nb32 <= 2) L(4, 1, 1, 2);
   else if (mb32 <= 4 && nb32 <= 4) L(4, 1, 1, 4);
   else if (mb32 <= 4 && nb32 <= 5) L(4, 1, 1, 5);
+  else if (mb32 <= 4 && nb32 <= 8) L(4, 1, 1, 8);
+  else if (mb32 <= 4 && nb32 <= 9) L(4, 1, 1, 9);
   else if (mb32 <= 8 && nb32 <= 2) L(4, 1, 2, 2);
   else if (mb32 <= 8 && nb32 <= 4) L(4, 1, 2, 4);
   else {
-    set_error("%s: %d x %d output (built for Cout <= 256, Cin <= 160)", W, cout, cin);
+    set_error("%s: %d x %d output (built for Cout <= 256 with Cin <= 128, Cout <= 128 with Cin <= 288)", W, cout, cin);
     return NESIE_ERR_UNSUPPORTED;
   }
 #undef L

@@ -361,7 +361,10 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
             constexpr int k1 = kk + 1 < KQ ? kk + 1 : kk;
             static_for<0, NBLK>([&](auto jc) {
               constexpr int j = decltype(jc)::value;
-              bq[gi & 1][j][i] = lds_read2st64<kk * UPK, k1 * UPK>(xa[j]);
+              if constexpr (k1 * UPK < 256)
+                bq[gi & 1][j][i] = lds_read2st64<kk * UPK, k1 * UPK>(xa[j]);
+              else   // beyond the 8-bit reach (the odd tail of K = 132 / 260): rebased by 64 KB
+                bq[gi & 1][j][i] = lds_read2st64<kk * UPK - 256, k1 * UPK - 256>(xa[j] + 65536u);
             });
           }
         });
@@ -462,6 +465,35 @@ __global__ __launch_bounds__(64) void pw_stats_finalize_kernel(
   coef[ch * 4 + 1] = (float)(bt - mean * gm * invstd);
   coef[ch * 4 + 2] = (float)mean;
   coef[ch * 4 + 3] = (float)invstd;
+}
+
+// The pooling tail after the layer kernel: combine the G / PG partial extrema of every group,
+// apply the layer's own BatchNorm + ReLU to the extremum the sign of the scale selects
+// (max_j relu(s y_j + b) = relu(s (s >= 0 ? max_j y_j : min_j y_j) + b), exactly) and record its
+// position inside the group.  rows = nb * channels, coef == NULL: plain max.
+__global__ __launch_bounds__(256) void pw_pool_finish_kernel(
+    long long total, int channels, int ng, int groups, int nsub, int pg, const float *__restrict__ pmax,
+    const float *__restrict__ pmin, const uint8_t *__restrict__ amax,
+    const uint8_t *__restrict__ amin, const float *__restrict__ coef, float lo,
+    float *__restrict__ pooled, uint8_t *__restrict__ arg) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (row, group)
+  if (i >= total) return;
+  const long long row = i / groups;
+  const int c = (int)((row / channels) % ng) * channels + (int)(row % channels);   // stacked layers
+  const float sc = coef ? coef[c * 4 + 0] : 1.f, bi = coef ? coef[c * 4 + 1] : 0.f;
+  const bool use_min = coef && sc < 0.f;
+  const float *src = use_min ? pmin : pmax;
+  const uint8_t *asrc = use_min ? amin : amax;
+  float e = src[i * nsub];
+  int at = asrc[i * nsub];
+  for (int u = 1; u < nsub; ++u) {
+    const float v = src[i * nsub + u];
+    const bool better = use_min ? v < e : v > e;   // first extremum wins ties
+    at = better ? u * pg + asrc[i * nsub + u] : at;
+    e = better ? v : e;
+  }
+  pooled[i] = coef ? fmaxf(__builtin_fmaf(e, sc, bi), lo) : e;
+  arg[i] = (uint8_t)at;
 }
 
 // tile geometry of a (K, Cout) layer
@@ -640,5 +672,21 @@ extern "C" int nesie_pw_stats_finalize(int channels, int cout, int nslots, const
   hipLaunchKernelGGL(pw_stats_finalize_kernel, dim3(channels), dim3(64), 0, (hipStream_t)stream,
                      cout, nslots, stat_part, gamma, beta, running_mean, running_var, momentum,
                      eps, coef);
+  return check_launch(W);
+}
+
+extern "C" int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, int pool_group,
+                                    const float *pmax, const float *pmin, const uint8_t *amax,
+                                    const uint8_t *amin, const float *coef, int relu,
+                                    float *pooled, uint8_t *argmax, void *stream) {
+  const char *W = "pw_pool_finish";
+  NESIE_REQUIRE(nb >= 0 && ng >= 1 && channels >= 1 && p >= 0 && group >= 1, W);
+  if (nb == 0 || p == 0) return NESIE_OK;
+  NESIE_REQUIRE((pool_group == 16 || pool_group == 32) && group % pool_group == 0 && p % group == 0, W);
+  NESIE_REQUIRE(group <= 256 && pmax && amax && pooled && argmax && (!coef || (pmin && amin)), W);
+  const long long total = (long long)nb * channels * (p / group);
+  hipLaunchKernelGGL(pw_pool_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     total, channels, ng, (int)(p / group), group / pool_group, pool_group, pmax, pmin,
+                     amax, amin, coef, relu ? 0.f : -__builtin_inff(), pooled, argmax);
   return check_launch(W);
 }

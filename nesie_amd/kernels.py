@@ -526,21 +526,27 @@ class HipKernels(_BNPoolMixin):
 
     def conv_wgrad(self, dy, x, dw, x_coef=None, x_relu=False):
         """dw (cout, cin) = sum_b dy[b] (cout, P) @ act(x[b]) (cin, P)^T on the matrix cores;
-        x may be a batch-strided view (each x[b] contiguous)."""
+        dy and x may be batch-strided views (each dy[b], x[b] contiguous)."""
         _f32(dy, x, dw)
-        if not (dy.is_cuda and dy.is_contiguous() and dw.is_contiguous()):
-            raise ValueError("conv_wgrad: dy / dw must be contiguous HIP tensors")
+        if not (dy.is_cuda and dw.is_contiguous()):
+            raise ValueError("conv_wgrad: HIP tensors, dw contiguous")
         b, cout, p = dy.shape
         cin = x.shape[1]
         assert x.shape[0] == b and x.shape[2] == p and tuple(dw.shape) == (cout, cin)
         assert x.stride(2) == 1 and x.stride(1) == p, "each x[b] must be (cin, P) contiguous"
+        assert dy.stride(2) == 1 and dy.stride(1) == p, "each dy[b] must be (cout, P) contiguous"
         lib = _lib.load()
         need = lib.nesie_conv_wgrad_workspace_bytes(b, cout, cin, p)
         with torch.cuda.device(dy.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
-            _lib.call("nesie_conv_wgrad", b, cout, cin, p, _ptr(dy), _ptr(x),
+            _lib.call("nesie_conv_wgrad", b, cout, cin, p, _ptr(dy),
+                      dy.stride(0) if b > 1 else cout * p, _ptr(x),
                       x.stride(0) if b > 1 else cin * p, 0 if x_coef is None else _ptr(x_coef),
                       int(bool(x_relu)), _ptr(dw), _ptr(ws), need, _stream(dy))
+
+    @staticmethod
+    def conv_wgrad_supported(cout, cin):
+        return (cout <= 128 and cin <= 288) or (cout <= 256 and cin <= 128)
 
     def bn_relu_forward(self, x, gamma, beta, running_mean, running_var, momentum, eps, relu,
                         y, save_mean, save_invstd, fwd_coef, row_bias=None, pre_partial=None):
@@ -561,12 +567,117 @@ class HipKernels(_BNPoolMixin):
                       0 if pre_partial is None else pre_partial.numel() // (2 * c),
                       _ptr(ws), need, _stream(x))
 
+    def pw_supported(self, k, cout, p):
+        return bool(_lib.load().nesie_pw_supported(int(k), int(cout), int(p)))
+
+    def pw_stat_slots(self, nb, ng, k, cout, p):
+        return int(_lib.load().nesie_pw_stat_slots(nb, ng, k, cout, p))
+
+    def pw_layer_forward(self, x, w, ng=1, in_coef=None, in_relu=True, row_bias=None, rb_group=0,
+                         bias=None, y=None, stat_part=None, pool_group=0, pool_min=False,
+                         pool_out=None):
+        """y[n] = W[n % ng] . act(x[n]) (+ row_bias) (+ bias) on the matrix cores
+        (nesie_pw_layer_forward).  x (NB, K, P) with each x[n] contiguous (batch stride free);
+        w (ng, Cout, K) as ANY strided view (a transposed view gives the input-gradient product);
+        in_coef (ng*K, 4) folded BatchNorm of the operand; y (NB, Cout, P) or None;
+        stat_part (ng, slots, Cout, 4); pool_out = (max, min | None, argmax, argmin | None), each
+        (NB, Cout, P / pool_group)."""
+        _f32(x, w)
+        nb, k, p = x.shape
+        assert w.dim() == 3 and w.shape[0] == ng and w.shape[2] == k and nb % ng == 0
+        cout = w.shape[1]
+        assert x.is_cuda and x.stride(2) == 1 and x.stride(1) == p, "each x[n] must be (K, P) contiguous"
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        if y is not None:
+            _f32(y)
+            assert y.is_cuda and tuple(y.shape) == (nb, cout, p) and y.stride(2) == 1 \
+                and y.stride(1) == p, "each y[n] must be (Cout, P) contiguous"
+        if stat_part is not None:
+            _check(stat_part); _f32(stat_part)
+            assert tuple(stat_part.shape) == (ng, self.pw_stat_slots(nb, ng, k, cout, p), cout, 4)
+        if in_coef is not None:
+            _check(in_coef); _f32(in_coef)
+            assert tuple(in_coef.shape) == (ng * k, 4)
+        if row_bias is not None:
+            _check(row_bias); _f32(row_bias)
+            assert row_bias.numel() == nb * cout * (p // rb_group)
+        if bias is not None:
+            _check(bias); _f32(bias)
+            assert bias.numel() == ng * cout
+        pmax = pmin = amax = amin = None
+        if pool_group:
+            pmax, pmin, amax, amin = pool_out
+            for t in (pmax, pmin):
+                if t is not None:
+                    _check(t); _f32(t)
+                    assert t.numel() == nb * cout * (p // pool_group)
+            for t in (amax, amin):
+                if t is not None:
+                    _check(t)
+                    assert t.dtype == torch.uint8 and t.numel() == nb * cout * (p // pool_group)
+            assert (pmin is not None) == bool(pool_min)
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_pw_layer_forward", nb, ng, k, cout, p, _ptr(x),
+                      x.stride(0) if nb > 1 else k * p, _ptr(w), w.stride(0) if ng > 1 else 0,
+                      w.stride(1), w.stride(2), opt(in_coef), int(bool(in_relu)), opt(row_bias),
+                      int(rb_group), opt(bias), opt(y),
+                      y.stride(0) if (y is not None and nb > 1) else cout * p, opt(stat_part),
+                      int(pool_group),
+                      int(bool(pool_min)), opt(pmax), opt(pmin), opt(amax), opt(amin), _stream(x))
+
+    def pw_stats_finalize(self, stat_part, gamma, beta, running_mean, running_var, momentum, eps,
+                          coef):
+        """(ng, slots, Cout, 4) shifted partials -> coef (ng*Cout, 4) = (scale, bias, mean,
+        invstd); running statistics (ng*Cout) updated in place (or None)."""
+        _check(stat_part, coef); _f32(stat_part, coef)
+        ng, nslots, cout, _ = stat_part.shape
+        assert tuple(coef.shape) == (ng * cout, 4)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(coef.device):
+            _lib.call("nesie_pw_stats_finalize", ng * cout, cout, nslots, _ptr(stat_part), opt(gamma),
+                      opt(beta), opt(running_mean), opt(running_var), float(momentum), float(eps),
+                      _ptr(coef), _stream(coef))
+
+    def pw_pool_finish(self, ng, p, group, pool_group, pool_out, coef, relu, pooled, argmax):
+        """partial extrema (NB, C, P / pool_group) -> pooled (NB, C, P / group) float,
+        argmax uint8 (position inside the group)."""
+        pmax, pmin, amax, amin = pool_out
+        _check(pmax, amax, pooled, argmax); _f32(pmax, pooled)
+        nb, c = pooled.shape[:2]
+        assert pooled.numel() == nb * c * (p // group) and argmax.dtype == torch.uint8
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(pooled.device):
+            _lib.call("nesie_pw_pool_finish", nb, ng, c, p, group, pool_group, _ptr(pmax), opt(pmin),
+                      _ptr(amax), opt(amin), opt(coef), int(bool(relu)), _ptr(pooled),
+                      _ptr(argmax), _stream(pooled))
+
+    def mlp_stat_finalize(self, part, count, gamma, beta, running_mean, running_var, momentum, eps,
+                          coef, channel_major=False):
+        """(parts, C, 2) -- or, channel_major, (C, parts, 2) -- unshifted (sum, sum of squares)
+        partials -> coef (C, 4); running statistics updated in place."""
+        _check(part, coef); _f32(part, coef)
+        if channel_major:
+            c, nparts, _ = part.shape
+        else:
+            nparts, c, _ = part.shape
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(coef.device):
+            _lib.call("nesie_mlp_stat_finalize", c, nparts, float(count), _ptr(part), opt(gamma),
+                      opt(beta), opt(running_mean), opt(running_var), float(momentum), float(eps),
+                      _ptr(coef), int(bool(channel_major)), _stream(coef))
+
     def bn_relu_backward(self, dy, x, y, gamma, beta, save_mean, save_invstd, fwd_coef, relu,
-                         dx, dgamma, dbeta, row_bias=None, d_row_bias=None):
+                         dx, dgamma, dbeta, row_bias=None, d_row_bias=None, group=None):
+        """y None with relu: x is the raw conv output of a fused forward (mask re-derived from
+        fwd_coef).  d_row_bias without row_bias (+ ``group``): per-group sums of dx."""
         _check(dy, x, dx, save_mean, save_invstd); _f32(dy, x, dx)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
-        group = _row_bias_group(x, row_bias)
+        if row_bias is None and d_row_bias is not None:
+            _check(d_row_bias); _f32(d_row_bias)
+            assert group and d_row_bias.numel() == b * c * (p // group)
+        else:
+            group = _row_bias_group(x, row_bias)
         if row_bias is not None:
             _check(d_row_bias); _f32(d_row_bias)
             assert d_row_bias.shape == row_bias.shape

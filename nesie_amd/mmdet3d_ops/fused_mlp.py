@@ -1,0 +1,343 @@
+"""conv -> BN -> ReLU chains of the grouped per-seed MLPs on the native layer kernel.
+
+The reference evaluates a shared MLP op by op -- mmcv ``ConvModule(Conv2d 1x1, BN2d, ReLU)`` three
+times, then ``F.max_pool2d([1, nsample])`` (point_sa_module.py:277-289, 136-158).  Here a layer is
+ONE launch of ``nesie_pw_layer_forward``: the previous layer's folded BatchNorm + ReLU is applied
+to the operand on its way to the matrix cores, the layer's own batch statistics (and, for the
+last layer, the max / min over the neighbourhood) leave from the accumulators, and the normalised
+activations are never written.  Per layer the forward moves its tensor through HBM twice (read
+the previous raw conv output, write this one) instead of five times.
+
+The backward is hand-written too: BatchNorm + ReLU backward from the RAW conv output and the
+saved (scale, bias, mean, invstd) (``nesie_bn_relu_backward`` with y = NULL), the input gradient
+through the same layer kernel on the transposed weight view, the weight gradient on the matrix
+cores with the activation recomputed on load (``nesie_conv_wgrad``).
+
+Same function as the module-by-module path (which stays the CPU checker's and serves shapes the
+kernels are not built for); differences are fp32 summation order and fma-vs-mul/add rounding.
+"""
+import torch
+from torch.autograd import Function
+
+from ..kernels import backend_for
+
+
+# Tests flip this to obtain the module-by-module evaluation of the same network on the device.
+ENABLED = True
+
+
+def _wgrad(backend, dy, x, x_coef):
+    """dW (Cout, Cin) = sum_b dy[b] @ act(x[b])^T; act = relu(scale * x + bias) when x_coef."""
+    b, co, p = dy.shape
+    ci = x.shape[1]
+    if backend.conv_wgrad_supported(co, ci):
+        dw = dy.new_empty(co, ci)
+        backend.conv_wgrad(dy, x, dw, x_coef=x_coef, x_relu=x_coef is not None)
+        return dw
+    a, dy = x.contiguous(), dy.contiguous()
+    if x_coef is not None:   # shapes outside the native weight-gradient kernel: materialise once
+        a = torch.empty_like(a)
+        backend.affine_relu_forward(x.contiguous(), x_coef, True, a)
+    if p <= 2048 and b > 1:
+        return torch.mm(dy.transpose(0, 1).reshape(co, b * p), a.transpose(0, 1).reshape(ci, b * p).t())
+    return torch.bmm(dy, a.transpose(1, 2)).sum(0)
+
+
+class SAStackFn(Function):
+    """x (B, C0, M, ns) -> max_ns relu(bn_L(conv_L(... relu(bn_1(conv_1(x)))))) (B, C_L, M)."""
+
+    @staticmethod
+    def forward(ctx, x, bufs, *params):
+        backend = backend_for(x)
+        x = x.contiguous()
+        B, c0, M, ns = x.shape
+        P = M * ns
+        L = len(params) // 3
+        x3 = x.view(B, c0, P)
+        ys, coefs, means, invstds = [], [], [], []
+        coef = None
+        pool_group = 16 if ns == 16 else 32
+        pool_out = None
+        for l in range(L):
+            w, gamma, beta = params[3 * l:3 * l + 3]
+            rm, rv, momentum, eps = bufs[l]
+            cout, cin = w.shape[0], w.shape[1]
+            w2 = w.reshape(1, cout, cin)
+            src = x3 if l == 0 else ys[-1]
+            y = x.new_empty(B, cout, P)
+            new_coef = x.new_empty(cout, 4)
+            last = l == L - 1
+            if l == 0 and cin <= 8 and not last:
+                part = x.new_empty(backend.mlp_stream_parts(B, P), cout, 2)
+                backend.mlp_stream_forward(src, w2[0].contiguous(), y, part)
+                backend.mlp_stat_finalize(part, B * P, gamma, beta, rm, rv, momentum, eps, new_coef)
+            else:
+                part = x.new_empty(1, backend.pw_stat_slots(B, 1, cin, cout, P), cout, 4)
+                if last:
+                    g = P // pool_group
+                    pool_out = (x.new_empty(B, cout, g), x.new_empty(B, cout, g),
+                                torch.empty(B, cout, g, dtype=torch.uint8, device=x.device),
+                                torch.empty(B, cout, g, dtype=torch.uint8, device=x.device))
+                backend.pw_layer_forward(src, w2, in_coef=coef, in_relu=True, y=y, stat_part=part,
+                                         pool_group=pool_group if last else 0, pool_min=last,
+                                         pool_out=pool_out)
+                backend.pw_stats_finalize(part, gamma, beta, rm, rv, momentum, eps, new_coef)
+            coef = new_coef
+            ys.append(y)
+            coefs.append(coef)
+            means.append(coef[:, 2].contiguous())
+            invstds.append(coef[:, 3].contiguous())
+        cl = ys[-1].shape[1]
+        pooled = x.new_empty(B, cl, M)
+        argmax = torch.empty(B, cl, M, dtype=torch.uint8, device=x.device)
+        backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
+        ctx.L, ctx.ns = L, ns
+        ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *means, *invstds, *params)
+        ctx.mark_non_differentiable(argmax)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        L, ns = ctx.L, ctx.ns
+        sv = ctx.saved_tensors
+        x3, pooled, argmax = sv[:3]
+        ys, coefs = sv[3:3 + L], sv[3 + L:3 + 2 * L]
+        means, invstds = sv[3 + 2 * L:3 + 3 * L], sv[3 + 3 * L:3 + 4 * L]
+        params = sv[3 + 4 * L:]
+        backend = backend_for(g)
+        B, c0, P = x3.shape
+        M = P // ns
+        grads = [None] * (3 * L)
+        # last layer: BatchNorm + ReLU + max backward into the dense raw-output gradient
+        yl = ys[-1]
+        cl = yl.shape[1]
+        dy = torch.empty_like(yl)
+        dgamma, dbeta = g.new_empty(cl), g.new_empty(cl)
+        backend.bn_relu_maxpool_backward(g.contiguous(), argmax, yl.view(B, cl, M, ns), pooled,
+                                         params[3 * (L - 1) + 1], invstds[-1], coefs[-1],
+                                         dy.view(B, cl, M, ns), dgamma, dbeta)
+        grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dgamma, dbeta
+        dx = None
+        for l in range(L - 1, -1, -1):
+            w = params[3 * l]
+            cout, cin = w.shape[0], w.shape[1]
+            w2 = w.reshape(cout, cin)
+            src = x3 if l == 0 else ys[l - 1]
+            src_coef = None if l == 0 else coefs[l - 1]
+            if ctx.needs_input_grad[2 + 3 * l]:
+                grads[3 * l] = _wgrad(backend, dy, src, src_coef).view_as(w)
+            if l == 0:
+                if ctx.needs_input_grad[0]:
+                    # grouped input: channels 0..2 are coordinates (no gradient consumer reads them)
+                    skip = 3 if c0 in (131, 259) else 0
+                    dx = dy.new_empty(B, c0, P)
+                    if backend.pw_supported(cout, c0 - skip, P):
+                        backend.pw_layer_forward(dy, w2[:, skip:].t().unsqueeze(0), y=dx[:, skip:])
+                        if skip:
+                            dx[:, :skip].zero_()
+                    else:
+                        dx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), dy)
+                break
+            # gradient of the previous layer's activation, then through its BatchNorm + ReLU
+            da = dy.new_empty(B, cin, P)
+            backend.pw_layer_forward(dy, w2.t().unsqueeze(0), y=da)
+            dyp = torch.empty_like(da)
+            dgamma, dbeta = g.new_empty(cin), g.new_empty(cin)
+            backend.bn_relu_backward(da, ys[l - 1], None, params[3 * (l - 1) + 1],
+                                     params[3 * (l - 1) + 2], means[l - 1], invstds[l - 1],
+                                     coefs[l - 1], True, dyp, dgamma, dbeta)
+            grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dgamma, dbeta
+            dy = dyp
+        if dx is not None:
+            dx = dx.view(B, c0, M, ns)
+        return (dx, None) + tuple(grads)
+
+
+def sa_stack_supported(backend, x, layers):
+    """True when ``SAStackFn`` serves this shared MLP: native training BatchNorm behind bias-free
+    1x1 convs, fp32, nsample in {16, 32, 64}, every layer inside the built tiles."""
+    from .norm import FusedBNReLU2d
+    if not ENABLED or backend.name != 'hip' or x.dtype != torch.float32 or x.dim() != 4 \
+            or len(layers) < 2:
+        return False
+    B, c0, M, ns = x.shape
+    if ns not in (16, 32, 64):
+        return False
+    P = M * ns
+    cin = c0
+    for i, layer in enumerate(layers):
+        norm = getattr(layer, 'norm', None)
+        if not (isinstance(norm, FusedBNReLU2d) and layer.act_fused and layer.conv.bias is None
+                and norm.training and norm.affine and norm.track_running_stats
+                and norm.momentum is not None):
+            return False
+        cout = layer.conv.out_channels
+        if layer.conv.in_channels != cin:
+            return False
+        first_stream = i == 0 and cin <= 8 and len(layers) > 1
+        if not first_stream and not backend.pw_supported(cin, cout, P):
+            return False
+        if i > 0 and not backend.pw_supported(cout, cin, P):   # input-gradient product
+            return False
+        cin = cout
+    return True
+
+
+def sa_stack(x, layers):
+    """Shared MLP + max pooling of a set-abstraction module through ``SAStackFn``."""
+    from . import norm as _norm
+    params, bufs = [], []
+    for layer in layers:
+        n = layer.norm
+        params += [layer.conv.weight, n.weight, n.bias]
+        bufs.append((n.running_mean, n.running_var, n.momentum, n.eps))
+        _norm.count_batch(n.num_batches_tracked)
+    return SAStackFn.apply(x, bufs, *params)
+
+
+# ---- MiniPointNet (side_pooling_module.py:343-370) -------------------------------------------
+# f = conv3(relu(bn0(c0))); g = max_G f; y = relu(bn1(W_g (g + b3) + W_l f + ...)); out = max_G conv4(y)
+# split at the two places where small per-proposal tensors leave the big ones (g, and the
+# per-proposal term `small` built from it with ordinary torch ops):
+#   MiniHeadFn : c0 -> (f without its bias, max_G of it)
+#   MiniTailFn : (f, small) -> max_G conv4(relu(bn1(W_l f + small)))
+
+def _pool_group(G):
+    return 16 if G == 16 else 32
+
+
+class MiniHeadFn(Function):
+    """c0 (B, S, H0, K*G) raw first-conv outputs of S stacked nets (+ their (sum, sum^2)
+    partials) -> c = W3 . relu(bn0(c0)) (B, S, half, K*G) and g = max_G c (B, S, half, K)."""
+
+    @staticmethod
+    def forward(ctx, c0, c0_part, bufs, G, gamma0, beta0, w3):
+        backend = backend_for(c0)
+        c0 = c0.contiguous()
+        B, S, H0, P = c0.shape
+        half = w3.shape[1]
+        rm, rv, momentum, eps = bufs
+        coef0 = c0.new_empty(S * H0, 4)
+        backend.mlp_stat_finalize(c0_part, B * P, gamma0, beta0, rm, rv, momentum, eps, coef0,
+                                  channel_major=True)
+        pg = _pool_group(G)
+        c = c0.new_empty(B, S, half, P)
+        npg = P // pg
+        pool_out = (c0.new_empty(B * S, half, npg), None,
+                    torch.empty(B * S, half, npg, dtype=torch.uint8, device=c0.device), None)
+        backend.pw_layer_forward(c0.view(B * S, H0, P), w3, ng=S, in_coef=coef0, in_relu=True,
+                                 y=c.view(B * S, half, P), pool_group=pg, pool_min=False,
+                                 pool_out=pool_out)
+        g = c0.new_empty(B, S, half, P // G)
+        arg = torch.empty(B, S, half, P // G, dtype=torch.uint8, device=c0.device)
+        backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, g.view(B * S, half, -1),
+                               arg.view(B * S, half, -1))
+        ctx.G = G
+        ctx.save_for_backward(c0, coef0, coef0[:, 2].contiguous(), coef0[:, 3].contiguous(), arg,
+                              gamma0, beta0, w3)
+        ctx.mark_non_differentiable(arg)
+        return c, g
+
+    @staticmethod
+    def backward(ctx, dc, dg):
+        c0, coef0, mean0, invstd0, arg, gamma0, beta0, w3 = ctx.saved_tensors
+        backend = backend_for(c0)
+        B, S, H0, P = c0.shape
+        half = w3.shape[1]
+        G = ctx.G
+        if dc is None:
+            dc = c0.new_zeros(B, S, half, P)
+        dc = dc.contiguous()
+        if dg is not None:   # the pooled gradient joins the dense one at the arg-max, in place
+            dcv = dc.view(B, S, half, P // G, G)
+            backend.group_max_pool_backward_add(dg.contiguous(), arg, dcv)
+        x0 = c0.view(B * S, H0, P)
+        dcf = dc.view(B * S, half, P)
+        dw3 = None
+        if ctx.needs_input_grad[6]:
+            # per-net weight gradient: the S nets are the S strided batch subsets
+            dw3 = torch.stack([_wgrad(backend, dcf[s::S], x0[s::S], coef0[s * H0:(s + 1) * H0].contiguous())
+                               for s in range(S)])
+        da0 = c0.new_empty(B * S, H0, P)
+        backend.pw_layer_forward(dcf, w3.transpose(1, 2), ng=S, y=da0)
+        dc0 = torch.empty_like(c0)
+        dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
+        backend.bn_relu_backward(da0.view(B, S * H0, P), c0.view(B, S * H0, P), None, gamma0, beta0,
+                                 mean0, invstd0, coef0, True, dc0.view(B, S * H0, P), dgamma, dbeta)
+        return dc0, None, None, None, dgamma, dbeta, dw3
+
+
+class MiniTailFn(Function):
+    """c (B, S, half, K*G), small (B, S, H2, K), W_l (S, H2, half), bn1, W4 (S, F, H2) ->
+    max_G W4 . relu(bn1(W_l c + small)) (B, S, F, K); the (B, S, F, K*G) tensor is never written."""
+
+    @staticmethod
+    def forward(ctx, c, small, bufs, G, wl, gamma1, beta1, w4):
+        backend = backend_for(c)
+        c, small = c.contiguous(), small.contiguous()
+        B, S, half, P = c.shape
+        H2, F = wl.shape[1], w4.shape[1]
+        rm, rv, momentum, eps = bufs
+        y = c.new_empty(B, S, H2, P)
+        part = c.new_empty(S, backend.pw_stat_slots(B * S, S, half, H2, P), H2, 4)
+        backend.pw_layer_forward(c.view(B * S, half, P), wl, ng=S, row_bias=small.view(B * S, H2, -1),
+                                 rb_group=G, y=y.view(B * S, H2, P), stat_part=part)
+        coef1 = c.new_empty(S * H2, 4)
+        backend.pw_stats_finalize(part, gamma1, beta1, rm, rv, momentum, eps, coef1)
+        pg = _pool_group(G)
+        npg = P // pg
+        pool_out = (c.new_empty(B * S, F, npg), None,
+                    torch.empty(B * S, F, npg, dtype=torch.uint8, device=c.device), None)
+        backend.pw_layer_forward(y.view(B * S, H2, P), w4, ng=S, in_coef=coef1, in_relu=True,
+                                 pool_group=pg, pool_min=False, pool_out=pool_out)
+        out = c.new_empty(B, S, F, P // G)
+        arg = torch.empty(B, S, F, P // G, dtype=torch.uint8, device=c.device)
+        backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, out.view(B * S, F, -1),
+                               arg.view(B * S, F, -1))
+        ctx.G = G
+        ctx.save_for_backward(c, y, coef1, coef1[:, 2].contiguous(), coef1[:, 3].contiguous(), arg,
+                              wl, gamma1, beta1, w4)
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        c, y, coef1, mean1, invstd1, arg, wl, gamma1, beta1, w4 = ctx.saved_tensors
+        backend = backend_for(c)
+        B, S, half, P = c.shape
+        H2, F = wl.shape[1], w4.shape[1]
+        G = ctx.G
+        # gradient of the last conv's output: the pooled gradient at the arg-max, zero elsewhere
+        dz = c.new_empty(B, S, F, P // G, G)
+        backend.group_max_pool_backward(dout.contiguous(), arg, dz)
+        dzf = dz.view(B * S, F, P)
+        yf = y.view(B * S, H2, P)
+        dw4 = None
+        if ctx.needs_input_grad[7]:
+            dw4 = torch.stack([_wgrad(backend, dzf[s::S], yf[s::S], coef1[s * H2:(s + 1) * H2].contiguous())
+                               for s in range(S)])
+        da = c.new_empty(B * S, H2, P)
+        backend.pw_layer_forward(dzf, w4.transpose(1, 2), ng=S, y=da)
+        dy = torch.empty_like(y)
+        dgamma, dbeta = c.new_empty(S * H2), c.new_empty(S * H2)
+        dsmall = c.new_empty(B, S, H2, P // G)
+        backend.bn_relu_backward(da.view(B, S * H2, P), y.view(B, S * H2, P), None, gamma1, beta1,
+                                 mean1, invstd1, coef1, True, dy.view(B, S * H2, P), dgamma, dbeta,
+                                 d_row_bias=dsmall.view(B, S * H2, -1), group=G)
+        dyf = dy.view(B * S, H2, P)
+        cf = c.view(B * S, half, P)
+        dwl = None
+        if ctx.needs_input_grad[4]:
+            dwl = torch.stack([_wgrad(backend, dyf[s::S], cf[s::S], None) for s in range(S)])
+        dc = torch.empty_like(c)
+        backend.pw_layer_forward(dyf, wl.transpose(1, 2), ng=S, y=dc.view(B * S, half, P))
+        return dc, dsmall, None, None, dwl, dgamma, dbeta, dw4
+
+
+def mini_pointnets_fused_supported(backend, c0, c0_part, G):
+    if not ENABLED or backend.name != 'hip' or c0.dtype != torch.float32 or c0_part is None \
+            or G not in (16, 64):
+        return False
+    B, S, H0, P = c0.shape[0], c0.shape[1], c0.shape[2], c0.shape[3] * c0.shape[4]
+    return (c0_part.numel() > 0 and backend.pw_supported(H0, H0 // 2, P)
+            and backend.pw_supported(H0 // 2, H0, P))

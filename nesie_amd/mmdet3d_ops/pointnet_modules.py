@@ -13,6 +13,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..kernels import backend_for
+from . import fused_mlp
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
 from .group_points import GroupAll, QueryAndGroup, inverted_index
@@ -268,6 +269,9 @@ class BasePointSAModule(nn.Module):
         fused op (the normalised (B, C, M, ns) tensor is never written)."""
         layers = list(mlp)
         last = layers[-1] if layers else None
+        if self.pool_mod == 'max' and all(isinstance(l, ConvModule) for l in layers) and \
+                fused_mlp.sa_stack_supported(backend_for(grouped), grouped, layers):
+            return fused_mlp.sa_stack(grouped, layers)
         if (self.pool_mod == 'max' and isinstance(last, ConvModule) and last.act_fused
                 and isinstance(last.norm, FusedBNReLU2d)):
             x = grouped

@@ -56,6 +56,8 @@ class MiniPointNet(nn.Module):
         Differences from the concatenated form are summation-order rounding only."""
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
+        if a0 is None and conv0_out is not None and fused_mini_ok([self], conv0_out.unsqueeze(1), c0_stats):
+            return fused_mini_pointnets([self], conv0_out.unsqueeze(1), c0_stats)[:, 0]
         if a0 is None:   # c0_stats: (sum, sum^2) partials of conv0_out left by its producer
             a0 = bn0(conv0(points)) if conv0_out is None else bn0(conv0_out, pre_partial=c0_stats)
         c = pointwise_conv(a0, conv3.weight)                           # f without its bias
@@ -114,6 +116,8 @@ def grouped_mini_pointnets(nets, c0, normed=False, c0_stats=None):
     1x1 conv is one broadcast batched GEMM over the stacked weights (48 instead of 8 matrices
     per launch at B = 8) and every norm layer one stacked BatchNorm."""
     B, S, H, K, G = c0.shape
+    if not normed and fused_mini_ok(nets, c0, c0_stats):
+        return fused_mini_pointnets(nets, c0, c0_stats)
     f, sc = [n.first_conv for n in nets], [n.second_conv for n in nets]
     stack = lambda ws: torch.stack([w.flatten(1) for w in ws]).unsqueeze(0)  # noqa: E731
     a0 = c0.reshape(B, S, H, K * G) if normed else \
@@ -133,6 +137,68 @@ def grouped_mini_pointnets(nets, c0, normed=False, c0_stats=None):
                     row_bias=small.reshape(B, S * H2, K))
     out = torch.matmul(stack([x[3].weight for x in sc]), y.view(B, S, H2, K * G))
     out = group_max_pool(out.view(B, S, -1, K, G))
+    if sc[0][3].bias is not None:
+        out = out + torch.stack([x[3].bias for x in sc]).view(1, S, -1, 1)
+    return out
+
+
+def fused_mini_ok(nets, c0, c0_stats):
+    """The S = len(nets) MiniPointNets can run on the fused layer kernels (fused_mlp.MiniHeadFn /
+    MiniTailFn): training-mode native norms, statistics partials of c0 at hand, built shapes."""
+    from ..mmdet3d_ops import fused_mlp
+    backend = backend_for(c0)
+    if c0_stats is None:
+        return False
+    bn0s, bn1s = [n.first_conv[1] for n in nets], [n.second_conv[1] for n in nets]
+    if not (all(l.training for l in bn0s + bn1s) and _stackable_bn(bn0s) and _stackable_bn(bn1s)):
+        return False
+    if any(n.first_conv[0].bias is not None or n.second_conv[0].bias is not None for n in nets):
+        return False
+    return fused_mlp.mini_pointnets_fused_supported(backend, c0, c0_stats, c0.shape[-1])
+
+
+def fused_mini_pointnets(nets, c0, c0_stats):
+    """c0 (B, S, H, K, G) raw first-conv outputs -> (B, S, F, K): the same function as
+    ``grouped_mini_pointnets`` / ``MiniPointNet.forward`` with every 1x1 conv as ONE launch of the
+    native layer kernel (norm + ReLU on the operand load, statistics / max from the
+    accumulators: no normalised tensor, no separate statistics or pooling pass)."""
+    from ..mmdet3d_ops import fused_mlp
+    from ..mmdet3d_ops import norm as _norm
+    B, S, H, K, G = c0.shape
+    f, sc = [n.first_conv for n in nets], [n.second_conv for n in nets]
+    bn0s, bn1s = [x[1] for x in f], [x[1] for x in sc]
+    half = f[0][3].out_channels
+
+    def stacked(layers):
+        rm = torch.cat([l.running_mean for l in layers])
+        rv = torch.cat([l.running_var for l in layers])
+        return rm, rv, (rm, rv, layers[0].momentum, layers[0].eps)
+
+    def unstack(layers, rm, rv):
+        C = layers[0].num_features
+        with torch.no_grad():
+            torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
+            torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
+            for l in layers:
+                _norm.count_batch(l.num_batches_tracked)
+
+    rm0, rv0, bufs0 = stacked(bn0s)
+    w3 = torch.stack([x[3].weight.flatten(1) for x in f])                      # (S, half, H)
+    c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, bufs0, G,
+                                      torch.cat([l.weight for l in bn0s]),
+                                      torch.cat([l.bias for l in bn0s]), w3)
+    unstack(bn0s, rm0, rv0)
+    w = torch.stack([x[0].weight.flatten(1) for x in sc])                      # (S, H2, 2*half)
+    H2 = w.shape[1]
+    b3 = torch.stack([x[3].bias if x[3].bias is not None else c.new_zeros(half) for x in f])
+    # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3
+    small = torch.matmul(w[:, :, :half].unsqueeze(0), g) \
+        + torch.matmul(w, torch.cat([b3, b3], 1).unsqueeze(-1)).view(1, S, H2, 1)
+    rm1, rv1, bufs1 = stacked(bn1s)
+    w4 = torch.stack([x[3].weight.flatten(1) for x in sc])                     # (S, F, H2)
+    out = fused_mlp.MiniTailFn.apply(c, small, bufs1, G, w[:, :, half:], torch.cat([l.weight for l in bn1s]),
+                                     torch.cat([l.bias for l in bn1s]), w4)
+    unstack(bn1s, rm1, rv1)
     if sc[0][3].bias is not None:
         out = out + torch.stack([x[3].bias for x in sc]).view(1, S, -1, 1)
     return out

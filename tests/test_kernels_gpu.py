@@ -476,53 +476,6 @@ def test_fused_bn_relu_maxpool_matches_two_step(hip_device, shape):
     assert y1[:, 1].abs().max() == 0 and x1.grad[:, 1].abs().max() == 0
 
 
-@pytest.mark.parametrize("cout,cin,p,b", [(64, 4, 1024, 2), (128, 64, 640, 2), (256, 259, 384, 2),
-                                         (18, 128, 100, 3), (70, 33, 257, 1), (128, 131, 4096, 2)])
-def test_mlp_layer_forward_matches_fp64(hip_device, cout, cin, p, b):
-    """nesie_mlp_layer_forward (1x1 conv on the matrix cores with the previous layer's folded
-    BN + ReLU applied on load and this layer's batch statistics from the epilogue) and
-    nesie_mlp_stat_finalize vs an fp64 evaluation of ConvModule's conv -> BN statistics
-    (point_sa_module.py:277-289).  north_star tolerance 1e-4."""
-    from nesie_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(cout + cin + p)
-    x = torch.randn(b, cin, p, generator=g).to(hip_device)
-    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(hip_device)
-    coef = torch.rand(cin, 4, generator=g).to(hip_device) + 0.5
-    coef[:, 1] -= 1.0
-    gamma = (torch.rand(cout, generator=g) + 0.5).to(hip_device)
-    beta = torch.randn(cout, generator=g).to(hip_device)
-    stream = torch.cuda.current_stream().cuda_stream
-    for use_coef in (False, True):
-        y = torch.full((b, cout, p), float('nan'), device=hip_device)
-        nparts = lib.nesie_mlp_stat_partials(b, cout, p)
-        part = torch.zeros(nparts, cout, 2, device=hip_device)
-        _lib.call('nesie_mlp_layer_forward', b, cin, cout, p, x.data_ptr(), cin * p,
-                  w.data_ptr(), coef.data_ptr() if use_coef else 0, 1, y.data_ptr(),
-                  part.data_ptr(), stream)
-        a = x.double()
-        if use_coef:
-            a = torch.relu(a * coef[:, 0].double().view(1, -1, 1) + coef[:, 1].double().view(1, -1, 1))
-        want = torch.matmul(w.double().unsqueeze(0), a)
-        tol = 1e-4 * max(1.0, want.abs().max().item())
-        assert (y.double() - want).abs().max().item() <= tol
-        rm, rv = torch.zeros(cout, device=hip_device), torch.ones(cout, device=hip_device)
-        out = torch.empty(cout, 4, device=hip_device)
-        _lib.call('nesie_mlp_stat_finalize', cout, nparts, float(b * p), part.data_ptr(),
-                  gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
-                  out.data_ptr(), stream)
-        mean, var = want.mean((0, 2)), want.var((0, 2), unbiased=False)
-        invstd = 1.0 / torch.sqrt(var + 1e-5)
-        torch.testing.assert_close(out[:, 2].double(), mean, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(out[:, 3].double(), invstd, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(out[:, 0].double(), gamma.double() * invstd, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(out[:, 1].double(), beta.double() - mean * gamma.double() * invstd,
-                                   rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-4, atol=1e-6)
-        n = b * p
-        torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-4, atol=1e-6)
-
-
 @pytest.mark.parametrize("cout,cin,p,b", [(64, 4, 4096, 2), (64, 64, 1000, 3), (128, 131, 640, 2),
                                          (256, 128, 320, 2), (18, 7, 130, 1), (128, 64, 8192, 2)])
 def test_conv_wgrad_matches_fp64(hip_device, cout, cin, p, b):
