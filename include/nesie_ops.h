@@ -432,6 +432,20 @@ int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, i
                          const uint8_t *amin, const float *coef, int relu, float *pooled,
                          uint8_t *argmax, void *stream);
 
+/* Weight gradient of the same layers: dw[g][co][ci] = sum over the batches n of group g (n % ng
+ * == g) and all positions of dy[n][co][pos] * act(x[n][ci][pos]), act as in
+ * nesie_pw_layer_forward (x_coef [ng*ci][4], NULL = identity): the Conv2d weight gradient that
+ * autograd computes for ConvModule (point_sa_module.py:277-289) with the normalised activation
+ * recomputed on load.  dy[n] (co, p) at dy + n*dy_bstride, x[n] (ci, p) at x + n*x_bstride;
+ * dw (ng, co, ci); partials are added in a fixed order (bitwise reproducible).
+ * workspace = nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p). */
+int nesie_pw_wgrad_supported(int co, int ci, long long p);
+size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p);
+int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
+                   long long dy_bstride, const float *x, long long x_bstride,
+                   const float *x_coef, int x_relu, float *dw, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
 /* The layer kernel for skinny HBM-bound first layers (cin <= 64, cout <= 128): W stays in
  * LDS / registers and every wave streams its own 32-position columns straight from global
  * memory into the MFMA operand registers (no LDS tile, no barrier in the main loop).

@@ -544,6 +544,31 @@ class HipKernels(_BNPoolMixin):
                       x.stride(0) if b > 1 else cin * p, 0 if x_coef is None else _ptr(x_coef),
                       int(bool(x_relu)), _ptr(dw), _ptr(ws), need, _stream(dy))
 
+    def pw_wgrad_supported(self, co, ci, p):
+        return bool(_lib.load().nesie_pw_wgrad_supported(int(co), int(ci), int(p)))
+
+    def pw_wgrad(self, dy, x, dw, ng=1, x_coef=None, x_relu=True):
+        """dw (ng, co, ci) = sum over n % ng == g and positions of dy[n] (co, P) act(x[n])^T
+        (nesie_pw_wgrad); dy (NB, co, P), x (NB, ci, P) batch-strided views allowed;
+        x_coef (ng*ci, 4) folded BatchNorm of x."""
+        _f32(dy, x, dw)
+        nb, co, p = dy.shape
+        ci = x.shape[1]
+        assert dy.is_cuda and x.shape[0] == nb and x.shape[2] == p and nb % ng == 0
+        assert dw.is_contiguous() and dw.numel() == ng * co * ci
+        assert x.stride(2) == 1 and x.stride(1) == p and dy.stride(2) == 1 and dy.stride(1) == p
+        if x_coef is not None:
+            _check(x_coef); _f32(x_coef)
+            assert tuple(x_coef.shape) == (ng * ci, 4)
+        lib = _lib.load()
+        need = lib.nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p)
+        with torch.cuda.device(dy.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
+            _lib.call("nesie_pw_wgrad", nb, ng, co, ci, p, _ptr(dy),
+                      dy.stride(0) if nb > 1 else co * p, _ptr(x), x.stride(0) if nb > 1 else ci * p,
+                      0 if x_coef is None else _ptr(x_coef), int(bool(x_relu)), _ptr(dw), _ptr(ws),
+                      need, _stream(dy))
+
     @staticmethod
     def conv_wgrad_supported(cout, cin):
         return (cout <= 128 and cin <= 288) or (cout <= 256 and cin <= 128)

@@ -26,21 +26,35 @@ from ..kernels import backend_for
 ENABLED = True
 
 
-def _wgrad(backend, dy, x, x_coef):
-    """dW (Cout, Cin) = sum_b dy[b] @ act(x[b])^T; act = relu(scale * x + bias) when x_coef."""
-    b, co, p = dy.shape
+def _wgrad(backend, dy, x, x_coef, ng=1):
+    """dW (ng, Cout, Cin) = sum over n % ng == g of dy[n] @ act(x[n])^T; act = relu(scale * x +
+    bias) when x_coef (ng * Cin, 4)."""
+    nb, co, p = dy.shape
     ci = x.shape[1]
-    if backend.conv_wgrad_supported(co, ci):
-        dw = dy.new_empty(co, ci)
-        backend.conv_wgrad(dy, x, dw, x_coef=x_coef, x_relu=x_coef is not None)
+    if backend.pw_wgrad_supported(co, ci, p):
+        dw = dy.new_empty(ng, co, ci)
+        backend.pw_wgrad(dy, x, dw, ng=ng, x_coef=x_coef, x_relu=True)
         return dw
-    a, dy = x.contiguous(), dy.contiguous()
-    if x_coef is not None:   # shapes outside the native weight-gradient kernel: materialise once
-        a = torch.empty_like(a)
-        backend.affine_relu_forward(x.contiguous(), x_coef, True, a)
-    if p <= 2048 and b > 1:
-        return torch.mm(dy.transpose(0, 1).reshape(co, b * p), a.transpose(0, 1).reshape(ci, b * p).t())
-    return torch.bmm(dy, a.transpose(1, 2)).sum(0)
+    out = []
+    for g in range(ng):      # shapes outside the native kernels (short rows, wide layers)
+        dyg, xg = dy[g::ng], x[g::ng]
+        cg = None if x_coef is None else x_coef[g * ci:(g + 1) * ci].contiguous()
+        if ci <= 8 and backend.conv_wgrad_supported(co, ci):
+            dw = dy.new_empty(co, ci)
+            backend.conv_wgrad(dyg, xg, dw, x_coef=cg, x_relu=cg is not None)
+            out.append(dw)
+            continue
+        a, d = xg.contiguous(), dyg.contiguous()
+        if cg is not None:
+            a2 = torch.empty_like(a)
+            backend.affine_relu_forward(a, cg, True, a2)
+            a = a2
+        b = d.shape[0]
+        if p <= 2048 and b > 1:
+            out.append(torch.mm(d.transpose(0, 1).reshape(co, b * p), a.transpose(0, 1).reshape(ci, b * p).t()))
+        else:
+            out.append(torch.bmm(d, a.transpose(1, 2)).sum(0))
+    return torch.stack(out)
 
 
 class SAStackFn(Function):
@@ -256,8 +270,7 @@ class MiniHeadFn(Function):
         dw3 = None
         if ctx.needs_input_grad[6]:
             # per-net weight gradient: the S nets are the S strided batch subsets
-            dw3 = torch.stack([_wgrad(backend, dcf[s::S], x0[s::S], coef0[s * H0:(s + 1) * H0].contiguous())
-                               for s in range(S)])
+            dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
         da0 = c0.new_empty(B * S, H0, P)
         backend.pw_layer_forward(dcf, w3.transpose(1, 2), ng=S, y=da0)
         dc0 = torch.empty_like(c0)
@@ -314,8 +327,7 @@ class MiniTailFn(Function):
         yf = y.view(B * S, H2, P)
         dw4 = None
         if ctx.needs_input_grad[7]:
-            dw4 = torch.stack([_wgrad(backend, dzf[s::S], yf[s::S], coef1[s * H2:(s + 1) * H2].contiguous())
-                               for s in range(S)])
+            dw4 = _wgrad(backend, dzf, yf, coef1, ng=S)
         da = c.new_empty(B * S, H2, P)
         backend.pw_layer_forward(dzf, w4.transpose(1, 2), ng=S, y=da)
         dy = torch.empty_like(y)
@@ -328,7 +340,7 @@ class MiniTailFn(Function):
         cf = c.view(B * S, half, P)
         dwl = None
         if ctx.needs_input_grad[4]:
-            dwl = torch.stack([_wgrad(backend, dyf[s::S], cf[s::S], None) for s in range(S)])
+            dwl = _wgrad(backend, dyf, cf, None, ng=S)
         dc = torch.empty_like(c)
         backend.pw_layer_forward(dyf, wl.transpose(1, 2), ng=S, y=dc.view(B * S, half, P))
         return dc, dsmall, None, None, dwl, dgamma, dbeta, dw4

@@ -38,7 +38,8 @@ def test_binding_covers_every_compute_entry_point():
     compute = [n for n in declared_symbols()
                if n not in ("nesie_abi_version", "nesie_last_error",
                             "nesie_fps_workspace_bytes", "nesie_bn_workspace_bytes",
-                            "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_blend_conv_runs",
+                            "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_pw_wgrad_supported",
+                            "nesie_pw_wgrad_workspace_bytes", "nesie_blend_conv_runs",
                             "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials",
                             "nesie_blend_conv_bn_workspace_bytes")]
     assert sorted(compute) == sorted(_lib.SIGNATURES)

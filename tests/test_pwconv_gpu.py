@@ -218,6 +218,33 @@ def test_weight_gradient_wide_shapes_and_strided_batches(cout, cin):
         assert (dw.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('nb,ng,co,ci,p', [(6, 3, 128, 256, 256), (4, 1, 256, 128, 512), (4, 2, 128, 128, 256),
+                                           (2, 1, 128, 131, 512), (2, 1, 128, 259, 256), (2, 1, 64, 64, 1024),
+                                           (2, 1, 128, 64, 512), (3, 1, 100, 70, 96), (2, 1, 40, 33, 64)])
+def test_layer_weight_gradient_matches_fp64(nb, ng, co, ci, p):
+    """nesie_pw_wgrad: sum over batches and positions of dy . act(x)^T per weight group, with the
+    activation recomputed on load, on batch-strided operands."""
+    hip = _hip()
+    assert hip.pw_wgrad_supported(co, ci, p)
+    g = torch.Generator(device=_dev()).manual_seed(co * 3 + ci + ng)
+    dy_all = torch.randn(nb, co + 5, p, device=_dev(), generator=g)
+    x_all = torch.randn(nb, ci + 3, p, device=_dev(), generator=g)
+    dy, x = dy_all[:, 5:], x_all[:, 3:]              # batch strides wider than the rows used
+    coef = torch.rand(ng * ci, 4, device=_dev(), generator=g) + 0.5
+    coef[:, 1] -= 1.0
+    coef[::3, 0] *= -1.0
+    for use_coef in (True, False):
+        dw = torch.empty(ng, co, ci, device=_dev())
+        hip.pw_wgrad(dy, x, dw, ng=ng, x_coef=coef if use_coef else None)
+        xd = x.double()
+        if use_coef:
+            c = coef.double().view(ng, ci, 4)[torch.arange(nb, device=_dev()) % ng]
+            xd = (xd * c[:, :, 0:1] + c[:, :, 1:2]).clamp_min(0)
+        full = torch.bmm(dy.double(), xd.transpose(1, 2))          # (nb, co, ci)
+        ref = full.view(nb // ng, ng, co, ci).sum(0)
+        assert (dw.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
 def _sa_module(c_in, mlp, ns):
     from nesie_amd.mmdet3d_ops import PointSAModule
     torch.manual_seed(0)
