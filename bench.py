@@ -100,11 +100,6 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         # views of the same scenes (train-010.py:319-336); value counts STUDENT scenes
         model = (semi.build_saqe_votenet_semi() if workload == 'saqe'
                  else semi.build_nesie_votenet_semi()).to(device)
-        model.teacher = semi.EMATeacher.__new__(semi.EMATeacher)
-        model.teacher.__dict__.update(
-            momentum=0.001, interval=1, warm_up=10,
-            params=[p for n, p in model.named_parameters()],
-            emas=[b for n, b in model.named_buffers() if n.startswith('ema_')])
         model.init_label_state(120, 1081, device)
         use_label = [i % 3 == 0 for i in range(batch)]
         g = torch.Generator().manual_seed(seed)

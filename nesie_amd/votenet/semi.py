@@ -148,38 +148,70 @@ class EMATeacher:
         assert isinstance(interval, int) and interval > 0 and 0 < momentum < 1
         self.momentum = momentum ** interval
         self.interval, self.warm_up = interval, warm_up
-        self.params, self.emas = [], []
+        # Only NAMES are kept: nn.Module.to() / .double() / .cuda() replace buffer tensors (the
+        # Parameter objects survive, their .data is swapped), so tensors cached here would be
+        # orphans of the original device after model.to('cuda').  The reference resolves its
+        # buffers in before_run, i.e. after the model has been moved (simi_teacher_hook.py:39-52).
+        self.model = model
+        self.names = []
         for name, p in list(model.named_parameters(recurse=True)):
             buf_name = f"ema_{name.replace('.', '_')}"
             model.register_buffer(buf_name, p.data.clone())
-            self.params.append(p)
-            self.emas.append(getattr(model, buf_name))
+            self.names.append((name, buf_name))
+        self._bound = None
+
+    def _bind(self):
+        """(parameters, EMA buffers) of the model as it is NOW; re-resolved whenever a buffer
+        object, device or dtype has changed since the last call."""
+        bufs = self.model._buffers
+        b = self._bound
+        if b is not None and all(bufs[bn] is e and e.device == p.device and e.dtype == p.dtype
+                                 for (_, bn), p, e in zip(self.names, b[0], b[1])):
+            return b
+        named = dict(self.model.named_parameters(recurse=True))
+        params = [named[n] for n, _ in self.names]
+        emas = [bufs[bn] for _, bn in self.names]
+        self._bound = (params, emas)
+        self._scratch = None
+        return self._bound
+
+    @property
+    def params(self):
+        return self._bind()[0]
+
+    @property
+    def emas(self):
+        return self._bind()[1]
 
     def resync(self):
         """EMA copies <- current parameters (e.g. after loading pre-trained weights)."""
+        params, emas = self._bind()
         with torch.no_grad():
-            torch._foreach_copy_(self.emas, [p.data for p in self.params])
+            torch._foreach_copy_(emas, [p.data for p in params])
 
     def update(self, curr_step):
         if curr_step % self.interval != 0:
             return
         m = min(self.momentum, (1 + curr_step) / (self.warm_up + curr_step))
+        params, emas = self._bind()
         with torch.no_grad():
-            torch._foreach_mul_(self.emas, 1 - m)
-            torch._foreach_add_(self.emas, [p.data for p in self.params], alpha=m)
+            torch._foreach_mul_(emas, 1 - m)
+            torch._foreach_add_(emas, [p.data for p in params], alpha=m)
 
     def swap(self):
         """Parameters <-> EMA copies, as three multi-tensor copies through a scratch list kept
         between calls (one clone launch per parameter otherwise: ~440 tiny copies per step)."""
+        params, emas = self._bind()
         with torch.no_grad():
-            params = [p.data for p in self.params]
+            data = [p.data for p in params]
             tmp = getattr(self, '_scratch', None)
-            if tmp is None or len(tmp) != len(params) or any(
-                    t.shape != p.shape or t.device != p.device for t, p in zip(tmp, params)):
-                tmp = self._scratch = [torch.empty_like(p) for p in params]
-            torch._foreach_copy_(tmp, params)
-            torch._foreach_copy_(params, self.emas)
-            torch._foreach_copy_(self.emas, tmp)
+            if tmp is None or len(tmp) != len(data) or any(
+                    t.shape != p.shape or t.device != p.device or t.dtype != p.dtype
+                    for t, p in zip(tmp, data)):
+                tmp = self._scratch = [torch.empty_like(p) for p in data]
+            torch._foreach_copy_(tmp, data)
+            torch._foreach_copy_(data, emas)
+            torch._foreach_copy_(emas, tmp)
 
 
 # ---- pseudo-label statistics ---------------------------------------------------------------

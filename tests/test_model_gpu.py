@@ -104,6 +104,29 @@ def test_hip_graph_replay_matches_eager_forward_backward(hip_device):
     assert rel < 1e-4, rel
 
 
+def test_ema_teacher_updates_the_registered_buffers_on_the_device(hip_device):
+    """The shipped constructor + .to(device): update / swap act on the ema_* buffers of the state
+    dict (simi_teacher_hook.py:54-92), on the device."""
+    from nesie_amd.votenet import semi
+    torch.manual_seed(0)
+    model = semi.build_nesie_votenet_semi().to(hip_device)
+    key = 'ema_backbone_SA_modules_0_mlps_0_layer0_conv_weight'
+    p0 = model.backbone.SA_modules[0].mlps[0].layer0.conv.weight
+    assert all(e.is_cuda for e in model.teacher.emas)
+    before = model.state_dict()[key].clone()
+    with torch.no_grad():
+        p0.add_(1.0)
+    model.teacher.update(0)
+    after = model.state_dict()[key].clone()
+    assert after.is_cuda
+    torch.testing.assert_close(after, before * 0.999 + (before + 1) * 0.001)
+    student = p0.detach().clone()
+    model.teacher.swap()
+    assert torch.equal(p0, after) and torch.equal(model.state_dict()[key], student)
+    model.teacher.swap()
+    assert torch.equal(p0, student)
+
+
 def test_semi_supervised_step_on_gpu(hip_device):
     """Student/teacher step (BASELINE config 4 shape per GPU, reduced batch) runs on the HIP
     path: teacher pseudo labels, re-augmentation, supervised + unsupervised losses, EMA."""
@@ -112,10 +135,6 @@ def test_semi_supervised_step_on_gpu(hip_device):
     from nesie_amd.votenet.nesie_head import GTBatch
     torch.manual_seed(0)
     model = semi.build_nesie_votenet_semi().to(hip_device)
-    model.teacher = semi.EMATeacher.__new__(semi.EMATeacher)
-    model.teacher.__dict__.update(momentum=0.001, interval=1, warm_up=10,
-                                  params=[p for _, p in model.named_parameters()],
-                                  emas=[b for n, b in model.named_buffers() if n.startswith('ema_')])
     model.init_label_state(12, 108, hip_device)
     pts, boxes, labels = make_batch(2000, 3)
     g = torch.Generator().manual_seed(1)

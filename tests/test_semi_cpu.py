@@ -52,6 +52,27 @@ def test_ema_update_swap_and_state_dict_names():
     assert torch.equal(p0, student) and torch.equal(e0, teacher)
 
 
+def test_ema_follows_the_model_through_module_to():
+    """nn.Module.to()/.double() replace the buffer tensors; the teacher must keep updating the
+    REGISTERED ema_* buffers (the ones in the state dict), not orphans of the old dtype/device."""
+    model = _semi_model().double()        # same replacement mechanism as .to(device)
+    key = 'ema_backbone_SA_modules_0_mlps_0_layer0_conv_weight'
+    p0 = model.backbone.SA_modules[0].mlps[0].layer0.conv.weight
+    assert model.teacher.emas[0].dtype == torch.float64
+    before = model.state_dict()[key].clone()
+    with torch.no_grad():
+        p0.add_(1.0)
+    model.teacher.update(0)
+    after = model.state_dict()[key].clone()
+    assert after.dtype == torch.float64 and not torch.equal(after, before)
+    torch.testing.assert_close(after, before * 0.999 + (before + 1) * 0.001)
+    model.teacher.swap()
+    assert torch.equal(p0, after)
+    model.teacher.swap()
+    model.teacher.resync()
+    assert torch.equal(model.state_dict()[key], p0)
+
+
 def test_classwise_thresholds_as_coded():
     st = semi.PseudoLabelState(num_labeled=12, num_unlabeled=108, num_classes=4, device='cpu')
     st.ulb_list[0] = torch.tensor([5., 0., 9., 2.])
