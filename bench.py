@@ -8,8 +8,12 @@ GPU, fp32), data-parallel over N MI355X -- BASELINE.json `metric`, workload conf
 
 Rank 0 prints ONE JSON line.  `value` = scenes all ranks processed / max-over-ranks
 time of exactly K steps (inputs resident in HBM before the timed region).  `roofline`
-prices the dominant kernel from HIP-event timings taken inside the timed region;
-`cpu_baseline` times the same step on the host through the CPU oracle (bounded sample).
+prices the dominant kernel family of the step -- the fp32-MFMA layer kernels of the grouped
+per-seed MLPs (nesie::pw_fwd_kernel / pw_wgrad_kernel) -- from HIP-event timings of every such
+launch; `roofline_step` divides the same FLOPs by the whole step; `parity_gate` is the SURVEY
+section 8(d) check run before anything is timed (CPU-oracle and HIP legs on identical inputs
+and weights, every loss term within 1e-4, non-zero exit otherwise); `cpu_baseline` times the
+same step on the host through the CPU oracle (bounded sample).
 """
 import argparse
 import json
@@ -76,6 +80,67 @@ class KernelTimer:
     def mean_ms(self):
         ts = [s.elapsed_time(e) for s, e in self.events]
         return sum(ts) / len(ts) if ts else None
+
+
+class GemmTimer:
+    """HIP-event timing + FLOP count of every launch of one matrix-core entry point."""
+
+    def __init__(self, backend, method, flops):
+        self.events, self.flop, self.enabled = [], [], False
+        inner = getattr(backend, method)
+
+        def wrapped(*args, **kw):
+            if not self.enabled:
+                return inner(*args, **kw)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = inner(*args, **kw)
+            e.record()
+            self.events.append((s, e))
+            self.flop.append(flops(*args, **kw))
+            return r
+        setattr(backend, method, wrapped)
+
+    def totals(self):
+        """(launches, ms, flop) summed over the recorded launches."""
+        ts = [s.elapsed_time(e) for s, e in self.events]
+        return len(ts), sum(ts), float(sum(self.flop))
+
+
+def parity_gate(device):
+    """before any timing, the CPU-oracle leg and the HIP leg run ONE step of
+    the same B = 2, 40 000-point batch with identical weights; every loss term must agree
+    within 1e-4 (relative to max(1, |value|)).  -> dict for the JSON line."""
+    import oracle
+    torch.manual_seed(0)
+    pts, boxes, labels = make_batch(4242, 2, NUM_POINTS)
+    cpu_model = build_nesie_votenet()
+    cpu_model.train()
+    state = {k: v.clone() for k, v in cpu_model.state_dict().items()}
+    # the head jitters its proposals with host-side Gaussian noise (nesie_head.py:178-209): both
+    # legs get the same draw
+    g = torch.Generator().manual_seed(3)
+    k = cpu_model.bbox_head.num_proposal
+    noise = (torch.randn(2, k, 3, generator=g), torch.randn(2, k, 3, generator=g))
+    cpu_model.bbox_head.jitter_noise = noise
+    with kernels.use_backend(oracle.OracleKernels()):
+        want = cpu_model.forward_train(pts, None, GTBatch.collate(boxes, labels, torch.device('cpu')), None)
+        want = {k: float(v.detach().sum()) for k, v in want.items()}
+    gpu_model = build_nesie_votenet()
+    gpu_model.load_state_dict(state)
+    gpu_model.to(device).train()
+    gpu_model.bbox_head.jitter_noise = noise
+    got = gpu_model.forward_train(pts.to(device), None, GTBatch.collate(boxes, labels, device), None)
+    got = {k: float(v.detach().sum()) for k, v in got.items()}
+    diffs = {k: abs(got[k] - want[k]) / max(1.0, abs(want[k])) for k in want}
+    worst = max(diffs, key=diffs.get)
+    del gpu_model, cpu_model
+    torch.cuda.empty_cache()
+    return dict(passed=bool(diffs[worst] <= 1e-4), max_rel_diff=diffs[worst], worst_term=worst,
+                terms=len(diffs), tolerance=1e-4,
+                sample='one supervised step, 2 scenes x 40000 pts, same weights and inputs on the '
+                       'CPU-oracle leg and the HIP leg')
 
 
 def transform_gt(boxes, meta, i):
@@ -315,6 +380,8 @@ def main():
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--parity-gate', type=int, default=1,
+                    help='0 to skip the CPU-vs-HIP loss check that precedes the timing (N = 1 only)')
     args = ap.parse_args()
 
     rank, world, local = dp.init_distributed()
@@ -325,6 +392,17 @@ def main():
     from nesie_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
 
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == args.gpus, \
+            f'process group has {dist.get_world_size()} ranks, --gpus {args.gpus}'
+    gate = None
+    if args.parity_gate and world == 1 and args.workload == 'pretrain':
+        gate = parity_gate(device)
+        if not gate['passed']:
+            print(json.dumps({'parity_gate': gate}), flush=True)
+            print(f"parity gate FAILED: {gate['worst_term']} differs by {gate['max_rel_diff']:.3e}",
+                  file=sys.stderr)
+            sys.exit(3)
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
                                      cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
@@ -344,7 +422,15 @@ def main():
                                  lambda g, a, x, *_: x.numel() == big)
     bn_fwd_timer = KernelTimer(hip, 'bn_relu_forward', lambda x, *_: x.numel() == mid)
     bn_bwd_timer = KernelTimer(hip, 'bn_relu_backward', lambda dy, *_: dy.numel() == mid)
-    timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer)
+    # the matrix-core family: every launch of the layer kernel (forward products and, on the
+    # transposed weight view, input gradients) and of the weight-gradient kernel
+    def fwd_flop(x, w, **kw):
+        return 2.0 * x.shape[0] * x.shape[1] * w.shape[1] * x.shape[2]
+
+    def wgrad_flop(dy, x, dw, **kw):
+        return 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] * dy.shape[2]
+    gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop))
+    timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer) + gemm_timers
 
     def sync():
         if world > 1:
@@ -365,7 +451,8 @@ def main():
     for t in timers:
         t.enabled = True
     eager = getattr(step, 'eager', step)
-    for _ in range(min(args.steps, 5)):
+    eager_steps = min(args.steps, 5)
+    for _ in range(eager_steps):
         eager()
     torch.cuda.synchronize()
     for t in timers:
@@ -399,6 +486,8 @@ def main():
                        'scenes_per_gpu': args.batch, 'global_batch': world * args.batch,
                        'points_per_scene': NUM_POINTS,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'world_size': dist.get_world_size() if dist.is_initialized() else 1,
+                       'collective_backend': dist.get_backend() if dist.is_initialized() else None,
                        'hip_graph': bool(args.graph),
                        'index_chain_pipelined': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes(),
@@ -419,23 +508,42 @@ def main():
                     'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'traffic': None,
                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes}
         pooled_bytes = args.batch * 128 * 2048 * 4
-        # PMC figure for the same pair at B = 8 (profiles/r01e_pmc_hbm_traffic.txt: FETCH_SIZE
-        # and WRITE_SIZE collected in separate rocprofv3 passes, streaming reads doubled per
-        # the gfx950 note of MI355X_MICROARCH.md): reduce 16 438 + 512 KB, apply 573 529 + 524 289 KB
-        measured_traffic = 1114768 * 1024 if args.batch == 8 else None
-        out['roofline'] = _stream(
-            'nesie::bn_pool_bwd_reduce_kernel + bn_pool_bwd_apply_kernel<16> (SA1 MLP tail, '
-            'x (B,128,2048,64)): largest launch on the critical path', pool_bwd_timer.mean_ms(),
-            2, big * 4, extra=3 * pooled_bytes + pooled_bytes // 4)
-        if out['roofline']:
-            out['roofline']['traffic'] = measured_traffic
-        out['roofline_streaming'] = [
-            _stream('nesie::bn_stats_kernel + bn_pool_fwd_kernel<16> (B,128,2048,64)',
-                    pool_fwd_timer.mean_ms(), 2, big * 4, extra=pooled_bytes + pooled_bytes // 4),
-            _stream('nesie::bn_stats_kernel + bn_apply_kernel<relu> (B,64,2048,64)',
-                    bn_fwd_timer.mean_ms(), 3, mid * 4),
+        # ---- the dominant family: the grouped per-seed MLP GEMMs on the fp32 matrix cores.
+        # achieved = algorithmic FLOPs (2 * batches * K * Cout * positions per launch) / HIP-event
+        # time, summed over every launch of the family in the un-captured steps.
+        n_l, ms_l, fl_l = gemm_timers[0].totals()
+        n_w, ms_w, fl_w = gemm_timers[1].totals()
+        if n_l + n_w:
+            tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
+            per_step = lambda v: v / eager_steps  # noqa: E731
+            out['roofline'] = {
+                'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients) + '
+                          'nesie::pw_wgrad_kernel: the 1x1-conv layers of the SA stacks and the '
+                          'MiniPointNets, fp32 MFMA (v_mfma_f32_16x16x4_f32)',
+                'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf / MFMA_F32_PEAK_TFLOPS,
+                'traffic': None,   # HBM bytes of this family: profiles/r02_pmc_hbm_traffic.txt
+                'launches_per_step': per_step(n_l + n_w),
+                'family_ms_per_step': per_step(ms_l + ms_w),
+                'avg_launch_ms': (ms_l + ms_w) / (n_l + n_w),
+                'algorithmic_flops_per_launch': (fl_l + fl_w) / (n_l + n_w),
+                'layer_kernel': {'launches_per_step': per_step(n_l), 'ms_per_step': per_step(ms_l),
+                                 'tflops': fl_l / (ms_l * 1e-3) / 1e12 if ms_l else None},
+                'wgrad_kernel': {'launches_per_step': per_step(n_w), 'ms_per_step': per_step(ms_w),
+                                 'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None}}
+            # the same FLOPs against the whole step (everything that is not a GEMM counts as lost)
+            step_tf = per_step(fl_l + fl_w) / (ms_per_step * 1e-3) / 1e12
+            out['roofline_step'] = {'bound': 'mfma', 'achieved': step_tf, 'peak': MFMA_F32_PEAK_TFLOPS,
+                                    'unit': 'TFLOP/s', 'frac': step_tf / MFMA_F32_PEAK_TFLOPS,
+                                    'native_gemm_flop_per_step': per_step(fl_l + fl_w)}
+        else:
+            out['roofline'] = None
+        out['roofline_streaming'] = [e for e in (
+            _stream('nesie::bn_pool_bwd_reduce_kernel + bn_pool_bwd_apply_kernel<16> (SA1 MLP tail, '
+                    'x (B,128,2048,64))', pool_bwd_timer.mean_ms(), 2, big * 4,
+                    extra=3 * pooled_bytes + pooled_bytes // 4),
             _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,64,2048,64)',
-                    bn_bwd_timer.mean_ms(), 5, mid * 4)]
+                    bn_bwd_timer.mean_ms(), 5, mid * 4)) if e]
         out['roofline_latency_bound'] = {
             'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048: 2047 dependent rounds; '
                       'longest single launch, overlapped with the previous step on a side '
@@ -443,6 +551,8 @@ def main():
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
             'avg_launch_ms': fps_ms, 'algorithmic_bytes_per_launch': alg_bytes}
+        if gate is not None:
+            out['parity_gate'] = gate
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
