@@ -222,6 +222,18 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
   };
   // previous layer's BatchNorm + ReLU in registers (packed fma; the backward's mask test uses
   // the same fused form), then into the LDS buffer
+  auto write_chunk = [&](auto ic, float *buf) {
+    constexpr int i = decltype(ic)::value;
+    f32x4 q = stg[i];
+    if (!(EVEN && all_k)) q = okslot[i] ? q : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (EPI & PW_AFFINE) {
+      const f32x2 lo = __builtin_elementwise_fma((f32x2){q[0], q[1]}, sc[i], bi[i]);
+      const f32x2 hi = __builtin_elementwise_fma((f32x2){q[2], q[3]}, sc[i], bi[i]);
+      q[0] = fmaxf(lo[0], a.in_lo); q[1] = fmaxf(lo[1], a.in_lo);
+      q[2] = fmaxf(hi[0], a.in_lo); q[3] = fmaxf(hi[1], a.in_lo);
+    }
+    if (EVEN || (i * NT + tid) < KPAD * CPR) *(f32x4 *)((char *)buf + lw[i]) = q;
+  };
   auto write_tile = [&](float *buf) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -343,7 +355,11 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
     __builtin_amdgcn_s_barrier();
     STAMP(1)
     const bool more = t + nwg < ntiles;
+#ifdef PW_INTERLEAVE
+    const float *nxb = a.x + (size_t)(g + a.ng * nq) * a.x_bs + (long long)nr * PT;   // uniform
+#else
     if (more) load_tile(g + a.ng * nq, (long long)nr * PT);
+#endif
     STAMP(2)
     const int n = g + a.ng * tq;
     const long long p0 = (long long)tr * PT;
@@ -399,10 +415,23 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
           }
         });
         __builtin_amdgcn_sched_barrier(0);
+#ifdef PW_INTERLEAVE
+        if (more) {
+          constexpr int H = NGRP / 2;
+          static_for<0, NX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr ((i * H) / NX == gi) stg[i] = load16_saddr(goff[i], nxb);
+            if constexpr (H + (i * (NGRP - H)) / NX == gi) write_chunk(ic, b1);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       });
     }
     STAMP(3)
+#ifndef PW_INTERLEAVE
     if (more) write_tile(b1);   // waits for the loads of tile t + 1 (issued before the MFMAs)
+#endif
     STAMP(4)
     if (do_mfma) epilogue(n, p0);
     STAMP(5)

@@ -211,6 +211,17 @@ class OracleKernels:
         lib().oracle_sort_vertices(b, n, m, vertices.data_ptr(), mask.data_ptr(),
                                    num_valid.data_ptr(), idx.data_ptr())
 
+    def rotated_iou_3d(self, box_a, box_b):
+        """the reference's differentiable torch chain around sort_vertices (oracle/rotated_iou.py)"""
+        from . import rotated_iou
+
+        def order(vertices, mask, num_valid):
+            v = vertices.float().contiguous()
+            idx = torch.empty(v.shape[0], v.shape[1], 9, dtype=torch.int32)
+            self.sort_vertices_forward(v, mask.contiguous(), num_valid.contiguous(), idx)
+            return idx
+        return rotated_iou.rotated_iou_3d(box_a, box_b, order)
+
     def points_in_boxes_batch(self, boxes, pts, out):
         _cpu(boxes, pts, out)
         b, t, _ = boxes.shape

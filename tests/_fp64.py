@@ -1,0 +1,86 @@
+"""An fp64 evaluation of the detector for the gradient-accuracy tests: the geometric index ops
+run through the CPU oracle in fp32 (so every index equals the fp32 run's), everything that
+carries values -- grouping, gathering, interpolation, and all dense torch ops -- runs in fp64.
+Test infrastructure only."""
+import torch
+
+import oracle
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+class Fp64Kernels(oracle.OracleKernels):
+    name = "oracle-fp64"
+
+    # ---- geometry in fp32 (indices / masks are what matters) --------------------------------
+    def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
+        t32 = _f32(temp)
+        super().furthest_point_sampling_wrapper(b, n, m, _f32(xyz), t32, idx)
+        temp.copy_(t32)
+
+    def ball_query_wrapper(self, b, n, m, min_radius, max_radius, nsample, new_xyz, xyz, idx):
+        super().ball_query_wrapper(b, n, m, min_radius, max_radius, nsample, _f32(new_xyz),
+                                   _f32(xyz), idx)
+
+    def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
+        u, k = unknown.detach(), known.detach()
+        super().three_nn_wrapper(b, n, m, _f32(u), _f32(k), torch.empty(b, n, 3), idx)
+        # distances recomputed in the working precision from the fp32-chosen neighbours
+        nb = torch.gather(k.unsqueeze(1).expand(-1, n, -1, -1), 2,
+                          idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+        dist2.copy_(((nb - u.unsqueeze(2)) ** 2).sum(-1))
+
+    def points_in_boxes_batch(self, boxes, pts, out):
+        super().points_in_boxes_batch(_f32(boxes), _f32(pts), out)
+
+    def sort_vertices_forward(self, vertices, mask, num_valid, idx):
+        super().sort_vertices_forward(_f32(vertices), mask, num_valid, idx)
+
+    def lhs_nms_samecls(self, boxes, thr, keep):
+        super().lhs_nms_samecls(_f32(boxes), thr, keep)
+
+    # ---- value-carrying ops in the tensor's own precision -----------------------------------
+    def group_points_forward(self, b, c, n, npoints, nsample, points, idx, out):
+        ix = idx.long().view(b, 1, npoints * nsample).expand(-1, c, -1)
+        out.copy_(torch.gather(points, 2, ix).view(b, c, npoints, nsample))
+
+    def group_points_backward(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        ix = idx.long().view(b, 1, npoints * nsample).expand(-1, c, -1)
+        grad_points.scatter_add_(2, ix, grad_out.reshape(b, c, -1))
+
+    def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
+        out.copy_(torch.gather(points, 2, idx.long().unsqueeze(1).expand(-1, c, -1)))
+
+    def gather_points_grad_wrapper(self, b, c, n, npoints, grad_out, idx, grad_points):
+        grad_points.scatter_add_(2, idx.long().unsqueeze(1).expand(-1, c, -1), grad_out)
+
+    def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
+        g = torch.gather(points.unsqueeze(2).expand(-1, -1, n, -1), 3,
+                         idx.long().unsqueeze(1).expand(-1, c, -1, -1))
+        out.copy_((g * weight.unsqueeze(1)).sum(-1))
+
+    def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight, grad_points):
+        contrib = grad_out.unsqueeze(-1) * weight.unsqueeze(1)          # (b, c, n, 3)
+        grad_points.scatter_add_(2, idx.long().view(b, 1, n * 3).expand(-1, c, -1),
+                                 contrib.reshape(b, c, n * 3))
+
+
+def train_step_fp64(model32, pts, boxes, labels, noise=None):
+    """One forward + backward of a float64 COPY of ``model32`` on float64 inputs through
+    ``Fp64Kernels`` -> (losses {name: float}, {parameter name: float64 gradient})."""
+    import copy
+
+    from nesie_amd import kernels
+    from nesie_amd.votenet.nesie_head import GTBatch
+    model = copy.deepcopy(model32).double()
+    if noise is not None:
+        model.bbox_head.jitter_noise = tuple(t.double() for t in noise)
+    gt = GTBatch.collate(boxes, labels, pts.device)
+    gt.boxes, gt.valid = gt.boxes.double(), gt.valid.double()
+    with kernels.use_backend(Fp64Kernels()):
+        losses = model.forward_train(pts.double(), None, gt, None)
+        model.parse_losses(losses).backward()
+    return ({k: float(v.detach().sum()) for k, v in losses.items()},
+            {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})

@@ -394,7 +394,10 @@ def test_fused_bn_relu_matches_aten(hip_device, shape, relu):
 @pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])
 def test_fused_iou3d_matches_torch_chain(oracle_kernels, hip_device, mode):
     """nesie_iou3d_forward (value + Jacobian) vs the reference-shaped torch chain."""
-    from nesie_amd.mmdet3d_ops.rotated_iou import cal_iou_3d_torch
+    from oracle.rotated_iou import rotated_iou_3d
+
+    def cal_iou_3d_torch(x, y):   # the chain on whatever device x lives, native sort_vertices
+        return rotated_iou_3d(x, y, lambda v, m, n: ops.sort_v(v, m, n))
     a, b = _cases.box_pairs(17, 4096, mode)
     ag = a.to(hip_device).requires_grad_(True)
     got = ops.cal_iou_3d(ag, b.to(hip_device))

@@ -153,14 +153,14 @@ def test_group_gather_interpolate_and_grads(oracle_kernels):
 
 
 def _vertices_for(mode, n, seed):
-    """Run the torch geometry of the rotated-IoU chain on CPU up to sort_v's inputs."""
-    from nesie_amd.mmdet3d_ops import rotated_iou as R
+    """The geometry of the rotated-IoU chain (oracle/rotated_iou.py) on CPU up to sort_v's inputs."""
+    from oracle import rotated_iou as R
     a, b = _cases.box_pairs(seed, n, mode)
-    c1 = R.box2corners_th(a[..., [0, 1, 3, 4, 6]])
-    c2 = R.box2corners_th(b[..., [0, 1, 3, 4, 6]])
-    inters, mi = R.box_intersection_th(c1, c2)
-    c12, c21 = R.box_in_box_th(c1, c2)
-    v, mask = R.build_vertices(c1, c2, c12, c21, inters, mi)
+    c1 = R.bev_corners(a[..., [0, 1, 3, 4, 6]])
+    c2 = R.bev_corners(b[..., [0, 1, 3, 4, 6]])
+    pts, hit = R.edge_crossings(c1, c2)
+    v = torch.cat([c1, c2, pts.reshape(*c1.shape[:2], 16, 2)], 2)
+    mask = torch.cat([R.corners_inside(c1, c2), R.corners_inside(c2, c1), hit.reshape(*c1.shape[:2], 16)], 2)
     nv = torch.sum(mask.int(), dim=2).int()
     mean = torch.sum(v * mask.float().unsqueeze(-1), dim=2, keepdim=True) / nv.unsqueeze(-1).unsqueeze(-1)
     return (v - mean).contiguous(), mask.contiguous(), nv.contiguous(), a, b
