@@ -150,11 +150,14 @@ def transform_gt(boxes, meta, i):
     return semi.transform_boxes(boxes.unsqueeze(0).to(meta.trans.device), one)[0].cpu()
 
 
-def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', resident=0):
+def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', resident=0,
+               noise=None):
     """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
     all-reduce (world > 1), clip, AdamW.  With graph=True the device work of a step is
     captured once into hipGraphs and replayed (the step has no host synchronisation);
-    the RCCL all-reduce stays an ordinary stream operation between the two graphs."""
+    the RCCL all-reduce stays an ordinary stream operation between the two graphs.
+    ``noise`` = a fixed (centre, size) proposal-jitter pair for the tests (default: drawn on
+    the device every step, as the reference does); ``step.inputs`` holds the batch tensors."""
     torch.manual_seed(0)
     on_gpu = device.type == 'cuda'
     pts, boxes, labels = make_batch(seed, batch, NUM_POINTS)
@@ -172,7 +175,6 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         meta_s = semi.AugMeta.random(batch, device, g, strong=True)
         pts_s, pts_t = meta_s.apply_points(pts), meta_t.apply_points(pts)
         lab = [i for i, f in enumerate(use_label) if f]
-        gt_boxes = torch.stack  # noqa: F841
         gt = GTBatch.collate([transform_gt(boxes[i], meta_s, i) for i in lab],
                              [labels[i] for i in lab], device)
         rows = torch.arange(sum(1 for f in use_label if not f), device=device)
@@ -197,6 +199,13 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         pts_next = pts.clone()
         gt_next = GTBatch(gt.boxes.clone(), gt.labels.clone(), gt.count.clone(), gt.valid.clone())
     model.train()
+    if noise is not None:
+        model.bbox_head.jitter_noise = tuple(t.to(device) for t in noise)
+    if workload in ('semi', 'saqe'):
+        inputs = dict(points_s=pts_s, points_t=pts_t, gt=gt, use_label=use_label, meta_s=meta_s,
+                      meta_t=meta_t, rows=rows)
+    else:
+        inputs = dict(points=pts, gt=gt)
     # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
     # all-reduce, the clip and AdamW each see ONE tensor
     bucket = dp.FlatTrainState(model.parameters())
@@ -228,6 +237,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         update()
         return loss_out
 
+    eager_step.inputs, eager_step.optimizer = inputs, opt
     if not (graph and on_gpu):
         return model, eager_step, bucket
 
@@ -340,6 +350,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         stage('update graph replayed')
         return loss_out
     graph_step.eager = eager_step
+    graph_step.inputs, graph_step.optimizer = inputs, opt
     return model, graph_step, bucket
 
 

@@ -58,10 +58,13 @@ def _wgrad(backend, dy, x, x_coef, ng=1):
 
 
 class SAStackFn(Function):
-    """x (B, C0, M, ns) -> max_ns relu(bn_L(conv_L(... relu(bn_1(conv_1(x)))))) (B, C_L, M)."""
+    """x (B, C0, M, ns) -> max_ns relu(bn_L(conv_L(... relu(bn_1(conv_1(x)))))) (B, C_L, M).
+    ``fixed_lead`` = number of leading input channels that are inputs of the step (grouped
+    coordinates of the backbone levels: nothing consumes their gradient).  It must be 0 when the
+    coordinates were computed by the network (vote aggregation groups the predicted votes)."""
 
     @staticmethod
-    def forward(ctx, x, bufs, *params):
+    def forward(ctx, x, bufs, fixed_lead, *params):
         backend = backend_for(x)
         x = x.contiguous()
         B, c0, M, ns = x.shape
@@ -105,7 +108,7 @@ class SAStackFn(Function):
         pooled = x.new_empty(B, cl, M)
         argmax = torch.empty(B, cl, M, dtype=torch.uint8, device=x.device)
         backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
-        ctx.L, ctx.ns = L, ns
+        ctx.L, ctx.ns, ctx.fixed_lead = L, ns, int(fixed_lead)
         ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *means, *invstds, *params)
         ctx.mark_non_differentiable(argmax)
         return pooled
@@ -138,17 +141,21 @@ class SAStackFn(Function):
             w2 = w.reshape(cout, cin)
             src = x3 if l == 0 else ys[l - 1]
             src_coef = None if l == 0 else coefs[l - 1]
-            if ctx.needs_input_grad[2 + 3 * l]:
+            if ctx.needs_input_grad[3 + 3 * l]:
                 grads[3 * l] = _wgrad(backend, dy, src, src_coef).view_as(w)
             if l == 0:
                 if ctx.needs_input_grad[0]:
-                    # grouped input: channels 0..2 are coordinates (no gradient consumer reads them)
-                    skip = 3 if c0 in (131, 259) else 0
+                    # the layer kernel serves up to 256 output rows: the (at most 3) coordinate
+                    # rows in front are a separate skinny product, or zero when nobody reads them
+                    lead = 3 if c0 in (131, 259) else 0
                     dx = dy.new_empty(B, c0, P)
-                    if backend.pw_supported(cout, c0 - skip, P):
-                        backend.pw_layer_forward(dy, w2[:, skip:].t().unsqueeze(0), y=dx[:, skip:])
-                        if skip:
-                            dx[:, :skip].zero_()
+                    if backend.pw_supported(cout, c0 - lead, P):
+                        backend.pw_layer_forward(dy, w2[:, lead:].t().unsqueeze(0), y=dx[:, lead:])
+                        if lead and ctx.fixed_lead >= lead:
+                            dx[:, :lead].zero_()
+                        elif lead:
+                            torch.bmm(w2[:, :lead].t().unsqueeze(0).expand(B, -1, -1), dy,
+                                      out=dx[:, :lead])
                     else:
                         dx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), dy)
                 break
@@ -164,7 +171,7 @@ class SAStackFn(Function):
             dy = dyp
         if dx is not None:
             dx = dx.view(B, c0, M, ns)
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
 def sa_stack_supported(backend, x, layers):
@@ -197,8 +204,9 @@ def sa_stack_supported(backend, x, layers):
     return True
 
 
-def sa_stack(x, layers):
-    """Shared MLP + max pooling of a set-abstraction module through ``SAStackFn``."""
+def sa_stack(x, layers, fixed_lead=0):
+    """Shared MLP + max pooling of a set-abstraction module through ``SAStackFn``;
+    ``fixed_lead`` = leading channels of x whose gradient nobody consumes (see SAStackFn)."""
     from . import norm as _norm
     params, bufs = [], []
     for layer in layers:
@@ -206,7 +214,7 @@ def sa_stack(x, layers):
         params += [layer.conv.weight, n.weight, n.bias]
         bufs.append((n.running_mean, n.running_var, n.momentum, n.eps))
         _norm.count_batch(n.num_batches_tracked)
-    return SAStackFn.apply(x, bufs, *params)
+    return SAStackFn.apply(x, bufs, fixed_lead, *params)
 
 
 # ---- MiniPointNet (side_pooling_module.py:343-370) -------------------------------------------

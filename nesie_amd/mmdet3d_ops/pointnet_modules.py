@@ -264,14 +264,15 @@ class BasePointSAModule(nn.Module):
             raise NotImplementedError
         return new_features.squeeze(-1).contiguous()
 
-    def _mlp_and_pool(self, mlp, grouped):
+    def _mlp_and_pool(self, mlp, grouped, fixed_lead=0):
         """Shared MLP then pooling; with max pooling the last layer's BN + ReLU + max is one
-        fused op (the normalised (B, C, M, ns) tensor is never written)."""
+        fused op (the normalised (B, C, M, ns) tensor is never written).  ``fixed_lead`` = leading
+        channels of ``grouped`` that nothing differentiates (grouped INPUT coordinates)."""
         layers = list(mlp)
         last = layers[-1] if layers else None
         if self.pool_mod == 'max' and all(isinstance(l, ConvModule) for l in layers) and \
                 fused_mlp.sa_stack_supported(backend_for(grouped), grouped, layers):
-            return fused_mlp.sa_stack(grouped, layers)
+            return fused_mlp.sa_stack(grouped, layers, fixed_lead)
         if (self.pool_mod == 'max' and isinstance(last, ConvModule) and last.act_fused
                 and isinstance(last.norm, FusedBNReLU2d)):
             x = grouped
@@ -302,7 +303,10 @@ class BasePointSAModule(nn.Module):
                                                    idx=precomputed['group_idx'][i], csr=csr[i])
             else:
                 grouped_results = self.groupers[i](points_xyz, new_xyz, features)
-            new_features_list.append(self._mlp_and_pool(self.mlps[i], grouped_results))
+            g = self.groupers[i]
+            lead = 3 if (getattr(g, 'use_xyz', False) and features is not None
+                         and not points_xyz.requires_grad and not new_xyz.requires_grad) else 0
+            new_features_list.append(self._mlp_and_pool(self.mlps[i], grouped_results, lead))
         return new_xyz, torch.cat(new_features_list, dim=1), indices
 
 

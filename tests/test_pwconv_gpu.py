@@ -292,6 +292,35 @@ def test_fused_sa_stack_matches_the_module_by_module_path(c_in, mlp, ns):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_fused_sa_stack_carries_the_coordinate_gradient():
+    """Vote aggregation groups coordinates the network predicted: the gradient of the grouped
+    (x, y, z) channels must reach them (the backbone levels group input coordinates and skip it)."""
+    from nesie_amd.mmdet3d_ops import fused_mlp
+    sa = _sa_module(256, [128, 128, 128], 16)
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    xyz0 = torch.rand(2, 512, 3, device=_dev(), generator=g)
+    feats = torch.randn(2, 256, 512, device=_dev(), generator=g)
+
+    def run(enabled):
+        fused_mlp.ENABLED = enabled
+        for p_ in sa.parameters():
+            p_.grad = None
+        xyz = xyz0.clone().requires_grad_(True)
+        f = feats.clone().requires_grad_(True)
+        new_xyz, out, _ = sa(xyz * 1.0, f)
+        (out * torch.linspace(-1, 1, out.numel(), device=_dev()).view_as(out)).sum().backward()
+        return xyz.grad, f.grad, sa.mlps[0][0].conv.weight.grad.clone()
+
+    try:
+        want = run(False)
+        got = run(True)
+    finally:
+        fused_mlp.ENABLED = True
+    assert want[0].abs().max().item() > 0
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * b.abs().max().item())
+
+
 @pytest.mark.parametrize('S,G', [(6, 16), (1, 64)])
 def test_fused_mini_pointnets_match_the_module_by_module_path(S, G):
     from nesie_amd.mmdet3d_ops import fused_mlp
