@@ -124,6 +124,11 @@ def parity_gate(device):
     k = cpu_model.bbox_head.num_proposal
     noise = (torch.randn(2, k, 3, generator=g), torch.randn(2, k, 3, generator=g))
     cpu_model.bbox_head.jitter_noise = noise
+    # ... and the same vote-sampling picks: furthest-point sampling of the PREDICTED votes is a
+    # chain of arg-max decisions that a last-bit difference can flip (oracle/forcing.py); the
+    # sampling kernel itself is compared bit-for-bit on identical inputs in tests/
+    from oracle.forcing import force_vote_sampling
+    sampler = force_vote_sampling(cpu_model, 'bench-gate')
     with kernels.use_backend(oracle.OracleKernels()):
         want = cpu_model.forward_train(pts, None, GTBatch.collate(boxes, labels, torch.device('cpu')), None)
         want = {k: float(v.detach().sum()) for k, v in want.items()}
@@ -131,6 +136,8 @@ def parity_gate(device):
     gpu_model.load_state_dict(state)
     gpu_model.to(device).train()
     gpu_model.bbox_head.jitter_noise = noise
+    gpu_sampler = force_vote_sampling(gpu_model, 'bench-gate-replay')
+    gpu_sampler.key = sampler.key   # replay the CPU leg's picks
     got = gpu_model.forward_train(pts.to(device), None, GTBatch.collate(boxes, labels, device), None)
     got = {k: float(v.detach().sum()) for k, v in got.items()}
     diffs = {k: abs(got[k] - want[k]) / max(1.0, abs(want[k])) for k in want}
@@ -138,7 +145,7 @@ def parity_gate(device):
     del gpu_model, cpu_model
     torch.cuda.empty_cache()
     return dict(passed=bool(diffs[worst] <= 1e-4), max_rel_diff=diffs[worst], worst_term=worst,
-                terms=len(diffs), tolerance=1e-4,
+                terms=len(diffs), tolerance=1e-4, own_vote_picks_agreed=bool(all(gpu_sampler.agreed)),
                 sample='one supervised step, 2 scenes x 40000 pts, same weights and inputs on the '
                        'CPU-oracle leg and the HIP leg')
 
