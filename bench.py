@@ -161,8 +161,10 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                noise=None):
     """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
     all-reduce (world > 1), clip, AdamW.  With graph=True the device work of a step is
-    captured once into hipGraphs and replayed (the step has no host synchronisation);
-    the RCCL all-reduce stays an ordinary stream operation between the two graphs.
+    captured once into hipGraphs and replayed (the step has no host synchronisation): g1a =
+    forward + the head's backward, g1b = the backbone's backward, g2 = clip + AdamW (+ EMA);
+    the RCCL all-reduce of the head's gradient segment runs on a communication stream during
+    g1b, the backbone's segment after it.
     ``noise`` = a fixed (centre, size) proposal-jitter pair for the tests (default: drawn on
     the device every step, as the reference does); ``step.inputs`` holds the batch tensors."""
     torch.manual_seed(0)
@@ -221,16 +223,34 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                             capturable=graph and on_gpu, **(dict(fused=True) if on_gpu
                                                              else dict(foreach=True)))
 
-    def fwd_bwd():
-        bucket.begin()
+    # The backward pass is cut at the backbone's output (dp.backward_head / backward_rest):
+    # the head's gradients (the tail of the flat vector) are complete after phase 1 and their
+    # all-reduce runs on a communication stream while phase 2 (the backbone) still computes.
+    n_bb, e_bb = bucket.split_after(model.backbone.parameters())
+    e_all = bucket.flat.numel()
+    head_params, backbone_params = bucket.params[n_bb:], bucket.params[:n_bb]
+    comm = dp.SegmentedAllReduce(bucket.flat)
+    model.keep_head_inputs = True
+    cut = {}
+
+    def forward_losses(pre=None):
         if workload in ('semi', 'saqe'):
-            losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows)
-        else:
-            losses = model.forward_train(pts, None, gt, None)
-        total = model.parse_losses(losses)
-        total.backward()
-        bucket.collect()
+            return model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows,
+                                       precomputed=pre)
+        return model.forward_train(pts, None, gt, None, precomputed=pre)
+
+    def phase1(pre=None):       # forward + the head's backward
+        bucket.begin()
+        total = model.parse_losses(forward_losses(pre))
+        cut['boundary'] = model.take_head_inputs()
+        cut['grads'] = dp.backward_head(total, cut['boundary'], head_params)
+        bucket.collect(n_bb, None)
         loss_out.copy_(total.detach())
+
+    def phase2():               # the backbone's backward
+        dp.backward_rest(cut['boundary'], cut['grads'], backbone_params)
+        bucket.collect(0, n_bb)
+        cut.clear()
 
     def update():
         torch.nn.utils.clip_grad_norm_([bucket.flat_param], max_norm=10, norm_type=2)
@@ -238,9 +258,12 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         if workload in ('semi', 'saqe'):
             model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)
 
-    def eager_step():
-        fwd_bwd()
-        bucket.all_reduce_mean()
+    def eager_step(pre=None):
+        phase1(pre)
+        comm.launch(e_bb, e_all)
+        phase2()
+        comm.launch(0, e_bb)
+        comm.wait()
         update()
         return loss_out
 
@@ -293,34 +316,24 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     stage('first input-only pass (eager)')
     nlev = len(idx_cur) // 2 if semi_like else len(idx_cur)
 
-    def fwd_bwd_pre():
-        bucket.begin()
+    def current_indices():
         if semi_like:
-            losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows,
-                                         precomputed=dict(student=idx_cur[:nlev],
-                                                          teacher=idx_cur[nlev:]))
-        else:
-            losses = model.forward_train(pts, None, gt, None,
-                                         precomputed=dict(indices=idx_cur,
-                                                          vote_targets=tuple(votes_cur)))
-        total = model.parse_losses(losses)
-        total.backward()
-        bucket.collect()
-        loss_out.copy_(total.detach())
+            return dict(student=idx_cur[:nlev], teacher=idx_cur[nlev:])
+        return dict(indices=idx_cur, vote_targets=tuple(votes_cur))
 
     side.wait_stream(main)
     with torch.cuda.stream(side):
         for _ in range(2):  # warm allocator / library handles before capture
-            fwd_bwd_pre()
-            bucket.all_reduce_mean()
-            update()
+            eager_step(current_indices())
     main.wait_stream(side)
     torch.cuda.synchronize(device)
     stage('eager warm-up steps')
-    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g1):
-        fwd_bwd_pre()
-    with torch.cuda.graph(g2, pool=g1.pool()):
+    g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1a):
+        phase1(current_indices())
+    with torch.cuda.graph(g1b, pool=g1a.pool()):
+        phase2()
+    with torch.cuda.graph(g2, pool=g1a.pool()):
         update()
     stage('step graphs captured')
     if pipelined:
@@ -350,9 +363,12 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                     g_idx.replay()
                 ready.record(side)
         stage('input graph launched for the next step')
-        g1.replay()
-        stage('forward/backward graph replayed')
-        bucket.all_reduce_mean()
+        g1a.replay()                 # forward + head backward
+        comm.launch(e_bb, e_all)     # the head's gradients travel ...
+        g1b.replay()                 # ... while the backbone's backward computes
+        comm.launch(0, e_bb)
+        comm.wait()
+        stage('forward/backward graphs replayed')
         g2.replay()
         stage('update graph replayed')
         return loss_out
@@ -509,6 +525,8 @@ def main():
                        'hip_graph': bool(args.graph),
                        'index_chain_pipelined': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes(),
+                       'grad_allreduce': 'two segments on a communication stream: head gradients '
+                                         'during the backbone backward graph, backbone gradients after it',
                        'resident_input_scenes': args.resident_input},
         }
         # HBM-streaming kernels, priced on their largest launches (537 MB / 268 MB tensors at

@@ -101,27 +101,102 @@ class FlatTrainState(FlatGradBucket):
         self._held = []
 
     def begin(self):
+        self._held = []
         for p in self.params:
             p.grad = None
 
-    def collect(self):
+    def split_after(self, first_params):
+        """-> (number of parameters, number of elements) of the leading block ``first_params``
+        (which must be a prefix of the bucket's parameter order, e.g. ``model.backbone``)."""
+        first = [p for p in first_params if p.requires_grad]
+        assert [id(p) for p in first] == [id(p) for p in self.params[:len(first)]], \
+            'not a prefix of the bucket'
+        return len(first), sum(p.numel() for p in first)
+
+    def collect(self, lo=0, hi=None):
+        """Gather the gradients of parameters [lo, hi) (default: all) into the flat vector."""
         src, dst, missing = [], [], []
-        for p, v in zip(self.params, self.grad_views):
+        for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:
                 missing.append(v)
             else:
                 src.append(p.grad)
                 dst.append(v)
-        self._held = src  # keeps graph-pool gradients alive between capture and replays
+        self._held = self._held + src  # keeps graph-pool gradients alive between capture and replays
         if dst:
             torch._foreach_copy_(dst, src)
         if missing:
             torch._foreach_zero_(missing)
-        for p, v in zip(self.params, self.grad_views):
+        for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             p.grad = v
 
     def zero_(self):
         self.flat.zero_()
+
+
+def backward_head(total, boundary, early_params):
+    """Phase 1 of a backward pass cut at ``boundary`` (tensors every path from the loss to the
+    remaining parameters runs through -- the backbone's output): the gradients of
+    ``early_params`` (the head) land in ``p.grad`` as fresh tensors; -> the boundary gradients."""
+    early, boundary = list(early_params), list(boundary)
+    g = torch.autograd.grad(total, boundary + early, allow_unused=True)
+    for p, gp in zip(early, g[len(boundary):]):
+        p.grad = gp
+    return g[:len(boundary)]
+
+
+def backward_rest(boundary, boundary_grads, late_params):
+    """Phase 2: carry the boundary gradients down to ``late_params`` (the backbone)."""
+    late = list(late_params)
+    live = [(b, gb) for b, gb in zip(boundary, boundary_grads) if gb is not None]
+    gl = torch.autograd.grad([b for b, _ in live], late, grad_outputs=[gb for _, gb in live],
+                             allow_unused=True)
+    for p, gp in zip(late, gl):
+        p.grad = gp
+
+
+def backward_in_two_phases(total, boundary, early_params, late_params, between=None):
+    """``total.backward()`` in two phases with ``between()`` in the middle.  With the phases in
+    two hipGraphs (bench.py) the head's share of the gradient all-reduce travels while the
+    backbone's backward pass still computes."""
+    gb = backward_head(total, boundary, early_params)
+    if between is not None:
+        between()
+    backward_rest(boundary, gb, late_params)
+
+
+class SegmentedAllReduce:
+    """all-reduce(mean) of segments of the flat gradient on a communication stream of its own:
+    ``launch(lo, hi)`` orders the segment's exchange after everything already queued on the
+    current stream and returns at once; ``wait()`` makes the current stream wait for every
+    exchange launched so far.  A single process (or no process group) does nothing; on the CPU
+    (gloo) the exchange is synchronous."""
+
+    def __init__(self, flat, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.stream = torch.cuda.Stream(flat.device) if flat.is_cuda and self.world > 1 else None
+        self.launched = []
+
+    def launch(self, lo, hi):
+        self.launched.append((lo, hi))
+        if self.world == 1:
+            return
+        seg = self.flat[lo:hi]
+        if self.stream is None:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            seg.div_(self.world)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            seg.div_(self.world)
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        done, self.launched = self.launched, []
+        return done
 
 
 def shard_range(total, rank, world):

@@ -89,6 +89,14 @@ class VoteNet(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
 
+    keep_head_inputs = False
+    head_inputs = None
+
+    def take_head_inputs(self):
+        """The boundary tensors of the last forward_train (needs ``keep_head_inputs = True``)."""
+        out, self.head_inputs = self.head_inputs, None
+        return out
+
     def extract_feat(self, points, precomputed=None):
         return self.backbone(points, precomputed=precomputed)
 
@@ -101,6 +109,11 @@ class VoteNet(nn.Module):
             precomputed, votes = precomputed.get('indices'), precomputed.get('vote_targets')
         with deferred_bn_counters():  # one launch for all num_batches_tracked increments
             x = self.extract_feat(points_cat, precomputed)
+            if self.keep_head_inputs:
+                # the one tensor that carries gradient from the head back into the backbone
+                # (dp.backward_in_two_phases cuts the backward pass here); opt-in, because it
+                # keeps the autograd graph alive until take_head_inputs()
+                self.head_inputs = [x['fp_features'][-1]]
             bbox_preds = self.bbox_head(x, self.train_cfg['sample_mod'])
         return self.bbox_head.loss(bbox_preds, points_cat, gt_bboxes_3d, gt_labels_3d,
                                    pts_semantic_mask, pts_instance_mask, img_metas,

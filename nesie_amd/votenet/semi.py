@@ -370,6 +370,8 @@ class VoteNetNesie(VoteNet):
         name = cfg.get('dataset_name', 'ScanNet')
         with deferred_bn_counters():
             x_s = self.extract_feat(points_s, pre.get('student'))
+            if self.keep_head_inputs:
+                self.head_inputs = [x_s['fp_features'][-1]]
             preds_s = self.bbox_head(x_s, cfg['sample_mod'], name)
             with torch.no_grad():
                 self.teacher.swap()                  # call_hook("switch_to_teacher")
