@@ -300,6 +300,15 @@ int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const flo
                            float *d_row_bias, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* The apply pass of nesie_bn_relu_backward alone (relu, y == NULL form), for a producer that has
+ * already left the reduction's partials: partial[(ch * nslice + i) * 2 + {0, 1}] = sum(g),
+ * sum(g * xhat) over slice i (nesie_pw_dgrad_bn_reduce).  dgamma / dbeta are written. */
+int nesie_bn_relu_backward_apply(int b, int c, long long p, const float *dy, const float *x,
+                                 const float *gamma, const float *save_invstd,
+                                 const float *fwd_coef, const float *partial, int nslice,
+                                 float *dx, float *dgamma, float *dbeta, int group,
+                                 float *d_row_bias, void *stream);
+
 /* Training BatchNorm + ReLU + max over the neighbourhood axis for the LAST layer of a
  * set-abstraction MLP: x[B, C, M, ns] -> pooled[B, C, M] (+ argmax[B, C, M], one byte, smallest
  * index on ties) without writing the normalised tensor.  Reference: ConvModule's BN2d + ReLU
@@ -416,6 +425,19 @@ int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p, const f
                            long long y_bstride, float *stat_part, int pool_group, int pool_min,
                            float *pool_max_out, float *pool_min_out, uint8_t *arg_max_out,
                            uint8_t *arg_min_out, void *stream);
+/* Input gradient of a layer whose input was relu(bn(Z)): y[n] = W[n % ng] . x[n] (W = the
+ * transposed weight view, x = the gradient of the layer's raw output) as nesie_pw_layer_forward
+ * computes it, and in the same launch the reduction pass of that BatchNorm's backward
+ * (torch.nn.BatchNorm2d backward behind mmcv ConvModule, point_sa_module.py:277-289):
+ *   bn_part[(g*cout + m) * nslots + slot][2] = sum(gg), sum(gg * zhat) over the slot's positions,
+ *   gg = y [fma(Z, bn_coef[.][0], bn_coef[.][1]) > 0], zhat = (Z - bn_coef[.][2]) * bn_coef[.][3]
+ * Z[n] (cout, p) at bn_z + n*bnz_bstride; nslots = nesie_pw_stat_slots(nb, ng, k, cout, p), every
+ * slot is written; nesie_bn_relu_backward_apply consumes bn_part with nslice = nslots. */
+int nesie_pw_dgrad_bn_reduce(int nb, int ng, int k, int cout, long long p, const float *x,
+                             long long x_bstride, const float *w, long long w_gstride,
+                             int w_rstride, int w_cstride, float *y, long long y_bstride,
+                             const float *bn_z, long long bnz_bstride, const float *bn_coef,
+                             float *bn_part, void *stream);
 /* stat_part -> coef[ch][4] = (scale, bias, mean, invstd), scale = gamma * invstd, bias = beta -
  * mean * scale (fp64, Chan's merge of the shifted partials), running statistics updated like
  * torch.nn.BatchNorm2d in training mode.  channels = ng * cout (stacked layers). */

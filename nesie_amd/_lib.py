@@ -69,6 +69,11 @@ SIGNATURES = {
     "nesie_pw_layer_forward": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                                ctypes.c_longlong, _I, _I, _P, _I, _P, _I, _P, _P, ctypes.c_longlong,
                                _P, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_pw_dgrad_bn_reduce": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                                 ctypes.c_longlong, _I, _I, _P, ctypes.c_longlong, _P,
+                                 ctypes.c_longlong, _P, _P, _P],
+    "nesie_bn_relu_backward_apply": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _I, _P,
+                                     _P, _P, _I, _P, _P],
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P],

@@ -568,6 +568,37 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
 }
 
 
+// The apply pass alone, for a producer that has already left the reduction's partials
+// (partial[(c * nslice + i) * 2 + {0,1}] = sum(g), sum(g * xhat); pwconv.hip's
+// nesie_pw_dgrad_bn_reduce): x is the RAW conv output of a fused forward (mask = fma(x, scale,
+// bias) > 0), dx = gamma invstd (g - sum(g)/n - xhat sum(g xhat)/n); dgamma / dbeta written.
+extern "C" int nesie_bn_relu_backward_apply(int b, int c, long long p, const float *dy,
+                                            const float *x, const float *gamma,
+                                            const float *save_invstd, const float *fwd_coef,
+                                            const float *partial, int nslice, float *dx,
+                                            float *dgamma, float *dbeta, int group,
+                                            float *d_row_bias, void *stream) {
+  const char *W = "bn_relu_backward_apply";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && p >= 0 && nslice >= 1, W);
+  if (b == 0 || c == 0 || p == 0) return NESIE_OK;
+  NESIE_REQUIRE(dy && x && dx && save_invstd && fwd_coef && partial, W);
+  if (!d_row_bias) group = 1;
+  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
+  NESIE_REQUIRE(!d_row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
+  NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(bn_sp(p), c, b);
+  const bool nt = bn_use_nt((long long)b * c * p);
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  if (nt)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x,
+                       fwd_coef, fin, (const float *)nullptr, group, d_row_bias, dx, 1);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x,
+                       fwd_coef, fin, (const float *)nullptr, group, d_row_bias, dx, 1);
+  return check_launch(W);
+}
+
 // For producers that compute the (sum, sum of squares) partials themselves
 // (partial[(c * nslice + i) * 2 + {0,1}], unshifted): interpolate.hip's blend + norm kernels.
 namespace nesie {

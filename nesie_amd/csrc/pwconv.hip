@@ -114,6 +114,7 @@ enum : int {
   PW_ROWBIAS = 16,  // Y += row_bias[n][m][pos / rb_group] before anything else
   PW_BIAS = 32,     // Y += bias[m]
   PW_AFFINE = 64,   // operand = max(scale * x + bias, lo)
+  PW_BNRED = 128,   // Y is the gradient of relu(bn(Z)): partial sums of g = Y [bn(Z) > 0] and g * zhat
 };
 
 struct PwFwd {
@@ -125,6 +126,8 @@ struct PwFwd {
   const float *bias;                       // [ng * cout]
   float *stat_part; int nslots;            // [ng][nslots][cout][4]
   float *pool_max, *pool_min; uint8_t *arg_max, *arg_min;  // (nb, cout, p / PG)
+  const float *bn_z; long long bnz_bs;     // PW_BNRED: raw conv output Z (nb, cout, p) ...
+  const float *bn_coef; float *bn_part;    // ... its [ng * cout][4] (scale, bias, mean, invstd); [ng * cout][nslots][2]
   int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout (128 rows each)
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
@@ -257,6 +260,22 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
   // byte offset of (row m, position q0 + 4 quad) from the tile's first output word
   const unsigned roff = (unsigned)(((size_t)m * p + q0 + 4 * quad) * 4);
 
+  // PW_BNRED: the raw output Z of the layer whose activation gradient this launch produces, at
+  // this lane's output elements (loaded ahead of the MFMAs of the tile), and the two sums
+  f32x4 zv[(EPI & PW_BNRED) ? NBLK : 1];
+  float r0 = 0.f, r1 = 0.f;
+  float4 zc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI & PW_BNRED) {
+    if (m < cout) zc = *(const float4 *)(a.bn_coef + ((size_t)g * cout + m) * 4);
+    asm volatile("" : "+v"(zc.x), "+v"(zc.y), "+v"(zc.z), "+v"(zc.w));
+  }
+  auto load_z = [&](int n, long long p0) {
+    const float *zt = a.bn_z + (size_t)n * a.bnz_bs + p0;   // wave-uniform
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+      zv[j] = m < cout ? load16_saddr(roff + 64u * j, zt) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
   f32x4 acc[NBLK];
   auto epilogue = [&](int n, long long p0) {
     constexpr bool full = true;   // p % PT == 0
@@ -276,6 +295,15 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
         }
         if (EPI & PW_STORE) {
           if (m < cout) store16_saddr<64 * j>(roff, acc[j], ytile);
+        }
+        if (EPI & PW_BNRED) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = zv[j][r];
+            const float gg = __builtin_fmaf(z, zc.x, zc.y) > 0.f ? acc[j][r] : 0.f;
+            r0 += gg;
+            r1 += gg * ((z - zc.z) * zc.w);
+          }
         }
         if (EPI & PW_STATS) {
           if (nblk_done == 0) shift = __shfl(acc[j][0], l16, 64);   // first value of the channel
@@ -358,6 +386,7 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
 #ifdef PW_INTERLEAVE
     const float *nxb = a.x + (size_t)(g + a.ng * nq) * a.x_bs + (long long)nr * PT;   // uniform
 #else
+    if (EPI & PW_BNRED) load_z(g + a.ng * tq, (long long)tr * PT);   // older than the operand loads
     if (more) load_tile(g + a.ng * nq, (long long)nr * PT);
 #endif
     STAMP(2)
@@ -440,6 +469,13 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
     float *const tb = b0; b0 = b1; b1 = tb;
   }
   STAMP_CLK(1)
+  if (EPI & PW_BNRED) {
+    const int slot = rank * WC + wc;
+    r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64);
+    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);
+    if (quad == 0 && m < cout)
+      *(float2 *)(a.bn_part + (((size_t)g * cout + m) * a.nslots + slot) * 2) = make_float2(r0, r1);
+  }
   if (EPI & PW_STATS) {
     // one partial per wave: (count, shift, sum, sum of squares) of its 16 channels; the four
     // quads hold different positions of the same channel
@@ -588,8 +624,9 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WR *WC * 64), lds, s, a);                       \
     return NESIE_OK;                                                                          \
   } while (0)
-#ifdef PW_DEV   // tools/pwbench development build: three instantiations per geometry
+#ifdef PW_DEV   // tools/pwbench development build: a few instantiations per geometry
   if (epi == PW_STORE) GO(PW_STORE, 16);
+  if (epi == (PW_STORE | PW_BNRED)) GO(PW_STORE | PW_BNRED, 16);
   if (epi == (PW_AFFINE | PW_STORE | PW_STATS)) GO(PW_AFFINE | PW_STORE | PW_STATS, 16);
   if (epi == (PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
     GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
@@ -614,6 +651,7 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
       GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
   } else {
     if (base == PW_STORE) GO(PW_STORE, 16);
+    if (base == (PW_STORE | PW_BNRED)) GO(PW_STORE | PW_BNRED, 16);
     if (base == (PW_STORE | PW_STATS)) GO(PW_STORE | PW_STATS, 16);
     if (base == (PW_STORE | PW_STATS | PW_ROWBIAS)) GO(PW_STORE | PW_STATS | PW_ROWBIAS, 16);
   }
@@ -623,15 +661,16 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
 #undef GO
 }
 
-extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p,
-                                      const float *x, long long x_bstride, const float *w,
-                                      long long w_gstride, int w_rstride, int w_cstride,
-                                      const float *in_coef, int in_relu, const float *row_bias,
-                                      int rb_group, const float *bias, float *y,
-                                      long long y_bstride, float *stat_part, int pool_group,
-                                      int pool_min, float *pool_max_out, float *pool_min_out,
-                                      uint8_t *arg_max_out, uint8_t *arg_min_out, void *stream) {
-  const char *W = "pw_layer_forward";
+static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long long p,
+                           const float *x, long long x_bstride, const float *w,
+                           long long w_gstride, int w_rstride, int w_cstride,
+                           const float *in_coef, int in_relu, const float *row_bias,
+                           int rb_group, const float *bias, float *y,
+                           long long y_bstride, float *stat_part, int pool_group,
+                           int pool_min, float *pool_max_out, float *pool_min_out,
+                           uint8_t *arg_max_out, uint8_t *arg_min_out, const float *bn_z,
+                           long long bnz_bstride, const float *bn_coef, float *bn_part,
+                           void *stream) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && k >= 1 && cout >= 1 && p >= 0, W);
   if (nb == 0 || p == 0) return NESIE_OK;
   NESIE_REQUIRE(nb % ng == 0 && x && w, W);
@@ -651,6 +690,10 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
     epi |= PW_ROWBIAS;
   }
   if (bias) epi |= PW_BIAS;
+  if (bn_z) {
+    NESIE_REQUIRE(y && bn_coef && bn_part && ((uintptr_t)bn_z & 15) == 0 && (bnz_bstride & 3) == 0, W);
+    epi |= PW_BNRED;
+  }
   if (pool_group) {
     NESIE_REQUIRE(pool_group == 16 || pool_group == 32, W);
     NESIE_REQUIRE(pool_max_out && arg_max_out && p % pool_group == 0, W);
@@ -667,6 +710,7 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
   a.bias = bias;
   a.stat_part = stat_part;
   a.pool_max = pool_max_out; a.pool_min = pool_min_out; a.arg_max = arg_max_out; a.arg_min = arg_min_out;
+  a.bn_z = bn_z; a.bnz_bs = bnz_bstride; a.bn_coef = bn_coef; a.bn_part = bn_part;
   a.stamps = nullptr;
 #ifdef PW_STAMP
   a.stamps = g_pw_stamps;
@@ -697,6 +741,38 @@ extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long
     return st;
   }
   return check_launch(W);
+}
+
+extern "C" int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p,
+                                      const float *x, long long x_bstride, const float *w,
+                                      long long w_gstride, int w_rstride, int w_cstride,
+                                      const float *in_coef, int in_relu, const float *row_bias,
+                                      int rb_group, const float *bias, float *y,
+                                      long long y_bstride, float *stat_part, int pool_group,
+                                      int pool_min, float *pool_max_out, float *pool_min_out,
+                                      uint8_t *arg_max_out, uint8_t *arg_min_out, void *stream) {
+  return pw_forward_impl("pw_layer_forward", nb, ng, k, cout, p, x, x_bstride, w, w_gstride,
+                         w_rstride, w_cstride, in_coef, in_relu, row_bias, rb_group, bias, y,
+                         y_bstride, stat_part, pool_group, pool_min, pool_max_out, pool_min_out,
+                         arg_max_out, arg_min_out, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// Input gradient of a layer, Y[n] = W[n % ng] . X[n] with W the transposed weight view, whose
+// consumer is the backward of relu(bn(Z)) (Z = the previous layer's raw output, same shape as
+// Y): the epilogue also leaves, per channel and slot, sum(g) and sum(g * zhat) with
+// g = Y [fma(Z, scale, bias) > 0] -- the reduction pass of the BatchNorm backward.
+// bn_part: [ng * cout][nesie_pw_stat_slots(...)][2], every slot written.
+extern "C" int nesie_pw_dgrad_bn_reduce(int nb, int ng, int k, int cout, long long p,
+                                        const float *x, long long x_bstride, const float *w,
+                                        long long w_gstride, int w_rstride, int w_cstride,
+                                        float *y, long long y_bstride, const float *bn_z,
+                                        long long bnz_bstride, const float *bn_coef,
+                                        float *bn_part, void *stream) {
+  const char *W = "pw_dgrad_bn_reduce";
+  NESIE_REQUIRE(y && bn_z && bn_coef && bn_part, W);
+  return pw_forward_impl(W, nb, ng, k, cout, p, x, x_bstride, w, w_gstride, w_rstride, w_cstride,
+                         nullptr, 0, nullptr, 0, nullptr, y, y_bstride, nullptr, 0, 0, nullptr,
+                         nullptr, nullptr, nullptr, bn_z, bnz_bstride, bn_coef, bn_part, stream);
 }
 
 extern "C" int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,

@@ -650,6 +650,45 @@ class HipKernels(_BNPoolMixin):
                       int(pool_group),
                       int(bool(pool_min)), opt(pmax), opt(pmin), opt(amax), opt(amin), _stream(x))
 
+    def pw_dgrad_bn_reduce(self, dy, w, z, z_coef, da, ng=1):
+        """da[n] = W[n % ng] . dy[n] (w = the transposed weight view (ng, Cin, Cout)) plus the
+        reduction of the backward of relu(bn(z)) that consumes da (nesie_pw_dgrad_bn_reduce):
+        -> partials (ng*Cin, slots, 2) for ``bn_relu_backward_apply``.  z (NB, Cin, P) raw conv
+        output, z_coef (ng*Cin, 4) its folded BatchNorm."""
+        _f32(dy, w, z, da); _check(z_coef); _f32(z_coef)
+        nb, k, p = dy.shape
+        cout = w.shape[1]
+        assert w.dim() == 3 and w.shape[0] == ng and w.shape[2] == k and nb % ng == 0
+        for t in (dy, z, da):
+            assert t.is_cuda and t.stride(2) == 1 and t.stride(1) == p
+        assert tuple(z.shape) == (nb, cout, p) == tuple(da.shape) and tuple(z_coef.shape) == (ng * cout, 4)
+        part = torch.empty(ng * cout, self.pw_stat_slots(nb, ng, k, cout, p), 2,
+                           dtype=torch.float32, device=dy.device)
+        bs = lambda t, rows: t.stride(0) if nb > 1 else rows * p  # noqa: E731
+        with torch.cuda.device(dy.device):
+            _lib.call("nesie_pw_dgrad_bn_reduce", nb, ng, k, cout, p, _ptr(dy), bs(dy, k), _ptr(w),
+                      w.stride(0) if ng > 1 else 0, w.stride(1), w.stride(2), _ptr(da),
+                      bs(da, cout), _ptr(z), bs(z, cout), _ptr(z_coef), _ptr(part), _stream(dy))
+        return part
+
+    def bn_relu_backward_apply(self, dy, x, gamma, save_invstd, fwd_coef, partial, dx, dgamma,
+                               dbeta, d_row_bias=None, group=None):
+        """Apply pass of the BatchNorm + ReLU backward from ready partials (C, nslice, 2); x is
+        the raw conv output of the fused forward (nesie_bn_relu_backward_apply)."""
+        _check(dy, x, dx, save_invstd, fwd_coef, partial); _f32(dy, x, dx, partial)
+        b, c = x.shape[:2]
+        p = x.numel() // (b * c) if b * c else 0
+        assert partial.dim() == 3 and partial.shape[0] == c and partial.shape[2] == 2
+        if d_row_bias is not None:
+            _check(d_row_bias); _f32(d_row_bias)
+            assert group and d_row_bias.numel() == b * c * (p // group)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_bn_relu_backward_apply", b, c, p, _ptr(dy), _ptr(x), opt(gamma),
+                      _ptr(save_invstd), _ptr(fwd_coef), _ptr(partial), int(partial.shape[1]),
+                      _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
+                      _stream(x))
+
     def pw_stats_finalize(self, stat_part, gamma, beta, running_mean, running_var, momentum, eps,
                           coef):
         """(ng, slots, Cout, 4) shifted partials -> coef (ng*Cout, 4) = (scale, bias, mean,

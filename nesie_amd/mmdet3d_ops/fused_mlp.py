@@ -161,12 +161,11 @@ class SAStackFn(Function):
                 break
             # gradient of the previous layer's activation, then through its BatchNorm + ReLU
             da = dy.new_empty(B, cin, P)
-            backend.pw_layer_forward(dy, w2.t().unsqueeze(0), y=da)
+            part = backend.pw_dgrad_bn_reduce(dy, w2.t().unsqueeze(0), ys[l - 1], coefs[l - 1], da)
             dyp = torch.empty_like(da)
             dgamma, dbeta = g.new_empty(cin), g.new_empty(cin)
-            backend.bn_relu_backward(da, ys[l - 1], None, params[3 * (l - 1) + 1],
-                                     params[3 * (l - 1) + 2], means[l - 1], invstds[l - 1],
-                                     coefs[l - 1], True, dyp, dgamma, dbeta)
+            backend.bn_relu_backward_apply(da, ys[l - 1], params[3 * (l - 1) + 1], invstds[l - 1],
+                                           coefs[l - 1], part, dyp, dgamma, dbeta)
             grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dgamma, dbeta
             dy = dyp
         if dx is not None:
@@ -280,11 +279,11 @@ class MiniHeadFn(Function):
             # per-net weight gradient: the S nets are the S strided batch subsets
             dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
         da0 = c0.new_empty(B * S, H0, P)
-        backend.pw_layer_forward(dcf, w3.transpose(1, 2), ng=S, y=da0)
+        part = backend.pw_dgrad_bn_reduce(dcf, w3.transpose(1, 2), x0, coef0, da0, ng=S)
         dc0 = torch.empty_like(c0)
         dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
-        backend.bn_relu_backward(da0.view(B, S * H0, P), c0.view(B, S * H0, P), None, gamma0, beta0,
-                                 mean0, invstd0, coef0, True, dc0.view(B, S * H0, P), dgamma, dbeta)
+        backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
+                                       invstd0, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
         return dc0, None, None, None, dgamma, dbeta, dw3
 
 
@@ -337,13 +336,13 @@ class MiniTailFn(Function):
         if ctx.needs_input_grad[7]:
             dw4 = _wgrad(backend, dzf, yf, coef1, ng=S)
         da = c.new_empty(B * S, H2, P)
-        backend.pw_layer_forward(dzf, w4.transpose(1, 2), ng=S, y=da)
+        part = backend.pw_dgrad_bn_reduce(dzf, w4.transpose(1, 2), yf, coef1, da, ng=S)
         dy = torch.empty_like(y)
         dgamma, dbeta = c.new_empty(S * H2), c.new_empty(S * H2)
         dsmall = c.new_empty(B, S, H2, P // G)
-        backend.bn_relu_backward(da.view(B, S * H2, P), y.view(B, S * H2, P), None, gamma1, beta1,
-                                 mean1, invstd1, coef1, True, dy.view(B, S * H2, P), dgamma, dbeta,
-                                 d_row_bias=dsmall.view(B, S * H2, -1), group=G)
+        backend.bn_relu_backward_apply(da.view(B, S * H2, P), y.view(B, S * H2, P), gamma1,
+                                       invstd1, coef1, part, dy.view(B, S * H2, P), dgamma, dbeta,
+                                       d_row_bias=dsmall.view(B, S * H2, -1), group=G)
         dyf = dy.view(B * S, H2, P)
         cf = c.view(B * S, half, P)
         dwl = None

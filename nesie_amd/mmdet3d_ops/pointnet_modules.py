@@ -6,6 +6,7 @@
 ``activate`` so reference checkpoints' keys line up, Kaiming-normal(fan_out, relu)
 conv weights, unit norm weight, zero biases.
 """
+from collections import OrderedDict
 from typing import List
 
 import torch
@@ -16,7 +17,7 @@ from ..kernels import backend_for
 from . import fused_mlp
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
-from .group_points import GroupAll, QueryAndGroup, inverted_index
+from .group_points import QueryAndGroup, inverted_index
 from .interpolate import three_interpolate, three_nn
 from .norm import FusedBNReLU1d, FusedBNReLU2d
 from .pool import group_max_pool
@@ -202,58 +203,52 @@ class ConvModule(nn.Module):
 
 
 class BasePointSAModule(nn.Module):
-    """sample -> group -> shared MLP -> pool (point_sa_module.py:12-211)."""
+    """Set abstraction: sample centres, group a neighbourhood around each (one grouper per
+    scale), run the scale's shared MLP over every neighbourhood, pool it, concatenate the scales.
+    Constructor keywords and attribute names as in point_sa_module.py:12-211."""
 
     def __init__(self, num_point, radii, sample_nums, mlp_channels, fps_mod=['D-FPS'],
                  fps_sample_range_list=[-1], dilated_group=False, use_xyz=True,
                  pool_mod='max', normalize_xyz=False, grouper_return_grouped_xyz=False,
                  grouper_return_grouped_idx=False):
         super().__init__()
-        assert len(radii) == len(sample_nums) == len(mlp_channels)
-        assert pool_mod in ['max', 'avg']
-        assert isinstance(fps_mod, (list, tuple))
-        assert isinstance(fps_sample_range_list, (list, tuple))
-        assert len(fps_mod) == len(fps_sample_range_list)
-        if isinstance(mlp_channels, tuple):
-            mlp_channels = list(map(list, mlp_channels))
-        self.mlp_channels = mlp_channels
+        scales = len(radii)
+        if not (len(sample_nums) == scales == len(mlp_channels)):
+            raise AssertionError('radii, sample_nums and mlp_channels need one entry per scale')
+        if pool_mod not in ('max', 'avg'):
+            raise AssertionError(f'unknown pool_mod {pool_mod!r}')
+        if not (isinstance(fps_mod, (list, tuple)) and isinstance(fps_sample_range_list, (list, tuple))
+                and len(fps_mod) == len(fps_sample_range_list)):
+            raise AssertionError('fps_mod and fps_sample_range_list must be sequences of one length')
         if isinstance(num_point, int):
-            self.num_point = [num_point]
-        elif isinstance(num_point, (list, tuple)):
-            self.num_point = num_point
-        else:
+            num_point = [num_point]
+        elif not isinstance(num_point, (list, tuple)):
             raise NotImplementedError('Error type of num_point!')
+        self.num_point = num_point
+        self.mlp_channels = [list(widths) for widths in mlp_channels]
         self.pool_mod = pool_mod
-        self.groupers = nn.ModuleList()
+        self.fps_mod_list, self.fps_sample_range_list = fps_mod, fps_sample_range_list
+        self.points_sampler = Points_Sampler(self.num_point, fps_mod, fps_sample_range_list)
+        # dilated grouping: scale i only takes neighbours beyond the previous scale's radius
+        inner = [0] + list(radii[:-1]) if dilated_group else [0] * scales
+        self.groupers = nn.ModuleList(
+            QueryAndGroup(outer, count, min_radius=lo, use_xyz=use_xyz, normalize_xyz=normalize_xyz,
+                          return_grouped_xyz=grouper_return_grouped_xyz,
+                          return_grouped_idx=grouper_return_grouped_idx)
+            for outer, count, lo in zip(radii, sample_nums, inner))
         self.mlps = nn.ModuleList()
-        self.fps_mod_list = fps_mod
-        self.fps_sample_range_list = fps_sample_range_list
-        self.points_sampler = Points_Sampler(self.num_point, self.fps_mod_list,
-                                             self.fps_sample_range_list)
-        for i in range(len(radii)):
-            if num_point is not None:
-                min_radius = radii[i - 1] if (dilated_group and i != 0) else 0
-                grouper = QueryAndGroup(radii[i], sample_nums[i], min_radius=min_radius,
-                                        use_xyz=use_xyz, normalize_xyz=normalize_xyz,
-                                        return_grouped_xyz=grouper_return_grouped_xyz,
-                                        return_grouped_idx=grouper_return_grouped_idx)
-            else:
-                grouper = GroupAll(use_xyz)
-            self.groupers.append(grouper)
 
     def _sample_points(self, points_xyz, features, indices, target_xyz):
-        xyz_flipped = points_xyz.transpose(1, 2).contiguous()
-        if indices is not None:
-            assert indices.shape[1] == self.num_point[0]
-            new_xyz = gather_points(xyz_flipped, indices).transpose(1, 2).contiguous() \
-                if self.num_point is not None else None
-        elif target_xyz is not None:
-            new_xyz = target_xyz.contiguous()
-        else:
+        """-> (centres (B, M, 3), their indices or None): given indices win, then given target
+        coordinates, else the configured sampler picks."""
+        if indices is None and target_xyz is not None:
+            return target_xyz.contiguous(), None
+        if indices is None:
             indices = self.points_sampler(points_xyz, features)
-            new_xyz = gather_points(xyz_flipped, indices).transpose(1, 2).contiguous() \
-                if self.num_point is not None else None
-        return new_xyz, indices
+        elif indices.shape[1] != self.num_point[0]:
+            raise AssertionError('indices must name num_point centres')
+        channel_major = points_xyz.transpose(1, 2).contiguous()
+        return gather_points(channel_major, indices).transpose(1, 2).contiguous(), indices
 
     def _pool_features(self, features):
         if self.pool_mod == 'max':
@@ -310,99 +305,87 @@ class BasePointSAModule(nn.Module):
         return new_xyz, torch.cat(new_features_list, dim=1), indices
 
 
+def _shared_mlp(widths, norm_cfg, **conv_kw):
+    """1x1 Conv2d -> norm -> ReLU per consecutive width pair, sub-modules ``layer0``, ``layer1`` ..."""
+    return nn.Sequential(OrderedDict(
+        (f'layer{j}', ConvModule(cin, cout, kernel_size=(1, 1), stride=(1, 1),
+                                 conv_cfg=dict(type='Conv2d'), norm_cfg=norm_cfg, **conv_kw))
+        for j, (cin, cout) in enumerate(zip(widths, widths[1:]))))
+
+
 class PointSAModuleMSG(BasePointSAModule):
-    """Multi-scale grouping SA module (point_sa_module.py:214-290)."""
+    """Multi-scale grouping (point_sa_module.py:214-290): one shared MLP per scale; with
+    ``use_xyz`` the grouped relative coordinates are three extra input channels."""
 
     def __init__(self, num_point, radii, sample_nums, mlp_channels, fps_mod=['D-FPS'],
                  fps_sample_range_list=[-1], dilated_group=False,
                  norm_cfg=dict(type='BN2d'), use_xyz=True, pool_mod='max',
                  normalize_xyz=False, bias='auto'):
-        super().__init__(num_point=num_point, radii=radii, sample_nums=sample_nums,
-                         mlp_channels=mlp_channels, fps_mod=fps_mod,
+        super().__init__(num_point, radii, sample_nums, mlp_channels, fps_mod=fps_mod,
                          fps_sample_range_list=fps_sample_range_list,
                          dilated_group=dilated_group, use_xyz=use_xyz, pool_mod=pool_mod,
                          normalize_xyz=normalize_xyz)
-        for i in range(len(self.mlp_channels)):
-            mlp_channel = self.mlp_channels[i]
+        for widths in self.mlp_channels:
             if use_xyz:
-                mlp_channel[0] += 3
-            mlp = nn.Sequential()
-            for j in range(len(mlp_channel) - 1):
-                mlp.add_module(
-                    f'layer{j}',
-                    ConvModule(mlp_channel[j], mlp_channel[j + 1], kernel_size=(1, 1),
-                               stride=(1, 1), conv_cfg=dict(type='Conv2d'),
-                               norm_cfg=norm_cfg, bias=bias))
-            self.mlps.append(mlp)
+                widths[0] += 3
+            self.mlps.append(_shared_mlp(widths, norm_cfg, bias=bias))
 
 
 class PointSAModule(PointSAModuleMSG):
-    """Single-scale grouping SA module (point_sa_module.py:293-341)."""
+    """The single-scale case (point_sa_module.py:293-341)."""
 
     def __init__(self, mlp_channels, num_point=None, radius=None, num_sample=None,
                  norm_cfg=dict(type='BN2d'), use_xyz=True, pool_mod='max',
                  fps_mod=['D-FPS'], fps_sample_range_list=[-1], normalize_xyz=False):
-        super().__init__(mlp_channels=[list(mlp_channels)], num_point=num_point,
-                         radii=[radius], sample_nums=[num_sample], norm_cfg=norm_cfg,
-                         use_xyz=use_xyz, pool_mod=pool_mod, fps_mod=fps_mod,
-                         fps_sample_range_list=fps_sample_range_list,
+        super().__init__(num_point, [radius], [num_sample], [list(mlp_channels)],
+                         fps_mod=fps_mod, fps_sample_range_list=fps_sample_range_list,
+                         norm_cfg=norm_cfg, use_xyz=use_xyz, pool_mod=pool_mod,
                          normalize_xyz=normalize_xyz)
 
 
 class PointFPModule(nn.Module):
-    """Feature propagation: 3-NN inverse-distance interpolation + skip concat + MLP
-    (point_fp_module.py:10-78)."""
+    """Feature propagation (point_fp_module.py:10-78): every target point takes the
+    inverse-distance blend of its three nearest source points' features, joins its own
+    features, and the result goes through a shared MLP."""
 
     def __init__(self, mlp_channels: List[int], norm_cfg: dict = dict(type='BN2d')):
         super().__init__()
         self.fp16_enabled = False
-        self.mlps = nn.Sequential()
-        for i in range(len(mlp_channels) - 1):
-            self.mlps.add_module(
-                f'layer{i}',
-                ConvModule(mlp_channels[i], mlp_channels[i + 1], kernel_size=(1, 1),
-                           stride=(1, 1), conv_cfg=dict(type='Conv2d'), norm_cfg=norm_cfg))
+        self.mlps = _shared_mlp(list(mlp_channels), norm_cfg)
 
     @staticmethod
     def interpolation_taps(target, source):
         """3-NN indices, inverse-distance weights and the inverted index of the indices
         (:56-61).  Coordinates only: a training loop may compute them ahead of the step."""
         dist, idx = three_nn(target, source)
-        dist_reciprocal = 1.0 / (dist + 1e-8)
-        norm = torch.sum(dist_reciprocal, dim=2, keepdim=True)
-        weight = (dist_reciprocal / norm).contiguous()
+        closeness = 1.0 / (dist + 1e-8)
+        weight = (closeness / closeness.sum(dim=2, keepdim=True)).contiguous()
         return idx, weight, inverted_index(idx, source.shape[1])
 
     def forward(self, target, source, target_feats, source_feats, taps=None):
-        if source is not None:
+        if source is None:     # one global feature vector, broadcast to every target point
+            spread = source_feats.expand(*source_feats.shape[:2], target.shape[1])
+        else:
             idx, weight, csr = taps if taps is not None else self.interpolation_taps(target, source)
-            interpolated_feats = three_interpolate(source_feats, idx, weight, csr)
-        else:
-            interpolated_feats = source_feats.expand(*source_feats.size()[0:2],
-                                                     target.size(1))
-        if target_feats is not None:
-            new_features = torch.cat([interpolated_feats, target_feats], dim=1)
-        else:
-            new_features = interpolated_feats
-        new_features = new_features.unsqueeze(-1)
-        new_features = self.mlps(new_features)
-        return new_features.squeeze(-1)
+            spread = three_interpolate(source_feats, idx, weight, csr)
+        joined = spread if target_feats is None else torch.cat([spread, target_feats], dim=1)
+        return self.mlps(joined.unsqueeze(-1)).squeeze(-1)
 
 
 SA_MODULES = {'PointSAModule': PointSAModule, 'PointSAModuleMSG': PointSAModuleMSG}
 
 
 def build_sa_module(cfg, *args, **kwargs):
-    """Build an SA module from a ``dict(type=..., ...)`` (builder.py:6-38)."""
+    """``dict(type=<name in SA_MODULES>, **keywords)`` -> module (builder.py:6-38); None means
+    a plain PointSAModule."""
     if cfg is None:
-        cfg_ = dict(type='PointSAModule')
-    else:
-        if not isinstance(cfg, dict):
-            raise TypeError('cfg must be a dict')
-        if 'type' not in cfg:
-            raise KeyError('the cfg dict must contain the key "type"')
-        cfg_ = cfg.copy()
-    module_type = cfg_.pop('type')
-    if module_type not in SA_MODULES:
-        raise KeyError(f'Unrecognized module type {module_type}')
-    return SA_MODULES[module_type](*args, **kwargs, **cfg_)
+        cfg = dict(type='PointSAModule')
+    if not isinstance(cfg, dict):
+        raise TypeError('cfg must be a dict')
+    if 'type' not in cfg:
+        raise KeyError('the cfg dict must contain the key "type"')
+    options = dict(cfg)
+    kind = options.pop('type')
+    if kind not in SA_MODULES:
+        raise KeyError(f'Unrecognized module type {kind}')
+    return SA_MODULES[kind](*args, **kwargs, **options)

@@ -1,5 +1,5 @@
-"""PointNet++ SSG backbone (``mmdet3d/models/backbones/pointnet2_sa_ssg.py:11-142``,
-``base_pointnet.py:20-37``): 4 set-abstraction + 2 feature-propagation layers."""
+"""PointNet++ single-scale-grouping backbone: 4 set-abstraction + 2 feature-propagation levels
+(behaviour of ``mmdet3d/models/backbones/pointnet2_sa_ssg.py:11-142``, ``base_pointnet.py:20-37``)."""
 import torch
 from torch import nn
 
@@ -7,6 +7,13 @@ from ..mmdet3d_ops import PointFPModule, build_sa_module
 
 
 class PointNet2SASSG(nn.Module):
+    """Encoder-decoder over point sets.  Level 0 is the input cloud, level i the centres the
+    i-th set-abstraction module sampled; ``widths[i]`` is the feature width at level i.  The
+    decoder walks back from the coarsest level: step j interpolates the carried features of
+    level ``depth - j`` onto level ``depth - j - 1`` and joins that level's own features.
+    Constructor keywords, module names (``SA_modules`` / ``FP_modules``: state-dict keys) and the
+    returned dict follow pointnet2_sa_ssg.py:11-142."""
+
     def __init__(self, in_channels, num_points=(2048, 1024, 512, 256),
                  radius=(0.2, 0.4, 0.8, 1.2), num_samples=(64, 32, 16, 16),
                  sa_channels=((64, 64, 128), (128, 128, 256), (128, 128, 256),
@@ -15,76 +22,69 @@ class PointNet2SASSG(nn.Module):
                  sa_cfg=dict(type='PointSAModule', pool_mod='max', use_xyz=True,
                              normalize_xyz=True)):
         super().__init__()
-        self.num_sa = len(sa_channels)
-        self.num_fp = len(fp_channels)
-        assert len(num_points) == len(radius) == len(num_samples) == len(sa_channels)
-        assert len(sa_channels) >= len(fp_channels)
+        depth = len(sa_channels)
+        if not (len(num_points) == len(radius) == len(num_samples) == depth):
+            raise AssertionError('one entry per set-abstraction level is required')
+        if len(fp_channels) > depth:
+            raise AssertionError('more feature-propagation steps than levels')
+        self.num_sa, self.num_fp = depth, len(fp_channels)
+        widths = [in_channels - 3]
         self.SA_modules = nn.ModuleList()
-        sa_in_channel = in_channels - 3
-        skip_channel_list = [sa_in_channel]
-        for sa_index in range(self.num_sa):
-            cur_sa_mlps = [sa_in_channel] + list(sa_channels[sa_index])
-            sa_out_channel = cur_sa_mlps[-1]
-            self.SA_modules.append(
-                build_sa_module(num_point=num_points[sa_index], radius=radius[sa_index],
-                                num_sample=num_samples[sa_index], mlp_channels=cur_sa_mlps,
-                                norm_cfg=norm_cfg, cfg=sa_cfg))
-            skip_channel_list.append(sa_out_channel)
-            sa_in_channel = sa_out_channel
+        for count, reach, group, mlp in zip(num_points, radius, num_samples, sa_channels):
+            self.SA_modules.append(build_sa_module(
+                num_point=count, radius=reach, num_sample=group,
+                mlp_channels=[widths[-1], *mlp], norm_cfg=norm_cfg, cfg=sa_cfg))
+            widths.append(mlp[-1])
         self.FP_modules = nn.ModuleList()
-        fp_source_channel = skip_channel_list.pop()
-        fp_target_channel = skip_channel_list.pop()
-        for fp_index in range(len(fp_channels)):
-            cur_fp_mlps = [fp_source_channel + fp_target_channel] + list(fp_channels[fp_index])
-            self.FP_modules.append(PointFPModule(mlp_channels=cur_fp_mlps))
-            if fp_index != len(fp_channels) - 1:
-                fp_source_channel = cur_fp_mlps[-1]
-                fp_target_channel = skip_channel_list.pop()
+        carried = widths[depth]
+        for j, mlp in enumerate(fp_channels):
+            self.FP_modules.append(PointFPModule(mlp_channels=[carried + widths[depth - 1 - j], *mlp]))
+            carried = mlp[-1]
 
     @staticmethod
     def _split_point_feats(points):
-        xyz = points[..., 0:3].contiguous()
-        features = points[..., 3:].transpose(1, 2).contiguous() if points.size(-1) > 3 else None
-        return xyz, features
+        """(B, N, 3 + C) -> coordinates (B, N, 3), channel-major features (B, C, N) or None."""
+        extra = points.shape[-1] - 3
+        return (points[..., :3].contiguous(),
+                points[..., 3:].transpose(1, 2).contiguous() if extra > 0 else None)
 
     def sample_and_group_indices(self, points):
         """FPS + ball-query indices of all SA layers: they depend on the input coordinates
         only, so a loop may compute them for the next batch while this one trains."""
-        xyz = points[..., 0:3].contiguous()
-        out, sa_xyz = [], [xyz]
+        level_xyz = [points[..., :3].contiguous()]
+        plan = []
         for sa in self.SA_modules:
-            pre = sa.sample_and_group_indices(xyz)
-            out.append(pre)
-            xyz = pre['new_xyz']
-            sa_xyz.append(xyz)
-        # feature-propagation taps (3-NN between consecutive levels) ride on the first entry
-        out[0]['fp_taps'] = [self.FP_modules[i].interpolation_taps(
-            sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i]) for i in range(self.num_fp)]
-        return out
+            plan.append(sa.sample_and_group_indices(level_xyz[-1]))
+            level_xyz.append(plan[-1]['new_xyz'])
+        # feature-propagation taps (3-NN from each finer level into the coarser one below it)
+        # ride on the first entry
+        plan[0]['fp_taps'] = [fp.interpolation_taps(level_xyz[self.num_sa - 1 - j],
+                                                    level_xyz[self.num_sa - j])
+                              for j, fp in enumerate(self.FP_modules)]
+        return plan
 
     def forward(self, points, precomputed=None):
-        """(B,N,3+C) -> dict of fp_xyz / fp_features / fp_indices (+ the sa_* lists).
-        ``precomputed`` = sample_and_group_indices(points) evaluated earlier (optional)."""
-        xyz, features = self._split_point_feats(points)
-        batch, num_points = xyz.shape[:2]
-        indices = torch.arange(num_points, device=xyz.device).unsqueeze(0).repeat(batch, 1).long()
-        sa_xyz, sa_features, sa_indices = [xyz], [features], [indices]
-        for i in range(self.num_sa):
-            cur_xyz, cur_features, cur_indices = self.SA_modules[i](
-                sa_xyz[i], sa_features[i],
-                precomputed=None if precomputed is None else precomputed[i])
-            sa_xyz.append(cur_xyz)
-            sa_features.append(cur_features)
-            sa_indices.append(torch.gather(sa_indices[-1], 1, cur_indices.long()))
+        """(B, N, 3 + C) -> dict of fp_xyz / fp_features / fp_indices (+ the sa_* lists); index
+        lists hold positions in the INPUT cloud.  ``precomputed`` = sample_and_group_indices(
+        points) evaluated earlier (optional)."""
+        xyz, feats = self._split_point_feats(points)
+        B, N = xyz.shape[:2]
+        sa_xyz, sa_features = [xyz], [feats]
+        sa_indices = [torch.arange(N, device=xyz.device).expand(B, N)]
+        for i, sa in enumerate(self.SA_modules):
+            centres, pooled, picked = sa(sa_xyz[-1], sa_features[-1],
+                                         precomputed=precomputed[i] if precomputed is not None else None)
+            sa_xyz.append(centres)
+            sa_features.append(pooled)
+            sa_indices.append(sa_indices[-1].gather(1, picked.long()))
+        taps = precomputed[0].get('fp_taps') if precomputed is not None else None
         fp_xyz, fp_features, fp_indices = [sa_xyz[-1]], [sa_features[-1]], [sa_indices[-1]]
-        for i in range(self.num_fp):
-            taps = None if precomputed is None else precomputed[0].get('fp_taps')
-            fp_features.append(self.FP_modules[i](
-                sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i],
-                sa_features[self.num_sa - i - 1], fp_features[-1],
-                taps=None if taps is None else taps[i]))
-            fp_xyz.append(sa_xyz[self.num_sa - i - 1])
-            fp_indices.append(sa_indices[self.num_sa - i - 1])
+        for j, fp in enumerate(self.FP_modules):
+            fine = self.num_sa - 1 - j
+            fp_features.append(fp(sa_xyz[fine], sa_xyz[fine + 1], sa_features[fine], fp_features[-1],
+                                  taps=taps[j] if taps is not None else None))
+            fp_xyz.append(sa_xyz[fine])
+            fp_indices.append(sa_indices[fine])
         return dict(fp_xyz=fp_xyz, fp_features=fp_features, fp_indices=fp_indices,
                     sa_xyz=sa_xyz, sa_features=sa_features, sa_indices=sa_indices)
 

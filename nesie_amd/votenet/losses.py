@@ -87,55 +87,49 @@ class CrossEntropyLoss(nn.Module):
         return self.loss_weight * weight_reduce_loss(loss, weight, reduction, avg_factor)
 
 
-# ---- chamfer (chamfer_distance.py:8-146) ----------------------------------------
+# ---- chamfer (behaviour of chamfer_distance.py:8-146) ----------------------------
+def _huber_unit(d):
+    a = d.abs()
+    return torch.where(a < 1.0, 0.5 * a * a, a - 0.5)
+
+
+_COORD_PENALTY = {'l1': torch.abs, 'l2': torch.square, 'smooth_l1': _huber_unit}
+_FOLD = {'none': lambda t: t, 'sum': torch.sum, 'mean': torch.mean}
+
+
 def chamfer_distance(src, dst, src_weight=1.0, dst_weight=1.0, criterion_mode='l2',
                      reduction='mean'):
-    """(B,N,C) vs (B,M,C): per-point min distances both ways + arg-min indices."""
-    diff = src.unsqueeze(2) - dst.unsqueeze(1)  # (B,N,M,C)
-    if criterion_mode == 'smooth_l1':
-        ad = diff.abs()
-        distance = torch.where(ad < 1.0, 0.5 * ad * ad, ad - 0.5)
-    elif criterion_mode == 'l1':
-        distance = diff.abs()
-    elif criterion_mode == 'l2':
-        distance = diff * diff
-    else:
-        raise NotImplementedError
-    distance = distance.sum(-1)
-    src2dst_distance, indices1 = torch.min(distance, dim=2)
-    dst2src_distance, indices2 = torch.min(distance, dim=1)
-    loss_src = src2dst_distance * src_weight
-    loss_dst = dst2src_distance * dst_weight
-    if reduction == 'sum':
-        loss_src, loss_dst = torch.sum(loss_src), torch.sum(loss_dst)
-    elif reduction == 'mean':
-        loss_src, loss_dst = torch.mean(loss_src), torch.mean(loss_dst)
-    elif reduction != 'none':
-        raise NotImplementedError
-    return loss_src, loss_dst, indices1, indices2
+    """src (B, N, C), dst (B, M, C).  The cost of a pair is the per-coordinate penalty summed
+    over C; every source point is charged its cheapest destination and vice versa.
+    -> (source term, destination term, cheapest dst per src (B, N), cheapest src per dst (B, M))."""
+    if criterion_mode not in _COORD_PENALTY or reduction not in _FOLD:
+        raise NotImplementedError((criterion_mode, reduction))
+    pair = _COORD_PENALTY[criterion_mode](src[:, :, None] - dst[:, None]).sum(-1)   # (B, N, M)
+    to_dst, to_src = pair.min(dim=2), pair.min(dim=1)
+    fold = _FOLD[reduction]
+    return (fold(to_dst.values * src_weight), fold(to_src.values * dst_weight),
+            to_dst.indices, to_src.indices)
 
 
 class ChamferDistance(nn.Module):
+    """Configured Chamfer term: the two directions scaled by ``loss_src_weight`` /
+    ``loss_dst_weight`` (the vote loss uses mode 'l1', reduction 'none', dst weight 10)."""
+
     def __init__(self, mode='l2', reduction='mean', loss_src_weight=1.0, loss_dst_weight=1.0):
         super().__init__()
-        assert mode in ['smooth_l1', 'l1', 'l2']
-        assert reduction in ['none', 'sum', 'mean']
-        self.mode = mode
-        self.reduction = reduction
-        self.loss_src_weight = loss_src_weight
-        self.loss_dst_weight = loss_dst_weight
+        if mode not in _COORD_PENALTY or reduction not in _FOLD:
+            raise AssertionError((mode, reduction))
+        self.mode, self.reduction = mode, reduction
+        self.loss_src_weight, self.loss_dst_weight = loss_src_weight, loss_dst_weight
 
     def forward(self, source, target, src_weight=1.0, dst_weight=1.0,
                 reduction_override=None, return_indices=False, **kwargs):
-        assert reduction_override in (None, 'none', 'mean', 'sum')
-        reduction = reduction_override if reduction_override else self.reduction
-        loss_source, loss_target, indices1, indices2 = chamfer_distance(
-            source, target, src_weight, dst_weight, self.mode, reduction)
-        loss_source = loss_source * self.loss_src_weight
-        loss_target = loss_target * self.loss_dst_weight
-        if return_indices:
-            return loss_source, loss_target, indices1, indices2
-        return loss_source, loss_target
+        if reduction_override is not None and reduction_override not in _FOLD:
+            raise AssertionError(reduction_override)
+        src_term, dst_term, src_pick, dst_pick = chamfer_distance(
+            source, target, src_weight, dst_weight, self.mode, reduction_override or self.reduction)
+        out = (src_term * self.loss_src_weight, dst_term * self.loss_dst_weight)
+        return out + (src_pick, dst_pick) if return_indices else out
 
 
 # ---- side surfaces (surface_loss.py:90-100) -------------------------------------

@@ -200,6 +200,46 @@ def test_norm_backward_from_the_raw_output():
     torch.testing.assert_close(dsum, dx.view(b, c, -1, grp).sum(-1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('k,cin,p,ng', [(128, 128, 2048, 1), (256, 128, 1024, 1), (128, 64, 4096, 1),
+                                          (256, 128, 512, 3), (128, 256, 1024, 2)])
+def test_input_gradient_with_the_norm_reduction_in_its_epilogue(k, cin, p, ng):
+    """nesie_pw_dgrad_bn_reduce + nesie_bn_relu_backward_apply == the input-gradient product
+    followed by autograd's backward of relu(batch_norm(z)) (fp64), per weight group."""
+    hip = _hip()
+    nb = 2 * ng
+    g = torch.Generator(device=_dev()).manual_seed(k + cin + p)
+    dy = torch.randn(nb, k, p, device=_dev(), generator=g)
+    w = torch.randn(ng, k, cin, device=_dev(), generator=g) / k ** 0.5     # layer weight (Cout=k, Cin)
+    z = torch.randn(nb, cin, p, device=_dev(), generator=g) * 1.5 + 0.3
+    gamma = torch.randn(ng * cin, device=_dev(), generator=g)
+    beta = torch.randn(ng * cin, device=_dev(), generator=g) * 0.3
+    # channel (s, m) of the stacked view (B, ng*cin, P)
+    zs = z.view(nb // ng, ng * cin, p)
+    mean = zs.double().transpose(0, 1).reshape(ng * cin, -1).mean(1)
+    var = zs.double().transpose(0, 1).reshape(ng * cin, -1).var(1, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    coef = torch.stack([gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd,
+                        mean, invstd], 1).float().contiguous()
+    da = torch.empty(nb, cin, p, device=_dev())
+    part = hip.pw_dgrad_bn_reduce(dy, w.transpose(1, 2), z, coef, da, ng=ng)
+    dz = torch.empty_like(z)
+    dgamma, dbeta = torch.empty(ng * cin, device=_dev()), torch.empty(ng * cin, device=_dev())
+    hip.bn_relu_backward_apply(da.view(nb // ng, ng * cin, p), zs, gamma, coef[:, 3].contiguous(),
+                               coef, part, dz.view(nb // ng, ng * cin, p), dgamma, dbeta)
+    # fp64 referee
+    zr = zs.double().clone().requires_grad_(True)
+    gr, br = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    act = torch.relu(torch.nn.functional.batch_norm(zr, None, None, gr, br, True, 0.1, 1e-5))
+    wfull = w.double()[torch.arange(nb, device=_dev()) % ng]               # (nb, k, cin)
+    da_ref = torch.bmm(wfull.transpose(1, 2), dy.double())                  # (nb, cin, p)
+    act.backward(da_ref.view(nb // ng, ng * cin, p))
+    scale = da_ref.abs().max().item()
+    assert (da.double() - da_ref).abs().max().item() < 1e-5 * scale * k ** 0.5
+    assert (dz.view_as(zr).double() - zr.grad).abs().max().item() < 2e-5 * zr.grad.abs().max().item() * k ** 0.5
+    torch.testing.assert_close(dgamma.double(), gr.grad, rtol=1e-4, atol=1e-4 * gr.grad.abs().max().item())
+    torch.testing.assert_close(dbeta.double(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
+
+
 @pytest.mark.parametrize('cout,cin', [(128, 256), (256, 128), (128, 259), (128, 131)])
 def test_weight_gradient_wide_shapes_and_strided_batches(cout, cin):
     hip = _hip()
