@@ -279,7 +279,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
     main = torch.cuda.current_stream(device)
 
-    from nesie_amd.votenet.backbone import clone_index_tree as clone_tree, index_tree_tensors as flat
+    from nesie_amd.votenet.backbone import index_tree_like, index_tree_tensors as flat, pack_tensors
 
     semi_like = workload in ('semi', 'saqe')
     # weight-independent work of a step: the backbone's index chain(s) and, for the supervised
@@ -312,7 +312,13 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     if scenes is not None:
         scenes.refresh_noise(noise)
     idx_next, votes_next = input_only_work()
-    idx_cur, votes_cur = clone_tree(idx_next), [t.clone() for t in votes_next]
+    # two static copies of the index set (next: written by the side-stream graph, cur: read by
+    # the step graphs), each packed into ONE buffer: the hand-over is a single copy
+    n_tree = len(flat(idx_next))
+    views, arena_next = pack_tensors(flat(idx_next) + votes_next)
+    idx_next, votes_next = index_tree_like(idx_next, views[:n_tree]), views[n_tree:]
+    views, arena_cur = pack_tensors(views)
+    idx_cur, votes_cur = index_tree_like(idx_next, views[:n_tree]), views[n_tree:]
     stage('first input-only pass (eager)')
     nlev = len(idx_cur) // 2 if semi_like else len(idx_cur)
 
@@ -351,7 +357,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     def graph_step():
         if pipelined:
             main.wait_event(ready)                       # this step's indices are complete
-            torch._foreach_copy_(flat(idx_cur) + votes_cur, flat(idx_next) + votes_next)
+            arena_cur.copy_(arena_next)
             if scenes is not None:                       # ... and so is this step's batch
                 torch._foreach_copy_([pts] + gt_parts(gt), [pts_next] + gt_parts(gt_next))
             copied.record(main)

@@ -101,9 +101,11 @@ int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample
  * by their source point, sources[B, M*ns] = that point for each (nesie_inverted_index builds
  * both, n <= 8192).  Lanes own sorted entries, a segmented scan inside each wave sums the runs
  * and only the last lane of a run adds its total into grad_features (zeroed by the caller):
- * a few float atomics per point instead of one per entry, balanced whatever the run lengths. */
+ * a few float atomics per point instead of one per entry, balanced whatever the run lengths.
+ * Inside a run the columns are in ascending order (scratch[B, M*ns] holds the arrival-order
+ * placement that the second pass ranks), so the sums are reproducible from run to run. */
 int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
-                         int *sources, void *stream);
+                         int *sources, int *scratch, void *stream);
 int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsample,
                                        const float *grad_out, const int *order,
                                        const int *sources, float *grad_features, void *stream);

@@ -51,7 +51,7 @@ SIGNATURES = {
     "nesie_query_and_group_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P],
     "nesie_query_and_group_backward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nesie_three_interpolate_grad_csr": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P],
+    "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_group_max_pool_backward_add": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],

@@ -58,12 +58,82 @@ def load_reference_checkpoint(model, checkpoint, strict=True, map_location='cpu'
     return meta, optim
 
 
+def per_parameter_optimizer_state(optimizer, flat_state):
+    """State dict of an optimiser built on ``dp.FlatTrainState.flat_param`` (ONE parameter, one
+    2.6 M-element moment pair) -> the reference's per-parameter form: one entry per model
+    parameter in ``parameters()`` order, ``exp_avg`` / ``exp_avg_sq`` cut at the flat vector's
+    offsets, ``step`` repeated, ``param_groups[0]['params'] = [0 .. n-1]`` (what
+    ``torch.optim.AdamW(model.parameters()).state_dict()`` holds after the same steps)."""
+    sd = optimizer.state_dict()
+    if len(sd['param_groups']) != 1 or len(sd['param_groups'][0]['params']) != 1:
+        raise ValueError('expected an optimiser over the single flat parameter')
+    flat = sd['state'].get(sd['param_groups'][0]['params'][0], {})
+    state, off = {}, 0
+    for i, p in enumerate(flat_state.params):
+        n = p.numel()
+        entry = {}
+        for k, v in flat.items():
+            if torch.is_tensor(v) and v.numel() == flat_state.flat.numel():
+                entry[k] = v[off:off + n].view_as(p).detach().cpu().clone()
+            else:
+                entry[k] = v.detach().cpu().clone() if torch.is_tensor(v) else v
+        if entry:
+            state[i] = entry
+        off += n
+    group = dict(sd['param_groups'][0], params=list(range(len(flat_state.params))))
+    return {'state': state, 'param_groups': [group]}
+
+
+def load_per_parameter_optimizer_state(optimizer, flat_state, reference_state):
+    """The inverse: a reference ``checkpoint['optimizer']`` (per-parameter AdamW state) into an
+    optimiser built on the flat parameter.  Shapes are checked entry by entry."""
+    groups = reference_state['param_groups']
+    order = [i for g in groups for i in g['params']]
+    if len(order) != len(flat_state.params):
+        raise RuntimeError(f'optimizer state holds {len(order)} parameters, the model '
+                           f'{len(flat_state.params)}')
+    sd = optimizer.state_dict()
+    key = sd['param_groups'][0]['params'][0]
+    ref = reference_state['state']
+    if ref:
+        total = flat_state.flat.numel()
+        like = flat_state.flat_param
+        merged, off, step = {}, 0, None
+        for i, p in zip(order, flat_state.params):
+            n = p.numel()
+            for k, v in ref.get(i, {}).items():
+                if torch.is_tensor(v) and v.numel() == n and k != 'step':
+                    if tuple(v.shape) != tuple(p.shape):
+                        raise RuntimeError(f'optimizer state {k} of parameter {i}: shape '
+                                           f'{tuple(v.shape)} != {tuple(p.shape)}')
+                    merged.setdefault(k, torch.zeros(total, dtype=like.dtype, device=like.device))
+                    merged[k][off:off + n] = v.reshape(-1).to(like.device, like.dtype)
+                elif k == 'step':
+                    step = v
+            off += n
+        if step is not None:
+            old = sd['state'].get(key, {}).get('step')
+            merged['step'] = (torch.as_tensor(float(step)).to(old.device, old.dtype)
+                              if torch.is_tensor(old) else
+                              (step.clone() if torch.is_tensor(step) else torch.tensor(float(step))))
+        sd['state'] = {key: merged}
+    for k, v in groups[0].items():          # learning rate, betas, weight decay ... (uniform)
+        if k != 'params':
+            sd['param_groups'][0][k] = v
+    optimizer.load_state_dict(sd)
+
+
 def save_reference_checkpoint(model, out_dir, epoch, iteration, optimizer=None, meta=None,
-                              ema_copy=False, create_symlink=True):
+                              ema_copy=False, create_symlink=True, flat_state=None):
     """Write ``epoch_{epoch}.pth`` (+ ``latest.pth``) in the reference's layout; with
     ``ema_copy`` also ``epoch_{epoch}_ema.pth`` holding the teacher's weights under the
     student's names (``model.teacher.swap()`` around the second save, as
-    ``SimiRunnerHook._save_checkpoint`` does).  Returns the paths written."""
+    ``SimiRunnerHook._save_checkpoint`` does).  Returns the paths written.
+
+    ``optimizer``: saved in the reference's PER-PARAMETER form.  An optimiser built on
+    ``dp.FlatTrainState.flat_param`` needs ``flat_state`` (the FlatTrainState) so that its single
+    flat moment pair can be cut at the parameter offsets; without it such an optimiser is refused
+    rather than written in a form the reference cannot resume from."""
     os.makedirs(out_dir, exist_ok=True)
     meta = dict(meta or {}, epoch=int(epoch), iter=int(iteration))
 
@@ -72,7 +142,18 @@ def save_reference_checkpoint(model, out_dir, epoch, iteration, optimizer=None, 
                 'state_dict': OrderedDict((k, v.detach().cpu())
                                           for k, v in model.state_dict().items())}
         if optimizer is not None:
-            ckpt['optimizer'] = optimizer.state_dict()
+            if flat_state is not None:
+                ckpt['optimizer'] = per_parameter_optimizer_state(optimizer, flat_state)
+            else:
+                n_opt = sum(len(g['params']) for g in optimizer.param_groups)
+                n_model = sum(1 for p in model.parameters() if p.requires_grad)
+                if n_opt != n_model:
+                    raise ValueError(
+                        f'the optimiser holds {n_opt} parameter(s), the model {n_model}: an '
+                        'optimiser over dp.FlatTrainState.flat_param must be saved with '
+                        'flat_state=<the FlatTrainState> (its state is converted to the '
+                        "reference's per-parameter layout)")
+                ckpt['optimizer'] = optimizer.state_dict()
         torch.save(ckpt, path)
 
     path = os.path.join(out_dir, f'epoch_{int(epoch)}.pth')

@@ -150,12 +150,15 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
 // Inverted index of idx[b][0..e_total) over n source points, one workgroup per scene: LDS
 // histogram (integer ds_add), exclusive scan, then each column takes the next free slot of its
 // point's run (returning ds_add).  Built on the side stream with the ball query: 8 workgroups,
-// tens of microseconds.  The order inside a run is not fixed.
+// tens of microseconds.  The slots are claimed in arrival order into `scratch`; a second pass
+// ranks every entry inside its run (runs are short: M ns / N on average), so `order` lists each
+// run in ascending column order and the segmented sums of the backward are reproducible (only a
+// run longer than a wave's 64 entries can still meet more than two float atomics).
 constexpr int II_BLOCK = 1024;
 
 __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
     int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
-    int *__restrict__ srcs) {
+    int *__restrict__ srcs, int *__restrict__ scratch_out) {
   extern __shared__ int lds[];  // hist[n] then cursor[n]; scan scratch [II_BLOCK]
   int *cur = lds, *scratch = lds + n;
   const int bi = blockIdx.x, tid = threadIdx.x;
@@ -190,12 +193,22 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
   __syncthreads();
   int *ord = order + (size_t)bi * e_total;
   int *sr = srcs + (size_t)bi * e_total;
+  int *tmp = scratch_out + (size_t)bi * e_total;
   for (int e = tid; e < e_total; e += II_BLOCK) {
     int s = ix[e];
     s = s < 0 ? 0 : (s >= n ? n - 1 : s);
-    const int slot = atomicAdd(&cur[s], 1);
-    ord[slot] = e;
-    sr[slot] = s;
+    tmp[atomicAdd(&cur[s], 1)] = e;
+  }
+  __syncthreads();   // cur[s] is now the END of run s; run s starts where run s - 1 ends
+  for (int i = tid; i < e_total; i += II_BLOCK) {
+    const int e = tmp[i];
+    int s = ix[e];
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    const int lo_s = s > 0 ? cur[s - 1] : 0, hi_s = cur[s];
+    int rank = 0;
+    for (int k = lo_s; k < hi_s; ++k) rank += tmp[k] < e ? 1 : 0;
+    ord[lo_s + rank] = e;
+    sr[i] = s;
   }
 }
 
@@ -308,18 +321,18 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
 }
 
 extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
-                                    int *sources, void *stream) {
+                                    int *sources, int *scratch, void *stream) {
   const char *W = "inverted_index";
   NESIE_REQUIRE(b >= 0 && n >= 1 && e_total >= 0 && e_total < (1ll << 31), W);
   if (b == 0) return NESIE_OK;
-  NESIE_REQUIRE(idx && order && sources, W);
+  NESIE_REQUIRE(idx && order && sources && scratch, W);
   if (n > 8192) {
     set_error("%s: %d source points (built for n <= 8192: one LDS histogram per scene)", W, n);
     return NESIE_ERR_UNSUPPORTED;
   }
   const size_t lds = ((size_t)n + II_BLOCK) * sizeof(int);
   hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, (hipStream_t)stream, n,
-                     (int)e_total, idx, order, sources);
+                     (int)e_total, idx, order, sources, scratch);
   return check_launch(W);
 }
 

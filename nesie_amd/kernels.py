@@ -192,15 +192,16 @@ class HipKernels(_BNPoolMixin):
 
     def inverted_index(self, idx, n):
         """idx (B, M, ns) int32 in [0, n) -> order, sources (B, M*ns) int32: the grouped columns
-        sorted by source point and that point for each."""
+        sorted by source point (ascending column inside a point's run) and that point for each."""
         _check(idx); _i32(idx)
         b = idx.shape[0]
         e = idx.numel() // b
         order = torch.empty(b, e, dtype=torch.int32, device=idx.device)
         sources = torch.empty(b, e, dtype=torch.int32, device=idx.device)
+        scratch = torch.empty(b, e, dtype=torch.int32, device=idx.device)
         with torch.cuda.device(idx.device):
             _lib.call("nesie_inverted_index", b, n, e, _ptr(idx), _ptr(order), _ptr(sources),
-                      _stream(idx))
+                      _ptr(scratch), _stream(idx))
         return order, sources
 
     def query_and_group_backward_csr(self, grad_out, idx_shape, order, offsets, grad_features):

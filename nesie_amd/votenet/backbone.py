@@ -112,3 +112,34 @@ def clone_index_tree(tree):
                                   None if c_ is None else tuple(t.clone() for t in c_))
                                  for i_, w_, c_ in d['fp_taps']]} if 'fp_taps' in d else {}))
             for d in tree]
+
+
+def index_tree_like(tree, tensors):
+    """``tree`` with its tensors replaced, in ``index_tree_tensors`` order, by ``tensors``."""
+    it = iter(tensors)
+    out = []
+    for d in tree:
+        e = dict(indices=next(it), new_xyz=next(it), group_idx=[next(it) for _ in d['group_idx']],
+                 group_csr=[None if csr is None else tuple(next(it) for _ in csr)
+                            for csr in d.get('group_csr', ())])
+        if 'fp_taps' in d:
+            e['fp_taps'] = [(next(it), next(it), None if c_ is None else tuple(next(it) for _ in c_))
+                            for _, _, c_ in d['fp_taps']]
+        out.append(e)
+    return out
+
+
+def pack_tensors(tensors):
+    """Copies of ``tensors`` as views into ONE byte buffer (16-byte aligned slots): handing a
+    whole set of index tensors from one static buffer set to another is then a single
+    device-to-device copy instead of one launch per tensor.  -> (views, buffer)."""
+    sizes = [t.numel() * t.element_size() for t in tensors]
+    slots = [(n + 15) // 16 * 16 for n in sizes]
+    arena = torch.empty(sum(slots), dtype=torch.uint8, device=tensors[0].device)
+    views, off = [], 0
+    for t, n, slot in zip(tensors, sizes, slots):
+        v = arena[off:off + n].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        views.append(v)
+        off += slot
+    return views, arena

@@ -78,3 +78,61 @@ def test_pretrain_checkpoint_into_semi_model_and_ema_copy(tmp_path):
     assert torch.equal(model.state_dict()[k], student)
     with pytest.raises(RuntimeError, match='does not match'):
         checkpoint.load_reference_checkpoint(pre, {'state_dict': {'nope': torch.zeros(1)}})
+
+
+def test_flat_optimizer_state_is_saved_in_the_per_parameter_form_and_back(tmp_path):
+    """The training loop runs AdamW over ONE flat parameter (dp.FlatTrainState); the checkpoint's
+    'optimizer' entry must still be the reference's per-parameter state: equal to what a
+    per-tensor AdamW holds after the same steps, loadable by one, and loadable back."""
+    import copy
+
+    from nesie_amd import checkpoint as ck
+    from nesie_amd import dp
+    torch.manual_seed(5)
+    a = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    b = copy.deepcopy(a)
+    state = dp.FlatTrainState(a.parameters())
+    opt_a = torch.optim.AdamW([state.flat_param], lr=1e-2, weight_decay=0.05)
+    opt_b = torch.optim.AdamW(b.parameters(), lr=1e-2, weight_decay=0.05)
+    for _ in range(3):
+        x = torch.randn(7, 6)
+        state.begin()
+        a(x).square().sum().backward()
+        state.collect()
+        opt_a.step()
+        opt_b.zero_grad()
+        b(x).square().sum().backward()
+        opt_b.step()
+    with pytest.raises(ValueError, match='flat_state'):
+        ck.save_reference_checkpoint(a, tmp_path, 1, 3, optimizer=opt_a)
+    path = ck.save_reference_checkpoint(a, tmp_path, 1, 3, optimizer=opt_a, flat_state=state)[0]
+    saved = torch.load(path, weights_only=False)['optimizer']
+    want = opt_b.state_dict()
+    assert saved['param_groups'][0]['params'] == want['param_groups'][0]['params'] == [0, 1, 2, 3]
+    for i in range(4):
+        assert float(saved['state'][i]['step']) == float(want['state'][i]['step']) == 3
+        for k in ('exp_avg', 'exp_avg_sq'):
+            assert saved['state'][i][k].shape == want['state'][i][k].shape
+            torch.testing.assert_close(saved['state'][i][k], want['state'][i][k], rtol=1e-6, atol=1e-8)
+    # a per-tensor optimiser (the reference's) resumes from it ...
+    fresh = torch.optim.AdamW(copy.deepcopy(b).parameters(), lr=1.0)
+    fresh.load_state_dict(saved)
+    assert fresh.param_groups[0]['lr'] == 1e-2
+    # ... and a flat optimiser resumes from the reference's state
+    c = copy.deepcopy(b)
+    cstate = dp.FlatTrainState(c.parameters())
+    opt_c = torch.optim.AdamW([cstate.flat_param], lr=1.0, weight_decay=0.0)
+    ck.load_per_parameter_optimizer_state(opt_c, cstate, want)
+    got = opt_c.state[cstate.flat_param]
+    ref = opt_a.state[state.flat_param]
+    torch.testing.assert_close(got['exp_avg'], ref['exp_avg'], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(got['exp_avg_sq'], ref['exp_avg_sq'], rtol=1e-6, atol=1e-8)
+    assert float(got['step']) == 3 and opt_c.param_groups[0]['weight_decay'] == 0.05
+    x = torch.randn(7, 6)
+    for st, m, o in ((state, a, opt_a), (cstate, c, opt_c)):
+        st.begin()
+        m(x).square().sum().backward()
+        st.collect()
+        o.step()
+    for pa, pc in zip(a.parameters(), c.parameters()):
+        torch.testing.assert_close(pa, pc, rtol=1e-5, atol=1e-7)

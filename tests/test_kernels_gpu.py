@@ -572,6 +572,8 @@ def test_query_group_cat_matches_the_literal_chain(oracle_kernels, hip_device, n
     assert torch.equal(torch.gather(flat, 1, order.cpu().long()), sources.cpu().long())
     assert torch.equal(sources.cpu().long(), flat.sort(1).values)       # grouped by point
     assert torch.equal(order.cpu().long().sort(1).values, torch.arange(m * ns).expand(2, -1))
+    # ascending column inside every run = a stable sort by source point: reproducible sums
+    assert torch.equal(order.cpu().long(), flat.argsort(dim=1, stable=True))
     grads = []
     for _ in range(2):
         f2 = feats.to(hip_device).requires_grad_(True)
