@@ -304,7 +304,8 @@ int nesie_bn_relu_backward(int b, int c, long long p, const float *dy, const flo
 
 /* The apply pass of nesie_bn_relu_backward alone (relu, y == NULL form), for a producer that has
  * already left the reduction's partials: partial[(ch * nslice + i) * 2 + {0, 1}] = sum(g),
- * sum(g * xhat) over slice i (nesie_pw_dgrad_bn_reduce).  dgamma / dbeta are written. */
+ * sum(g * xhat) over slice i (nesie_pw_dgrad_bn_reduce).  dgamma / dbeta are written.
+ * save_invstd == NULL: column 3 of fwd_coef (also accepted by nesie_bn_relu_maxpool_backward). */
 int nesie_bn_relu_backward_apply(int b, int c, long long p, const float *dy, const float *x,
                                  const float *gamma, const float *save_invstd,
                                  const float *fwd_coef, const float *partial, int nslice,

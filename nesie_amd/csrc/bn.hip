@@ -271,6 +271,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
 struct BnBwdFin {
   int nslice; double n; const float *partial; const float *gamma; const float *save_invstd;
   float *dgamma; float *dbeta;
+  int istride;   // save_invstd[c * istride]: 1 for a plain vector, 4 for column 3 of fwd_coef
 };
 
 // -> sh[0] = gamma * invstd, sh[1] = sum(dy) / n, sh[2] = sum(dy * xhat) / n
@@ -285,7 +286,7 @@ __device__ __forceinline__ void bn_bwd_finalize(const BnBwdFin &f, int c, bool w
     s1 = wave_sum_f64(s1);
     if (threadIdx.x == 0) {
       const double g = f.gamma ? (double)f.gamma[c] : 1.0;
-      sh[0] = (float)(g * (double)f.save_invstd[c]);
+      sh[0] = (float)(g * (double)f.save_invstd[(size_t)c * f.istride]);
       sh[1] = (float)(s0 / f.n);
       sh[2] = (float)(s1 / f.n);
       if (writer) {
@@ -557,7 +558,7 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   if (relu) { if (nt) LR(true, true); else LR(true, false); }
   else { if (nt) LR(false, true); else LR(false, false); }
 #undef LR
-  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd ? save_invstd : fwd_coef + 3, dgamma, dbeta, save_invstd ? 1 : 4};
   (void)coef;
 #define LA(R, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x, \
                                     fwd_coef, fin, row_bias, group, d_row_bias, dx, raw)
@@ -581,7 +582,7 @@ extern "C" int nesie_bn_relu_backward_apply(int b, int c, long long p, const flo
   const char *W = "bn_relu_backward_apply";
   NESIE_REQUIRE(b >= 0 && c >= 0 && p >= 0 && nslice >= 1, W);
   if (b == 0 || c == 0 || p == 0) return NESIE_OK;
-  NESIE_REQUIRE(dy && x && dx && save_invstd && fwd_coef && partial, W);
+  NESIE_REQUIRE(dy && x && dx && fwd_coef && partial, W);   // save_invstd NULL: column 3 of fwd_coef
   if (!d_row_bias) group = 1;
   NESIE_REQUIRE(group >= 1 && p % group == 0, W);
   NESIE_REQUIRE(!d_row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
@@ -589,7 +590,7 @@ extern "C" int nesie_bn_relu_backward_apply(int b, int c, long long p, const flo
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(bn_sp(p), c, b);
   const bool nt = bn_use_nt((long long)b * c * p);
-  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd ? save_invstd : fwd_coef + 3, dgamma, dbeta, save_invstd ? 1 : 4};
   if (nt)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(BN_BLOCK), 0, s, c, p, dy, x,
                        fwd_coef, fin, (const float *)nullptr, group, d_row_bias, dx, 1);
@@ -614,7 +615,7 @@ int launch_bn_finalize(int c, int nslice, double count, const float *partial,
 int launch_bn_bwd_finalize(int c, int nslice, double count, const float *partial,
                            const float *gamma, const float *save_invstd, float *dgamma,
                            float *dbeta, float *coef, hipStream_t s) {
-  const BnBwdFin fin{nslice, count, partial, gamma, save_invstd, dgamma, dbeta};
+  const BnBwdFin fin{nslice, count, partial, gamma, save_invstd, dgamma, dbeta, 1};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c, coef);
   return check_launch("bn_bwd_finalize");
 }
@@ -683,14 +684,14 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
   const long long p = (long long)m * ns;
   st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st) return st;
-  NESIE_REQUIRE(grad_pooled && argmax && x && pooled && save_invstd && fwd_coef && dx, W);
+  NESIE_REQUIRE(grad_pooled && argmax && x && pooled && fwd_coef && dx, W);   // save_invstd NULL: column 3 of fwd_coef
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dx) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp, rows_per = cdiv(m, sp);
   float *partial = (float *)workspace, *coef = partial + (size_t)c * nslice * 2;
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(sp, c, b), dim3(BN_BLOCK), 0, s, c, m, ns,
                      rows_per, grad_pooled, pooled, argmax, x, fwd_coef, partial);
-  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd, dgamma, dbeta};
+  const BnBwdFin fin{nslice, (double)b * (double)p, partial, gamma, save_invstd ? save_invstd : fwd_coef + 3, dgamma, dbeta, save_invstd ? 1 : 4};
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, s, fin, c, coef);
   const long long rows = (long long)b * c * m;
   const int lpr = ns / 4;

@@ -73,7 +73,7 @@ class _BNPoolMixin:
             ws, need = _bn_pool_ws(x)
             opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
             _lib.call("nesie_bn_relu_maxpool_backward", b, c, m, ns, _ptr(grad_pooled),
-                      _ptr(argmax), _ptr(x), _ptr(pooled), opt(gamma), _ptr(save_invstd),
+                      _ptr(argmax), _ptr(x), _ptr(pooled), opt(gamma), opt(save_invstd),
                       _ptr(fwd_coef), _ptr(dx), opt(dgamma), opt(dbeta), _ptr(ws), need,
                       _stream(x))
 
@@ -675,8 +675,9 @@ class HipKernels(_BNPoolMixin):
     def bn_relu_backward_apply(self, dy, x, gamma, save_invstd, fwd_coef, partial, dx, dgamma,
                                dbeta, d_row_bias=None, group=None):
         """Apply pass of the BatchNorm + ReLU backward from ready partials (C, nslice, 2); x is
-        the raw conv output of the fused forward (nesie_bn_relu_backward_apply)."""
-        _check(dy, x, dx, save_invstd, fwd_coef, partial); _f32(dy, x, dx, partial)
+        the raw conv output of the fused forward (nesie_bn_relu_backward_apply).  save_invstd None:
+        column 3 of fwd_coef."""
+        _check(dy, x, dx, fwd_coef, partial); _f32(dy, x, dx, partial)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
         assert partial.dim() == 3 and partial.shape[0] == c and partial.shape[2] == 2
@@ -686,7 +687,7 @@ class HipKernels(_BNPoolMixin):
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
         with torch.cuda.device(x.device):
             _lib.call("nesie_bn_relu_backward_apply", b, c, p, _ptr(dy), _ptr(x), opt(gamma),
-                      _ptr(save_invstd), _ptr(fwd_coef), _ptr(partial), int(partial.shape[1]),
+                      opt(save_invstd), _ptr(fwd_coef), _ptr(partial), int(partial.shape[1]),
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
 

@@ -71,7 +71,7 @@ class SAStackFn(Function):
         P = M * ns
         L = len(params) // 3
         x3 = x.view(B, c0, P)
-        ys, coefs, means, invstds = [], [], [], []
+        ys, coefs = [], []
         coef = None
         pool_group = 16 if ns == 16 else 32
         pool_out = None
@@ -102,14 +102,12 @@ class SAStackFn(Function):
             coef = new_coef
             ys.append(y)
             coefs.append(coef)
-            means.append(coef[:, 2].contiguous())
-            invstds.append(coef[:, 3].contiguous())
         cl = ys[-1].shape[1]
         pooled = x.new_empty(B, cl, M)
         argmax = torch.empty(B, cl, M, dtype=torch.uint8, device=x.device)
         backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
         ctx.L, ctx.ns, ctx.fixed_lead = L, ns, int(fixed_lead)
-        ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *means, *invstds, *params)
+        ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *params)
         ctx.mark_non_differentiable(argmax)
         return pooled
 
@@ -119,8 +117,7 @@ class SAStackFn(Function):
         sv = ctx.saved_tensors
         x3, pooled, argmax = sv[:3]
         ys, coefs = sv[3:3 + L], sv[3 + L:3 + 2 * L]
-        means, invstds = sv[3 + 2 * L:3 + 3 * L], sv[3 + 3 * L:3 + 4 * L]
-        params = sv[3 + 4 * L:]
+        params = sv[3 + 2 * L:]
         backend = backend_for(g)
         B, c0, P = x3.shape
         M = P // ns
@@ -131,7 +128,7 @@ class SAStackFn(Function):
         dy = torch.empty_like(yl)
         dgamma, dbeta = g.new_empty(cl), g.new_empty(cl)
         backend.bn_relu_maxpool_backward(g.contiguous(), argmax, yl.view(B, cl, M, ns), pooled,
-                                         params[3 * (L - 1) + 1], invstds[-1], coefs[-1],
+                                         params[3 * (L - 1) + 1], None, coefs[-1],
                                          dy.view(B, cl, M, ns), dgamma, dbeta)
         grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dgamma, dbeta
         dx = None
@@ -164,7 +161,7 @@ class SAStackFn(Function):
             part = backend.pw_dgrad_bn_reduce(dy, w2.t().unsqueeze(0), ys[l - 1], coefs[l - 1], da)
             dyp = torch.empty_like(da)
             dgamma, dbeta = g.new_empty(cin), g.new_empty(cin)
-            backend.bn_relu_backward_apply(da, ys[l - 1], params[3 * (l - 1) + 1], invstds[l - 1],
+            backend.bn_relu_backward_apply(da, ys[l - 1], params[3 * (l - 1) + 1], None,
                                            coefs[l - 1], part, dyp, dgamma, dbeta)
             grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dgamma, dbeta
             dy = dyp
@@ -216,6 +213,40 @@ def sa_stack(x, layers, fixed_lead=0):
     return SAStackFn.apply(x, bufs, fixed_lead, *params)
 
 
+class StackGroups(Function):
+    """Several groups of S same-shaped tensors -> one stacked (S, ...) tensor per group, all
+    filled by ONE multi-tensor copy (a ``torch.stack`` per group is a launch per group).  The
+    gradient of a stacked tensor goes back as S views."""
+
+    @staticmethod
+    def forward(ctx, sizes, *tensors):
+        outs, dst, off = [], [], 0
+        for n in sizes:
+            group = tensors[off:off + n]
+            o = group[0].new_empty(n, *group[0].shape)
+            outs.append(o)
+            dst += list(o.unbind(0))
+            off += n
+        torch._foreach_copy_(dst, list(tensors))
+        ctx.sizes = sizes
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = [None]
+        for n, g in zip(ctx.sizes, grads):
+            out += [None] * n if g is None else list(g.unbind(0))
+        return tuple(out)
+
+
+def stack_groups(groups):
+    """[[t_0 .. t_{S-1}], ...] -> [stacked (S, ...) per group]; S = 1 needs no copy at all."""
+    if len(groups[0]) == 1:
+        return [g[0].unsqueeze(0) for g in groups]
+    flat = [t for g in groups for t in g]
+    return list(StackGroups.apply(tuple(len(g) for g in groups), *flat))
+
+
 # ---- MiniPointNet (side_pooling_module.py:343-370) -------------------------------------------
 # f = conv3(relu(bn0(c0))); g = max_G f; y = relu(bn1(W_g (g + b3) + W_l f + ...)); out = max_G conv4(y)
 # split at the two places where small per-proposal tensors leave the big ones (g, and the
@@ -254,14 +285,13 @@ class MiniHeadFn(Function):
         backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, g.view(B * S, half, -1),
                                arg.view(B * S, half, -1))
         ctx.G = G
-        ctx.save_for_backward(c0, coef0, coef0[:, 2].contiguous(), coef0[:, 3].contiguous(), arg,
-                              gamma0, beta0, w3)
+        ctx.save_for_backward(c0, coef0, arg, gamma0, beta0, w3)
         ctx.mark_non_differentiable(arg)
         return c, g
 
     @staticmethod
     def backward(ctx, dc, dg):
-        c0, coef0, mean0, invstd0, arg, gamma0, beta0, w3 = ctx.saved_tensors
+        c0, coef0, arg, gamma0, beta0, w3 = ctx.saved_tensors
         backend = backend_for(c0)
         B, S, H0, P = c0.shape
         half = w3.shape[1]
@@ -283,7 +313,7 @@ class MiniHeadFn(Function):
         dc0 = torch.empty_like(c0)
         dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
         backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
-                                       invstd0, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
+                                       None, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
         return dc0, None, None, None, dgamma, dbeta, dw3
 
 
@@ -315,14 +345,13 @@ class MiniTailFn(Function):
         backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, out.view(B * S, F, -1),
                                arg.view(B * S, F, -1))
         ctx.G = G
-        ctx.save_for_backward(c, y, coef1, coef1[:, 2].contiguous(), coef1[:, 3].contiguous(), arg,
-                              wl, gamma1, beta1, w4)
+        ctx.save_for_backward(c, y, coef1, arg, wl, gamma1, beta1, w4)
         ctx.mark_non_differentiable(arg)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        c, y, coef1, mean1, invstd1, arg, wl, gamma1, beta1, w4 = ctx.saved_tensors
+        c, y, coef1, arg, wl, gamma1, beta1, w4 = ctx.saved_tensors
         backend = backend_for(c)
         B, S, half, P = c.shape
         H2, F = wl.shape[1], w4.shape[1]
@@ -341,7 +370,7 @@ class MiniTailFn(Function):
         dgamma, dbeta = c.new_empty(S * H2), c.new_empty(S * H2)
         dsmall = c.new_empty(B, S, H2, P // G)
         backend.bn_relu_backward_apply(da.view(B, S * H2, P), y.view(B, S * H2, P), gamma1,
-                                       invstd1, coef1, part, dy.view(B, S * H2, P), dgamma, dbeta,
+                                       None, coef1, part, dy.view(B, S * H2, P), dgamma, dbeta,
                                        d_row_bias=dsmall.view(B, S * H2, -1), group=G)
         dyf = dy.view(B * S, H2, P)
         cf = c.view(B * S, half, P)

@@ -170,37 +170,45 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     half = f[0][3].out_channels
 
     def stacked(layers):
-        rm = torch.cat([l.running_mean for l in layers])
-        rv = torch.cat([l.running_var for l in layers])
-        return rm, rv, (rm, rv, layers[0].momentum, layers[0].eps)
-
-    def unstack(layers, rm, rv):
+        """The S layers' running statistics as one (S*C,) pair the kernels update in place: the
+        per-layer buffers are kept as VIEWS of it (re-made if a .to() / load replaced them)."""
         C = layers[0].num_features
-        with torch.no_grad():
-            torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
-            torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
-            for l in layers:
-                _norm.count_batch(l.num_batches_tracked)
+        owner = layers[0]
+        pack = getattr(owner, '_stacked_stats', None)
+        if pack is None or pack.device != owner.running_mean.device or any(
+                l.running_mean.data_ptr() != pack[0, i * C:].data_ptr() for i, l in enumerate(layers)):
+            pack = torch.stack([torch.cat([l.running_mean for l in layers]),
+                                torch.cat([l.running_var for l in layers])])
+            for i, l in enumerate(layers):
+                l.running_mean = pack[0, i * C:(i + 1) * C]
+                l.running_var = pack[1, i * C:(i + 1) * C]
+            owner._stacked_stats = pack
+        for l in layers:
+            _norm.count_batch(l.num_batches_tracked)
+        return pack[0], pack[1], layers[0].momentum, layers[0].eps
 
-    rm0, rv0, bufs0 = stacked(bn0s)
-    w3 = torch.stack([x[3].weight.flatten(1) for x in f])                      # (S, half, H)
-    c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, bufs0, G,
-                                      torch.cat([l.weight for l in bn0s]),
-                                      torch.cat([l.bias for l in bn0s]), w3)
-    unstack(bn0s, rm0, rv0)
-    w = torch.stack([x[0].weight.flatten(1) for x in sc])                      # (S, H2, 2*half)
-    H2 = w.shape[1]
-    b3 = torch.stack([x[3].bias if x[3].bias is not None else c.new_zeros(half) for x in f])
+    conv3, conv_g, conv4 = [x[3] for x in f], [x[0] for x in sc], [x[3] for x in sc]
+    zero = None
+    if conv3[0].bias is None:
+        zero = c0.new_zeros(half)
+    groups = [[l.weight for l in bn0s], [l.bias for l in bn0s],
+              [m.weight.flatten(1) for m in conv3], [m.weight.flatten(1) for m in conv_g],
+              [m.bias if m.bias is not None else zero for m in conv3],
+              [l.weight for l in bn1s], [l.bias for l in bn1s],
+              [m.weight.flatten(1) for m in conv4]]
+    if conv4[0].bias is not None:
+        groups.append([m.bias for m in conv4])
+    gamma0, beta0, w3, w, b3, gamma1, beta1, w4, *b4 = fused_mlp.stack_groups(groups)
+    c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
+                                      gamma0.reshape(-1), beta0.reshape(-1), w3)     # w3 (S, half, H)
+    H2 = w.shape[1]                                                                  # w (S, H2, 2*half)
     # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3
     small = torch.matmul(w[:, :, :half].unsqueeze(0), g) \
         + torch.matmul(w, torch.cat([b3, b3], 1).unsqueeze(-1)).view(1, S, H2, 1)
-    rm1, rv1, bufs1 = stacked(bn1s)
-    w4 = torch.stack([x[3].weight.flatten(1) for x in sc])                     # (S, F, H2)
-    out = fused_mlp.MiniTailFn.apply(c, small, bufs1, G, w[:, :, half:], torch.cat([l.weight for l in bn1s]),
-                                     torch.cat([l.bias for l in bn1s]), w4)
-    unstack(bn1s, rm1, rv1)
-    if sc[0][3].bias is not None:
-        out = out + torch.stack([x[3].bias for x in sc]).view(1, S, -1, 1)
+    out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w[:, :, half:],
+                                     gamma1.reshape(-1), beta1.reshape(-1), w4)      # w4 (S, F, H2)
+    if b4:
+        out = out + b4[0].view(1, S, -1, 1)
     return out
 
 
