@@ -1,0 +1,72 @@
+/* nesie_head_ops.h -- C ABI of the Nesie head's training targets and loss terms (part of
+ * libnesie_hip.so; conventions as in nesie_ops.h: plain pointers, sizes, a HIP stream handle, int
+ * status, nesie_last_error()).
+ *
+ * Replaces, for the shipped Nesie-VoteNet configuration, the python of
+ *   mmdet3d/models/dense_heads/nesie_head.py:566-588, 656-676  (get_targets: assignment, weights)
+ *   mmdet3d/models/dense_heads/nesie_head.py:279-413           (loss: seven per-proposal terms)
+ * and the loss classes it calls (losses/{chamfer_distance,surface_loss,side_pred_loss,
+ * iou3d_loss,gfocal_loss}.py, mmdet CrossEntropyLoss).  The reference has no native entry for
+ * these; a maintainer binds them from NesieHead.loss (see nesie_amd/votenet/head_loss.py). */
+#ifndef NESIE_HEAD_OPS_H
+#define NESIE_HEAD_OPS_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Proposal <-> ground-truth assignment and the batch-level weights.
+ *   agg (B,K,3) aggregated points; gt_boxes (B,T,7) bottom-centre boxes; gt_labels (B,T) int64;
+ *   gt_count (B) int64 = box columns in use; gt_valid (B,T) 1 for real boxes.
+ * -> assignment (B,K) int64 = nearest used column by squared distance to the box CENTRE (first
+ *    minimum), obj_targets (B,K) int64 = [sqrt(d + 1e-6) < pos_thr], obj_weights = [pos or
+ *    sqrt(d + 1e-6) > neg_thr] / (their number + 1e-6), box_weights = pos / (number of pos +
+ *    1e-6), mask_targets (B,K) int64 = the assigned label, bbox_targets (B,K,7) = (centre, size,
+ *    yaw) of the assigned box, center_targets (B,T,3) (zero for unused columns), valid_weights
+ *    (B,T) = gt_valid / (number valid + 1e-6). */
+int nesie_head_targets(int b, int k, int t, const float *agg, const float *gt_boxes,
+                       const long long *gt_labels, const long long *gt_count,
+                       const float *gt_valid, float pos_thr, float neg_thr,
+                       long long *assignment, long long *obj_targets, float *obj_weights,
+                       long long *mask_targets, float *bbox_targets, float *center_targets,
+                       float *box_weights, float *valid_weights, void *stream);
+
+/* The seven loss terms, loss[7] = (objectness, semantic, centre, surface, iou, iou_pred, side),
+ * and the gradient of each term w.r.t. its inputs (s_* outputs, unit incoming gradient).  Inputs
+ * are read in their producers' layouts (no copies):
+ *   cls (B, 2 + C, K): rows 0..1 objectness logits, rows 2.. class logits (conv_pred output);
+ *   bbox (B,K,7) decoded boxes (columns 0..2 = centre); surface (B,K,6);
+ *   side (6, B, C, 2K) side-quality PROBABILITIES, plain proposals then jittered copies;
+ *   iou_s (B, 2K, C) IoU-quality probabilities, plain then jittered;
+ *   iou / iou_j (B*K) IoU of the predicted / jittered box with its target box.
+ *   config: HOST array of 11 floats = alpha, objectness weight, objectness class weights (2),
+ *   semantic weight, chamfer source / destination weights, surface, iou, iou_pred, side weights.
+ * s_cls (B,2+C,K), s_centre (B*K,3), s_surface (B*K,6), s_iou (B*K), s_iou_s (B,2K,C); the three
+ * s_side_* (B*K,6) are the side-score gradients of the surface term and the iou term (both at
+ * class sem_pick[p] = arg-max class logit) and of the side term (at class label[p]).
+ * kstar (B*T) int32, dmin (B*T): scratch. */
+int nesie_head_loss_forward(int b, int k, int t, int c, const float *cls, const float *bbox,
+                            const float *surface, const float *side, const float *iou_s,
+                            const float *iou, const float *iou_j, const long long *obj_t,
+                            const long long *label, const float *obj_w, const float *box_w,
+                            const float *bbox_t, const float *centre_t, const float *valid_w,
+                            const float *config, float *loss, float *s_cls, float *s_centre,
+                            float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf,
+                            float *s_side_iou, float *s_side_pred, int *sem_pick, int *kstar,
+                            float *dmin, void *stream);
+
+/* Gradient assembly: the saved per-term gradients times the incoming gradients g[7] (device) of
+ * the seven terms, in the producers' layouts: d_cls (B,2+C,K), d_bbox (B,K,7) (size and yaw
+ * columns zero), d_surface, d_iou (B*K), d_iou_s (B,2K,C), d_side (6,B,C,2K) which must arrive
+ * ZERO-FILLED (two class columns per proposal and side are written). */
+int nesie_head_loss_backward(int b, int k, int c, const float *g, const long long *label,
+                             const int *sem_pick, const float *s_cls, const float *s_centre,
+                             const float *s_surface, const float *s_iou, const float *s_iou_s,
+                             const float *s_side_surf, const float *s_side_iou,
+                             const float *s_side_pred, float *d_cls, float *d_bbox,
+                             float *d_surface, float *d_iou, float *d_iou_s, float *d_side,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

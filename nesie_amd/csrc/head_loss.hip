@@ -1,0 +1,400 @@
+// The Nesie head's training targets and its seven per-proposal loss terms, forward and gradient.
+//
+// Stands in for NesieHead.get_targets (proposal <-> ground-truth assignment and the batch-level
+// weights, reference mmdet3d/models/dense_heads/nesie_head.py:566-588, 656-676) and for the loss
+// terms of NesieHead.loss (:279-413) with the loss classes they call (CrossEntropyLoss with class
+// weights, ChamferDistance l2, SurfaceLoss/MSE, IoU3DLoss, GeneralQualityFocalLoss on
+// probabilities, SidePredLoss): ~300 small ATen launches (forward + autograd backward) become
+// three.  Every term is a sum over <= a few thousand proposals of closed-form expressions, so ONE
+// workgroup evaluates the batch: the normalisers (number of positive / assigned proposals, valid
+// boxes) are block-wide integer counts, the seven sums are reduced in a fixed order (bitwise
+// reproducible), and the analytic gradients leave with the forward.
+#include "common.h"
+#include <math.h>
+#include <stdint.h>
+
+namespace nesie {
+
+constexpr int HL_BLOCK = 1024;
+constexpr int HL_MAXC = 32;      // classes
+
+__device__ __forceinline__ float hl_block_sum(float v, float *sh) {
+  // fixed-order tree over the block: lanes by DPP-free shuffles, waves through LDS
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < HL_BLOCK / 64; ++w) t += sh[w];
+  return t;
+}
+
+__device__ __forceinline__ int hl_block_count(int v, int *sh) {
+  __syncthreads();
+  if (threadIdx.x == 0) *sh = 0;
+  __syncthreads();
+  if (v) atomicAdd(sh, v);
+  __syncthreads();
+  return *sh;
+}
+
+// ---- targets ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(HL_BLOCK) void head_targets_kernel(
+    int b, int k, int t, const float *__restrict__ agg, const float *__restrict__ gt_boxes,
+    const long long *__restrict__ gt_labels, const long long *__restrict__ gt_count,
+    const float *__restrict__ gt_valid, float pos_thr, float neg_thr,
+    long long *__restrict__ assignment, long long *__restrict__ obj_targets,
+    float *__restrict__ obj_weights, long long *__restrict__ mask_targets,
+    float *__restrict__ bbox_targets, float *__restrict__ center_targets,
+    float *__restrict__ box_weights, float *__restrict__ valid_weights) {
+  __shared__ int cnt;
+  const int np = b * k, ng = b * t;
+  int n_pos = 0, n_mask = 0, n_valid = 0;
+  for (int p = threadIdx.x; p < np; p += HL_BLOCK) {
+    const int bi = p / k;
+    const float ax = agg[p * 3], ay = agg[p * 3 + 1], az = agg[p * 3 + 2];
+    const int cols = (int)gt_count[bi];
+    float best = INFINITY;
+    int at = 0;
+    for (int j = 0; j < t; ++j) {
+      const float *g = gt_boxes + ((size_t)bi * t + j) * 7;
+      const float dx = ax - g[0], dy = ay - g[1], dz = az - (g[2] + g[5] * 0.5f);
+      float d = (dx * dx + dy * dy) + dz * dz;
+      d = j < cols ? d : INFINITY;
+      if (d < best) { best = d; at = j; }      // first minimum wins (torch.min)
+    }
+    const float e = sqrtf(best + 1e-6f);
+    const bool pos = e < pos_thr, neg = e > neg_thr;
+    assignment[p] = at;
+    obj_targets[p] = pos ? 1 : 0;
+    obj_weights[p] = (pos || neg) ? 1.f : 0.f;     // normalised below
+    box_weights[p] = pos ? 1.f : 0.f;
+    mask_targets[p] = gt_labels[(size_t)bi * t + at];
+    const float *g = gt_boxes + ((size_t)bi * t + at) * 7;
+    float *o = bbox_targets + (size_t)p * 7;
+    o[0] = g[0]; o[1] = g[1]; o[2] = g[2] + g[5] * 0.5f;
+    o[3] = g[3]; o[4] = g[4]; o[5] = g[5]; o[6] = g[6];
+    n_pos += pos ? 1 : 0;
+    n_mask += (pos || neg) ? 1 : 0;
+  }
+  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) {
+    const int bi = q / t, j = q % t;
+    const float *g = gt_boxes + (size_t)q * 7;
+    const bool col = j < (int)gt_count[bi];
+    center_targets[q * 3] = col ? g[0] : 0.f;
+    center_targets[q * 3 + 1] = col ? g[1] : 0.f;
+    center_targets[q * 3 + 2] = col ? g[2] + g[5] * 0.5f : 0.f;
+    n_valid += gt_valid[q] != 0.f ? 1 : 0;
+  }
+  const float f_pos = (float)hl_block_count(n_pos, &cnt) + 1e-6f;
+  const float f_mask = (float)hl_block_count(n_mask, &cnt) + 1e-6f;
+  const float f_valid = (float)hl_block_count(n_valid, &cnt) + 1e-6f;
+  for (int p = threadIdx.x; p < np; p += HL_BLOCK) {
+    obj_weights[p] = obj_weights[p] / f_mask;
+    box_weights[p] = box_weights[p] / f_pos;
+  }
+  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) valid_weights[q] = gt_valid[q] / f_valid;
+}
+
+// ---- losses -----------------------------------------------------------------------------------
+// Layouts are the producers' own (no copies on the way in or out):
+//   cls     (B, 2 + C, K)   prediction-head output: rows 0..1 objectness logits, 2.. class logits
+//   bbox    (B, K, 7)       decoded boxes; columns 0..2 are the centres
+//   surface (B, K, 6)
+//   side    (6, B, C, 2K)   side-quality probabilities, plain proposals then jittered copies
+//   iou_s   (B, 2K, C)      IoU-quality probabilities, plain then jittered
+struct HeadLoss {
+  int b, k, t, c;
+  const float *cls, *bbox, *surface, *side, *iou_s;
+  const float *iou;        // (B*K) IoU of the predicted box with its target
+  const float *iou_j;      // (B*K) IoU of the jittered box with its target
+  // targets (head_targets_kernel)
+  const long long *obj_t, *label;
+  const float *obj_w, *box_w, *bbox_t, *centre_t, *valid_w;
+  // configuration
+  float alpha, w_obj, cw0, cw1, w_sem, w_csrc, w_cdst, w_surf, w_iou, w_qfl, w_side;
+  // outputs: loss[7] = objectness, semantic, centre, surface, iou, iou_pred, side; s_* = the
+  // gradient of each term w.r.t. its inputs (unit incoming gradient), in the input's layout
+  float *loss;
+  float *s_cls, *s_centre /* (B*K,3) */, *s_surface, *s_iou /* (B*K) */, *s_iou_s;
+  float *s_side_surf, *s_side_iou, *s_side_pred;   // (B*K, 6) each
+  int *sem_pick;           // (B*K) arg-max class of the class logits (the column the sigmas read)
+  int *kstar;              // (B*T) scratch: nearest proposal of every ground-truth centre
+  float *dmin;             // (B*T) scratch
+};
+
+__device__ __forceinline__ float hl_log_clamped(float v) { return fmaxf(logf(v), -100.f); }
+
+__global__ __launch_bounds__(HL_BLOCK) void head_loss_kernel(const HeadLoss a) {
+  __shared__ float sh[HL_BLOCK / 64];
+  const int np = a.b * a.k, ng = a.b * a.t, C = a.c, K = a.k, NC = 2 + a.c;
+  // nearest proposal of every ground-truth centre (the destination half of the chamfer term)
+  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) {
+    const int bi = q / a.t;
+    const float gx = a.centre_t[q * 3], gy = a.centre_t[q * 3 + 1], gz = a.centre_t[q * 3 + 2];
+    float best = INFINITY;
+    int at = 0;
+    for (int j = 0; j < K; ++j) {
+      const float *cc = a.bbox + (size_t)(bi * K + j) * 7;
+      const float dx = cc[0] - gx, dy = cc[1] - gy, dz = cc[2] - gz;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d < best) { best = d; at = j; }
+    }
+    a.kstar[q] = at;
+    a.dmin[q] = best;
+  }
+  __syncthreads();
+  float l_obj = 0.f, l_sem = 0.f, l_c = 0.f, l_surf = 0.f, l_iou = 0.f, l_qfl = 0.f, l_side = 0.f;
+  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) l_c += a.w_cdst * (a.dmin[q] * a.valid_w[q]);
+  for (int p = threadIdx.x; p < np; p += HL_BLOCK) {
+    const int bi = p / K, kk = p % K;
+    const float w = a.box_w[p], ow = a.obj_w[p];
+    const int y = (int)a.obj_t[p], lab = (int)a.label[p];
+    const float *z = a.cls + (size_t)bi * NC * K + kk;        // channel j at z[j * K]
+    float *dzp = a.s_cls + (size_t)bi * NC * K + kk;
+    // -- objectness: class-weighted softmax cross entropy
+    {
+      const float z0 = z[0], z1 = z[K];
+      const float m = fmaxf(z0, z1);
+      const float e0 = expf(z0 - m), e1 = expf(z1 - m), s = e0 + e1;
+      const float lse = m + logf(s);
+      const float cw = y ? a.cw1 : a.cw0;
+      l_obj += a.w_obj * ((-cw * ((y ? z1 : z0) - lse)) * ow);
+      const float gsc = a.w_obj * ow * cw;
+      dzp[0] = gsc * (e0 / s - (y ? 0.f : 1.f));
+      dzp[K] = gsc * (e1 / s - (y ? 1.f : 0.f));
+    }
+    // -- semantic cross entropy + the arg-max class (first maximum)
+    int pick = 0;
+    {
+      const float *zs = z + 2 * K;
+      float m = zs[0];
+      for (int j = 1; j < C; ++j) { if (zs[(size_t)j * K] > m) { m = zs[(size_t)j * K]; pick = j; } }
+      float s = 0.f;
+      for (int j = 0; j < C; ++j) s += expf(zs[(size_t)j * K] - m);
+      const float lse = m + logf(s);
+      l_sem += a.w_sem * ((-(zs[(size_t)lab * K] - lse)) * w);
+      const float gsc = a.w_sem * w;
+      for (int j = 0; j < C; ++j)
+        dzp[(size_t)(2 + j) * K] = gsc * (expf(zs[(size_t)j * K] - m) / s - (j == lab ? 1.f : 0.f));
+      a.sem_pick[p] = pick;
+    }
+    // -- centre: nearest (padded) ground-truth centre, and this proposal's share of the
+    //    destination half
+    const float *cc = a.bbox + (size_t)p * 7;
+    {
+      float best = INFINITY;
+      int at = 0;
+      const float *ct = a.centre_t + (size_t)bi * a.t * 3;
+      for (int j = 0; j < a.t; ++j) {
+        const float dx = cc[0] - ct[j * 3], dy = cc[1] - ct[j * 3 + 1], dz = cc[2] - ct[j * 3 + 2];
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < best) { best = d; at = j; }
+      }
+      l_c += a.w_csrc * (best * w);
+      float gx = a.w_csrc * w * 2.f * (cc[0] - ct[at * 3]);
+      float gy = a.w_csrc * w * 2.f * (cc[1] - ct[at * 3 + 1]);
+      float gz = a.w_csrc * w * 2.f * (cc[2] - ct[at * 3 + 2]);
+      for (int j = 0; j < a.t; ++j) {
+        if (a.kstar[bi * a.t + j] == kk) {
+          const float vw = a.w_cdst * a.valid_w[bi * a.t + j] * 2.f;
+          gx += vw * (cc[0] - ct[j * 3]); gy += vw * (cc[1] - ct[j * 3 + 1]);
+          gz += vw * (cc[2] - ct[j * 3 + 2]);
+        }
+      }
+      a.s_centre[p * 3] = gx; a.s_centre[p * 3 + 1] = gy; a.s_centre[p * 3 + 2] = gz;
+    }
+    // -- the six sides: surface regression, side quality, and the uncertainty weights
+    const float *tb = a.bbox_t + (size_t)p * 7;
+    const size_t side_k = (size_t)2 * K;     // proposals per (side, scene, class) row
+    float sig[6], dsig_ds[6], sig_mean = 0.f;
+    for (int i = 0; i < 6; ++i) {
+      const float s = a.side[(((size_t)i * a.b + bi) * C + pick) * side_k + kk];
+      sig[i] = 0.8f * s * s - 1.8f * s + 1.f;
+      dsig_ds[i] = 1.6f * s - 1.8f;
+      sig_mean += sig[i];
+    }
+    sig_mean = sig_mean / 6.f;
+    for (int i = 0; i < 6; ++i) {
+      const float half = 0.5f * tb[3 + i % 3];
+      const float ts = i < 3 ? tb[i] - half : tb[i - 3] + half;
+      const float sp = a.surface[p * 6 + i];
+      const float e = sp - ts;
+      const float l = a.w_surf * ((e * e) * w);
+      const float ex = expf(-sig[i]);
+      l_surf += ex * l + a.alpha * sig[i] * w;
+      a.s_surface[p * 6 + i] = ex * (a.w_surf * (2.f * e) * w);
+      a.s_side_surf[p * 6 + i] = (-ex * l + a.alpha * w) * dsig_ds[i];
+      // side quality: label = min(1, 4 |error|), squared error of the assigned class's score
+      const float lbl = fminf(4.f * fabsf(e), 1.f);
+      const float sc = a.side[(((size_t)i * a.b + bi) * C + lab) * side_k + kk];
+      const float r = sc - lbl;
+      l_side += a.w_side * ((r * r) * w);
+      a.s_side_pred[p * 6 + i] = a.w_side * (2.f * r) * w;
+    }
+    // -- IoU regression under the mean uncertainty
+    {
+      const float li = a.w_iou * ((w > 0.f ? 1.f - a.iou[p] : 0.f) * w);
+      const float ex = expf(-sig_mean);
+      l_iou += ex * li + a.alpha * sig_mean * w;
+      a.s_iou[p] = ex * (a.w_iou * (w > 0.f ? -1.f : 0.f) * w);
+      const float dmean = (-ex * li + a.alpha * w) / 6.f;
+      for (int i = 0; i < 6; ++i) a.s_side_iou[p * 6 + i] = dmean * dsig_ds[i];
+    }
+    // -- IoU prediction: quality focal loss on probabilities, plain and jittered halves
+    for (int hj = 0; hj < 2; ++hj) {
+      const size_t row = ((size_t)bi * 2 * K + (size_t)hj * K + kk) * C;
+      const float *pr = a.iou_s + row;
+      float *dp = a.s_iou_s + row;
+      const float score = hj ? a.iou_j[p] : a.iou[p];
+      float acc = 0.f;
+      for (int j = 0; j < C; ++j) {
+        const float q = pr[j];
+        const float den = fmaxf((1.f - q) * q, 1e-12f);
+        if (j == lab) {
+          const float bce = -(score * hl_log_clamped(q) + (1.f - score) * hl_log_clamped(1.f - q));
+          const float df = score - q, mod = df * df;
+          acc += bce * mod;
+          dp[j] = a.w_qfl * w * (((q - score) / den) * mod + bce * (2.f * (q - score)));
+        } else {
+          const float bce = -hl_log_clamped(1.f - q);
+          acc += bce * (q * q);
+          dp[j] = a.w_qfl * w * ((q / den) * (q * q) + bce * (2.f * q));
+        }
+      }
+      l_qfl += a.w_qfl * (acc * w);
+    }
+  }
+  const float s0 = hl_block_sum(l_obj, sh), s1 = hl_block_sum(l_sem, sh), s2 = hl_block_sum(l_c, sh);
+  const float s3 = hl_block_sum(l_surf, sh), s4 = hl_block_sum(l_iou, sh);
+  const float s5 = hl_block_sum(l_qfl, sh), s6 = hl_block_sum(l_side, sh);
+  if (threadIdx.x == 0) {
+    a.loss[0] = s0; a.loss[1] = s1; a.loss[2] = s2; a.loss[3] = s3; a.loss[4] = s4;
+    a.loss[5] = s5; a.loss[6] = s6;
+  }
+}
+
+// gradient assembly: every saved per-term gradient times the incoming gradient of its term, in
+// the producers' layouts; d_side must arrive zero-filled (only two class columns per proposal and
+// side are touched)
+struct HeadLossBwd {
+  int b, k, c;
+  const float *g;            // [7] incoming gradients of the seven terms
+  const long long *label;
+  const int *sem_pick;
+  const float *s_cls, *s_centre, *s_surface, *s_iou, *s_iou_s;
+  const float *s_side_surf, *s_side_iou, *s_side_pred;
+  float *d_cls, *d_bbox, *d_surface, *d_iou, *d_iou_s, *d_side;
+};
+
+__global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadLossBwd a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int K = a.k, C = a.c, NC = 2 + a.c;
+  if (p >= a.b * K) return;
+  const int bi = p / K, kk = p % K;
+  const float g0 = a.g[0], g1 = a.g[1], g2 = a.g[2], g3 = a.g[3], g4 = a.g[4], g5 = a.g[5], g6 = a.g[6];
+  const size_t zo = (size_t)bi * NC * K + kk;
+  a.d_cls[zo] = g0 * a.s_cls[zo];
+  a.d_cls[zo + K] = g0 * a.s_cls[zo + K];
+  for (int j = 0; j < C; ++j) a.d_cls[zo + (size_t)(2 + j) * K] = g1 * a.s_cls[zo + (size_t)(2 + j) * K];
+  for (int hj = 0; hj < 2; ++hj) {
+    const size_t row = ((size_t)bi * 2 * K + (size_t)hj * K + kk) * C;
+    for (int j = 0; j < C; ++j) a.d_iou_s[row + j] = g5 * a.s_iou_s[row + j];
+  }
+  float *db = a.d_bbox + (size_t)p * 7;
+  for (int i = 0; i < 3; ++i) db[i] = g2 * a.s_centre[p * 3 + i];
+  db[3] = db[4] = db[5] = db[6] = 0.f;
+  a.d_iou[p] = g4 * a.s_iou[p];
+  const int pick = a.sem_pick[p], lab = (int)a.label[p];
+  const size_t side_k = (size_t)2 * K;
+  for (int i = 0; i < 6; ++i) {
+    a.d_surface[p * 6 + i] = g3 * a.s_surface[p * 6 + i];
+    float *base = a.d_side + (((size_t)i * a.b + bi) * C) * side_k + kk;
+    base[(size_t)pick * side_k] = g3 * a.s_side_surf[p * 6 + i] + g4 * a.s_side_iou[p * 6 + i];
+    base[(size_t)lab * side_k] += g6 * a.s_side_pred[p * 6 + i];
+  }
+}
+
+}  // namespace nesie
+
+using namespace nesie;
+
+extern "C" int nesie_head_targets(int b, int k, int t, const float *agg, const float *gt_boxes,
+                                  const long long *gt_labels, const long long *gt_count,
+                                  const float *gt_valid, float pos_thr, float neg_thr,
+                                  long long *assignment, long long *obj_targets,
+                                  float *obj_weights, long long *mask_targets,
+                                  float *bbox_targets, float *center_targets,
+                                  float *box_weights, float *valid_weights, void *stream) {
+  const char *W = "head_targets";
+  NESIE_REQUIRE(b >= 0 && k >= 1 && t >= 1, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(agg && gt_boxes && gt_labels && gt_count && gt_valid && assignment && obj_targets &&
+                    obj_weights && mask_targets && bbox_targets && center_targets && box_weights &&
+                    valid_weights, W);
+  NESIE_REQUIRE((long long)b * k < (1 << 22) && (long long)b * t < (1 << 22), W);
+  hipLaunchKernelGGL(head_targets_kernel, dim3(1), dim3(HL_BLOCK), 0, (hipStream_t)stream, b, k, t,
+                     agg, gt_boxes, gt_labels, gt_count, gt_valid, pos_thr, neg_thr, assignment,
+                     obj_targets, obj_weights, mask_targets, bbox_targets, center_targets,
+                     box_weights, valid_weights);
+  return check_launch(W);
+}
+
+extern "C" int nesie_head_loss_forward(
+    int b, int k, int t, int c, const float *cls, const float *bbox, const float *surface,
+    const float *side, const float *iou_s, const float *iou, const float *iou_j,
+    const long long *obj_t, const long long *label, const float *obj_w, const float *box_w,
+    const float *bbox_t, const float *centre_t, const float *valid_w,
+    const float *config /* [11] */, float *loss, float *s_cls, float *s_centre,
+    float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
+    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, void *stream) {
+  const char *W = "head_loss_forward";
+  NESIE_REQUIRE(b >= 0 && k >= 1 && t >= 1 && c >= 1 && c <= HL_MAXC, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(cls && bbox && surface && side && iou_s && iou && iou_j && obj_t && label && obj_w &&
+                    box_w && bbox_t && centre_t && valid_w && config && loss, W);
+  NESIE_REQUIRE(s_cls && s_centre && s_surface && s_iou && s_iou_s && s_side_surf && s_side_iou &&
+                    s_side_pred && sem_pick && kstar && dmin, W);
+  NESIE_REQUIRE((long long)b * k < (1 << 22) && (long long)b * t < (1 << 22), W);
+  // config is a HOST array: the eleven scalars travel as kernel arguments
+  HeadLoss a;
+  a.b = b; a.k = k; a.t = t; a.c = c;
+  a.cls = cls; a.bbox = bbox; a.surface = surface; a.side = side; a.iou_s = iou_s;
+  a.iou = iou; a.iou_j = iou_j;
+  a.obj_t = obj_t; a.label = label; a.obj_w = obj_w; a.box_w = box_w; a.bbox_t = bbox_t;
+  a.centre_t = centre_t; a.valid_w = valid_w;
+  a.alpha = config[0]; a.w_obj = config[1]; a.cw0 = config[2]; a.cw1 = config[3];
+  a.w_sem = config[4]; a.w_csrc = config[5]; a.w_cdst = config[6]; a.w_surf = config[7];
+  a.w_iou = config[8]; a.w_qfl = config[9]; a.w_side = config[10];
+  a.loss = loss; a.s_cls = s_cls; a.s_centre = s_centre; a.s_surface = s_surface; a.s_iou = s_iou;
+  a.s_iou_s = s_iou_s; a.s_side_surf = s_side_surf; a.s_side_iou = s_side_iou;
+  a.s_side_pred = s_side_pred; a.sem_pick = sem_pick; a.kstar = kstar; a.dmin = dmin;
+  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(HL_BLOCK), 0, (hipStream_t)stream, a);
+  return check_launch(W);
+}
+
+extern "C" int nesie_head_loss_backward(
+    int b, int k, int c, const float *g, const long long *label, const int *sem_pick,
+    const float *s_cls, const float *s_centre, const float *s_surface, const float *s_iou,
+    const float *s_iou_s, const float *s_side_surf, const float *s_side_iou,
+    const float *s_side_pred, float *d_cls, float *d_bbox, float *d_surface, float *d_iou,
+    float *d_iou_s, float *d_side /* zero-filled */, void *stream) {
+  const char *W = "head_loss_backward";
+  NESIE_REQUIRE(b >= 0 && k >= 1 && c >= 1 && c <= HL_MAXC, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(g && label && sem_pick && s_cls && s_centre && s_surface && s_iou && s_iou_s &&
+                    s_side_surf && s_side_iou && s_side_pred, W);
+  NESIE_REQUIRE(d_cls && d_bbox && d_surface && d_iou && d_iou_s && d_side, W);
+  HeadLossBwd a;
+  a.b = b; a.k = k; a.c = c; a.g = g; a.label = label; a.sem_pick = sem_pick;
+  a.s_cls = s_cls; a.s_centre = s_centre; a.s_surface = s_surface; a.s_iou = s_iou;
+  a.s_iou_s = s_iou_s; a.s_side_surf = s_side_surf; a.s_side_iou = s_side_iou;
+  a.s_side_pred = s_side_pred;
+  a.d_cls = d_cls; a.d_bbox = d_bbox; a.d_surface = d_surface; a.d_iou = d_iou; a.d_iou_s = d_iou_s;
+  a.d_side = d_side;
+  hipLaunchKernelGGL(head_loss_bwd_kernel, dim3((b * k + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return check_launch(W);
+}

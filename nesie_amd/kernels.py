@@ -12,6 +12,8 @@ pre-allocated by the caller and written in place.
 """
 import contextlib
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -690,6 +692,82 @@ class HipKernels(_BNPoolMixin):
                       opt(save_invstd), _ptr(fwd_coef), _ptr(partial), int(partial.shape[1]),
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
+
+    # ---- Nesie head: targets and loss terms (include/nesie_head_ops.h) -----------------------
+    def head_targets(self, agg, gt_boxes, gt_labels, gt_count, gt_valid, pos_thr, neg_thr):
+        """-> dict(assignment, obj_targets, obj_weights, mask_targets, bbox_targets,
+        center_targets, box_weights, valid_weights) (nesie_head_targets)."""
+        _check(agg, gt_boxes, gt_labels, gt_count, gt_valid); _f32(agg, gt_boxes, gt_valid)
+        assert gt_labels.dtype == torch.int64 and gt_count.dtype == torch.int64
+        b, k = agg.shape[:2]
+        t = gt_boxes.shape[1]
+        dev = agg.device
+        i64 = lambda *s_: torch.empty(*s_, dtype=torch.int64, device=dev)  # noqa: E731
+        f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)  # noqa: E731
+        out = dict(assignment=i64(b, k), obj_targets=i64(b, k), obj_weights=f32(b, k),
+                   mask_targets=i64(b, k), bbox_targets=f32(b, k, 7), center_targets=f32(b, t, 3),
+                   box_weights=f32(b, k), valid_weights=f32(b, t))
+        with torch.cuda.device(dev):
+            _lib.call("nesie_head_targets", b, k, t, _ptr(agg), _ptr(gt_boxes), _ptr(gt_labels),
+                      _ptr(gt_count), _ptr(gt_valid), float(pos_thr), float(neg_thr),
+                      _ptr(out['assignment']), _ptr(out['obj_targets']), _ptr(out['obj_weights']),
+                      _ptr(out['mask_targets']), _ptr(out['bbox_targets']),
+                      _ptr(out['center_targets']), _ptr(out['box_weights']),
+                      _ptr(out['valid_weights']), _stream(agg))
+        return out
+
+    def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config):
+        """The seven loss terms + their saved gradients (nesie_head_loss_forward).  cls
+        (B,2+C,K), bbox (B,K,7), surface (B,K,6), side (6,B,C,2K), iou_s (B,2K,C), iou / iou_j
+        (B*K); tg = head_targets(...); config = 11 python floats.  -> (loss (7,), saved dict)."""
+        _check(cls, bbox, surface, side, iou_s, iou, iou_j)
+        _f32(cls, bbox, surface, side, iou_s, iou, iou_j)
+        b, nc, k = cls.shape
+        c = nc - 2
+        t = tg['center_targets'].shape[1]
+        assert tuple(side.shape) == (6, b, c, 2 * k) and tuple(bbox.shape) == (b, k, 7)
+        assert tuple(iou_s.shape) == (b, 2 * k, c) and tuple(surface.shape) == (b, k, 6)
+        assert iou.numel() == b * k == iou_j.numel() and len(config) == 11
+        dev = cls.device
+        f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)  # noqa: E731
+        i32 = lambda *s_: torch.empty(*s_, dtype=torch.int32, device=dev)  # noqa: E731
+        sv = dict(cls=f32(b, nc, k), centre=f32(b * k, 3), surface=f32(b, k, 6), iou=f32(b * k),
+                  iou_s=f32(b, 2 * k, c), side_surf=f32(b * k, 6), side_iou=f32(b * k, 6),
+                  side_pred=f32(b * k, 6), sem_pick=i32(b * k))
+        loss, kstar, dmin = f32(7), i32(b * t), f32(b * t)
+        cfg = (ctypes.c_float * 11)(*[float(v) for v in config])
+        with torch.cuda.device(dev):
+            _lib.call("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
+                      _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(iou_j), _ptr(tg['obj_targets']),
+                      _ptr(tg['mask_targets']), _ptr(tg['obj_weights']), _ptr(tg['box_weights']),
+                      _ptr(tg['bbox_targets']), _ptr(tg['center_targets']),
+                      _ptr(tg['valid_weights']), ctypes.cast(cfg, ctypes.c_void_p), _ptr(loss),
+                      _ptr(sv['cls']), _ptr(sv['centre']), _ptr(sv['surface']), _ptr(sv['iou']),
+                      _ptr(sv['iou_s']), _ptr(sv['side_surf']), _ptr(sv['side_iou']),
+                      _ptr(sv['side_pred']), _ptr(sv['sem_pick']), _ptr(kstar), _ptr(dmin),
+                      _stream(cls))
+        return loss, sv
+
+    def head_loss_backward(self, g, label, sv, k):
+        """g (7,) incoming gradients (device) -> dict(cls, bbox, surface, iou, iou_s, side) in the
+        producers' layouts (nesie_head_loss_backward)."""
+        _check(g, label); _f32(g)
+        b, nc, _ = sv['cls'].shape
+        c = nc - 2
+        dev = g.device
+        out = dict(cls=torch.empty_like(sv['cls']),
+                   bbox=torch.empty(b, k, 7, dtype=torch.float32, device=dev),
+                   surface=torch.empty_like(sv['surface']), iou=torch.empty_like(sv['iou']),
+                   iou_s=torch.empty_like(sv['iou_s']),
+                   side=torch.zeros(6, b, c, 2 * k, dtype=torch.float32, device=dev))
+        with torch.cuda.device(dev):
+            _lib.call("nesie_head_loss_backward", b, k, c, _ptr(g), _ptr(label), _ptr(sv['sem_pick']),
+                      _ptr(sv['cls']), _ptr(sv['centre']), _ptr(sv['surface']), _ptr(sv['iou']),
+                      _ptr(sv['iou_s']), _ptr(sv['side_surf']), _ptr(sv['side_iou']),
+                      _ptr(sv['side_pred']), _ptr(out['cls']), _ptr(out['bbox']),
+                      _ptr(out['surface']), _ptr(out['iou']), _ptr(out['iou_s']), _ptr(out['side']),
+                      _stream(g))
+        return out
 
     def pw_stats_finalize(self, stat_part, gamma, beta, running_mean, running_var, momentum, eps,
                           coef):

@@ -1,0 +1,81 @@
+"""The seven per-proposal loss terms of ``NesieHead.loss`` as one forward and one backward launch.
+
+``nesie_head.py:279-413`` of the reference evaluates objectness / semantic cross entropy, the
+centre Chamfer term, the uncertainty-weighted surface and IoU regressions, the IoU-quality focal
+loss (plain + jittered proposals) and the side-quality loss through ~150 small tensor ops, and
+autograd replays as many for the gradients.  All of them are closed-form sums over the (at most a
+few thousand) proposals of the batch: ``csrc/head_loss.hip`` evaluates the sums and their analytic
+gradients in one workgroup (``nesie_head_loss_forward``), and the backward only scales the saved
+gradients by the incoming ones and lays them out for the producers (``nesie_head_loss_backward``).
+The module-by-module evaluation in ``nesie_head.py`` stays the definition (CPU checker, other
+configurations); ``tests/test_head_loss_gpu.py`` holds the two against each other.
+"""
+import torch
+from torch.autograd import Function
+
+from ..kernels import backend_for
+
+ENABLED = True   # tests flip this to get the module-by-module evaluation on the device
+
+TERMS = ('objectness_loss', 'semantic_loss', 'center_loss', 'surface_loss', 'iou_loss',
+         'iou_pred_loss', 'side_loss')
+
+
+class HeadLossFn(Function):
+    """(cls, bbox, surface, side_all, iou_all, iou, iou_jitter) -> loss (7,) in ``TERMS`` order."""
+
+    @staticmethod
+    def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config):
+        backend = backend_for(cls)
+        loss, saved = backend.head_loss_forward(cls, bbox, surface, side_all, iou_all,
+                                                iou.reshape(-1), iou_j.reshape(-1), targets, config)
+        ctx.saved, ctx.label, ctx.k, ctx.iou_shape = saved, targets['mask_targets'], bbox.shape[1], iou.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        backend = backend_for(g)
+        d = backend.head_loss_backward(g.contiguous(), ctx.label, ctx.saved, ctx.k)
+        return (d['cls'], d['bbox'], d['surface'], d['side'], d['iou_s'],
+                d['iou'].view(ctx.iou_shape), None, None, None)
+
+
+def config_of(head):
+    """The eleven scalars of the shipped configuration, or None when the head's loss modules are
+    not the ones the kernel implements."""
+    from . import losses as L
+    o, s, c = head.objectness_loss, head.semantic_loss, head.center_loss
+    su, io, q, sd = head.surface_loss, head.iou_loss, head.iou_pred_loss, head.side_loss
+    ok = (isinstance(o, L.CrossEntropyLoss) and o.reduction == 'sum' and o.class_weight is not None
+          and len(o.class_weight) == 2
+          and isinstance(s, L.CrossEntropyLoss) and s.reduction == 'sum' and s.class_weight is None
+          and isinstance(c, L.ChamferDistance) and c.mode == 'l2' and c.reduction == 'sum'
+          and isinstance(su, L.SurfaceLoss) and su.func_type == 'MSELoss'
+          and isinstance(io, L.IoU3DLoss)
+          and isinstance(q, L.GeneralQualityFocalLoss) and not q.use_sigmoid and q.beta == 2.0
+          and q.reduction == 'sum'
+          and isinstance(sd, L.SidePredLoss) and sd.label_func_type == 'SmoothL1Loss'
+          and isinstance(sd.loss_func, L.MSELoss) and sd.loss_func.reduction == 'sum')
+    if not ok:
+        return None
+    return [head.alpha, o.loss_weight, o.class_weight[0], o.class_weight[1], s.loss_weight,
+            c.loss_src_weight, c.loss_dst_weight, su.loss_func.loss_weight, io.loss_weight,
+            q.loss_weight, sd.loss_func.loss_weight]
+
+
+def usable(head, bbox_preds):
+    """True when ``NesieHead.loss`` can take the fused path for these predictions."""
+    if not ENABLED or type(head).__name__ != 'NesieHead':
+        return False
+    need = ('_cls_all', '_side_all', '_iou_all')
+    if any(k not in bbox_preds for k in need):
+        return False
+    cls = bbox_preds['_cls_all']
+    if backend_for(cls).name != 'hip' or cls.dtype != torch.float32:
+        return False
+    B, K = bbox_preds['bbox_preds'].shape[:2]
+    C = cls.shape[1] - 2
+    return (cls.shape[0] == B and cls.shape[2] == K and C <= 32
+            and tuple(bbox_preds['_side_all'].shape) == (6, B, C, 2 * K)
+            and tuple(bbox_preds['_iou_all'].shape) == (B, 2 * K, C)
+            and config_of(head) is not None)

@@ -18,9 +18,11 @@ from torch.nn import functional as F
 from ..mmdet3d_ops import (build_sa_module, furthest_point_sample, points_in_boxes_batch,
                            points_in_boxes_count)
 from ..post_processing import batched_aligned_3d_nms
+from ..kernels import backend_for
 from ..mmdet3d_ops.rotated_iou import cal_iou_3d
 from .bbox_module import ReliableConvBboxHead
 from .boxes import DepthInstance3DBoxes, depth_to_lidar_boxes, depth_to_lidar_points
+from . import head_loss
 from .losses import build_loss
 from ..streams import fork_join
 from .side_pooling import SidePooling
@@ -228,6 +230,7 @@ class NesieHead(nn.Module):
         cls_predictions, reg_predictions = self.conv_pred(features)
         origin_proposal_num = cls_predictions.shape[-1]
         cls_preds_trans = cls_predictions.transpose(2, 1)
+        results['_cls_all'] = cls_predictions          # (B, 2 + C, K), for the fused loss kernel
         results['obj_scores'] = cls_preds_trans[..., :2]
         results['sem_scores'] = cls_preds_trans[..., 2:]
         B = reg_predictions.shape[0]
@@ -259,7 +262,9 @@ class NesieHead(nn.Module):
         iou = results['iou_scores'].sigmoid()
         results['iou_scores_jitter'] = iou[:, origin_proposal_num:]
         results['iou_scores'] = iou[:, :origin_proposal_num]
-        side = results['side_scores'].sigmoid().permute(1, 3, 0, 2)  # (B, 2K, 6, C)
+        side_all = results['side_scores'].sigmoid()                   # (6, B, C, 2K)
+        results['_iou_all'], results['_side_all'] = iou, side_all     # for the fused loss kernel
+        side = side_all.permute(1, 3, 0, 2)  # (B, 2K, 6, C)
         results['side_scores_jitter'] = side[:, origin_proposal_num:]
         results['side_scores'] = side[:, :origin_proposal_num]
         return results
@@ -376,6 +381,8 @@ class NesieHead(nn.Module):
          valid_gt_masks, objectness_targets, objectness_weights, box_loss_weights,
          valid_gt_weights, assignment) = targets
         bbox_targets_cat = bbox_targets.reshape(-1, 7)
+        if head_loss.usable(self, bbox_preds):
+            return self._fused_loss(bbox_preds, targets, ret_target)
 
         # shared by several terms
         surface_weight = box_loss_weights.reshape(-1).unsqueeze(-1).repeat(1, 6)
@@ -455,6 +462,31 @@ class NesieHead(nn.Module):
                       iou_pred_loss=iou_pred_loss, side_loss=side_loss)
         if ret_target:
             losses['targets'] = targets_b
+        return losses
+
+    def _fused_loss(self, bbox_preds, targets, ret_target):
+        """The same eight terms with the seven per-proposal ones in one launch
+        (``head_loss.HeadLossFn``); the vote term and the two rotated-IoU evaluations stay."""
+        (vote_targets, vote_target_masks, center_targets, bbox_targets, mask_targets,
+         valid_gt_masks, objectness_targets, objectness_weights, box_loss_weights,
+         valid_gt_weights, assignment) = targets
+        vote_loss = self.vote_module.get_loss(
+            bbox_preds['seed_points'], bbox_preds['vote_points'], bbox_preds['seed_indices'],
+            vote_target_masks, vote_targets)
+        boxes = bbox_preds['bbox_preds']
+        iou = cal_iou_3d(boxes, bbox_targets)                              # (B, K), with gradient
+        iou_jitter = cal_iou_3d(bbox_preds['jitter_bbox_preds'], bbox_targets).detach()
+        tg = dict(obj_targets=objectness_targets, mask_targets=mask_targets,
+                  obj_weights=objectness_weights, box_weights=box_loss_weights,
+                  bbox_targets=bbox_targets, center_targets=center_targets,
+                  valid_weights=valid_gt_weights)
+        terms = head_loss.HeadLossFn.apply(
+            bbox_preds['_cls_all'].contiguous(), boxes.contiguous(),
+            bbox_preds['surface_pred'].contiguous(), bbox_preds['_side_all'].contiguous(),
+            bbox_preds['_iou_all'].contiguous(), iou, iou_jitter, tg, head_loss.config_of(self))
+        losses = dict(vote_loss=vote_loss, **{n: terms[i] for i, n in enumerate(head_loss.TERMS)})
+        if ret_target:
+            losses['targets'] = bbox_targets.view_as(boxes)
         return losses
 
     # ---- unsupervised loss (:415-509) -------------------------------------------
@@ -573,6 +605,18 @@ class NesieHead(nn.Module):
 
         # --- proposal <-> GT assignment (:656-676) ---
         aggregated_points = bbox_preds['aggregated_points']
+        backend = backend_for(aggregated_points)
+        if (head_loss.ENABLED and backend.name == 'hip' and aggregated_points.dtype == torch.float32
+                and gt.boxes.dtype == torch.float32):
+            # assignment, labels, box targets and the three batch-level weights in one launch
+            tg = backend.head_targets(aggregated_points.contiguous(), gt.boxes.contiguous(),
+                                      gt.labels.contiguous(), gt.count.contiguous(),
+                                      gt.valid.float().contiguous(),
+                                      self.train_cfg['pos_distance_thr'],
+                                      self.train_cfg['neg_distance_thr'])
+            return (vote_targets, vote_target_masks, tg['center_targets'], tg['bbox_targets'],
+                    tg['mask_targets'], gt.valid, tg['obj_targets'], tg['obj_weights'],
+                    tg['box_weights'], tg['valid_weights'], tg['assignment'])
         d = aggregated_points.unsqueeze(2) - centres.unsqueeze(1)
         d = (d * d).sum(-1)  # (B,K,T) squared L2
         d = torch.where(is_col.unsqueeze(1), d, torch.full_like(d, float('inf')))

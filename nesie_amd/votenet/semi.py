@@ -280,7 +280,8 @@ class VoteNetNesie(VoteNet):
 
     @staticmethod
     def _select(bbox_preds, index):
-        return {k: v.index_select(0, index) for k, v in bbox_preds.items()}
+        # ('_*' entries are whole-batch tensors in their producers' layouts: not selectable)
+        return {k: v.index_select(0, index) for k, v in bbox_preds.items() if not k.startswith('_')}
 
     # -- pseudo labels (:129-299) -------------------------------------------------------
     def get_pseudo_labels(self, preds, dataset_name='ScanNet'):

@@ -1,0 +1,87 @@
+"""The fused Nesie-head targets / loss kernels against the module-by-module evaluation (the
+definition, the same code the CPU oracle path and the reference goldens pin), on the device."""
+import copy
+
+import pytest
+import torch
+
+from nesie_amd.votenet import head_loss
+from nesie_amd.votenet.nesie_head import GTBatch
+from tests import _small
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, pts, gt, fused, weights=None):
+    head_loss.ENABLED = fused
+    try:
+        for p in model.parameters():
+            p.grad = None
+        x = model.extract_feat(pts)
+        preds = model.bbox_head(x, 'vote')
+        keep = {}
+        for k in ('_cls_all', 'bbox_preds', 'surface_pred', '_side_all', '_iou_all'):
+            preds[k].retain_grad()
+            keep[k] = preds[k]
+        assert head_loss.usable(model.bbox_head, preds) == fused
+        losses = model.bbox_head.loss(preds, pts, gt, None)
+        w = weights or {k: 1.0 for k in losses}
+        sum(losses[k] * w[k] for k in losses).backward()
+        return ({k: v.detach().clone() for k, v in losses.items()},
+                {k: v.grad.detach().clone() for k, v in keep.items()},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        head_loss.ENABLED = True
+
+
+@pytest.mark.parametrize('thresholds', [(0.3, 0.6), (1.0, 1.5)])
+def test_fused_loss_matches_the_module_by_module_loss(hip_device, thresholds):
+    model = _small.small_model().to(hip_device)
+    model.train_cfg['pos_distance_thr'], model.train_cfg['neg_distance_thr'] = thresholds
+    model.bbox_head.train_cfg = model.train_cfg
+    pts, boxes, labels = _small.small_batch()
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(2, 32))
+    # unequal incoming gradients: the backward must scale every term by its own
+    weights = dict(vote_loss=1.0, objectness_loss=0.7, semantic_loss=1.3, center_loss=0.9,
+                   surface_loss=1.1, iou_loss=0.8, iou_pred_loss=1.2, side_loss=0.6)
+    want = _run(model, pts, gt, False, weights)
+    got = _run(model, pts, gt, True, weights)
+    assert list(got[0]) == list(want[0])
+    for k in want[0]:
+        torch.testing.assert_close(got[0][k], want[0][k], rtol=2e-5, atol=1e-6, msg=k)
+    for k in want[1]:
+        scale = want[1][k].abs().max().item()
+        torch.testing.assert_close(got[1][k], want[1][k], rtol=1e-4, atol=2e-5 * max(scale, 1e-6), msg=k)
+    flat_w = torch.cat([want[2][n].flatten() for n in sorted(want[2])]).double()
+    flat_g = torch.cat([got[2][n].flatten() for n in sorted(want[2])]).double()
+    assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-4
+
+
+def test_targets_kernel_matches_the_tensor_ops(hip_device):
+    """nesie_head_targets vs get_targets' tensor-op form: indices exact, weights bit-equal."""
+    model = _small.small_model().to(hip_device)
+    model.train_cfg['pos_distance_thr'], model.train_cfg['neg_distance_thr'] = 0.6, 1.0
+    model.bbox_head.train_cfg = model.train_cfg
+    pts, boxes, labels = _small.small_batch(batch=3)
+    boxes[1] = boxes[1][:0]          # an empty scene: the reference's all-zero fake box
+    labels[1] = labels[1][:0]
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    with torch.no_grad():
+        preds = model.bbox_head(model.extract_feat(pts), 'vote')
+        outs = []
+        for fused in (False, True):
+            head_loss.ENABLED = fused
+            try:
+                outs.append(model.bbox_head.get_targets(pts, gt, None, bbox_preds=preds))
+            finally:
+                head_loss.ENABLED = True
+    names = ['vote_targets', 'vote_target_masks', 'center_targets', 'bbox_targets', 'mask_targets',
+             'valid_gt_masks', 'objectness_targets', 'objectness_weights', 'box_loss_weights',
+             'valid_gt_weights', 'assignment']
+    assert outs[0][6].sum() > 0
+    for n, a, b in zip(names, outs[0], outs[1]):
+        assert a.dtype == b.dtype and a.shape == b.shape, n
+        assert torch.equal(a, b), n
