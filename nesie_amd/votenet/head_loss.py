@@ -22,7 +22,9 @@ TERMS = ('objectness_loss', 'semantic_loss', 'center_loss', 'surface_loss', 'iou
 
 
 class HeadLossFn(Function):
-    """(cls, bbox, surface, side_all, iou_all, iou, iou_jitter) -> loss (7,) in ``TERMS`` order."""
+    """(cls, bbox, surface, side_all, iou_all, iou, iou_jitter) -> the seven terms in ``TERMS``
+    order, as seven 0-dim views of one tensor (so that summing them back-propagates seven scalars
+    and not seven zero-padded vectors)."""
 
     @staticmethod
     def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config):
@@ -30,12 +32,14 @@ class HeadLossFn(Function):
         loss, saved = backend.head_loss_forward(cls, bbox, surface, side_all, iou_all,
                                                 iou.reshape(-1), iou_j.reshape(-1), targets, config)
         ctx.saved, ctx.label, ctx.k, ctx.iou_shape = saved, targets['mask_targets'], bbox.shape[1], iou.shape
-        return loss
+        return tuple(loss.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        g = torch.stack([gi if gi is not None else torch.zeros_like(ref) for gi in gs])
         backend = backend_for(g)
-        d = backend.head_loss_backward(g.contiguous(), ctx.label, ctx.saved, ctx.k)
+        d = backend.head_loss_backward(g, ctx.label, ctx.saved, ctx.k)
         return (d['cls'], d['bbox'], d['surface'], d['side'], d['iou_s'],
                 d['iou'].view(ctx.iou_shape), None, None, None)
 

@@ -484,7 +484,7 @@ class NesieHead(nn.Module):
             bbox_preds['_cls_all'].contiguous(), boxes.contiguous(),
             bbox_preds['surface_pred'].contiguous(), bbox_preds['_side_all'].contiguous(),
             bbox_preds['_iou_all'].contiguous(), iou, iou_jitter, tg, head_loss.config_of(self))
-        losses = dict(vote_loss=vote_loss, **{n: terms[i] for i, n in enumerate(head_loss.TERMS)})
+        losses = dict(vote_loss=vote_loss, **dict(zip(head_loss.TERMS, terms)))
         if ret_target:
             losses['targets'] = bbox_targets.view_as(boxes)
         return losses
