@@ -218,10 +218,11 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
     # all-reduce, the clip and AdamW each see ONE tensor
     bucket = dp.FlatTrainState(model.parameters())
-    # on the GPU: torch's single-kernel ("fused") AdamW over the one flat parameter
-    opt = torch.optim.AdamW([bucket.flat_param], lr=lr, weight_decay=wd,
-                            capturable=graph and on_gpu, **(dict(fused=True) if on_gpu
-                                                             else dict(foreach=True)))
+    if on_gpu:
+        # clip (max_norm 10) + AdamW as two launches over the flat vectors (dp.FlatAdamW)
+        opt = dp.FlatAdamW(bucket.flat_param, lr=lr, weight_decay=wd, max_norm=10)
+    else:
+        opt = torch.optim.AdamW([bucket.flat_param], lr=lr, weight_decay=wd, foreach=True)
 
     # The backward pass is cut at the backbone's output (dp.backward_head / backward_rest):
     # the head's gradients (the tail of the flat vector) are complete after phase 1 and their
@@ -253,7 +254,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         cut.clear()
 
     def update():
-        torch.nn.utils.clip_grad_norm_([bucket.flat_param], max_norm=10, norm_type=2)
+        if not on_gpu:
+            torch.nn.utils.clip_grad_norm_([bucket.flat_param], max_norm=10, norm_type=2)
         opt.step()
         if workload in ('semi', 'saqe'):
             model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)

@@ -10,6 +10,7 @@
  * these; a maintainer binds them from NesieHead.loss (see nesie_amd/votenet/head_loss.py). */
 #ifndef NESIE_HEAD_OPS_H
 #define NESIE_HEAD_OPS_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -65,6 +66,17 @@ int nesie_head_loss_backward(int b, int k, int c, const float *g, const long lon
                              const float *s_side_pred, float *d_cls, float *d_bbox,
                              float *d_surface, float *d_iou, float *d_iou_s, float *d_side,
                              void *stream);
+
+/* Clip-by-global-norm + AdamW over ONE flat parameter vector (dp.FlatTrainState), two launches,
+ * no host round trip: torch.nn.utils.clip_grad_norm_(max_norm, 2) followed by torch.optim.AdamW's
+ * update (mmcv OptimizerHook grad_clip + the reference's AdamW schedule).  step: device scalar
+ * (float), incremented here; grad is left clipped; grad_norm_out (device scalar) or NULL.
+ * max_norm <= 0: no clipping.  workspace: nesie_flat_adamw_workspace_bytes(). */
+size_t nesie_flat_adamw_workspace_bytes(void);
+int nesie_flat_adamw_step(long long n, float *param, float *grad, float *exp_avg,
+                          float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float max_norm, float *grad_norm_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,8 @@ SIGNATURES = {
     "nesie_head_targets": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_head_loss_forward": [_I, _I, _I, _I] + [_P] * 28,
     "nesie_head_loss_backward": [_I, _I, _I] + [_P] * 18,
+    "nesie_flat_adamw_step": [ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P,
+                              ctypes.c_size_t, _P],
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P],
@@ -124,6 +126,8 @@ def load():
     lib.nesie_pw_wgrad_supported.restype = _I
     lib.nesie_pw_wgrad_workspace_bytes.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_flat_adamw_workspace_bytes.argtypes = []
+    lib.nesie_flat_adamw_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_pw_supported.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_pw_supported.restype = _I
     lib.nesie_pw_stat_slots.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]

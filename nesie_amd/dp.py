@@ -134,6 +134,35 @@ class FlatTrainState(FlatGradBucket):
         self.flat.zero_()
 
 
+class FlatAdamW(torch.optim.Optimizer):
+    """``clip_grad_norm_(max_norm)`` + ``torch.optim.AdamW`` over ``FlatTrainState.flat_param`` as
+    two launches of ``nesie_flat_adamw_step`` (capture-safe: the step count is a device scalar,
+    the clip coefficient never visits the host).  State keys are torch's (``step``, ``exp_avg``,
+    ``exp_avg_sq``), so ``checkpoint.per_parameter_optimizer_state`` applies unchanged."""
+
+    def __init__(self, flat_param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 max_norm=None):
+        super().__init__([flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = max_norm
+        self.grad_norm = None      # device scalar: the un-clipped global norm of the last step
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from .kernels import backend_for
+        group = self.param_groups[0]
+        p = group['params'][0]
+        st = self.state[p]
+        if not st:
+            st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st['exp_avg'] = torch.zeros_like(p)
+            st['exp_avg_sq'] = torch.zeros_like(p)
+        if self.grad_norm is None:
+            self.grad_norm = torch.zeros((), dtype=torch.float32, device=p.device)
+        backend_for(p).flat_adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], st['step'],
+                                       group['lr'], group['betas'], group['eps'],
+                                       group['weight_decay'], self.max_norm, self.grad_norm)
+
+
 def backward_head(total, boundary, early_params):
     """Phase 1 of a backward pass cut at ``boundary`` (tensors every path from the loss to the
     remaining parameters runs through -- the backbone's output): the gradients of

@@ -693,6 +693,22 @@ class HipKernels(_BNPoolMixin):
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
 
+    def flat_adamw_step(self, param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay,
+                        max_norm, grad_norm_out=None):
+        """clip_grad_norm_(max_norm) + AdamW over flat vectors, in place (nesie_flat_adamw_step);
+        ``step`` is a float32 device scalar that the call increments."""
+        _check(param, grad, exp_avg, exp_avg_sq, step); _f32(param, grad, exp_avg, exp_avg_sq, step)
+        n = param.numel()
+        assert grad.numel() == n == exp_avg.numel() == exp_avg_sq.numel() and step.numel() == 1
+        need = _lib.load().nesie_flat_adamw_workspace_bytes()
+        ws = torch.empty(need, dtype=torch.uint8, device=param.device)
+        with torch.cuda.device(param.device):
+            _lib.call("nesie_flat_adamw_step", n, _ptr(param), _ptr(grad), _ptr(exp_avg),
+                      _ptr(exp_avg_sq), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
+                      float(eps), float(weight_decay), float(max_norm or 0.0),
+                      0 if grad_norm_out is None else _ptr(grad_norm_out), _ptr(ws), need,
+                      _stream(param))
+
     # ---- Nesie head: targets and loss terms (include/nesie_head_ops.h) -----------------------
     def head_targets(self, agg, gt_boxes, gt_labels, gt_count, gt_valid, pos_thr, neg_thr):
         """-> dict(assignment, obj_targets, obj_weights, mask_targets, bbox_targets,

@@ -41,7 +41,8 @@ def test_binding_covers_every_compute_entry_point():
                             "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_pw_wgrad_supported",
                             "nesie_pw_wgrad_workspace_bytes", "nesie_blend_conv_runs",
                             "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials",
-                            "nesie_blend_conv_bn_workspace_bytes")]
+                            "nesie_blend_conv_bn_workspace_bytes",
+                            "nesie_flat_adamw_workspace_bytes")]
     assert sorted(compute) == sorted(_lib.SIGNATURES)
     lib = _lib.load()
     assert lib.nesie_abi_version() >= 1

@@ -702,3 +702,29 @@ def test_grid_taps_equal_three_nn_on_the_same_points(hip_device, m, dups):
     assert torch.equal(idx, ref_idx)
     w = 1.0 / (d + 1e-8)
     torch.testing.assert_close(weight, w / w.sum(-1, keepdim=True), rtol=1e-6, atol=1e-7)
+
+
+def test_flat_adamw_with_clipping_matches_torch(hip_device):
+    """dp.FlatAdamW (nesie_flat_adamw_step) == clip_grad_norm_ + torch.optim.AdamW, several steps,
+    with and without the clip active."""
+    from nesie_amd import dp
+    g = torch.Generator(device=hip_device).manual_seed(4)
+    n = 300_001
+    p0 = torch.randn(n, device=hip_device, generator=g)
+    a = torch.nn.Parameter(p0.clone())
+    b = torch.nn.Parameter(p0.clone())
+    opt_a = dp.FlatAdamW(a, lr=8e-3, weight_decay=0.01, max_norm=10.0)
+    opt_b = torch.optim.AdamW([b], lr=8e-3, weight_decay=0.01)
+    for it, scale in enumerate([1e-3, 5.0, 1e-2, 40.0, 1.0]):
+        grad = torch.randn(n, device=hip_device, generator=g) * scale
+        a.grad, b.grad = grad.clone(), grad.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([b], max_norm=10.0, norm_type=2)
+        opt_b.step()
+        opt_a.step()
+        torch.testing.assert_close(opt_a.grad_norm, want_norm, rtol=1e-5, atol=0)
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-9)       # left clipped
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=1e-7, msg=str(it))
+    st_a, st_b = opt_a.state[a], opt_b.state[b]
+    assert float(st_a['step']) == float(st_b['step']) == 5
+    torch.testing.assert_close(st_a['exp_avg'], st_b['exp_avg'], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(st_a['exp_avg_sq'], st_b['exp_avg_sq'], rtol=1e-5, atol=1e-10)
