@@ -44,7 +44,8 @@ int nesie_head_targets(int b, int k, int t, const float *agg, const float *gt_bo
  * s_cls (B,2+C,K), s_centre (B*K,3), s_surface (B*K,6), s_iou (B*K), s_iou_s (B,2K,C); the three
  * s_side_* (B*K,6) are the side-score gradients of the surface term and the iou term (both at
  * class sem_pick[p] = arg-max class logit) and of the side term (at class label[p]).
- * kstar (B*T) int32, dmin (B*T): scratch. */
+ * kstar (B*T) int32, dmin (B*T), partial (ceil(B*K / 64), 8): scratch; ticket: one int32 that is
+ * ZERO before the first call (the kernel leaves it zero). */
 int nesie_head_loss_forward(int b, int k, int t, int c, const float *cls, const float *bbox,
                             const float *surface, const float *side, const float *iou_s,
                             const float *iou, const float *iou_j, const long long *obj_t,
@@ -53,7 +54,7 @@ int nesie_head_loss_forward(int b, int k, int t, int c, const float *cls, const 
                             const float *config, float *loss, float *s_cls, float *s_centre,
                             float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf,
                             float *s_side_iou, float *s_side_pred, int *sem_pick, int *kstar,
-                            float *dmin, void *stream);
+                            float *dmin, float *partial, int *ticket, void *stream);
 
 /* Gradient assembly: the saved per-term gradients times the incoming gradients g[7] (device) of
  * the seven terms, in the producers' layouts: d_cls (B,2+C,K), d_bbox (B,K,7) (size and yaw

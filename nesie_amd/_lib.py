@@ -75,7 +75,7 @@ SIGNATURES = {
     "nesie_bn_relu_backward_apply": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _I, _P,
                                      _P, _P, _I, _P, _P],
     "nesie_head_targets": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "nesie_head_loss_forward": [_I, _I, _I, _I] + [_P] * 28,
+    "nesie_head_loss_forward": [_I, _I, _I, _I] + [_P] * 30,
     "nesie_head_loss_backward": [_I, _I, _I] + [_P] * 18,
     "nesie_flat_adamw_step": [ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P,
                               ctypes.c_size_t, _P],

@@ -123,32 +123,41 @@ struct HeadLoss {
   int *sem_pick;           // (B*K) arg-max class of the class logits (the column the sigmas read)
   int *kstar;              // (B*T) scratch: nearest proposal of every ground-truth centre
   float *dmin;             // (B*T) scratch
+  float *partial;          // (workgroups, 8) scratch
+  int *ticket;             // zero before the first launch; the kernel leaves it zero
 };
 
 __device__ __forceinline__ float hl_log_clamped(float v) { return fmaxf(logf(v), -100.f); }
 
-__global__ __launch_bounds__(HL_BLOCK) void head_loss_kernel(const HeadLoss a) {
-  __shared__ float sh[HL_BLOCK / 64];
-  const int np = a.b * a.k, ng = a.b * a.t, C = a.c, K = a.k, NC = 2 + a.c;
-  // nearest proposal of every ground-truth centre (the destination half of the chamfer term)
-  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) {
-    const int bi = q / a.t;
-    const float gx = a.centre_t[q * 3], gy = a.centre_t[q * 3 + 1], gz = a.centre_t[q * 3 + 2];
-    float best = INFINITY;
-    int at = 0;
-    for (int j = 0; j < K; ++j) {
-      const float *cc = a.bbox + (size_t)(bi * K + j) * 7;
-      const float dx = cc[0] - gx, dy = cc[1] - gy, dz = cc[2] - gz;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      if (d < best) { best = d; at = j; }
-    }
-    a.kstar[q] = at;
-    a.dmin[q] = best;
+// nearest proposal of every ground-truth centre (the destination half of the chamfer term)
+__global__ __launch_bounds__(64) void head_loss_nearest_kernel(const HeadLoss a) {
+  const int q = blockIdx.x * 64 + threadIdx.x, K = a.k;
+  if (q >= a.b * a.t) return;
+  const int bi = q / a.t;
+  const float gx = a.centre_t[q * 3], gy = a.centre_t[q * 3 + 1], gz = a.centre_t[q * 3 + 2];
+  float best = INFINITY;
+  int at = 0;
+  for (int j = 0; j < K; ++j) {
+    const float *cc = a.bbox + (size_t)(bi * K + j) * 7;
+    const float dx = cc[0] - gx, dy = cc[1] - gy, dz = cc[2] - gz;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d < best) { best = d; at = j; }
   }
-  __syncthreads();
+  a.kstar[q] = at;
+  a.dmin[q] = best;
+}
+
+constexpr int HL_PB = 64;        // proposals (threads) per workgroup of the loss kernel
+
+// One thread per proposal; every workgroup leaves seven partial sums and the LAST one to finish
+// (a self-resetting ticket) adds the partials in workgroup order: reproducible, one launch.
+__global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
+  __shared__ int last;
+  const int np = a.b * a.k, ng = a.b * a.t, C = a.c, K = a.k, NC = 2 + a.c;
   float l_obj = 0.f, l_sem = 0.f, l_c = 0.f, l_surf = 0.f, l_iou = 0.f, l_qfl = 0.f, l_side = 0.f;
-  for (int q = threadIdx.x; q < ng; q += HL_BLOCK) l_c += a.w_cdst * (a.dmin[q] * a.valid_w[q]);
-  for (int p = threadIdx.x; p < np; p += HL_BLOCK) {
+  for (int q = blockIdx.x * HL_PB + threadIdx.x; q < ng; q += gridDim.x * HL_PB)
+    l_c += a.w_cdst * (a.dmin[q] * a.valid_w[q]);
+  for (int p = blockIdx.x * HL_PB + threadIdx.x; p < np; p += gridDim.x * HL_PB) {
     const int bi = p / K, kk = p % K;
     const float w = a.box_w[p], ow = a.obj_w[p];
     const int y = (int)a.obj_t[p], lab = (int)a.label[p];
@@ -267,13 +276,27 @@ __global__ __launch_bounds__(HL_BLOCK) void head_loss_kernel(const HeadLoss a) {
       l_qfl += a.w_qfl * (acc * w);
     }
   }
-  const float s0 = hl_block_sum(l_obj, sh), s1 = hl_block_sum(l_sem, sh), s2 = hl_block_sum(l_c, sh);
-  const float s3 = hl_block_sum(l_surf, sh), s4 = hl_block_sum(l_iou, sh);
-  const float s5 = hl_block_sum(l_qfl, sh), s6 = hl_block_sum(l_side, sh);
-  if (threadIdx.x == 0) {
-    a.loss[0] = s0; a.loss[1] = s1; a.loss[2] = s2; a.loss[3] = s3; a.loss[4] = s4;
-    a.loss[5] = s5; a.loss[6] = s6;
+  float v[7] = {l_obj, l_sem, l_c, l_surf, l_iou, l_qfl, l_side};
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
   }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a.partial[(size_t)blockIdx.x * 8 + i] = v[i];
+    __threadfence();
+    last = atomicAdd(a.ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 7) {
+    float t = 0.f;
+    for (unsigned w = 0; w < gridDim.x; ++w) t += __builtin_nontemporal_load(a.partial + (size_t)w * 8 + threadIdx.x);
+    a.loss[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) *a.ticket = 0;
 }
 
 // gradient assembly: every saved per-term gradient times the incoming gradient of its term, in
@@ -349,14 +372,15 @@ extern "C" int nesie_head_loss_forward(
     const float *bbox_t, const float *centre_t, const float *valid_w,
     const float *config /* [11] */, float *loss, float *s_cls, float *s_centre,
     float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
-    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, void *stream) {
+    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
+    void *stream) {
   const char *W = "head_loss_forward";
   NESIE_REQUIRE(b >= 0 && k >= 1 && t >= 1 && c >= 1 && c <= HL_MAXC, W);
   if (b == 0) return NESIE_OK;
   NESIE_REQUIRE(cls && bbox && surface && side && iou_s && iou && iou_j && obj_t && label && obj_w &&
                     box_w && bbox_t && centre_t && valid_w && config && loss, W);
   NESIE_REQUIRE(s_cls && s_centre && s_surface && s_iou && s_iou_s && s_side_surf && s_side_iou &&
-                    s_side_pred && sem_pick && kstar && dmin, W);
+                    s_side_pred && sem_pick && kstar && dmin && partial && ticket, W);
   NESIE_REQUIRE((long long)b * k < (1 << 22) && (long long)b * t < (1 << 22), W);
   // config is a HOST array: the eleven scalars travel as kernel arguments
   HeadLoss a;
@@ -371,7 +395,10 @@ extern "C" int nesie_head_loss_forward(
   a.loss = loss; a.s_cls = s_cls; a.s_centre = s_centre; a.s_surface = s_surface; a.s_iou = s_iou;
   a.s_iou_s = s_iou_s; a.s_side_surf = s_side_surf; a.s_side_iou = s_side_iou;
   a.s_side_pred = s_side_pred; a.sem_pick = sem_pick; a.kstar = kstar; a.dmin = dmin;
-  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(HL_BLOCK), 0, (hipStream_t)stream, a);
+  a.partial = partial; a.ticket = ticket;
+  hipLaunchKernelGGL(head_loss_nearest_kernel, dim3((b * t + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(head_loss_kernel, dim3((b * k + HL_PB - 1) / HL_PB), dim3(HL_PB), 0,
+                     (hipStream_t)stream, a);
   return check_launch(W);
 }
 

@@ -751,6 +751,8 @@ class HipKernels(_BNPoolMixin):
                   iou_s=f32(b, 2 * k, c), side_surf=f32(b * k, 6), side_iou=f32(b * k, 6),
                   side_pred=f32(b * k, 6), sem_pick=i32(b * k))
         loss, kstar, dmin = f32(7), i32(b * t), f32(b * t)
+        partial = f32((b * k + 63) // 64, 8)
+        ticket = self._head_loss_ticket(dev)
         cfg = (ctypes.c_float * 11)(*[float(v) for v in config])
         with torch.cuda.device(dev):
             _lib.call("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
@@ -761,8 +763,17 @@ class HipKernels(_BNPoolMixin):
                       _ptr(sv['cls']), _ptr(sv['centre']), _ptr(sv['surface']), _ptr(sv['iou']),
                       _ptr(sv['iou_s']), _ptr(sv['side_surf']), _ptr(sv['side_iou']),
                       _ptr(sv['side_pred']), _ptr(sv['sem_pick']), _ptr(kstar), _ptr(dmin),
-                      _stream(cls))
+                      _ptr(partial), _ptr(ticket), _stream(cls))
         return loss, sv
+
+    _tickets = {}
+
+    def _head_loss_ticket(self, dev):
+        """One persistent zeroed int32 per device (the loss kernel resets it itself)."""
+        t = self._tickets.get(dev)
+        if t is None:
+            t = self._tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return t
 
     def head_loss_backward(self, g, label, sv, k):
         """g (7,) incoming gradients (device) -> dict(cls, bbox, surface, iou, iou_s, side) in the
