@@ -68,6 +68,13 @@ int nesie_head_loss_backward(int b, int k, int c, const float *g, const long lon
                              float *d_surface, float *d_iou, float *d_iou_s, float *d_side,
                              void *stream);
 
+/* SidePooling.dist_feature (side_pooling_module.py:245-264) in one launch: probs (B, 6, bins, K)
+ * side-bin distributions -> out (6, B, bins + 5, copies * K) = per face the bins, their four
+ * largest values (descending) and their unbiased variance, repeated `copies` times along the
+ * proposal axis.  bins >= 5. */
+int nesie_side_prob_stats(int b, int bins, int kprop, int copies, const float *probs, float *out,
+                          void *stream);
+
 /* Clip-by-global-norm + AdamW over ONE flat parameter vector (dp.FlatTrainState), two launches,
  * no host round trip: torch.nn.utils.clip_grad_norm_(max_norm, 2) followed by torch.optim.AdamW's
  * update (mmcv OptimizerHook grad_clip + the reference's AdamW schedule).  step: device scalar

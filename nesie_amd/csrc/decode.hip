@@ -145,3 +145,58 @@ extern "C" int nesie_side_decode_backward(int b, int k, int bins, const float *r
                      d_reg, d_agg);
   return check_launch(W);
 }
+
+// ---- per-face statistics of the side-bin distributions -----------------------------------------
+// SidePooling.dist_feature (side_pooling_module.py:245-264): for every (scene, face, proposal) the
+// bins' probabilities, their four largest values (descending) and their unbiased variance,
+// face-major and repeated `copies` times along the proposal axis (the jittered half of the
+// quality head reads the same statistics): probs (B, 6, bins, K) -> out (6, B, bins + 5, copies K).
+// One launch instead of topk + sort + var + cat + permute + repeat.
+namespace nesie {
+__global__ __launch_bounds__(256) void side_prob_stats_kernel(int b, int bins, int kprop, int copies,
+                                                              const float *__restrict__ probs,
+                                                              float *__restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y, bi = blockIdx.z;
+  if (k >= kprop) return;
+  const float *p = probs + (((size_t)bi * 6 + s) * bins) * kprop + k;
+  const size_t row = (size_t)copies * kprop;
+  float *o = out + (((size_t)s * b + bi) * (bins + 5)) * row + k;
+  float t0 = -INFINITY, t1 = -INFINITY, t2 = -INFINITY, t3 = -INFINITY, sum = 0.f;
+  for (int j = 0; j < bins; ++j) {
+    const float v = p[(size_t)j * kprop];
+    sum += v;
+    for (int c = 0; c < copies; ++c) o[(size_t)j * row + (size_t)c * kprop] = v;
+    // insert into the running top four (descending)
+    if (v > t3) {
+      t3 = v;
+      if (t3 > t2) { const float x = t2; t2 = t3; t3 = x; }
+      if (t2 > t1) { const float x = t1; t1 = t2; t2 = x; }
+      if (t1 > t0) { const float x = t0; t0 = t1; t1 = x; }
+    }
+  }
+  const float mean = sum / (float)bins;
+  float m2 = 0.f;
+  for (int j = 0; j < bins; ++j) {
+    const float d = p[(size_t)j * kprop] - mean;
+    m2 += d * d;
+  }
+  const float var = m2 / (float)(bins - 1);
+  for (int c = 0; c < copies; ++c) {
+    float *oc = o + (size_t)c * kprop;
+    oc[(size_t)bins * row] = t0; oc[(size_t)(bins + 1) * row] = t1;
+    oc[(size_t)(bins + 2) * row] = t2; oc[(size_t)(bins + 3) * row] = t3;
+    oc[(size_t)(bins + 4) * row] = var;
+  }
+}
+}  // namespace nesie
+
+extern "C" int nesie_side_prob_stats(int b, int bins, int kprop, int copies, const float *probs,
+                                     float *out, void *stream) {
+  const char *W = "side_prob_stats";
+  NESIE_REQUIRE(b >= 0 && bins >= 5 && kprop >= 0 && copies >= 1, W);
+  if (b == 0 || kprop == 0) return NESIE_OK;
+  NESIE_REQUIRE(probs && out && b <= 65535, W);
+  hipLaunchKernelGGL(nesie::side_prob_stats_kernel, dim3((kprop + 255) / 256, 6, b), dim3(256), 0,
+                     (hipStream_t)stream, b, bins, kprop, copies, probs, out);
+  return nesie::check_launch(W);
+}

@@ -693,6 +693,18 @@ class HipKernels(_BNPoolMixin):
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
 
+    def side_prob_stats(self, probs, copies):
+        """probs (B, 6, bins, K) -> (6, B, bins + 5, copies*K): bins, top-4, unbiased variance per
+        face (nesie_side_prob_stats)."""
+        _check(probs); _f32(probs)
+        b, six, bins, k = probs.shape
+        assert six == 6 and bins >= 5
+        out = torch.empty(6, b, bins + 5, copies * k, dtype=torch.float32, device=probs.device)
+        with torch.cuda.device(probs.device):
+            _lib.call("nesie_side_prob_stats", b, bins, k, int(copies), _ptr(probs), _ptr(out),
+                      _stream(probs))
+        return out
+
     def flat_adamw_step(self, param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay,
                         max_norm, grad_norm_out=None):
         """clip_grad_norm_(max_norm) + AdamW over flat vectors, in place (nesie_flat_adamw_step);

@@ -448,6 +448,10 @@ class SidePooling(nn.Module):
         """[33 side-bin probabilities, top-4, unbiased variance] per face, duplicated
         for the jittered half -> (6, B, 38, 2K)  (:245-264)."""
         prob = end_points[f'{prefix}bbox_probs'].detach()
+        backend = backend_for(prob)
+        if (backend.name == 'hip' and self.reg_topk == 4 and prob.dtype == torch.float32
+                and prob.dim() == 4 and prob.shape[1] == 6 and prob.shape[2] >= 5):
+            return backend.side_prob_stats(prob.contiguous(), copies)
         stat = torch.cat([prob, prob.topk(self.reg_topk, dim=2)[0],
                           prob.var(dim=2, keepdim=True)], dim=2)
         return stat.permute(1, 0, 2, 3).repeat(1, 1, 1, copies)   # copies = 1: no jittered half

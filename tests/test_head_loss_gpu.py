@@ -85,3 +85,18 @@ def test_targets_kernel_matches_the_tensor_ops(hip_device):
     for n, a, b in zip(names, outs[0], outs[1]):
         assert a.dtype == b.dtype and a.shape == b.shape, n
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize('bins,copies', [(17, 2), (33, 1)])
+def test_side_prob_stats_match_topk_and_var(hip_device, bins, copies):
+    """nesie_side_prob_stats vs SidePooling.dist_feature's tensor form (cat[prob, topk 4, var])."""
+    from nesie_amd import kernels
+    g = torch.Generator(device=hip_device).manual_seed(bins)
+    prob = torch.softmax(torch.randn(3, 6, bins, 200, device=hip_device, generator=g) * 2, dim=2)
+    prob[0, 1, :, 5] = 1.0 / bins                      # ties
+    want = torch.cat([prob, prob.topk(4, dim=2)[0], prob.var(dim=2, keepdim=True)], dim=2)
+    want = want.permute(1, 0, 2, 3).repeat(1, 1, 1, copies)
+    got = kernels.backend_for(prob).side_prob_stats(prob, copies)
+    assert got.shape == want.shape
+    assert torch.equal(got[:, :, :bins + 4], want[:, :, :bins + 4])
+    torch.testing.assert_close(got[:, :, bins + 4], want[:, :, bins + 4], rtol=1e-5, atol=1e-9)
