@@ -68,6 +68,19 @@ int nesie_head_loss_backward(int b, int k, int c, const float *g, const long lon
                              float *d_surface, float *d_iou, float *d_iou_s, float *d_side,
                              void *stream);
 
+/* VoteModule.get_loss (vote_module.py:149-180) for one vote per seed:
+ *   loss = w_dst * sum_seeds [mask / (sum mask + 1e-6)] * min_g |vote - (seed + targets_g)|_1
+ * seed, vote (B,N,3); seed_idx (B,N) int64 into the N_pts input points; mask (B,N_pts) int64;
+ * targets (B,N_pts,3*gt_per_seed) offsets.  -> loss (device scalar), sign_out (B,N,3) = mask *
+ * sign(vote - nearest target), scale_out = w_dst / (sum mask + 1e-6); partial (64, 2) scratch,
+ * ticket as in nesie_head_loss_forward.  Backward: d_vote = g * scale * sign. */
+int nesie_vote_loss_forward(int b, int n, long long npts, int gt_per_seed, const float *seed,
+                            const float *vote, const long long *seed_idx, const long long *mask,
+                            const float *targets, float w_dst, float *sign_out, float *loss,
+                            float *scale_out, float *partial, int *ticket, void *stream);
+int nesie_vote_loss_backward(long long n3, const float *g, const float *scale, const float *sign,
+                             float *d_vote, void *stream);
+
 /* SidePooling.dist_feature (side_pooling_module.py:245-264) in one launch: probs (B, 6, bins, K)
  * side-bin distributions -> out (6, B, bins + 5, copies * K) = per face the bins, their four
  * largest values (descending) and their unbiased variance, repeated `copies` times along the

@@ -425,3 +425,100 @@ extern "C" int nesie_head_loss_backward(
                      (hipStream_t)stream, a);
   return check_launch(W);
 }
+
+// ---- vote loss -----------------------------------------------------------------------------------
+// VoteModule.get_loss (vote_module.py:149-180) for one vote per seed: every seed inside an object
+// is pulled to the nearest (L1) of its up to three ground-truth centres,
+//   loss = w_dst * sum_seeds [mask / (sum mask + 1e-6)] * min_g |vote - (seed + offset_g)|_1 .
+// Forward: per-workgroup (sum, count) partials, the last workgroup folds them in order; the sign
+// pattern of the winning target is kept for the backward, which is one scaled copy.
+namespace nesie {
+constexpr int VL_BLOCK = 256;
+
+__global__ __launch_bounds__(VL_BLOCK) void vote_loss_kernel(
+    int b, int n, long long npts, int gt_per_seed, const float *__restrict__ seed,
+    const float *__restrict__ vote, const long long *__restrict__ seed_idx,
+    const long long *__restrict__ mask, const float *__restrict__ targets, float w_dst,
+    float *__restrict__ sign_out, float *__restrict__ loss, float *__restrict__ scale_out,
+    float *__restrict__ partial, int *__restrict__ ticket) {
+  __shared__ float sh[2][VL_BLOCK / 64];
+  __shared__ int last;
+  const int total = b * n;
+  float s = 0.f, cnt = 0.f;
+  for (int i = blockIdx.x * VL_BLOCK + threadIdx.x; i < total; i += gridDim.x * VL_BLOCK) {
+    const int bi = i / n;
+    const long long src = seed_idx[i];
+    const float m = (float)mask[(size_t)bi * npts + src];
+    const float *tg = targets + ((size_t)bi * npts + src) * (3 * gt_per_seed);
+    const float sx = seed[i * 3], sy = seed[i * 3 + 1], sz = seed[i * 3 + 2];
+    const float vx = vote[i * 3], vy = vote[i * 3 + 1], vz = vote[i * 3 + 2];
+    float best = INFINITY, bx = 0.f, by = 0.f, bz = 0.f;
+    for (int g = 0; g < gt_per_seed; ++g) {
+      const float dx = vx - (tg[g * 3] + sx), dy = vy - (tg[g * 3 + 1] + sy), dz = vz - (tg[g * 3 + 2] + sz);
+      const float d = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
+      if (d < best) { best = d; bx = dx; by = dy; bz = dz; }
+    }
+    s += m * best;
+    cnt += m;
+    // d|x|/dx with torch's sign(0) = 0
+    sign_out[i * 3] = m * (float)((bx > 0.f) - (bx < 0.f));
+    sign_out[i * 3 + 1] = m * (float)((by > 0.f) - (by < 0.f));
+    sign_out[i * 3 + 2] = m * (float)((bz > 0.f) - (bz < 0.f));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    partial[blockIdx.x * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    __threadfence();
+    last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last || threadIdx.x != 0) return;
+  __threadfence();
+  float ts = 0.f, tc = 0.f;
+  for (unsigned w = 0; w < gridDim.x; ++w) { ts += partial[w * 2]; tc += partial[w * 2 + 1]; }
+  const float scale = w_dst / (tc + 1e-6f);
+  *loss = ts * scale;
+  *scale_out = scale;
+  *ticket = 0;
+}
+
+__global__ __launch_bounds__(256) void vote_loss_bwd_kernel(long long n3, const float *__restrict__ g,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ sign,
+                                                            float *__restrict__ d_vote) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n3) d_vote[i] = (*g * *scale) * sign[i];
+}
+}  // namespace nesie
+
+extern "C" int nesie_vote_loss_forward(int b, int n, long long npts, int gt_per_seed, const float *seed,
+                                       const float *vote, const long long *seed_idx,
+                                       const long long *mask, const float *targets, float w_dst,
+                                       float *sign_out, float *loss, float *scale_out,
+                                       float *partial, int *ticket, void *stream) {
+  const char *W = "vote_loss_forward";
+  NESIE_REQUIRE(b >= 0 && n >= 1 && npts >= 1 && gt_per_seed >= 1, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(seed && vote && seed_idx && mask && targets && sign_out && loss && scale_out &&
+                    partial && ticket, W);
+  const int blocks = (b * n + VL_BLOCK - 1) / VL_BLOCK < 64 ? (b * n + VL_BLOCK - 1) / VL_BLOCK : 64;
+  hipLaunchKernelGGL(vote_loss_kernel, dim3(blocks), dim3(VL_BLOCK), 0, (hipStream_t)stream, b, n, npts,
+                     gt_per_seed, seed, vote, seed_idx, mask, targets, w_dst, sign_out, loss, scale_out,
+                     partial, ticket);
+  return check_launch(W);
+}
+
+extern "C" int nesie_vote_loss_backward(long long n3, const float *g, const float *scale,
+                                        const float *sign, float *d_vote, void *stream) {
+  const char *W = "vote_loss_backward";
+  NESIE_REQUIRE(n3 >= 0, W);
+  if (n3 == 0) return NESIE_OK;
+  NESIE_REQUIRE(g && scale && sign && d_vote, W);
+  hipLaunchKernelGGL(vote_loss_bwd_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, n3, g, scale, sign, d_vote);
+  return check_launch(W);
+}

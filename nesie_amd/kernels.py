@@ -693,6 +693,34 @@ class HipKernels(_BNPoolMixin):
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
 
+    def vote_loss_forward(self, seed, vote, seed_idx, mask, targets, w_dst):
+        """-> (loss scalar, sign (B,N,3), scale scalar) (nesie_vote_loss_forward)."""
+        _check(seed, vote, seed_idx, mask, targets); _f32(seed, vote, targets)
+        assert seed_idx.dtype == torch.int64 and mask.dtype == torch.int64
+        b, n = seed.shape[:2]
+        npts = mask.shape[1]
+        gps = targets.shape[2] // 3
+        assert tuple(vote.shape) == (b, n, 3) and tuple(targets.shape) == (b, npts, 3 * gps)
+        dev = seed.device
+        sign = torch.empty(b, n, 3, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        scale = torch.empty((), dtype=torch.float32, device=dev)
+        partial = torch.empty(64, 2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("nesie_vote_loss_forward", b, n, npts, gps, _ptr(seed), _ptr(vote),
+                      _ptr(seed_idx), _ptr(mask), _ptr(targets), float(w_dst), _ptr(sign),
+                      _ptr(loss), _ptr(scale), _ptr(partial), _ptr(self._head_loss_ticket(dev, 1)),
+                      _stream(seed))
+        return loss, sign, scale
+
+    def vote_loss_backward(self, g, scale, sign):
+        _check(g, scale, sign); _f32(g, scale, sign)
+        d = torch.empty_like(sign)
+        with torch.cuda.device(sign.device):
+            _lib.call("nesie_vote_loss_backward", sign.numel(), _ptr(g), _ptr(scale), _ptr(sign),
+                      _ptr(d), _stream(sign))
+        return d
+
     def side_prob_stats(self, probs, copies):
         """probs (B, 6, bins, K) -> (6, B, bins + 5, copies*K): bins, top-4, unbiased variance per
         face (nesie_side_prob_stats)."""
@@ -780,12 +808,12 @@ class HipKernels(_BNPoolMixin):
 
     _tickets = {}
 
-    def _head_loss_ticket(self, dev):
-        """One persistent zeroed int32 per device (the loss kernel resets it itself)."""
+    def _head_loss_ticket(self, dev, slot=0):
+        """Persistent zeroed int32 tickets per device (the kernels reset them themselves)."""
         t = self._tickets.get(dev)
         if t is None:
-            t = self._tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-        return t
+            t = self._tickets[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+        return t[slot:slot + 1]
 
     def head_loss_backward(self, g, label, sv, k):
         """g (7,) incoming gradients (device) -> dict(cls, bbox, surface, iou, iou_s, side) in the

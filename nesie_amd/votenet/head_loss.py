@@ -83,3 +83,32 @@ def usable(head, bbox_preds):
             and tuple(bbox_preds['_side_all'].shape) == (6, B, C, 2 * K)
             and tuple(bbox_preds['_iou_all'].shape) == (B, 2 * K, C)
             and config_of(head) is not None)
+
+
+class VoteLossFn(Function):
+    """``VoteModule.get_loss`` for one vote per seed as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, vote_points, seed_points, seed_indices, mask, targets, w_dst):
+        backend = backend_for(vote_points)
+        loss, sign, scale = backend.vote_loss_forward(
+            seed_points.contiguous(), vote_points.contiguous(), seed_indices.contiguous(),
+            mask.contiguous(), targets.contiguous(), w_dst)
+        ctx.save_for_backward(sign, scale)
+        ctx.shape = vote_points.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        sign, scale = ctx.saved_tensors
+        d = backend_for(g).vote_loss_backward(g.contiguous(), scale, sign)
+        return d.view(ctx.shape), None, None, None, None, None
+
+
+def vote_loss_usable(vote_module, vote_points, seed_indices, mask, targets):
+    from . import losses as L
+    vl = getattr(vote_module, 'vote_loss', None)
+    return (ENABLED and isinstance(vl, L.ChamferDistance) and vl.mode == 'l1' and vl.reduction == 'none'
+            and vote_module.vote_per_seed == 1 and backend_for(vote_points).name == 'hip'
+            and vote_points.dtype == torch.float32 and seed_indices.dtype == torch.int64
+            and mask.dtype == torch.int64 and targets.dtype == torch.float32)

@@ -63,6 +63,11 @@ class VoteModule(nn.Module):
         ``gt_per_seed``) ground-truth centres: configured Chamfer term, vote -> target direction,
         closest target per vote, weights = in-object mask / number of in-object seeds
         (:149-180).  vote_targets holds OFFSETS from the input point, 3 per ground truth."""
+        from . import head_loss
+        if head_loss.vote_loss_usable(self, vote_points, seed_indices, vote_targets_mask, vote_targets):
+            return head_loss.VoteLossFn.apply(vote_points, seed_points, seed_indices,
+                                              vote_targets_mask, vote_targets,
+                                              self.vote_loss.loss_dst_weight)
         B, N = seed_points.shape[:2]
         G = self.gt_per_seed
         inside = vote_targets_mask.gather(1, seed_indices).float()                     # (B, N)
