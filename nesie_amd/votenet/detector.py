@@ -145,7 +145,12 @@ class VoteNet(nn.Module):
 
     @staticmethod
     def parse_losses(losses):
-        return sum(v for k, v in losses.items() if 'loss' in k)
+        """Total = sum of every entry whose key contains 'loss' (mmdet BaseDetector._parse_losses);
+        0-dim terms are added in one stack + sum instead of a chain of scalar additions."""
+        terms = [v for k, v in losses.items() if 'loss' in k]
+        if len(terms) > 2 and all(torch.is_tensor(v) and v.dim() == 0 for v in terms):
+            return torch.stack(terms).sum()
+        return sum(terms)
 
 
 class GraphedSimpleTest:

@@ -280,8 +280,8 @@ class VoteNetNesie(VoteNet):
 
     @staticmethod
     def _select(bbox_preds, index):
-        # ('_*' entries are whole-batch tensors in their producers' layouts: not selectable)
-        return {k: v.index_select(0, index) for k, v in bbox_preds.items() if not k.startswith('_')}
+        # ('_*' entries keep their producers' layouts: the scene axis of '_side_all' is axis 1)
+        return {k: v.index_select(1 if k == '_side_all' else 0, index) for k, v in bbox_preds.items()}
 
     # -- pseudo labels (:129-299) -------------------------------------------------------
     def get_pseudo_labels(self, preds, dataset_name='ScanNet'):
