@@ -471,8 +471,12 @@ def main():
 
     def wgrad_flop(dy, x, dw, **kw):
         return 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] * dy.shape[2]
-    gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop))
-    timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer) + gemm_timers
+    def dgrad_flop(dy, w, *a, **kw):
+        return 2.0 * dy.shape[0] * dy.shape[1] * w.shape[1] * dy.shape[2]
+    gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
+                   GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop))
+    bn_apply_timer = KernelTimer(hip, 'bn_relu_backward_apply', lambda dy, *_: dy.numel() == mid)
+    timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer, bn_apply_timer) + gemm_timers
 
     def sync():
         if world > 1:
@@ -555,13 +559,14 @@ def main():
         # ---- the dominant family: the grouped per-seed MLP GEMMs on the fp32 matrix cores.
         # achieved = algorithmic FLOPs (2 * batches * K * Cout * positions per launch) / HIP-event
         # time, summed over every launch of the family in the un-captured steps.
-        n_l, ms_l, fl_l = gemm_timers[0].totals()
+        n_l, ms_l, fl_l = (a + b for a, b in zip(gemm_timers[0].totals(), gemm_timers[2].totals()))
         n_w, ms_w, fl_w = gemm_timers[1].totals()
         if n_l + n_w:
             tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             per_step = lambda v: v / eager_steps  # noqa: E731
             out['roofline'] = {
-                'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients) + '
+                'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients, with the operand '
+                          'normalisation / statistics / pooling / norm-backward reduction epilogues) + '
                           'nesie::pw_wgrad_kernel: the 1x1-conv layers of the SA stacks and the '
                           'MiniPointNets, fp32 MFMA (v_mfma_f32_16x16x4_f32)',
                 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -587,7 +592,9 @@ def main():
                     'x (B,128,2048,64))', pool_bwd_timer.mean_ms(), 2, big * 4,
                     extra=3 * pooled_bytes + pooled_bytes // 4),
             _stream('nesie::bn_bwd_reduce_kernel + bn_bwd_apply_kernel<relu> (B,64,2048,64)',
-                    bn_bwd_timer.mean_ms(), 5, mid * 4)) if e]
+                    bn_bwd_timer.mean_ms(), 5, mid * 4),
+            _stream('nesie::bn_bwd_apply_kernel<relu> from the input-gradient kernel\'s partials '
+                    '(B,64,2048,64): read da, z; write dz', bn_apply_timer.mean_ms(), 3, mid * 4)) if e]
         out['roofline_latency_bound'] = {
             'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048: 2047 dependent rounds; '
                       'longest single launch, overlapped with the previous step on a side '
