@@ -1,0 +1,3 @@
+// pw_fwd_kernel<16, 8, 1, 128, *, *>: K <= 64, 8 x 1 waves, 128-position tiles (pwconv_fwd.h)
+#include "pwconv_fwd.h"
+PW_GEOM_DEF(16, 8, 1, 128)
