@@ -693,7 +693,7 @@ class HipKernels(_BNPoolMixin):
                       _ptr(dx), opt(dgamma), opt(dbeta), int(group or 1), opt(d_row_bias),
                       _stream(x))
 
-    def vote_loss_forward(self, seed, vote, seed_idx, mask, targets, w_dst):
+    def vote_loss_forward(self, seed, vote, seed_idx, mask, targets, w_dst, ticket):
         """-> (loss scalar, sign (B,N,3), scale scalar) (nesie_vote_loss_forward)."""
         _check(seed, vote, seed_idx, mask, targets); _f32(seed, vote, targets)
         assert seed_idx.dtype == torch.int64 and mask.dtype == torch.int64
@@ -709,7 +709,7 @@ class HipKernels(_BNPoolMixin):
         with torch.cuda.device(dev):
             _lib.call("nesie_vote_loss_forward", b, n, npts, gps, _ptr(seed), _ptr(vote),
                       _ptr(seed_idx), _ptr(mask), _ptr(targets), float(w_dst), _ptr(sign),
-                      _ptr(loss), _ptr(scale), _ptr(partial), _ptr(self._head_loss_ticket(dev, 1)),
+                      _ptr(loss), _ptr(scale), _ptr(partial), _ptr(ticket),
                       _stream(seed))
         return loss, sign, scale
 
@@ -772,10 +772,11 @@ class HipKernels(_BNPoolMixin):
                       _ptr(out['valid_weights']), _stream(agg))
         return out
 
-    def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config):
+    def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config, ticket):
         """The seven loss terms + their saved gradients (nesie_head_loss_forward).  cls
         (B,2+C,K), bbox (B,K,7), surface (B,K,6), side (6,B,C,2K), iou_s (B,2K,C), iou / iou_j
-        (B*K); tg = head_targets(...); config = 11 python floats.  -> (loss (7,), saved dict)."""
+        (B*K); tg = head_targets(...); config = 11 python floats; ticket = a zeroed int32 scalar
+        that lives outside any graph capture (the kernel leaves it zero).  -> (loss (7,), saved dict)."""
         _check(cls, bbox, surface, side, iou_s, iou, iou_j)
         _f32(cls, bbox, surface, side, iou_s, iou, iou_j)
         b, nc, k = cls.shape
@@ -792,7 +793,7 @@ class HipKernels(_BNPoolMixin):
                   side_pred=f32(b * k, 6), sem_pick=i32(b * k))
         loss, kstar, dmin = f32(7), i32(b * t), f32(b * t)
         partial = f32((b * k + 63) // 64, 8)
-        ticket = self._head_loss_ticket(dev)
+        assert ticket.dtype == torch.int32 and ticket.is_cuda and ticket.numel() == 1
         cfg = (ctypes.c_float * 11)(*[float(v) for v in config])
         with torch.cuda.device(dev):
             _lib.call("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
@@ -805,15 +806,6 @@ class HipKernels(_BNPoolMixin):
                       _ptr(sv['side_pred']), _ptr(sv['sem_pick']), _ptr(kstar), _ptr(dmin),
                       _ptr(partial), _ptr(ticket), _stream(cls))
         return loss, sv
-
-    _tickets = {}
-
-    def _head_loss_ticket(self, dev, slot=0):
-        """Persistent zeroed int32 tickets per device (the kernels reset them themselves)."""
-        t = self._tickets.get(dev)
-        if t is None:
-            t = self._tickets[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
-        return t[slot:slot + 1]
 
     def head_loss_backward(self, g, label, sv, k):
         """g (7,) incoming gradients (device) -> dict(cls, bbox, surface, iou, iou_s, side) in the

@@ -17,6 +17,13 @@ from ..kernels import backend_for
 
 ENABLED = True   # tests flip this to get the module-by-module evaluation on the device
 
+
+def new_ticket():
+    """The 'last workgroup reduces' counter of the loss kernels: a zeroed int32 the kernels reset
+    themselves.  Kept as a NON-persistent module buffer so that it is allocated with the model
+    (never inside a hipGraph capture) and follows ``.to(device)``."""
+    return torch.zeros(1, dtype=torch.int32)
+
 TERMS = ('objectness_loss', 'semantic_loss', 'center_loss', 'surface_loss', 'iou_loss',
          'iou_pred_loss', 'side_loss')
 
@@ -27,10 +34,11 @@ class HeadLossFn(Function):
     and not seven zero-padded vectors)."""
 
     @staticmethod
-    def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config):
+    def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config, ticket):
         backend = backend_for(cls)
         loss, saved = backend.head_loss_forward(cls, bbox, surface, side_all, iou_all,
-                                                iou.reshape(-1), iou_j.reshape(-1), targets, config)
+                                                iou.reshape(-1), iou_j.reshape(-1), targets, config,
+                                                ticket)
         ctx.saved, ctx.label, ctx.k, ctx.iou_shape = saved, targets['mask_targets'], bbox.shape[1], iou.shape
         return tuple(loss.unbind(0))
 
@@ -41,7 +49,7 @@ class HeadLossFn(Function):
         backend = backend_for(g)
         d = backend.head_loss_backward(g, ctx.label, ctx.saved, ctx.k)
         return (d['cls'], d['bbox'], d['surface'], d['side'], d['iou_s'],
-                d['iou'].view(ctx.iou_shape), None, None, None)
+                d['iou'].view(ctx.iou_shape), None, None, None, None)
 
 
 def config_of(head):
@@ -89,11 +97,11 @@ class VoteLossFn(Function):
     """``VoteModule.get_loss`` for one vote per seed as one launch each way."""
 
     @staticmethod
-    def forward(ctx, vote_points, seed_points, seed_indices, mask, targets, w_dst):
+    def forward(ctx, vote_points, seed_points, seed_indices, mask, targets, w_dst, ticket):
         backend = backend_for(vote_points)
         loss, sign, scale = backend.vote_loss_forward(
             seed_points.contiguous(), vote_points.contiguous(), seed_indices.contiguous(),
-            mask.contiguous(), targets.contiguous(), w_dst)
+            mask.contiguous(), targets.contiguous(), w_dst, ticket)
         ctx.save_for_backward(sign, scale)
         ctx.shape = vote_points.shape
         return loss
@@ -102,7 +110,7 @@ class VoteLossFn(Function):
     def backward(ctx, g):
         sign, scale = ctx.saved_tensors
         d = backend_for(g).vote_loss_backward(g.contiguous(), scale, sign)
-        return d.view(ctx.shape), None, None, None, None, None
+        return d.view(ctx.shape), None, None, None, None, None, None
 
 
 def vote_loss_usable(vote_module, vote_points, seed_indices, mask, targets):

@@ -145,6 +145,7 @@ class NesieHead(nn.Module):
         # with forked branches replays the whole step 2x slower (43 vs 20 ms), so off
         self.parallel_loss_terms = False
         self.jitter_noise = None  # optional (noise_center, noise_size), each (B,K,3)
+        self.register_buffer('_loss_ticket', head_loss.new_ticket(), persistent=False)
         # device-resident constants (no host->device copy inside the step: hipGraph-safe)
         self.register_buffer('_side_scale', torch.tensor(self.sizes + self.sizes), persistent=False)
         self.register_buffer('_side_sign', torch.tensor([-1., -1., -1., 1., 1., 1.]),
@@ -483,7 +484,8 @@ class NesieHead(nn.Module):
         terms = head_loss.HeadLossFn.apply(
             bbox_preds['_cls_all'].contiguous(), boxes.contiguous(),
             bbox_preds['surface_pred'].contiguous(), bbox_preds['_side_all'].contiguous(),
-            bbox_preds['_iou_all'].contiguous(), iou, iou_jitter, tg, head_loss.config_of(self))
+            bbox_preds['_iou_all'].contiguous(), iou, iou_jitter, tg, head_loss.config_of(self),
+            self._loss_ticket)
         losses = dict(vote_loss=vote_loss, **dict(zip(head_loss.TERMS, terms)))
         if ret_target:
             losses['targets'] = bbox_targets.view_as(boxes)

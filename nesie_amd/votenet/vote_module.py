@@ -32,6 +32,8 @@ class VoteModule(nn.Module):
             for cin, cout in zip(widths, widths[1:])])
         self.per_vote = 3 + in_channels if with_res_feat else 3
         self.conv_out = PointwiseConv1d(widths[-1], self.per_vote * vote_per_seed, 1)
+        from .head_loss import new_ticket
+        self.register_buffer('_loss_ticket', new_ticket(), persistent=False)
 
     def forward(self, seed_points, seed_feats):
         """seed_points (B, N, 3), seed_feats (B, C, N) -> vote_points (B, N*V, 3), vote_feats
@@ -67,7 +69,7 @@ class VoteModule(nn.Module):
         if head_loss.vote_loss_usable(self, vote_points, seed_indices, vote_targets_mask, vote_targets):
             return head_loss.VoteLossFn.apply(vote_points, seed_points, seed_indices,
                                               vote_targets_mask, vote_targets,
-                                              self.vote_loss.loss_dst_weight)
+                                              self.vote_loss.loss_dst_weight, self._loss_ticket)
         B, N = seed_points.shape[:2]
         G = self.gt_per_seed
         inside = vote_targets_mask.gather(1, seed_indices).float()                     # (B, N)
