@@ -77,7 +77,7 @@ class _StreamConvStatsFn(torch.autograd.Function):
     """out[b] = W @ x[b] for a skinny first layer (Cin <= 64 over >= 32768 positions) through the
     streaming matrix-core kernel, which also leaves the (sum, sum of squares) partials of the
     output for the BatchNorm that follows: one pass instead of GEMM + statistics pass
-    (tools/mlp_bench.py: 0.069 vs 0.093 + 0.058 ms for 4 -> 64 at SA1).  Backward = that of
+    (measured in round 1: 0.069 vs 0.093 + 0.058 ms for 4 -> 64 at SA1).  Backward = that of
     ``_PointwiseConvFn``."""
 
     @staticmethod
