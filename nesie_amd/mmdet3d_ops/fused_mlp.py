@@ -200,6 +200,59 @@ def sa_stack_supported(backend, x, layers):
     return True
 
 
+def sa_stack_eval_supported(backend, x, layers):
+    """True when ``sa_stack_eval`` serves this shared MLP: evaluation-mode norms with running
+    statistics, no autograd, shapes inside the built tiles."""
+    from .norm import FusedBNReLU2d
+    if not ENABLED or backend.name != 'hip' or x.dtype != torch.float32 or x.dim() != 4 \
+            or len(layers) < 2 or torch.is_grad_enabled():
+        return False
+    B, cin, M, ns = x.shape
+    if ns not in (16, 32, 64):
+        return False
+    for layer in layers:
+        norm = getattr(layer, 'norm', None)
+        if not (isinstance(norm, FusedBNReLU2d) and layer.act_fused and layer.conv.bias is None
+                and not norm.training and norm.track_running_stats and norm.running_mean is not None
+                and layer.conv.in_channels == cin
+                and backend.pw_supported(cin, layer.conv.out_channels, M * ns)):
+            return False
+        cin = layer.conv.out_channels
+    return True
+
+
+def sa_stack_eval(x, layers):
+    """Evaluation-mode shared MLP + max pooling on the layer kernel: every layer's folded running
+    statistics are the next layer's operand transform, the last layer leaves through the pooled
+    tail (test path, ``simple_test``: conv + scale/bias pass + pooling pass per layer otherwise)."""
+    backend = backend_for(x)
+    x = x.contiguous()
+    B, c0, M, ns = x.shape
+    P = M * ns
+    src, coef = x.view(B, c0, P), None
+    pool_group = 16 if ns == 16 else 32
+    pool_out = None
+    for i, layer in enumerate(layers):
+        cout, cin = layer.conv.out_channels, layer.conv.in_channels
+        w2 = layer.conv.weight.reshape(1, cout, cin)
+        y = x.new_empty(B, cout, P)
+        if i == len(layers) - 1:
+            g = P // pool_group
+            pool_out = (x.new_empty(B, cout, g), x.new_empty(B, cout, g),
+                        torch.empty(B, cout, g, dtype=torch.uint8, device=x.device),
+                        torch.empty(B, cout, g, dtype=torch.uint8, device=x.device))
+            part = x.new_empty(1, backend.pw_stat_slots(B, 1, cin, cout, P), cout, 4)
+            backend.pw_layer_forward(src, w2, in_coef=coef, in_relu=True, y=y, stat_part=part,
+                                     pool_group=pool_group, pool_min=True, pool_out=pool_out)
+        else:
+            backend.pw_layer_forward(src, w2, in_coef=coef, in_relu=True, y=y)
+        src, coef = y, layer.norm.eval_coef()
+    pooled = x.new_empty(B, src.shape[1], M)
+    argmax = torch.empty(B, src.shape[1], M, dtype=torch.uint8, device=x.device)
+    backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
+    return pooled
+
+
 def sa_stack(x, layers, fixed_lead=0):
     """Shared MLP + max pooling of a set-abstraction module through ``SAStackFn``;
     ``fixed_lead`` = leading channels of x whose gradient nobody consumes (see SAStackFn)."""

@@ -160,9 +160,7 @@ class _FusedBNReLU:
             if not ((native or native_eval) and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
                 x, row_bias = x + row_bias.unsqueeze(-1), None
         if native_eval:
-            return affine_relu_eval(x, eval_coefficients(self.weight, self.bias, self.running_mean,
-                                                         self.running_var, self.eps),
-                                    self.fuse_relu, row_bias)
+            return affine_relu_eval(x, self.eval_coef(), self.fuse_relu, row_bias)
         if native:
             if _counter_sink is not None:
                 _counter_sink.append(self.num_batches_tracked)
@@ -174,6 +172,20 @@ class _FusedBNReLU:
         y = super().forward(x)
         return F.relu(y) if self.fuse_relu else y
 
+
+    def eval_coef(self):
+        """(C,4) = (scale, shift, 0, 0) of this layer in evaluation mode, cached until a
+        parameter or running statistic changes (six small launches otherwise, per call)."""
+        key = (self.running_mean.data_ptr(), self.running_mean._version, self.running_var._version,
+               None if self.weight is None else self.weight._version,
+               None if self.bias is None else self.bias._version, self.running_mean.device)
+        hit = getattr(self, '_eval_coef_cache', None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, eval_coefficients(self.weight, self.bias, self.running_mean,
+                                              self.running_var, self.eps))
+            self._eval_coef_cache = hit
+        return hit[1]
 
     def _native_eval(self, x, backend):
         return (backend.name == 'hip' and not self.training and self.track_running_stats
@@ -193,9 +205,7 @@ class _FusedBNReLU:
             x = x.contiguous()
             pooled = x.new_empty(x.shape[:3])
             argmax = torch.empty(x.shape[:3], dtype=torch.uint8, device=x.device)
-            backend.affine_relu_maxpool_forward(
-                x, eval_coefficients(self.weight, self.bias, self.running_mean, self.running_var,
-                                     self.eps), pooled, argmax)
+            backend.affine_relu_maxpool_forward(x, self.eval_coef(), pooled, argmax)
             return pooled
         if not native:
             from .pool import group_max_pool

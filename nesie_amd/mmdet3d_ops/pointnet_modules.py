@@ -268,6 +268,9 @@ class BasePointSAModule(nn.Module):
         if self.pool_mod == 'max' and all(isinstance(l, ConvModule) for l in layers) and \
                 fused_mlp.sa_stack_supported(backend_for(grouped), grouped, layers):
             return fused_mlp.sa_stack(grouped, layers, fixed_lead)
+        if self.pool_mod == 'max' and all(isinstance(l, ConvModule) for l in layers) and \
+                fused_mlp.sa_stack_eval_supported(backend_for(grouped), grouped, layers):
+            return fused_mlp.sa_stack_eval(grouped, layers)
         if (self.pool_mod == 'max' and isinstance(last, ConvModule) and last.act_fused
                 and isinstance(last.norm, FusedBNReLU2d)):
             x = grouped

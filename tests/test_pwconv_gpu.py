@@ -404,3 +404,36 @@ def test_fused_mini_pointnets_match_the_module_by_module_path(S, G):
         assert (a is None) == (b is None)
         if a is not None:
             torch.testing.assert_close(a, b, rtol=1e-3, atol=3e-4 * max(b.abs().max().item(), 1e-2 * scale))
+
+
+@pytest.mark.parametrize('c_in,mlp,ns', [(1, [64, 64, 128], 64), (256, [128, 128, 256], 16)])
+def test_eval_mode_sa_stack_matches_the_module_by_module_path(c_in, mlp, ns):
+    from nesie_amd.mmdet3d_ops import fused_mlp
+    sa = _sa_module(c_in, mlp, ns)
+    with torch.no_grad():
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(-1.0, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_(0, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+    sa.eval()
+    g = torch.Generator(device=_dev()).manual_seed(ns)
+    xyz = torch.rand(2, 512, 3, device=_dev(), generator=g)
+    feats = torch.randn(2, c_in, 512, device=_dev(), generator=g)
+    outs = []
+    try:
+        for enabled in (False, True):
+            fused_mlp.ENABLED = enabled
+            with torch.no_grad():
+                outs.append(sa(xyz, feats)[1])
+    finally:
+        fused_mlp.ENABLED = True
+    torch.testing.assert_close(outs[1], outs[0], rtol=1e-4, atol=1e-4)
+    # a changed running statistic must invalidate the cached coefficients
+    with torch.no_grad():
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.add_(0.25)
+        again = sa(xyz, feats)[1]
+    assert (again - outs[1]).abs().max().item() > 1e-3
