@@ -74,27 +74,45 @@ class MiniPointNet(nn.Module):
         return out + sconv3.bias.view(1, -1, 1) if sconv3.bias is not None else out
 
 
+def stacked_running_stats(layers):
+    """The S layers' running statistics as one (2, S*C) tensor that kernels update in place: the
+    per-layer buffers are kept as VIEWS of it (re-made if a .to() / load replaced them), so
+    stacking and un-stacking them costs no launch."""
+    C = layers[0].num_features
+    owner = layers[0]
+    pack = getattr(owner, '_stacked_stats', None)
+    if pack is None or pack.device != owner.running_mean.device or any(
+            l.running_mean.data_ptr() != pack[0, i * C:].data_ptr()
+            or l.running_var.data_ptr() != pack[1, i * C:].data_ptr() for i, l in enumerate(layers)):
+        with torch.no_grad():
+            pack = torch.stack([torch.cat([l.running_mean for l in layers]),
+                                torch.cat([l.running_var for l in layers])])
+        for i, l in enumerate(layers):
+            l.running_mean = pack[0, i * C:(i + 1) * C]
+            l.running_var = pack[1, i * C:(i + 1) * C]
+        owner._stacked_stats = pack
+    return pack
+
+
 def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     """ONE fused BatchNorm(+ReLU) over the S*C channels of x (B, S*C, ...) for the S norm
     layers ``layers`` (each C channels): statistics are per channel, so stacking the layers
     along the channel axis is the same arithmetic as calling them one by one.  Running
     statistics and batch counters of every layer are updated as its own forward would."""
+    from ..mmdet3d_ops import fused_mlp
     from ..mmdet3d_ops import norm as _norm
-    first, C = layers[0], layers[0].num_features
-    rm = torch.cat([l.running_mean for l in layers])
-    rv = torch.cat([l.running_var for l in layers])
+    first = layers[0]
+    pack = stacked_running_stats(layers)
+    rm, rv = pack[0], pack[1]
+    gamma, beta = fused_mlp.stack_groups([[l.weight for l in layers], [l.bias for l in layers]])
+    gamma, beta = gamma.reshape(-1), beta.reshape(-1)
     if not first.training:   # evaluation: one scale / bias pass over the stacked channels
-        coef = _norm.eval_coefficients(torch.cat([l.weight for l in layers]),
-                                       torch.cat([l.bias for l in layers]), rm, rv, first.eps)
+        coef = _norm.eval_coefficients(gamma, beta, rm, rv, first.eps)
         return _norm.affine_relu_eval(x, coef, first.fuse_relu, row_bias)
-    y = _norm.BNReLUTrain.apply(x, torch.cat([l.weight for l in layers]),
-                                torch.cat([l.bias for l in layers]), rm, rv, first.momentum,
-                                first.eps, first.fuse_relu, row_bias, pre_partial)
-    with torch.no_grad():
-        torch._foreach_copy_([l.running_mean for l in layers], list(rm.split(C)))
-        torch._foreach_copy_([l.running_var for l in layers], list(rv.split(C)))
-        for l in layers:
-            _norm.count_batch(l.num_batches_tracked)
+    y = _norm.BNReLUTrain.apply(x, gamma, beta, rm, rv, first.momentum, first.eps, first.fuse_relu,
+                                row_bias, pre_partial)
+    for l in layers:    # (the running statistics were updated in place through their views)
+        _norm.count_batch(l.num_batches_tracked)
     return y
 
 
@@ -170,19 +188,7 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     half = f[0][3].out_channels
 
     def stacked(layers):
-        """The S layers' running statistics as one (S*C,) pair the kernels update in place: the
-        per-layer buffers are kept as VIEWS of it (re-made if a .to() / load replaced them)."""
-        C = layers[0].num_features
-        owner = layers[0]
-        pack = getattr(owner, '_stacked_stats', None)
-        if pack is None or pack.device != owner.running_mean.device or any(
-                l.running_mean.data_ptr() != pack[0, i * C:].data_ptr() for i, l in enumerate(layers)):
-            pack = torch.stack([torch.cat([l.running_mean for l in layers]),
-                                torch.cat([l.running_var for l in layers])])
-            for i, l in enumerate(layers):
-                l.running_mean = pack[0, i * C:(i + 1) * C]
-                l.running_var = pack[1, i * C:(i + 1) * C]
-            owner._stacked_stats = pack
+        pack = stacked_running_stats(layers)
         for l in layers:
             _norm.count_batch(l.num_batches_tracked)
         return pack[0], pack[1], layers[0].momentum, layers[0].eps
@@ -229,16 +235,22 @@ def batched_heads(heads, x):
     every norm layer as ONE BatchNorm over the S*C stacked channels (statistics are per channel,
     so stacking heads along the channel axis changes nothing) -- the same arithmetic as calling
     the heads one by one (side_pooling_module.py:314-321), at a sixth of the launches."""
+    from ..mmdet3d_ops import fused_mlp
     B, S = x.shape[:2]
+    convs = [layers for layers in zip(*heads) if isinstance(layers[0], PointwiseConv1d)]
+    groups = [[l.weight.flatten(1) for l in layers] for layers in convs] \
+        + [[l.bias for l in layers] for layers in convs if layers[0].bias is not None]
+    stacked = iter(fused_mlp.stack_groups(groups))          # one multi-tensor copy for all of them
+    weights = {id(layers[0]): next(stacked) for layers in convs}
+    biases = {id(layers[0]): next(stacked) for layers in convs if layers[0].bias is not None}
     for layers in zip(*heads):
         first = layers[0]
         if isinstance(first, nn.Identity):
             continue
         if isinstance(first, PointwiseConv1d):
-            w = torch.stack([l.weight.flatten(1) for l in layers])             # (S, Co, Ci)
-            x = torch.matmul(w.unsqueeze(0), x)
+            x = torch.matmul(weights[id(first)].unsqueeze(0), x)               # (S, Co, Ci) stacks
             if first.bias is not None:
-                x = x + torch.stack([l.bias for l in layers]).view(1, S, -1, 1)
+                x = x + biases[id(first)].view(1, S, -1, 1)
         elif isinstance(first, FusedBNReLU1d):
             C, P = x.shape[2], x.shape[3]
             x = _stacked_bn(layers, x.reshape(B, S * C, P)).view(B, S, C, P)
