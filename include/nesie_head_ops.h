@@ -88,6 +88,16 @@ int nesie_vote_loss_backward(long long n3, const float *g, const float *scale, c
 int nesie_side_prob_stats(int b, int bins, int kprop, int copies, const float *probs, float *out,
                           void *stream);
 
+/* NesieHead.jitter_bbox_preds (nesie_head.py:178-209; SAQE variant with size_bias) in one launch:
+ * bbox (B,K,7), noise_c / noise_s (B,K,3) -> centre_all, size_all (B,2K,3) = [original,
+ * jittered], heading_all (B,2K) (zero when zero_heading), jitter_bbox (B,K,7).
+ * centre_j = c + (s n_c) sigma; size_j = max(s + (s n_s) sigma, 1e-8) (size_bias == 0) or
+ * max(s + s (n_s sigma + size_bias), 1e-8). */
+int nesie_proposal_jitter(int b, int k, const float *bbox, const float *noise_c,
+                          const float *noise_s, float sigma, float size_bias, int zero_heading,
+                          float *centre_all, float *size_all, float *heading_all,
+                          float *jitter_bbox, void *stream);
+
 /* Clip-by-global-norm + AdamW over ONE flat parameter vector (dp.FlatTrainState), two launches,
  * no host round trip: torch.nn.utils.clip_grad_norm_(max_norm, 2) followed by torch.optim.AdamW's
  * update (mmcv OptimizerHook grad_clip + the reference's AdamW schedule).  step: device scalar

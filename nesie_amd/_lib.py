@@ -80,6 +80,7 @@ SIGNATURES = {
     "nesie_vote_loss_forward": [_I, _I, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                 _P, _P],
     "nesie_vote_loss_backward": [ctypes.c_longlong, _P, _P, _P, _P, _P],
+    "nesie_proposal_jitter": [_I, _I, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P],
     "nesie_side_prob_stats": [_I, _I, _I, _I, _P, _P, _P],
     "nesie_flat_adamw_step": [ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P,
                               ctypes.c_size_t, _P],

@@ -200,3 +200,54 @@ extern "C" int nesie_side_prob_stats(int b, int bins, int kprop, int copies, con
                      (hipStream_t)stream, b, bins, kprop, copies, probs, out);
   return nesie::check_launch(W);
 }
+
+// ---- proposal jitter ----------------------------------------------------------------------------
+// NesieHead.jitter_bbox_preds (nesie_head.py:178-209): every proposal gets a perturbed copy
+// (centre += size * n_c * sigma, size = max(size + size * (n_s * sigma + size_bias), 1e-8)); the
+// quality head scores the 2K boxes [original, jittered].  One launch for the ~14 element-wise /
+// concatenation ops: bbox (B,K,7), noise_c / noise_s (B,K,3) ->
+//   centre_all (B,2K,3), size_all (B,2K,3), heading_all (B,2K) (zero when zero_heading),
+//   jitter_bbox (B,K,7) = (jittered centre, jittered size, heading).
+namespace nesie {
+__global__ __launch_bounds__(256) void proposal_jitter_kernel(
+    int b, int k, const float *__restrict__ bbox, const float *__restrict__ nc,
+    const float *__restrict__ ns, float sigma, float size_bias, int zero_heading,
+    float *__restrict__ centre_all, float *__restrict__ size_all, float *__restrict__ heading_all,
+    float *__restrict__ jitter) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= b * k) return;
+  const int bi = p / k, kk = p % k;
+  const float *bx = bbox + (size_t)p * 7;
+  const size_t o0 = ((size_t)bi * 2 * k + kk) * 3, o1 = ((size_t)bi * 2 * k + k + kk) * 3;
+  float *jo = jitter + (size_t)p * 7;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float c = bx[a], s = bx[3 + a];
+    const float cj = c + s * nc[(size_t)p * 3 + a] * sigma;
+    // the two heads' own operation orders: s + (s n) sigma (Nesie), s + s (n sigma + bias) (SAQE)
+    const float nsv = ns[(size_t)p * 3 + a];
+    const float sj = fmaxf(size_bias == 0.f ? s + (s * nsv) * sigma : s + s * (nsv * sigma + size_bias), 1e-8f);
+    centre_all[o0 + a] = c; centre_all[o1 + a] = cj;
+    size_all[o0 + a] = s; size_all[o1 + a] = sj;
+    jo[a] = cj; jo[3 + a] = sj;
+  }
+  const float h = bx[6];
+  jo[6] = h;
+  heading_all[(size_t)bi * 2 * k + kk] = zero_heading ? 0.f : h;
+  heading_all[(size_t)bi * 2 * k + k + kk] = zero_heading ? 0.f : h;
+}
+}  // namespace nesie
+
+extern "C" int nesie_proposal_jitter(int b, int k, const float *bbox, const float *noise_c,
+                                     const float *noise_s, float sigma, float size_bias,
+                                     int zero_heading, float *centre_all, float *size_all,
+                                     float *heading_all, float *jitter_bbox, void *stream) {
+  const char *W = "proposal_jitter";
+  NESIE_REQUIRE(b >= 0 && k >= 0, W);
+  if (b == 0 || k == 0) return NESIE_OK;
+  NESIE_REQUIRE(bbox && noise_c && noise_s && centre_all && size_all && heading_all && jitter_bbox, W);
+  hipLaunchKernelGGL(nesie::proposal_jitter_kernel, dim3((b * k + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, b, k, bbox, noise_c, noise_s, sigma, size_bias, zero_heading,
+                     centre_all, size_all, heading_all, jitter_bbox);
+  return nesie::check_launch(W);
+}

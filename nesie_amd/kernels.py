@@ -721,6 +721,20 @@ class HipKernels(_BNPoolMixin):
                       _ptr(d), _stream(sign))
         return d
 
+    def proposal_jitter(self, bbox, noise_c, noise_s, sigma, size_bias, zero_heading):
+        """-> (centre_all (B,2K,3), size_all (B,2K,3), heading_all (B,2K), jitter_bbox (B,K,7))
+        (nesie_proposal_jitter)."""
+        _check(bbox, noise_c, noise_s); _f32(bbox, noise_c, noise_s)
+        b, k, _ = bbox.shape
+        dev = bbox.device
+        f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)  # noqa: E731
+        ca, sa, ha, jb = f32(b, 2 * k, 3), f32(b, 2 * k, 3), f32(b, 2 * k), f32(b, k, 7)
+        with torch.cuda.device(dev):
+            _lib.call("nesie_proposal_jitter", b, k, _ptr(bbox), _ptr(noise_c), _ptr(noise_s),
+                      float(sigma), float(size_bias), int(bool(zero_heading)), _ptr(ca), _ptr(sa),
+                      _ptr(ha), _ptr(jb), _stream(bbox))
+        return ca, sa, ha, jb
+
     def side_prob_stats(self, probs, copies):
         """probs (B, 6, bins, K) -> (6, B, bins + 5, copies*K): bins, top-4, unbiased variance per
         face (nesie_side_prob_stats)."""

@@ -188,6 +188,16 @@ class NesieHead(nn.Module):
             n_c, n_s = (t.to(size) for t in self.jitter_noise)
         else:
             n_c, n_s = torch.randn_like(size), torch.randn_like(size)
+        backend = backend_for(bp)
+        if backend.name == 'hip' and bp.dtype == torch.float32 and head_loss.ENABLED:
+            # every consumer reads these detached (the quality head's grid, the IoU labels): one
+            # launch, outside autograd
+            with torch.no_grad():
+                center_all, size_all, heading_all, jit = backend.proposal_jitter(
+                    bp.detach().contiguous(), n_c.contiguous(), n_s.contiguous(), 0.3, 0.0,
+                    dataset_name == 'ScanNet')
+            results['jitter_bbox_preds'] = jit
+            return center_all, size_all, heading_all, results
         center_jitter = center + size * n_c * 0.3
         size_jitter = torch.clamp(size + size * n_s * 0.3, min=1e-8)  # SAQEHead overrides
         heading_jitter = heading

@@ -100,3 +100,25 @@ def test_side_prob_stats_match_topk_and_var(hip_device, bins, copies):
     assert got.shape == want.shape
     assert torch.equal(got[:, :, :bins + 4], want[:, :, :bins + 4])
     torch.testing.assert_close(got[:, :, bins + 4], want[:, :, bins + 4], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('sigma,size_bias,zero_heading', [(0.3, 0.0, True), (0.5, 0.2, False)])
+def test_proposal_jitter_matches_the_tensor_ops(hip_device, sigma, size_bias, zero_heading):
+    """nesie_proposal_jitter vs the element-wise form of jitter_bbox_preds (Nesie and SAQE)."""
+    from nesie_amd import kernels
+    g = torch.Generator(device=hip_device).manual_seed(9)
+    bp = torch.randn(3, 50, 7, device=hip_device, generator=g)
+    bp[..., 3:6] = bp[..., 3:6].abs() + 0.05
+    n_c = torch.randn(3, 50, 3, device=hip_device, generator=g)
+    n_s = torch.randn(3, 50, 3, device=hip_device, generator=g)
+    center, size, heading = bp[..., :3], bp[..., 3:6], bp[..., -1]
+    cj = center + size * n_c * sigma
+    sj = torch.clamp(size + size * n_s * sigma if size_bias == 0 else
+                     size + size * (n_s * sigma + size_bias), min=1e-8)
+    heading_all = torch.cat([heading, heading], 1)
+    want = (torch.cat([center, cj], 1), torch.cat([size, sj], 1),
+            torch.zeros_like(heading_all) if zero_heading else heading_all,
+            torch.cat([cj, sj, heading.unsqueeze(-1)], -1))
+    got = kernels.backend_for(bp).proposal_jitter(bp, n_c, n_s, sigma, size_bias, zero_heading)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
