@@ -325,14 +325,23 @@ struct FpsCand { unsigned val, lo; float x, y, z; };
 constexpr int FPS_CELLS = 8192;
 
 // NW waves per scene; lane j of wave w owns buckets (q*64 + j)*NW + w, q < BPL.
-template <int NW>
+// LT: the running-min distances of the sorted points live in LDS for the whole selection loop
+// (n floats, overlaying the phase-0 histogram) instead of in the w component of the workspace.
+// On gfx9 stores and loads share vmcnt and return in order: with the distances in global memory
+// every round's wait for its bucket loads also waits out the store acknowledgements of the
+// previous round's updates.  Fits up to n = 40 192 points in the 160 KB of a CU.
+template <int NW, bool LT>
 __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
     int *__restrict__ idx, float4 *__restrict__ ws_pts, unsigned *__restrict__ ws_orig) {
   constexpr int L = 10, BLOCK = NW * 64, BPL = 16 / NW;  // 1024 buckets max
   constexpr int BINS_PER_THREAD = FPS_CELLS / BLOCK;
-  __shared__ unsigned hist[FPS_CELLS];
-  __shared__ unsigned scan_part[BLOCK];
+  extern __shared__ __attribute__((aligned(16))) unsigned fps_dyn[];
+  __shared__ unsigned hist_static[LT ? 1 : FPS_CELLS];
+  __shared__ unsigned scan_static[LT ? 1 : BLOCK];
+  unsigned *hist = LT ? fps_dyn : hist_static;
+  unsigned *scan_part = LT ? fps_dyn + FPS_CELLS : scan_static;
+  float *lt = (float *)fps_dyn;                      // phase 1 only (LT)
   __shared__ float bb[NW][6];
   __shared__ FpsCand red[2][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -410,6 +419,10 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     ws_orig[pos] = (unsigned)k;
   }
   __syncthreads();  // also drains the stores: the block re-reads them below
+  if (LT) {         // the histogram is dead: its bytes become the distance array
+    for (int s_ = tid; s_ < n; s_ += BLOCK) lt[s_] = ws_pts[s_].w;
+    __syncthreads();
+  }
 
   // ---- phase 1 -------------------------------------------------------------------
   const int nb = (n + 63) >> 6;  // buckets
@@ -434,6 +447,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     l.ss = l.valid ? s : n - 1;
     l.p = ws_pts[l.ss];
     l.o = ws_orig[l.ss];
+    if (LT) l.p.w = lt[l.ss];
     return l;
   };
   // Re-evaluate one bucket against the centre; INIT only (re)builds its box and best.
@@ -443,7 +457,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     if (!init) {
       float d = sqdist_nofma(l.p.x - cx, l.p.y - cy, l.p.z - cz);
       d2 = fminf(d, l.p.w);
-      if (l.valid && d2 != l.p.w) ws_pts[l.ss].w = d2;
+      if (l.valid && d2 != l.p.w) {
+        if (LT) lt[l.ss] = d2; else ws_pts[l.ss].w = d2;
+      }
     }
     const unsigned lo = l.valid ? key_lo_of((int)l.o, L) : 0u;
     unsigned vmax, lomax;
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   }
   __syncthreads();
   // running-min distances back to the caller's order
-  for (int s = tid; s < n; s += BLOCK) temp[ws_orig[s]] = ws_pts[s].w;
+  for (int s = tid; s < n; s += BLOCK) temp[ws_orig[s]] = LT ? lt[s] : ws_pts[s].w;
 }
 
 }  // namespace nesie
@@ -564,12 +580,25 @@ static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *i
       const char *e = getenv("NESIE_FPS_WAVES");
       return e ? atoi(e) : 16;
     }();
-    if (nw == 16)
-      hipLaunchKernelGGL(fps_pruned_kernel<16>, grid, dim3(1024), 0, s, n, m, xyz, temp, idx, wp, wo);
+    static const int lds_temps = [] {
+      const char *e = getenv("NESIE_FPS_LDS");
+      return e ? atoi(e) : 1;
+    }();
+    const size_t lt_bytes = (size_t)n * 4 > (FPS_CELLS + 1024) * 4 ? (size_t)n * 4 : (FPS_CELLS + 1024) * 4;
+    if (nw == 16 && lds_temps && lt_bytes <= 160768) {
+      auto kern = fps_pruned_kernel<16, true>;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160768);
+        attr = true;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(1024), lt_bytes, s, n, m, xyz, temp, idx, wp, wo);
+    } else if (nw == 16)
+      hipLaunchKernelGGL((fps_pruned_kernel<16, false>), grid, dim3(1024), 0, s, n, m, xyz, temp, idx, wp, wo);
     else if (nw == 8)
-      hipLaunchKernelGGL(fps_pruned_kernel<8>, grid, dim3(512), 0, s, n, m, xyz, temp, idx, wp, wo);
+      hipLaunchKernelGGL((fps_pruned_kernel<8, false>), grid, dim3(512), 0, s, n, m, xyz, temp, idx, wp, wo);
     else
-      hipLaunchKernelGGL(fps_pruned_kernel<4>, grid, dim3(256), 0, s, n, m, xyz, temp, idx, wp, wo);
+      hipLaunchKernelGGL((fps_pruned_kernel<4, false>), grid, dim3(256), 0, s, n, m, xyz, temp, idx, wp, wo);
     return check_launch(W);
   }
   if (n <= 64) REG(64, 1);
