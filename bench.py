@@ -337,16 +337,18 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     torch.cuda.synchronize(device)
     stage('eager warm-up steps')
     g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g1a):
+    # thread_local: a process group's watchdog thread may query events while this thread captures
+    mode = dict(capture_error_mode='thread_local')
+    with torch.cuda.graph(g1a, **mode):
         phase1(current_indices())
-    with torch.cuda.graph(g1b, pool=g1a.pool()):
+    with torch.cuda.graph(g1b, pool=g1a.pool(), **mode):
         phase2()
-    with torch.cuda.graph(g2, pool=g1a.pool()):
+    with torch.cuda.graph(g2, pool=g1a.pool(), **mode):
         update()
     stage('step graphs captured')
     if pipelined:
         g_idx = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_idx, stream=side):
+        with torch.cuda.graph(g_idx, stream=side, **mode):
             fresh, fresh_votes = input_only_work()
             torch._foreach_copy_(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
         ready, copied = torch.cuda.Event(), torch.cuda.Event()
