@@ -8,10 +8,12 @@ last layer, the max / min over the neighbourhood) leave from the accumulators, a
 activations are never written.  Per layer the forward moves its tensor through HBM twice (read
 the previous raw conv output, write this one) instead of five times.
 
-The backward is hand-written too: BatchNorm + ReLU backward from the RAW conv output and the
-saved (scale, bias, mean, invstd) (``nesie_bn_relu_backward`` with y = NULL), the input gradient
-through the same layer kernel on the transposed weight view, the weight gradient on the matrix
-cores with the activation recomputed on load (``nesie_conv_wgrad``).
+The backward is hand-written too: per layer ONE input-gradient launch (the same layer kernel on
+the transposed weight view, ``nesie_pw_dgrad_bn_reduce``: its epilogue also leaves the two sums of
+the BatchNorm backward), one weight-gradient launch on the matrix cores with the activation
+recomputed on load (``nesie_pw_wgrad``), and the BatchNorm + ReLU apply pass from the RAW conv
+output and the saved (scale, bias, mean, invstd) (``nesie_bn_relu_backward_apply``; the mask is
+re-derived with the same fused multiply-add the forward's operand load used).
 
 Same function as the module-by-module path (which stays the CPU checker's and serves shapes the
 kernels are not built for); differences are fp32 summation order and fma-vs-mul/add rounding.
