@@ -313,6 +313,54 @@ def _pool_group(G):
     return 16 if G == 16 else 32
 
 
+def mini_head_kernels(backend, c0, coef0, w3, G):
+    """c0 (B,S,H0,P) raw, coef0 (S*H0,4) -> c = W3 . relu(coef0 c0) (B,S,half,P), its max over
+    groups of G positions g (B,S,half,P/G) and the arg-max."""
+    B, S, H0, P = c0.shape
+    half = w3.shape[1]
+    pg = _pool_group(G)
+    c = c0.new_empty(B, S, half, P)
+    npg = P // pg
+    pool_out = (c0.new_empty(B * S, half, npg), None,
+                torch.empty(B * S, half, npg, dtype=torch.uint8, device=c0.device), None)
+    backend.pw_layer_forward(c0.view(B * S, H0, P), w3, ng=S, in_coef=coef0, in_relu=True,
+                             y=c.view(B * S, half, P), pool_group=pg, pool_min=False,
+                             pool_out=pool_out)
+    g = c0.new_empty(B, S, half, P // G)
+    arg = torch.empty(B, S, half, P // G, dtype=torch.uint8, device=c0.device)
+    backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, g.view(B * S, half, -1),
+                           arg.view(B * S, half, -1))
+    return c, g, arg
+
+
+def mini_tail_first(backend, c, small, wl, G):
+    """y = W_l c + small (row bias per group of G positions) (B,S,H2,P) + its statistics partials."""
+    B, S, half, P = c.shape
+    H2 = wl.shape[1]
+    y = c.new_empty(B, S, H2, P)
+    part = c.new_empty(S, backend.pw_stat_slots(B * S, S, half, H2, P), H2, 4)
+    backend.pw_layer_forward(c.view(B * S, half, P), wl, ng=S, row_bias=small.view(B * S, H2, -1),
+                             rb_group=G, y=y.view(B * S, H2, P), stat_part=part)
+    return y, part
+
+
+def mini_tail_second(backend, y, coef1, w4, G):
+    """max over groups of G positions of W4 . relu(coef1 y) -> (B,S,F,P/G) and the arg-max."""
+    B, S, H2, P = y.shape
+    F = w4.shape[1]
+    pg = _pool_group(G)
+    npg = P // pg
+    pool_out = (y.new_empty(B * S, F, npg), None,
+                torch.empty(B * S, F, npg, dtype=torch.uint8, device=y.device), None)
+    backend.pw_layer_forward(y.view(B * S, H2, P), w4, ng=S, in_coef=coef1, in_relu=True,
+                             pool_group=pg, pool_min=False, pool_out=pool_out)
+    out = y.new_empty(B, S, F, P // G)
+    arg = torch.empty(B, S, F, P // G, dtype=torch.uint8, device=y.device)
+    backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, out.view(B * S, F, -1),
+                           arg.view(B * S, F, -1))
+    return out, arg
+
+
 class MiniHeadFn(Function):
     """c0 (B, S, H0, K*G) raw first-conv outputs of S stacked nets (+ their (sum, sum^2)
     partials) -> c = W3 . relu(bn0(c0)) (B, S, half, K*G) and g = max_G c (B, S, half, K)."""
@@ -327,18 +375,7 @@ class MiniHeadFn(Function):
         coef0 = c0.new_empty(S * H0, 4)
         backend.mlp_stat_finalize(c0_part, B * P, gamma0, beta0, rm, rv, momentum, eps, coef0,
                                   channel_major=True)
-        pg = _pool_group(G)
-        c = c0.new_empty(B, S, half, P)
-        npg = P // pg
-        pool_out = (c0.new_empty(B * S, half, npg), None,
-                    torch.empty(B * S, half, npg, dtype=torch.uint8, device=c0.device), None)
-        backend.pw_layer_forward(c0.view(B * S, H0, P), w3, ng=S, in_coef=coef0, in_relu=True,
-                                 y=c.view(B * S, half, P), pool_group=pg, pool_min=False,
-                                 pool_out=pool_out)
-        g = c0.new_empty(B, S, half, P // G)
-        arg = torch.empty(B, S, half, P // G, dtype=torch.uint8, device=c0.device)
-        backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, g.view(B * S, half, -1),
-                               arg.view(B * S, half, -1))
+        c, g, arg = mini_head_kernels(backend, c0, coef0, w3, G)
         ctx.G = G
         ctx.save_for_backward(c0, coef0, arg, gamma0, beta0, w3)
         ctx.mark_non_differentiable(arg)
@@ -383,22 +420,10 @@ class MiniTailFn(Function):
         B, S, half, P = c.shape
         H2, F = wl.shape[1], w4.shape[1]
         rm, rv, momentum, eps = bufs
-        y = c.new_empty(B, S, H2, P)
-        part = c.new_empty(S, backend.pw_stat_slots(B * S, S, half, H2, P), H2, 4)
-        backend.pw_layer_forward(c.view(B * S, half, P), wl, ng=S, row_bias=small.view(B * S, H2, -1),
-                                 rb_group=G, y=y.view(B * S, H2, P), stat_part=part)
+        y, part = mini_tail_first(backend, c, small, wl, G)
         coef1 = c.new_empty(S * H2, 4)
         backend.pw_stats_finalize(part, gamma1, beta1, rm, rv, momentum, eps, coef1)
-        pg = _pool_group(G)
-        npg = P // pg
-        pool_out = (c.new_empty(B * S, F, npg), None,
-                    torch.empty(B * S, F, npg, dtype=torch.uint8, device=c.device), None)
-        backend.pw_layer_forward(y.view(B * S, H2, P), w4, ng=S, in_coef=coef1, in_relu=True,
-                                 pool_group=pg, pool_min=False, pool_out=pool_out)
-        out = c.new_empty(B, S, F, P // G)
-        arg = torch.empty(B, S, F, P // G, dtype=torch.uint8, device=c.device)
-        backend.pw_pool_finish(S, P, G, pg, pool_out, None, False, out.view(B * S, F, -1),
-                               arg.view(B * S, F, -1))
+        out, arg = mini_tail_second(backend, y, coef1, w4, G)
         ctx.G = G
         ctx.save_for_backward(c, y, coef1, arg, wl, gamma1, beta1, w4)
         ctx.mark_non_differentiable(arg)

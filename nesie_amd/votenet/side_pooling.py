@@ -165,14 +165,17 @@ def fused_mini_ok(nets, c0, c0_stats):
     MiniTailFn): training-mode native norms, statistics partials of c0 at hand, built shapes."""
     from ..mmdet3d_ops import fused_mlp
     backend = backend_for(c0)
-    if c0_stats is None:
-        return False
     bn0s, bn1s = [n.first_conv[1] for n in nets], [n.second_conv[1] for n in nets]
-    if not (all(l.training for l in bn0s + bn1s) and _stackable_bn(bn0s) and _stackable_bn(bn1s)):
+    training = all(l.training for l in bn0s + bn1s)
+    evaluating = not any(l.training for l in bn0s + bn1s) and not torch.is_grad_enabled()
+    if not (training or evaluating) or (training and c0_stats is None):
+        return False
+    if not (_stackable_bn(bn0s) and _stackable_bn(bn1s)):
         return False
     if any(n.first_conv[0].bias is not None or n.second_conv[0].bias is not None for n in nets):
         return False
-    return fused_mlp.mini_pointnets_fused_supported(backend, c0, c0_stats, c0.shape[-1])
+    return fused_mlp.mini_pointnets_fused_supported(backend, c0, c0_stats if training else c0,
+                                                    c0.shape[-1])
 
 
 def fused_mini_pointnets(nets, c0, c0_stats):
@@ -205,14 +208,26 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     if conv4[0].bias is not None:
         groups.append([m.bias for m in conv4])
     gamma0, beta0, w3, w, b3, gamma1, beta1, w4, *b4 = fused_mlp.stack_groups(groups)
-    c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
-                                      gamma0.reshape(-1), beta0.reshape(-1), w3)     # w3 (S, half, H)
+    evaluating = not bn0s[0].training
+    backend = backend_for(c0)
+    if evaluating:   # test path: the cached folded running statistics are the operand transforms
+        coef0 = torch.cat([l.eval_coef() for l in bn0s]) if S > 1 else bn0s[0].eval_coef()
+        c, g, _ = fused_mlp.mini_head_kernels(backend, c0.reshape(B, S, H, K * G).contiguous(),
+                                               coef0, w3, G)
+    else:
+        c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
+                                          gamma0.reshape(-1), beta0.reshape(-1), w3)  # w3 (S, half, H)
     H2 = w.shape[1]                                                                  # w (S, H2, 2*half)
     # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3
     small = torch.matmul(w[:, :, :half].unsqueeze(0), g) \
         + torch.matmul(w, torch.cat([b3, b3], 1).unsqueeze(-1)).view(1, S, H2, 1)
-    out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w[:, :, half:],
-                                     gamma1.reshape(-1), beta1.reshape(-1), w4)      # w4 (S, F, H2)
+    if evaluating:
+        y, _ = fused_mlp.mini_tail_first(backend, c, small.contiguous(), w[:, :, half:], G)
+        coef1 = torch.cat([l.eval_coef() for l in bn1s]) if S > 1 else bn1s[0].eval_coef()
+        out, _ = fused_mlp.mini_tail_second(backend, y, coef1, w4, G)
+    else:
+        out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w[:, :, half:],
+                                         gamma1.reshape(-1), beta1.reshape(-1), w4)  # w4 (S, F, H2)
     if b4:
         out = out + b4[0].view(1, S, -1, 1)
     return out
