@@ -102,13 +102,13 @@ def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     from ..mmdet3d_ops import fused_mlp
     from ..mmdet3d_ops import norm as _norm
     first = layers[0]
+    if not first.training:   # evaluation: one scale / bias pass over the stacked channels
+        coef = torch.cat([l.eval_coef() for l in layers]) if len(layers) > 1 else first.eval_coef()
+        return _norm.affine_relu_eval(x, coef, first.fuse_relu, row_bias)
     pack = stacked_running_stats(layers)
     rm, rv = pack[0], pack[1]
     gamma, beta = fused_mlp.stack_groups([[l.weight for l in layers], [l.bias for l in layers]])
     gamma, beta = gamma.reshape(-1), beta.reshape(-1)
-    if not first.training:   # evaluation: one scale / bias pass over the stacked channels
-        coef = _norm.eval_coefficients(gamma, beta, rm, rv, first.eps)
-        return _norm.affine_relu_eval(x, coef, first.fuse_relu, row_bias)
     y = _norm.BNReLUTrain.apply(x, gamma, beta, rm, rv, first.momentum, first.eps, first.fuse_relu,
                                 row_bias, pre_partial)
     for l in layers:    # (the running statistics were updated in place through their views)
