@@ -218,15 +218,18 @@ def fused_mini_pointnets(nets, c0, c0_stats):
         c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
                                           gamma0.reshape(-1), beta0.reshape(-1), w3)  # w3 (S, half, H)
     H2 = w.shape[1]                                                                  # w (S, H2, 2*half)
-    # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3
-    small = torch.matmul(w[:, :, :half].unsqueeze(0), g) \
-        + torch.matmul(w, torch.cat([b3, b3], 1).unsqueeze(-1)).view(1, S, H2, 1)
+    # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3.  The two halves
+    # of w come from ONE split (its backward is one concatenation; three overlapping uses of w
+    # cost two zero-filled slice gradients and two additions)
+    w_g, w_l = w.split(half, dim=2)
+    small = torch.matmul(w_g.unsqueeze(0), g + b3.view(1, S, half, 1)) \
+        + torch.matmul(w_l, b3.unsqueeze(-1)).view(1, S, H2, 1)
     if evaluating:
-        y, _ = fused_mlp.mini_tail_first(backend, c, small.contiguous(), w[:, :, half:], G)
+        y, _ = fused_mlp.mini_tail_first(backend, c, small.contiguous(), w_l, G)
         coef1 = torch.cat([l.eval_coef() for l in bn1s]) if S > 1 else bn1s[0].eval_coef()
         out, _ = fused_mlp.mini_tail_second(backend, y, coef1, w4, G)
     else:
-        out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w[:, :, half:],
+        out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w_l,
                                          gamma1.reshape(-1), beta1.reshape(-1), w4)  # w4 (S, F, H2)
     if b4:
         out = out + b4[0].view(1, S, -1, 1)

@@ -45,7 +45,9 @@ class VoteModule(nn.Module):
         B, C, N = seed_feats.shape
         V = self.vote_per_seed
         raw = self.conv_out(self.vote_conv(seed_feats)).view(B, V, self.per_vote, N)
-        shift = raw[:, :, :3]                                             # (B, V, 3, N)
+        # one split: its backward is one concatenation (two slices cost two zero fills + an add)
+        shift, residual = raw.split([3, self.per_vote - 3], dim=2) if self.with_res_feat \
+            else (raw, None)                                              # (B, V, 3, N), (B, V, C, N)
         moved = shift
         if self.vote_xyz_range is not None:
             # each axis limited to its own +-range; the returned offset stays unlimited (:117-133)
@@ -55,7 +57,7 @@ class VoteModule(nn.Module):
         offset = shift.permute(0, 2, 3, 1).reshape(B, 3, N * V)
         if not self.with_res_feat:
             return vote_points, seed_feats, offset
-        vote_feats = (seed_feats.unsqueeze(-1) + raw[:, :, 3:].permute(0, 2, 3, 1)).reshape(B, C, N * V)
+        vote_feats = (seed_feats.unsqueeze(-1) + residual.permute(0, 2, 3, 1)).reshape(B, C, N * V)
         if self.norm_feats:
             vote_feats = vote_feats / vote_feats.norm(p=2, dim=1, keepdim=True)
         return vote_points, vote_feats, offset

@@ -1,0 +1,39 @@
+"""Which python lines launch the small ATen kernels of one eager training step (count, time)."""
+import collections, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+from nesie_amd.votenet import nesie_votenet_scannet_cfg
+
+dev = torch.device('cuda:0')
+cfg = nesie_votenet_scannet_cfg()['optimizer']
+model, step, bucket = bench.build_step(dev, 8, 1000, cfg['lr'], cfg['weight_decay'], graph=False)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+acc = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith('aten::'):
+        continue
+    if not ev.kernels:
+        continue
+    k_us = sum(k.duration for k in ev.kernels)
+    names = ' '.join(k.name for k in ev.kernels)
+    if 'nesie::' in names or 'Cijk' in names:
+        continue
+    chain, par = [], ev.cpu_parent
+    while par is not None:
+        chain.append(par.name)
+        par = par.cpu_parent
+    site = ' < '.join(n.replace('autograd::engine::evaluate_function: ', 'bwd ') for n in chain[:3]) or 'top level (forward python)'
+    a = acc[(ev.name, site[:110])]
+    a[0] += len(ev.kernels); a[1] += k_us
+rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
+tot = sum(v[0] for v in acc.values())
+print('ATen launches with a python site:', tot)
+for (op, site), (n, us) in rows[:70]:
+    print(f'{n:4d} {us:8.1f} us  {op:28s} {site}')
