@@ -121,20 +121,13 @@ class Points_Sampler(nn.Module):
         points_xyz = points_xyz.float()  # @force_fp32 in the reference (:65)
         if features is not None:
             features = features.float()
-        indices = []
-        last_fps_end_index = 0
-        for fps_sample_range, sampler, npoint in zip(
-                self.fps_sample_range_list, self.samplers, self.num_point):
-            assert fps_sample_range < points_xyz.shape[1]
-            if fps_sample_range == -1:
-                sample_points_xyz = points_xyz[:, last_fps_end_index:]
-                sample_features = features[:, :, last_fps_end_index:] \
-                    if features is not None else None
-            else:
-                sample_points_xyz = points_xyz[:, last_fps_end_index:fps_sample_range]
-                sample_features = features[:, :, last_fps_end_index:fps_sample_range] \
-                    if features is not None else None
-            fps_idx = sampler(sample_points_xyz.contiguous(), sample_features, npoint)
-            indices.append(fps_idx + last_fps_end_index)
-            last_fps_end_index += fps_sample_range
-        return torch.cat(indices, dim=1)
+        picked, start = [], 0
+        for stop, sampler, npoint in zip(self.fps_sample_range_list, self.samplers, self.num_point):
+            assert stop < points_xyz.shape[1]
+            end = None if stop == -1 else stop
+            part_xyz = points_xyz[:, start:end]
+            part_feats = features[:, :, start:end] if features is not None else None
+            idx = sampler(part_xyz.contiguous(), part_feats, npoint)
+            picked.append(idx + start if start else idx)      # (no launch for the usual offset 0)
+            start += stop
+        return picked[0] if len(picked) == 1 else torch.cat(picked, dim=1)

@@ -305,7 +305,9 @@ class BasePointSAModule(nn.Module):
             lead = 3 if (getattr(g, 'use_xyz', False) and features is not None
                          and not points_xyz.requires_grad and not new_xyz.requires_grad) else 0
             new_features_list.append(self._mlp_and_pool(self.mlps[i], grouped_results, lead))
-        return new_xyz, torch.cat(new_features_list, dim=1), indices
+        pooled = new_features_list[0] if len(new_features_list) == 1 \
+            else torch.cat(new_features_list, dim=1)
+        return new_xyz, pooled, indices
 
 
 def _shared_mlp(widths, norm_cfg, **conv_kw):

@@ -52,10 +52,14 @@ class PointNet2SASSG(nn.Module):
         """FPS + ball-query indices of all SA layers: they depend on the input coordinates
         only, so a loop may compute them for the next batch while this one trains."""
         level_xyz = [points[..., :3].contiguous()]
-        plan = []
+        plan, cum = [], None
         for sa in self.SA_modules:
             plan.append(sa.sample_and_group_indices(level_xyz[-1]))
             level_xyz.append(plan[-1]['new_xyz'])
+            # positions of this level's centres in the INPUT cloud (index bookkeeping only)
+            picked = plan[-1]['indices'].long()
+            cum = picked if cum is None else cum.gather(1, picked)
+            plan[-1]['input_indices'] = cum
         # feature-propagation taps (3-NN from each finer level into the coarser one below it)
         # ride on the first entry
         plan[0]['fp_taps'] = [fp.interpolation_taps(level_xyz[self.num_sa - 1 - j],
@@ -76,7 +80,9 @@ class PointNet2SASSG(nn.Module):
                                          precomputed=precomputed[i] if precomputed is not None else None)
             sa_xyz.append(centres)
             sa_features.append(pooled)
-            sa_indices.append(sa_indices[-1].gather(1, picked.long()))
+            pre_idx = precomputed[i].get('input_indices') if precomputed is not None else None
+            sa_indices.append(pre_idx if pre_idx is not None
+                              else sa_indices[-1].gather(1, picked.long()))
         taps = precomputed[0].get('fp_taps') if precomputed is not None else None
         fp_xyz, fp_features, fp_indices = [sa_xyz[-1]], [sa_features[-1]], [sa_indices[-1]]
         for j, fp in enumerate(self.FP_modules):
@@ -96,6 +102,8 @@ def index_tree_tensors(tree):
     out = []
     for d in tree:
         out += [d['indices'], d['new_xyz']] + list(d['group_idx'])
+        if 'input_indices' in d:
+            out.append(d['input_indices'])
         for csr in d.get('group_csr', ()):
             out += list(csr or ())
         for idx_, w_, csr in d.get('fp_taps', ()):
@@ -106,6 +114,7 @@ def index_tree_tensors(tree):
 def clone_index_tree(tree):
     return [dict(indices=d['indices'].clone(), new_xyz=d['new_xyz'].clone(),
                  group_idx=[t.clone() for t in d['group_idx']],
+                 **({'input_indices': d['input_indices'].clone()} if 'input_indices' in d else {}),
                  group_csr=[None if csr is None else tuple(t.clone() for t in csr)
                             for csr in d.get('group_csr', ())],
                  **({'fp_taps': [(i_.clone(), w_.clone(),
@@ -119,8 +128,10 @@ def index_tree_like(tree, tensors):
     it = iter(tensors)
     out = []
     for d in tree:
-        e = dict(indices=next(it), new_xyz=next(it), group_idx=[next(it) for _ in d['group_idx']],
-                 group_csr=[None if csr is None else tuple(next(it) for _ in csr)
+        e = dict(indices=next(it), new_xyz=next(it), group_idx=[next(it) for _ in d['group_idx']])
+        if 'input_indices' in d:
+            e['input_indices'] = next(it)
+        e.update(group_csr=[None if csr is None else tuple(next(it) for _ in csr)
                             for csr in d.get('group_csr', ())])
         if 'fp_taps' in d:
             e['fp_taps'] = [(next(it), next(it), None if c_ is None else tuple(next(it) for _ in c_))

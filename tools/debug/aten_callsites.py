@@ -12,7 +12,8 @@ model, step, bucket = bench.build_step(dev, 8, 1000, cfg['lr'], cfg['weight_deca
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
     torch.cuda.synchronize()
 acc = collections.defaultdict(lambda: [0, 0.0])
@@ -29,7 +30,10 @@ for ev in prof.events():
     while par is not None:
         chain.append(par.name)
         par = par.cpu_parent
-    site = ' < '.join(n.replace('autograd::engine::evaluate_function: ', 'bwd ') for n in chain[:3]) or 'top level (forward python)'
+    site = ' < '.join(n.replace('autograd::engine::evaluate_function: ', 'bwd ') for n in chain[:3])
+    if not site:
+        frames = [f for f in (ev.stack or []) if f.startswith('nesie_amd/') or f.startswith('bench.py')]
+        site = 'py ' + (frames[0] if frames else '?')
     a = acc[(ev.name, site[:110])]
     a[0] += len(ev.kernels); a[1] += k_us
 rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
