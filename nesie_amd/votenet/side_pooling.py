@@ -57,7 +57,7 @@ class MiniPointNet(nn.Module):
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
         if a0 is None and conv0_out is not None and fused_mini_ok([self], conv0_out.unsqueeze(1), c0_stats):
-            return fused_mini_pointnets([self], conv0_out.unsqueeze(1), c0_stats)[:, 0]
+            return fused_mini_pointnets([self], conv0_out.unsqueeze(1), c0_stats).squeeze(1)
         if a0 is None:   # c0_stats: (sum, sum^2) partials of conv0_out left by its producer
             a0 = bn0(conv0(points)) if conv0_out is None else bn0(conv0_out, pre_partial=c0_stats)
         c = pointwise_conv(a0, conv3.weight)                           # f without its bias
@@ -501,7 +501,7 @@ class SidePooling(nn.Module):
                 self.mlps_before[6:7], origin_xyz, origin_features, None, center,
                 taps=self.fused_taps(origin_xyz, center, size, heading, 'box'),
                 with_norm=self.fuse_first_norm)
-            bbox_c0 = bbox_c0[:, 0]
+            bbox_c0 = bbox_c0.squeeze(1)   # (a view: indexing [:, 0] costs a zero-filled gradient)
         else:
             whole_grid = self.generate_grid(size)
             side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()

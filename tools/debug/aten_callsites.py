@@ -31,13 +31,12 @@ for ev in prof.events():
         chain.append(par.name)
         par = par.cpu_parent
     site = ' < '.join(n.replace('autograd::engine::evaluate_function: ', 'bwd ') for n in chain[:3])
-    if not site:
-        frames = [f for f in (ev.stack or []) if f.startswith('nesie_amd/') or f.startswith('bench.py')]
-        site = 'py ' + (frames[0] if frames else '?')
-    a = acc[(ev.name, site[:110])]
+    frames = [f for f in (ev.stack or []) if f.startswith('nesie_amd/') or f.startswith('bench.py')]
+    site = (site + ' @ ' if site else 'py ') + (frames[0] if frames else '?')
+    a = acc[(ev.name, site[:150])]
     a[0] += len(ev.kernels); a[1] += k_us
 rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
 tot = sum(v[0] for v in acc.values())
 print('ATen launches with a python site:', tot)
 for (op, site), (n, us) in rows[:70]:
-    print(f'{n:4d} {us:8.1f} us  {op:28s} {site}')
+    print(f'{n:4d} {us:8.1f} us  {op:22s} {site}')
