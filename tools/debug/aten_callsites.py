@@ -35,7 +35,7 @@ for ev in prof.events():
     site = (site + ' @ ' if site else 'py ') + (frames[0] if frames else '?')
     a = acc[(ev.name, site[:150])]
     a[0] += len(ev.kernels); a[1] += k_us
-rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
+rows = sorted(acc.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[0] for v in acc.values())
 print('ATen launches with a python site:', tot)
 for (op, site), (n, us) in rows[:70]:
