@@ -73,7 +73,9 @@ __device__ __forceinline__ unsigned long long block_max_u64(
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+  // old = 0 with bound_ctrl: every permutation used here reads a live lane, and a zero fill is the
+  // identity of the unsigned max that follows, so the compiler folds the move into v_max_u32_dpp
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 // max over the 64 lanes, returned wave-uniform
 __device__ __forceinline__ unsigned wave_umax(unsigned v) {
@@ -103,15 +105,44 @@ __device__ __forceinline__ float wave_fmin(float f) {
 __device__ __forceinline__ int wave_argmax(bool valid, unsigned val, unsigned lo,
                                            unsigned &vmax, unsigned &lomax) {
   vmax = wave_umax(valid ? val : 0u);
-  unsigned long long eq = __ballot(valid && val == vmax);
+  unsigned long long eq = __builtin_amdgcn_ballot_w64(valid && val == vmax);
   if (__popcll(eq) == 1) {
     const int wl = __builtin_ctzll(eq);
     lomax = (unsigned)__builtin_amdgcn_readlane((int)lo, wl);
     return wl;
   }
   lomax = wave_umax((valid && val == vmax) ? lo : 0u);
-  eq = __ballot(valid && val == vmax && lo == lomax);
+  eq = __builtin_amdgcn_ballot_w64(valid && val == vmax && lo == lomax);
   return eq ? __builtin_ctzll(eq) : 0;
+}
+
+// The same arg-max when the wave holds G identical groups of `GROUP` consecutive lanes (the
+// cross-wave stage: lane i carries candidate i mod GROUP): the reduction stays inside a DPP row,
+// so the four cross-row readlanes of wave_umax and their scalar maxima are not needed.
+template <int GROUP>
+__device__ __forceinline__ unsigned group_umax(unsigned v) {
+  unsigned o;
+  o = dpp_u32<0xB1>(v);  v = o > v ? o : v;   // quad_perm [1,0,3,2]
+  o = dpp_u32<0x4E>(v);  v = o > v ? o : v;   // quad_perm [2,3,0,1]
+  if (GROUP >= 8) { o = dpp_u32<0x141>(v); v = o > v ? o : v; }  // row_half_mirror
+  if (GROUP >= 16) { o = dpp_u32<0x140>(v); v = o > v ? o : v; } // row_mirror
+  return v;
+}
+template <int GROUP>
+__device__ __forceinline__ int group_argmax(bool valid, unsigned val, unsigned lo, unsigned &lomax) {
+  static_assert(GROUP == 4 || GROUP == 8 || GROUP == 16, "one DPP row or less");
+  const unsigned vmax = group_umax<GROUP>(valid ? val : 0u);
+  unsigned long long eq = __builtin_amdgcn_ballot_w64(valid && val == vmax);
+  if (__popcll(eq) == 64 / GROUP) {
+    const int wl = __builtin_ctzll(eq);
+    lomax = (unsigned)__builtin_amdgcn_readlane((int)lo, wl);
+    return wl;
+  }
+  const unsigned lm = group_umax<GROUP>((valid && val == vmax) ? lo : 0u);
+  eq = __builtin_amdgcn_ballot_w64(valid && val == vmax && lo == lm);
+  const int wl = eq ? __builtin_ctzll(eq) : 0;
+  lomax = (unsigned)__builtin_amdgcn_readlane((int)lm, wl);
+  return wl;
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l) {
@@ -307,7 +338,8 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
 // skipped with results bit-identical to the full scan.  After a few dozen rounds
 // only the buckets around the new sample are touched instead of all n points.
 //
-// Layout: workspace pts[s] = (x, y, z, temp) as float4 in sorted order + orig[s];
+// Layout: workspace pts[s] = (x, y, z, temp) as float4 in sorted order + key[s], the tie-break
+// key (key_lo_of) of the point's original index;
 // bucket b belongs to wave b % 16 and its metadata (box, best value/key, the best
 // point's xyz) lives in lane b / 16 of that wave.  Per round: prune test (one lane
 // per bucket) -> ballot -> the active buckets are re-evaluated 64 points at a time
@@ -330,7 +362,7 @@ constexpr int FPS_CELLS = 8192;
 // On gfx9 stores and loads share vmcnt and return in order: with the distances in global memory
 // every round's wait for its bucket loads also waits out the store acknowledgements of the
 // previous round's updates.  Fits up to n = 40 192 points in the 160 KB of a CU.
-template <int NW, bool LT>
+template <int NW, bool LT, bool FULL>
 __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
     int *__restrict__ idx, float4 *__restrict__ ws_pts, unsigned *__restrict__ ws_orig) {
@@ -416,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
     unsigned pos = atomicAdd(&hist[cell_of(x, y, z)], 1u);
     ws_pts[pos] = make_float4(x, y, z, temp[k]);
-    ws_orig[pos] = (unsigned)k;
+    ws_orig[pos] = key_lo_of(k, L);  // the tie-break key of the original index (and its inverse)
   }
   __syncthreads();  // also drains the stores: the block re-reads them below
   if (LT) {         // the histogram is dead: its bytes become the distance array
@@ -443,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   auto fetch = [&](int q, int j) {
     Loaded l;
     const int s = (((q * 64 + j) * NW + wave) << 6) + lane;
-    l.valid = s < n;
+    l.valid = FULL || s < n;  // FULL: n is a multiple of 64, every slot holds a point
     l.ss = l.valid ? s : n - 1;
     l.p = ws_pts[l.ss];
     l.o = ws_orig[l.ss];
@@ -461,7 +493,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
         if (LT) lt[l.ss] = d2; else ws_pts[l.ss].w = d2;
       }
     }
-    const unsigned lo = l.valid ? key_lo_of((int)l.o, L) : 0u;
+    const unsigned lo = l.valid ? l.o : 0u;
     unsigned vmax, lomax;
     const int wl = wave_argmax(l.valid, __float_as_uint(d2), lo, vmax, lomax);
     const float rx = readlane_f(l.p.x, wl), ry = readlane_f(l.p.y, wl);
@@ -485,7 +517,12 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   }
 
   if (tid == 0) idx[0] = 0;
+  // The wave's candidate survives a round in which the bucket that holds it was not re-evaluated:
+  // running minima only fall, so every other bucket's best can only have dropped further.
+  FpsCand c{0u, 0u, 0.f, 0.f, 0.f};
+  int c_lane = -1;  // lane (bucket slot) the candidate came from; -1 = none yet
   for (int r = 1; r < m; ++r) {
+    unsigned long long touched = 0ull;
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       if (q * 64 * NW >= nb) break;  // no bucket in this slot for any lane
@@ -494,7 +531,8 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
       const float ey = fmaxf(fmaxf(bloy[q] - cy, cy - bhiy[q]), 0.f);
       const float ez = fmaxf(fmaxf(bloz[q] - cz, cz - bhiz[q]), 0.f);
       const float d2box = sqdist_nofma(ex, ey, ez);
-      unsigned long long mask = __ballot(have[q] && d2box < __uint_as_float(bmax[q]));
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(have[q] && d2box < __uint_as_float(bmax[q]));
+      touched |= mask;
       while (mask) {  // two buckets per trip so their loads overlap
         const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -507,30 +545,33 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
         if (two) evaluate(l1, j1, false, bmax[q], blo[q], bx[q], by[q], bz[q]);
       }
     }
-    // best bucket of this lane, then of this wave
-    unsigned mv = have[0] ? bmax[0] : 0u, ml = have[0] ? blo[0] : 0u;
-    float mxx = bx[0], myy = by[0], mzz = bz[0];
+    if (BPL > 1 || c_lane < 0 || ((touched >> c_lane) & 1ull)) {
+      // best bucket of this lane, then of this wave
+      unsigned mv = have[0] ? bmax[0] : 0u, ml = have[0] ? blo[0] : 0u;
+      float mxx = bx[0], myy = by[0], mzz = bz[0];
 #pragma unroll
-    for (int q = 1; q < BPL; ++q) {
-      const bool better = have[q] && (bmax[q] > mv || (bmax[q] == mv && blo[q] > ml));
-      mv = better ? bmax[q] : mv; ml = better ? blo[q] : ml;
-      mxx = better ? bx[q] : mxx; myy = better ? by[q] : myy; mzz = better ? bz[q] : mzz;
+      for (int q = 1; q < BPL; ++q) {
+        const bool better = have[q] && (bmax[q] > mv || (bmax[q] == mv && blo[q] > ml));
+        mv = better ? bmax[q] : mv; ml = better ? blo[q] : ml;
+        mxx = better ? bx[q] : mxx; myy = better ? by[q] : myy; mzz = better ? bz[q] : mzz;
+      }
+      const int wl = wave_argmax(ml != 0u, mv, ml, c.val, c.lo);
+      c.x = readlane_f(mxx, wl); c.y = readlane_f(myy, wl); c.z = readlane_f(mzz, wl);
+      c_lane = wl;
     }
-    FpsCand c;
-    const int wl = wave_argmax(ml != 0u, mv, ml, c.val, c.lo);
-    c.x = readlane_f(mxx, wl); c.y = readlane_f(myy, wl); c.z = readlane_f(mzz, wl);
     if (lane == 0) red[r & 1][wave] = c;
     __syncthreads();
     // every wave reduces the NW candidates (lane i holds candidate i mod NW)
     const FpsCand g = red[r & 1][lane & (NW - 1)];
-    unsigned gv, gl;
-    const int gwl = wave_argmax(g.lo != 0u, g.val, g.lo, gv, gl);
+    unsigned gl;
+    const int gwl = group_argmax<NW>(g.lo != 0u, g.val, g.lo, gl);
     cx = readlane_f(g.x, gwl); cy = readlane_f(g.y, gwl); cz = readlane_f(g.z, gwl);
     if (tid == 0) idx[r] = k_of_key_lo(gl, L);
   }
   __syncthreads();
   // running-min distances back to the caller's order
-  for (int s = tid; s < n; s += BLOCK) temp[ws_orig[s]] = LT ? lt[s] : ws_pts[s].w;
+  for (int s = tid; s < n; s += BLOCK)
+    temp[k_of_key_lo(ws_orig[s], L)] = LT ? lt[s] : ws_pts[s].w;
 }
 
 }  // namespace nesie
@@ -585,20 +626,36 @@ static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *i
       return e ? atoi(e) : 1;
     }();
     const size_t lt_bytes = (size_t)n * 4 > (FPS_CELLS + 1024) * 4 ? (size_t)n * 4 : (FPS_CELLS + 1024) * 4;
-    if (nw == 16 && lds_temps && lt_bytes <= 160768) {
-      auto kern = fps_pruned_kernel<16, true>;
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160768);
-        attr = true;
-      }
-      hipLaunchKernelGGL(kern, grid, dim3(1024), lt_bytes, s, n, m, xyz, temp, idx, wp, wo);
-    } else if (nw == 16)
-      hipLaunchKernelGGL((fps_pruned_kernel<16, false>), grid, dim3(1024), 0, s, n, m, xyz, temp, idx, wp, wo);
-    else if (nw == 8)
-      hipLaunchKernelGGL((fps_pruned_kernel<8, false>), grid, dim3(512), 0, s, n, m, xyz, temp, idx, wp, wo);
-    else
-      hipLaunchKernelGGL((fps_pruned_kernel<4, false>), grid, dim3(256), 0, s, n, m, xyz, temp, idx, wp, wo);
+    const bool lds_ok = lds_temps && lt_bytes <= 160768;
+#define PRUNED(NWV)                                                                              \
+  do {                                                                                           \
+    if (lds_ok && n % 64 == 0) {                                                                 \
+      auto kern = fps_pruned_kernel<NWV, true, true>;                                            \
+      static bool attr = false;                                                                  \
+      if (!attr) {                                                                               \
+        (void)hipFuncSetAttribute((const void *)kern,                                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160768);           \
+        attr = true;                                                                             \
+      }                                                                                          \
+      hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lt_bytes, s, n, m, xyz, temp, idx, wp, wo); \
+    } else if (lds_ok) {                                                                         \
+      auto kern = fps_pruned_kernel<NWV, true, false>;                                           \
+      static bool attr = false;                                                                  \
+      if (!attr) {                                                                               \
+        (void)hipFuncSetAttribute((const void *)kern,                                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160768);           \
+        attr = true;                                                                             \
+      }                                                                                          \
+      hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lt_bytes, s, n, m, xyz, temp, idx, wp, wo); \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((fps_pruned_kernel<NWV, false, false>), grid, dim3(NWV * 64), 0, s, n, m, xyz, \
+                         temp, idx, wp, wo);                                                     \
+    }                                                                                            \
+  } while (0)
+    if (nw == 16) PRUNED(16);
+    else if (nw == 8) PRUNED(8);
+    else PRUNED(4);
+#undef PRUNED
     return check_launch(W);
   }
   if (n <= 64) REG(64, 1);
