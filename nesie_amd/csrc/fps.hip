@@ -447,12 +447,16 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   for (int k = tid; k < n; k += BLOCK) {
     float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
     unsigned pos = atomicAdd(&hist[cell_of(x, y, z)], 1u);
-    ws_pts[pos] = make_float4(x, y, z, temp[k]);
-    ws_orig[pos] = key_lo_of(k, L);  // the tie-break key of the original index (and its inverse)
+    // the tie-break key of the original index (k_of_key_lo inverts it).  LT: the key rides in the
+    // w component (one 16-byte load per point in the loop) and the initial distance is parked
+    // in the key array until it moves to LDS below.
+    const unsigned key = key_lo_of(k, L);
+    ws_pts[pos] = make_float4(x, y, z, LT ? __uint_as_float(key) : temp[k]);
+    ws_orig[pos] = LT ? __float_as_uint(temp[k]) : key;
   }
   __syncthreads();  // also drains the stores: the block re-reads them below
   if (LT) {         // the histogram is dead: its bytes become the distance array
-    for (int s_ = tid; s_ < n; s_ += BLOCK) lt[s_] = ws_pts[s_].w;
+    for (int s_ = tid; s_ < n; s_ += BLOCK) lt[s_] = __uint_as_float(ws_orig[s_]);
     __syncthreads();
   }
 
@@ -478,8 +482,8 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     l.valid = FULL || s < n;  // FULL: n is a multiple of 64, every slot holds a point
     l.ss = l.valid ? s : n - 1;
     l.p = ws_pts[l.ss];
-    l.o = ws_orig[l.ss];
-    if (LT) l.p.w = lt[l.ss];
+    if (LT) { l.o = __float_as_uint(l.p.w); l.p.w = lt[l.ss]; }
+    else l.o = ws_orig[l.ss];
     return l;
   };
   // Re-evaluate one bucket against the centre; INIT only (re)builds its box and best.
@@ -487,10 +491,15 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
                       float &o_x, float &o_y, float &o_z) {
     float d2 = l.p.w;
     if (!init) {
-      float d = sqdist_nofma(l.p.x - cx, l.p.y - cy, l.p.z - cz);
-      d2 = fminf(d, l.p.w);
-      if (l.valid && d2 != l.p.w) {
-        if (LT) lt[l.ss] = d2; else ws_pts[l.ss].w = d2;
+      const float d = sqdist_nofma(l.p.x - cx, l.p.y - cy, l.p.z - cz);
+      // fminf() without the NaN-quieting pre-pass (distances are never NaN)
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(l.p.w));
+      if (LT) {
+        // unconditional: cheaper than the compare + exec-mask round trip; the padding lanes of
+        // the last bucket hold copies of point n-1 and write the value its own lane writes
+        lt[l.ss] = d2;
+      } else if (l.valid && d2 != l.p.w) {
+        ws_pts[l.ss].w = d2;
       }
     }
     const unsigned lo = l.valid ? l.o : 0u;
@@ -498,7 +507,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     const int wl = wave_argmax(l.valid, __float_as_uint(d2), lo, vmax, lomax);
     const float rx = readlane_f(l.p.x, wl), ry = readlane_f(l.p.y, wl);
     const float rz = readlane_f(l.p.z, wl);
-    if (lane == j) { o_max = vmax; o_lo = lomax; o_x = rx; o_y = ry; o_z = rz; }
+    const bool mine = lane == j;  // selects, not a branch: no exec-mask round trip
+    o_max = mine ? vmax : o_max; o_lo = mine ? lomax : o_lo;
+    o_x = mine ? rx : o_x; o_y = mine ? ry : o_y; o_z = mine ? rz : o_z;
   };
 
 #pragma unroll
@@ -521,6 +532,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   // running minima only fall, so every other bucket's best can only have dropped further.
   FpsCand c{0u, 0u, 0.f, 0.f, 0.f};
   int c_lane = -1;  // lane (bucket slot) the candidate came from; -1 = none yet
+  int c_age = 0;    // exchange slots already holding the candidate (0..2)
   for (int r = 1; r < m; ++r) {
     unsigned long long touched = 0ull;
 #pragma unroll
@@ -558,8 +570,12 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
       const int wl = wave_argmax(ml != 0u, mv, ml, c.val, c.lo);
       c.x = readlane_f(mxx, wl); c.y = readlane_f(myy, wl); c.z = readlane_f(mzz, wl);
       c_lane = wl;
+      c_age = 0;
     }
-    if (lane == 0) red[r & 1][wave] = c;
+    if (c_age < 2) {  // both exchange slots of this wave hold the candidate after two rounds
+      if (lane == 0) red[r & 1][wave] = c;
+      ++c_age;
+    }
     __syncthreads();
     // every wave reduces the NW candidates (lane i holds candidate i mod NW)
     const FpsCand g = red[r & 1][lane & (NW - 1)];
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   __syncthreads();
   // running-min distances back to the caller's order
   for (int s = tid; s < n; s += BLOCK)
-    temp[k_of_key_lo(ws_orig[s], L)] = LT ? lt[s] : ws_pts[s].w;
+    temp[k_of_key_lo(LT ? __float_as_uint(ws_pts[s].w) : ws_orig[s], L)] = LT ? lt[s] : ws_pts[s].w;
 }
 
 }  // namespace nesie
