@@ -533,6 +533,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
   FpsCand c{0u, 0u, 0.f, 0.f, 0.f};
   int c_lane = -1;  // lane (bucket slot) the candidate came from; -1 = none yet
   int c_age = 0;    // exchange slots already holding the candidate (0..2)
+  unsigned my_key = key_lo_of(0, L);  // idx[0] = 0
   for (int r = 1; r < m; ++r) {
     unsigned long long touched = 0ull;
 #pragma unroll
@@ -545,6 +546,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
       const float d2box = sqdist_nofma(ex, ey, ez);
       unsigned long long mask = __builtin_amdgcn_ballot_w64(have[q] && d2box < __uint_as_float(bmax[q]));
       touched |= mask;
+      // waves with buckets to re-evaluate are the round's critical path: let them win the SIMD's
+      // issue arbitration over the waves that only run the fixed prune / exchange steps
+      if (mask) __builtin_amdgcn_s_setprio(3);
       while (mask) {  // two buckets per trip so their loads overlap
         const int j0 = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -576,13 +580,22 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
       if (lane == 0) red[r & 1][wave] = c;
       ++c_age;
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     // every wave reduces the NW candidates (lane i holds candidate i mod NW)
     const FpsCand g = red[r & 1][lane & (NW - 1)];
     unsigned gl;
-    const int gwl = group_argmax<NW>(g.lo != 0u, g.val, g.lo, gl);
+    // every wave owns buckets (n > 4096 means nb > NW), so all NW candidates are live
+    const int gwl = group_argmax<NW>(true, g.val, g.lo, gl);
     cx = readlane_f(g.x, gwl); cy = readlane_f(g.y, gwl); cz = readlane_f(g.z, gwl);
-    if (tid == 0) idx[r] = k_of_key_lo(gl, L);
+    // thread (r mod BLOCK) keeps round r's winner in a register; stored BLOCK rounds at a time, so
+    // no global store (and its acknowledgement in wave 0's vmcnt queue) sits inside a round
+    my_key = tid == (r & (BLOCK - 1)) ? gl : my_key;
+    if ((r & (BLOCK - 1)) == BLOCK - 1) idx[(r & ~(BLOCK - 1)) + tid] = k_of_key_lo(my_key, L);
+  }
+  if (((m - 1) & (BLOCK - 1)) != BLOCK - 1) {
+    const int base = (m - 1) & ~(BLOCK - 1);
+    if (base + tid <= m - 1) idx[base + tid] = k_of_key_lo(my_key, L);
   }
   __syncthreads();
   // running-min distances back to the caller's order

@@ -39,6 +39,8 @@ FPS_CASES = [
     (1500, 64, 2, dict(dup_frac=0.3)), (5000, 100, 2, {}), (9000, 64, 1, {}),
     (20000, 64, 1, {}), (30000, 33, 1, dict(dup_frac=0.2)), (45000, 40, 1, {}),
     (60000, 40, 1, {}), (70000, 20, 1, {}),     # > 65536: generic kernel
+    # pruned kernel's buffered index stores: a flush plus a tail, exactly one flush, flush + 1
+    (5000, 1500, 2, {}), (8192, 1024, 1, {}), (6400, 1025, 1, dict(dup_frac=0.2)),
 ]
 
 
