@@ -71,6 +71,16 @@ int nesie_ball_query_wrapper(int b, int n, int m, float min_radius,
                              const float *new_xyz, const float *xyz, int *idx,
                              void *stream);
 
+/* ball_query_wrapper over the spatial index nesie_furthest_point_sampling_ws leaves in its
+ * workspace (no reference counterpart; same results as nesie_ball_query_wrapper).  For sizes
+ * where nesie_fps_leaves_index(b, n) != 0 the workspace holds, after the call returns, the scene
+ * sorted into 64-point buckets with one bounding box each; a ball query of the SAME xyz then
+ * visits only the buckets within max_radius.  nsample <= 64; NESIE_ERR_UNSUPPORTED otherwise. */
+int nesie_fps_leaves_index(int b, int n);
+int nesie_ball_query_indexed(int b, int n, int m, float min_radius, float max_radius,
+                             int nsample, const float *new_xyz, const void *fps_workspace,
+                             size_t workspace_bytes, int *idx, void *stream);
+
 /* mmdet3d/ops/group_points/src/group_points.cpp:31-45  forward
  * (b, c, n, npoints, nsample, points[B,C,N], idx[B,M,ns], out[B,C,M,ns]). */
 int nesie_group_points_forward(int b, int c, int n, int npoints, int nsample,

@@ -21,6 +21,7 @@ SIGNATURES = {
     "nesie_furthest_point_sampling_ws": [_I, _I, _I, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "nesie_furthest_point_sampling_with_dist_wrapper": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_ball_query_wrapper": [_I, _I, _I, _F, _F, _I, _P, _P, _P, _P],
+    "nesie_ball_query_indexed": [_I, _I, _I, _F, _F, _I, _P, _P, ctypes.c_size_t, _P, _P],
     "nesie_group_points_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nesie_group_points_backward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nesie_gather_points_wrapper": [_I, _I, _I, _I, _P, _P, _P, _P],
@@ -117,6 +118,8 @@ def load():
         fn.restype = _I
     lib.nesie_fps_workspace_bytes.argtypes = [_I, _I]
     lib.nesie_fps_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_fps_leaves_index.argtypes = [_I, _I]
+    lib.nesie_fps_leaves_index.restype = _I
     lib.nesie_bn_workspace_bytes.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_conv_wgrad_workspace_bytes.argtypes = [_I, _I, _I, ctypes.c_longlong]

@@ -18,30 +18,10 @@
 // that they are re-streamed from L2 each round with dense 12-byte-per-lane
 // loads (480 KB per scene at n = 40000 does not fit one CU's registers + LDS).
 #include "common.h"
+#include "fps_keys.h"
 #include <stdlib.h>
 
 namespace nesie {
-
-__host__ __device__ inline int fps_ref_log2_block(int n) {
-  // reference opt_n_threads(): largest power of two <= n, capped at 1024.
-  int l = 0;
-  while ((2 << l) <= n && l < 10) ++l;
-  return l;
-}
-
-__device__ __forceinline__ unsigned key_lo_of(int k, int L) {
-  unsigned t = (unsigned)k & ((1u << L) - 1u);
-  unsigned q = (unsigned)k >> L;
-  unsigned rb = L == 0 ? 0u : (__brev(t) >> (32 - L));
-  return 0xFFFFFFFFu - ((rb << 22) | q);
-}
-
-__device__ __forceinline__ int k_of_key_lo(unsigned lo, int L) {
-  unsigned v = 0xFFFFFFFFu - lo;
-  unsigned rb = v >> 22, q = v & 0x3FFFFFu;
-  unsigned t = L == 0 ? 0u : (__brev(rb) >> (32 - L));
-  return (int)((q << L) | t);
-}
 
 // Order-preserving map float -> u32 for ANY sign (the F-FPS distance matrix is
 // a^2 + b^2 - 2ab and goes slightly negative); -0 is folded onto +0 first
@@ -598,6 +578,19 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(
     if (base + tid <= m - 1) idx[base + tid] = k_of_key_lo(my_key, L);
   }
   __syncthreads();
+  if (LT) {
+    // the key array is dead in this mode (the keys ride in pts.w): leave the bucket boxes there,
+    // box[6][nb], so that the sorted scene doubles as a spatial index (nesie_ball_query_indexed)
+    float *box = (float *)ws_orig;
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) {
+      const int bid = (q * 64 + lane) * NW + wave;
+      if (bid < nb) {
+        box[bid] = blox[q]; box[nb + bid] = bloy[q]; box[2 * nb + bid] = bloz[q];
+        box[3 * nb + bid] = bhix[q]; box[4 * nb + bid] = bhiy[q]; box[5 * nb + bid] = bhiz[q];
+      }
+    }
+  }
   // running-min distances back to the caller's order
   for (int s = tid; s < n; s += BLOCK)
     temp[k_of_key_lo(LT ? __float_as_uint(ws_pts[s].w) : ws_orig[s], L)] = LT ? lt[s] : ws_pts[s].w;
@@ -609,6 +602,19 @@ using namespace nesie;
 
 static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *idx,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+// running-min distances in LDS (and the spatial index left behind): n floats must fit the CU
+static bool fps_lds_mode(int n) {
+  static const int enabled = [] {
+    const char *e = getenv("NESIE_FPS_LDS");
+    return e ? atoi(e) : 1;
+  }();
+  return enabled && n <= FPS_INDEX_MAX_N;
+}
+
+extern "C" int nesie_fps_leaves_index(int b, int n) {
+  return nesie_fps_workspace_bytes(b, n) != 0 && fps_lds_mode(n);
+}
 
 extern "C" size_t nesie_fps_workspace_bytes(int b, int n) {
   if (b <= 0 || n <= 4096 || n > 65536) return 0;
@@ -650,12 +656,9 @@ static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *i
       const char *e = getenv("NESIE_FPS_WAVES");
       return e ? atoi(e) : 16;
     }();
-    static const int lds_temps = [] {
-      const char *e = getenv("NESIE_FPS_LDS");
-      return e ? atoi(e) : 1;
-    }();
+    const bool lds_temps = fps_lds_mode(n);
     const size_t lt_bytes = (size_t)n * 4 > (FPS_CELLS + 1024) * 4 ? (size_t)n * 4 : (FPS_CELLS + 1024) * 4;
-    const bool lds_ok = lds_temps && lt_bytes <= 160768;
+    const bool lds_ok = lds_temps;
 #define PRUNED(NWV)                                                                              \
   do {                                                                                           \
     if (lds_ok && n % 64 == 0) {                                                                 \

@@ -91,16 +91,38 @@ class HipKernels(_BNPoolMixin):
 
     name = "hip"
 
+    # The bucket-pruned FPS kernel leaves the scene spatially sorted in its scratch; the ball
+    # query that follows on the SAME coordinates (every set-abstraction module samples and then
+    # groups one cloud) can use it as an index.  The entry keeps the coordinate tensor alive, so
+    # its address cannot be handed to another tensor while the entry exists, and records its
+    # version counter, so an in-place change invalidates it.  One entry per device.
+    _spatial_index = {}
+
+    @classmethod
+    def _index_for(cls, xyz, b, n):
+        hit = cls._spatial_index.get(xyz.device)
+        if hit is None:
+            return None
+        ref, version, shape, ws, stream = hit
+        same = (ref.data_ptr() == xyz.data_ptr() and ref._version == version
+                and xyz._version == version and shape == (b, n) and ref.dtype == xyz.dtype
+                and stream == _stream(xyz))
+        return ws if same else None
+
     def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
         _check(xyz, temp, idx); _f32(xyz, temp); _i32(idx)
         assert xyz.numel() == b * n * 3 and temp.numel() == b * n and idx.numel() == b * m
-        need = _lib.load().nesie_fps_workspace_bytes(b, n)
+        lib = _lib.load()
+        need = lib.nesie_fps_workspace_bytes(b, n)
         with torch.cuda.device(xyz.device):
             if need:
                 # scratch for the bucket-pruned kernel, from torch's caching allocator
                 ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
                 _lib.call("nesie_furthest_point_sampling_ws", b, n, m, _ptr(xyz),
                           _ptr(temp), _ptr(idx), _ptr(ws), need, _stream(xyz))
+                if lib.nesie_fps_leaves_index(b, n):
+                    HipKernels._spatial_index[xyz.device] = (xyz, xyz._version, (b, n), ws,
+                                                             _stream(xyz))
             else:
                 _lib.call("nesie_furthest_point_sampling_wrapper", b, n, m, _ptr(xyz),
                           _ptr(temp), _ptr(idx), _stream(xyz))
@@ -118,6 +140,12 @@ class HipKernels(_BNPoolMixin):
         assert new_xyz.numel() == b * m * 3 and xyz.numel() == b * n * 3
         assert idx.numel() == b * m * nsample
         with torch.cuda.device(xyz.device):
+            ws = self._index_for(xyz, b, n) if nsample <= 64 else None
+            if ws is not None:  # same results, only the buckets within max_radius are visited
+                _lib.call("nesie_ball_query_indexed", b, n, m, float(min_radius),
+                          float(max_radius), nsample, _ptr(new_xyz), _ptr(ws), ws.numel(),
+                          _ptr(idx), _stream(xyz))
+                return
             _lib.call("nesie_ball_query_wrapper", b, n, m, float(min_radius),
                       float(max_radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx),
                       _stream(xyz))

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_every_compute_entry_point():
     compute = [n for n in declared_symbols()
                if n not in ("nesie_abi_version", "nesie_last_error",
-                            "nesie_fps_workspace_bytes", "nesie_bn_workspace_bytes",
+                            "nesie_fps_workspace_bytes", "nesie_fps_leaves_index",
+                            "nesie_bn_workspace_bytes",
                             "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_pw_wgrad_supported",
                             "nesie_pw_wgrad_workspace_bytes", "nesie_blend_conv_runs",
                             "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials",

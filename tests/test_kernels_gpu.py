@@ -112,6 +112,45 @@ def test_ball_query_bit_exact(oracle_kernels, hip_device, n, m, r, ns, min_r, b,
     assert (got[:, -1] == 0).all()
 
 
+@pytest.mark.parametrize("n,m,r,ns,min_r,b,kw", [
+    (40000, 2048, 0.2, 64, 0.0, 2, {}),                    # SA1 as trained
+    (40000, 2048, 0.2, 64, 0.0, 2, dict(dup_frac=0.3)),    # duplicates: > 64 hits per ball
+    (5000, 300, 0.4, 16, 0.0, 2, {}),                      # n not a multiple of 64
+    (8192, 512, 0.6, 32, 0.1, 1, dict(dup_frac=0.5)),      # hundreds of hits, inner radius
+    (6400, 100, 5.0, 64, 0.0, 1, {}),                      # every point is a hit
+    (20000, 700, 0.05, 8, 0.0, 2, {}),                     # mostly one or zero hits
+])
+def test_ball_query_over_the_fps_index_matches_the_full_scan(oracle_kernels, hip_device, n, m, r,
+                                                             ns, min_r, b, kw):
+    """FPS leaves the spatially sorted scene; the ball query of the same cloud goes through it
+    (nesie_ball_query_indexed) and must return what the full scan and the oracle return."""
+    from nesie_amd import _lib
+    assert _lib.load().nesie_fps_leaves_index(b, n) == 1
+    xyz_cpu = _cases.cloud(11 + n + m, b, n, **kw)
+    xyz = xyz_cpu.to(hip_device)
+    picks = ops.furthest_point_sample(xyz, m)
+    centres = torch.gather(xyz, 1, picks.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    centres[:, -1] += 100.0  # an empty ball
+    back = kernels.backend_for(xyz)
+    assert back._index_for(xyz, b, n) is not None
+    got = ops.ball_query(min_r, r, ns, xyz, centres)
+    full = torch.zeros_like(got)
+    _lib.call("nesie_ball_query_wrapper", b, n, m, min_r, r, ns, centres.data_ptr(),
+              xyz.data_ptr(), full.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(got, full)
+    with kernels.use_backend(oracle_kernels):
+        want = ops.ball_query(min_r, r, ns, xyz_cpu, centres.cpu())
+    eq(got, want)
+    assert (got[:, -1] == 0).all()
+    # an in-place change of the cloud retires the index: the full scan answers for the new cloud
+    xyz.add_(0.25)
+    assert back._index_for(xyz, b, n) is None
+    moved = ops.ball_query(min_r, r, ns, xyz, centres + 0.25)
+    with kernels.use_backend(oracle_kernels):
+        want_moved = ops.ball_query(min_r, r, ns, xyz.cpu(), (centres + 0.25).cpu())
+    eq(moved, want_moved)
+
+
 @pytest.mark.parametrize("n,m,b", [(512, 256, 3), (1024, 512, 3), (49152, 1024, 2),
                                    (32768, 1024, 1), (300, 0, 1), (300, 1, 2), (300, 2, 2),
                                    (300, 3, 2), (64, 1500, 2), (1000, 2500, 1)])
