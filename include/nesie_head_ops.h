@@ -15,6 +15,17 @@
 extern "C" {
 #endif
 
+/* Per-point vote targets of NesieHead.get_targets_single (nesie_head.py:593-654) for a batch:
+ *   gt_boxes (B,T,7) DEPTH-frame bottom-centre boxes, gt_count (B) int64 = columns in use,
+ *   points (B,N,pt_stride) with xyz in the first three floats
+ * -> vote_targets (B,N,9): gravity centre minus point for the first / second / last box holding
+ *    the point (empty slots repeat the first; zeros when in no box), vote_target_masks (B,N)
+ *    int64 = [in some box].  Same in-box test as nesie_points_in_boxes_batch on the LiDAR-frame
+ *    operands of depth_box3d.py:263-266. */
+int nesie_vote_targets(int b, int boxes_num, int pts_num, int pt_stride, const float *gt_boxes,
+                       const long long *gt_count, const float *points, float *vote_targets,
+                       long long *vote_target_masks, void *stream);
+
 /* Proposal <-> ground-truth assignment and the batch-level weights.
  *   agg (B,K,3) aggregated points; gt_boxes (B,T,7) bottom-centre boxes; gt_labels (B,T) int64;
  *   gt_count (B) int64 = box columns in use; gt_valid (B,T) 1 for real boxes.

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nesie_blend_conv_backward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_vote_targets": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "nesie_group_max_pool_forward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_group_max_pool_backward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_query_and_group_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P],

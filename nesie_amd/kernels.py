@@ -503,6 +503,19 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_points_in_boxes_batch", b, t, m, _ptr(boxes), _ptr(pts),
                       _ptr(out), _stream(boxes))
 
+    def vote_targets(self, points, gt_boxes, gt_count):
+        """points (B,N,C>=3), depth-frame gt_boxes (B,T,7), gt_count (B) int64 -> vote targets
+        (B,N,9) and masks (B,N) int64 of get_targets_single, one launch."""
+        _check(points, gt_boxes, gt_count); _f32(points, gt_boxes)
+        b, n, c = points.shape
+        t = gt_boxes.shape[1]
+        assert gt_boxes.shape == (b, t, 7) and gt_count.shape == (b,) and gt_count.dtype == torch.int64
+        votes = points.new_empty(b, n, 9)
+        masks = torch.empty(b, n, dtype=torch.int64, device=points.device)
+        with torch.cuda.device(points.device):
+            _lib.call("nesie_vote_targets", b, t, n, c, _ptr(gt_boxes) if t else 0,
+                      _ptr(gt_count), _ptr(points), _ptr(votes), _ptr(masks), _stream(points))
+        return votes, masks
 
     def group_max_pool_forward(self, x, out, argmax):
         """x (..., ns) -> out (...), argmax (...) uint8."""

@@ -567,6 +567,12 @@ class NesieHead(nn.Module):
             GTBatch.collate(gt_bboxes_3d, gt_labels_3d, device)
         B, N = pts.shape[:2]
         T = gt.boxes.shape[1]
+        backend = backend_for(pts)
+        if (head_loss.ENABLED and backend.name == 'hip' and pts.dtype == torch.float32
+                and gt.boxes.dtype == torch.float32 and N > 0):
+            # in-box test, slot bookkeeping and the nine offsets in one launch
+            return backend.vote_targets(pts.contiguous(), gt.boxes.contiguous(),
+                                        gt.count.contiguous())
         xyz = pts[..., :3]
         col = torch.arange(T, device=device).unsqueeze(0)
         is_col = col < gt.count.unsqueeze(1)  # (B,T) columns the reference iterates over

@@ -87,6 +87,39 @@ def test_targets_kernel_matches_the_tensor_ops(hip_device):
         assert torch.equal(a, b), n
 
 
+def test_vote_targets_kernel_on_nested_rotated_boxes(hip_device):
+    """nesie_vote_targets vs the tensor-op form where points sit in up to five boxes (first /
+    second / LAST slots differ), boxes are rotated, one scene has no box and one has more boxes
+    than the kernel's 128-box tile."""
+    from nesie_amd.votenet.nesie_head import NesieHead
+    g = torch.Generator().manual_seed(5)
+    B, N = 4, 6000
+    pts = torch.cat([torch.rand(B, N, 3, generator=g) * torch.tensor([6.0, 6.0, 2.5]),
+                     torch.rand(B, N, 1, generator=g)], -1)
+    boxes, labels = [], []
+    for b, t in enumerate([40, 0, 150, 7]):
+        centre = torch.rand(t, 3, generator=g) * torch.tensor([6.0, 6.0, 1.0])
+        size = 0.3 + 2.5 * torch.rand(t, 3, generator=g)       # large: heavy nesting
+        yaw = (torch.rand(t, 1, generator=g) - 0.5) * 6.0
+        boxes.append(torch.cat([centre, size, yaw], -1))
+        labels.append(torch.randint(0, 18, (t,), generator=g))
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    outs = []
+    for fused in (False, True):
+        head_loss.ENABLED = fused
+        try:
+            outs.append(NesieHead.vote_targets_of(pts, gt))
+        finally:
+            head_loss.ENABLED = True
+    (v0, m0), (v1, m1) = outs
+    assert v0.dtype == v1.dtype and m0.dtype == m1.dtype and v0.shape == v1.shape == (B, N, 9)
+    assert torch.equal(m0, m1) and torch.equal(v0, v1)
+    # the case is not vacuous: all three slots differ somewhere, and some points are in no box
+    assert ((v0[..., 0:3] != v0[..., 3:6]).any(-1) & (v0[..., 3:6] != v0[..., 6:9]).any(-1)).any()
+    assert (m0 == 0).any() and (m0[1] == 0).all()
+
+
 @pytest.mark.parametrize('bins,copies', [(17, 2), (33, 1)])
 def test_side_prob_stats_match_topk_and_var(hip_device, bins, copies):
     """nesie_side_prob_stats vs SidePooling.dist_feature's tensor form (cat[prob, topk 4, var])."""
