@@ -290,6 +290,10 @@ int nesie_iou3d_forward(int n, const float *box1, const float *box2, float *iou,
  *           points of a proposal), added on the fly instead of materialising the repeat+concat;
  *           group must be a power of two in 4..256.  backward writes d_row_bias (same shape)
  *           = sum of dx over each group.
+ *           group == 0: row_bias[C] is ONE value per channel -- the bias of the convolution in
+ *           front (mmcv ConvModule with bias=True and a norm: vote_module.py / base_conv_bbox_head),
+ *           added in registers with the rounding of the separate add.  Its gradient is identically
+ *           zero (the mean subtraction removes it): d_row_bias must be NULL.
  * workspace: nesie_bn_workspace_bytes(b, c, p) bytes, 16-byte aligned tensors. */
 size_t nesie_bn_workspace_bytes(int b, int c, long long p);
 int nesie_bn_relu_forward(int b, int c, long long p, const float *x, const float *gamma,

@@ -22,7 +22,13 @@ constexpr int BN_BLOCK = 256;
 constexpr int BN_SPAN = 8192;  // floats of one (b, c) row handled by a stats/reduce block
 
 // log2 of the row-bias group (a power of two; 1 when there is no row bias)
-__device__ __forceinline__ int group_shift(int group) { return __ffs(group) - 1; }
+// group == 0: row_bias holds ONE value per channel (a conv bias folded into the norm: the sum
+// x + bias is formed in registers with the rounding of the separate add, never stored); the
+// element index is then shifted out entirely.
+__device__ __forceinline__ int group_shift(int group) { return group ? __ffs(group) - 1 : 62; }
+__device__ __forceinline__ size_t rb_offset(int b, int c, int c_total, long long p, int group) {
+  return group ? ((size_t)b * c_total + c) * (size_t)(p / group) : (size_t)c;
+}
 
 __device__ __forceinline__ float block_sum(float v, float *sh) {
 #pragma unroll
@@ -46,8 +52,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(
   const float *row = x + ((size_t)b * c_total + c) * p;
   // row_bias (optional): x_eff[b,c,i] = x[b,c,i] + row_bias[b,c,i / group]  (a per-proposal
   // term broadcast over its `group` grid points, never materialised)
-  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
-  const float shift = x[(size_t)c * p] + (row_bias ? row_bias[(size_t)c * (p / group)] : 0.f);
+  const float *rb = row_bias ? row_bias + rb_offset(b, c, c_total, p, group) : nullptr;
+  const float shift = x[(size_t)c * p] + (row_bias ? row_bias[rb_offset(0, c, c_total, p, group)] : 0.f);
   const long long lo = (long long)s * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   const int gs = group_shift(group);
@@ -108,7 +114,7 @@ __device__ __forceinline__ void bn_fwd_finalize(const BnFwdFin &f, int c, bool w
       // sums are taken about the channel's first element (no shift when the producer of the
       // partials had no such element at hand: f.x == NULL)
       const double shift = f.x ? (double)(f.x[(size_t)c * f.p] +
-                                          (f.row_bias ? f.row_bias[(size_t)c * (f.p / f.group)] : 0.f))
+                                          (f.row_bias ? f.row_bias[f.group ? (size_t)c * (f.p / f.group) : (size_t)c] : 0.f))
                                : 0.0;
       const double m = s0 / f.n;
       double var = s1 / f.n - m * m;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(
   bn_fwd_finalize(fin, c, blockIdx.x == 0 && b == 0, shc);
   const float sc = shc[0], bi = shc[1];
   const size_t base = ((size_t)b * c_total + c) * p;
-  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
+  const float *rb = row_bias ? row_bias + rb_offset(b, c, c_total, p, group) : nullptr;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   const int gs = group_shift(group);
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(BN_BLOCK) void affine_apply_kernel(
   const int c = blockIdx.y, b = blockIdx.z;
   const float sc = coef[c * 4 + 0], bi = coef[c * 4 + 1];
   const size_t base = ((size_t)b * c_total + c) * p;
-  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
+  const float *rb = row_bias ? row_bias + rb_offset(b, c, c_total, p, group) : nullptr;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   const int gs = group_shift(group);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   __shared__ float sh[BN_BLOCK / 64];
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c_total + c) * p;
-  const float *rb = row_bias ? row_bias + ((size_t)b * c_total + c) * (p / group) : nullptr;
+  const float *rb = row_bias ? row_bias + rb_offset(b, c, c_total, p, group) : nullptr;
   float mean = save_mean[c], invstd = save_invstd[c];
   const float rsc = raw_coef ? raw_coef[c * 4 + 0] : 0.f, rbi = raw_coef ? raw_coef[c * 4 + 1] : 0.f;
   // With the ReLU fused, xhat is only needed where y > 0, and there y = gamma*xhat + beta:
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   const float sc = fwd_coef[c * 4 + 0], bi = fwd_coef[c * 4 + 1];
   const float mean = fwd_coef[c * 4 + 2], invstd = fwd_coef[c * 4 + 3];
   const size_t base = ((size_t)b * c_total + c) * p;
-  const size_t rbase = (row_bias || d_row_bias) ? ((size_t)b * c_total + c) * (p / group) : 0;
+  const size_t rbase = (row_bias || d_row_bias) ? rb_offset(b, c, c_total, p, group) : 0;
   const long long lo = (long long)blockIdx.x * BN_SPAN;
   const long long hi = lo + BN_SPAN < p ? lo + BN_SPAN : p;
   const int gs = group_shift(group);
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(
   } else {
     for (long long i = lo + threadIdx.x; i < hi; i += BN_BLOCK) {
       float g = dy[base + i];
-      const float v = x[base + i];  // the row-bias form requires p % 4 == 0 (checked on the host)
+      // (the grouped row-bias form requires p % 4 == 0, checked on the host; the per-channel one not)
+      const float v = x[base + i] + (row_bias ? row_bias[rbase + (i >> gs)] : 0.f);
       if (RELU) g = (fused_mask ? __builtin_fmaf(v, sc, bi) : v * sc + bi) > 0.f ? g : 0.f;
       dx[base + i] = a * (g - k1 - (v - mean) * invstd * k2);
     }
@@ -502,9 +509,10 @@ extern "C" int nesie_bn_relu_forward(int b, int c, long long p, const float *x,
   NESIE_REQUIRE(x && y && save_mean && save_invstd && fwd_coef, W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
   if (!row_bias) group = 1;
-  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
-  if (row_bias && (group < 4 || group > 256 || (group & (group - 1)) || (BN_SPAN % group))) {
-    set_error("%s: row_bias group %d (needs a power of two in 4..256)", W, group);
+  // group 0: row_bias is one value per channel (a folded conv bias)
+  NESIE_REQUIRE(group >= 0 && (group == 0 || p % group == 0), W);
+  if (row_bias && group != 0 && (group < 4 || group > 256 || (group & (group - 1)) || (BN_SPAN % group))) {
+    set_error("%s: row_bias group %d (needs 0 = per channel, or a power of two in 4..256)", W, group);
     return NESIE_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -544,8 +552,11 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   // the per-group sums of dx are wanted (the producer had added the row term itself).
   const int raw = relu && !y;
   if (!row_bias && !d_row_bias) group = 1;
-  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
-  NESIE_REQUIRE(!(row_bias || d_row_bias) || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
+  NESIE_REQUIRE(group >= 0 && (group == 0 || p % group == 0), W);
+  // group 0 (per-channel bias): no d_row_bias -- the gradient of a bias that feeds a batch norm
+  // is identically zero (the mean subtraction removes it)
+  NESIE_REQUIRE(group != 0 || (row_bias && !d_row_bias), W);
+  NESIE_REQUIRE(group == 0 || !(row_bias || d_row_bias) || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
   NESIE_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)y) & 15) == 0, W);
   hipStream_t s = (hipStream_t)stream;
   const int sp = bn_sp(p), nslice = b * sp;
@@ -716,8 +727,8 @@ extern "C" int nesie_affine_relu_forward(int b, int c, long long p, const float 
   if (b == 0 || c == 0 || p == 0) return NESIE_OK;
   NESIE_REQUIRE(x && coef && y && b <= 65535 && c <= 65535, W);
   if (!row_bias) group = 1;
-  NESIE_REQUIRE(group >= 1 && p % group == 0, W);
-  NESIE_REQUIRE(!row_bias || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
+  NESIE_REQUIRE(group >= 0 && (group == 0 || p % group == 0), W);
+  NESIE_REQUIRE(!row_bias || group == 0 || (group >= 4 && group <= 256 && !(group & (group - 1)) && (p & 3) == 0), W);
   NESIE_REQUIRE((p & 3) != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) == 0, W);
   const dim3 grid(bn_sp(p), c, b);
   hipStream_t s = (hipStream_t)stream;

@@ -936,9 +936,11 @@ class HipKernels(_BNPoolMixin):
             assert group and d_row_bias.numel() == b * c * (p // group)
         else:
             group = _row_bias_group(x, row_bias)
-        if row_bias is not None:
+        if row_bias is not None and row_bias.dim() != 1:
             _check(d_row_bias); _f32(d_row_bias)
             assert d_row_bias.shape == row_bias.shape
+        elif row_bias is not None:
+            assert d_row_bias is None  # per-channel bias before a batch norm: gradient is zero
         need = _lib.load().nesie_bn_workspace_bytes(b, c, p)
         with torch.cuda.device(x.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
@@ -953,6 +955,9 @@ def _row_bias_group(x, row_bias):
     if row_bias is None:
         return 1
     _check(row_bias); _f32(row_bias)
+    if row_bias.dim() == 1:  # one value per channel (a conv bias folded into the norm): group 0
+        assert row_bias.shape[0] == x.shape[1], (tuple(x.shape), tuple(row_bias.shape))
+        return 0
     assert x.dim() == 4 and tuple(row_bias.shape) == tuple(x.shape[:3]), \
         (tuple(x.shape), tuple(row_bias.shape))
     return int(x.shape[3])

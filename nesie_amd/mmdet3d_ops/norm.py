@@ -77,7 +77,10 @@ class BNReLUTrain(Function):
     def backward(ctx, dy):
         x, y, weight, bias, save_mean, save_invstd, fwd_coef = ctx.saved_tensors[:7]
         row_bias = ctx.saved_tensors[7] if ctx.has_row_bias else None
-        d_row_bias = torch.empty_like(row_bias) if ctx.has_row_bias else None
+        # a per-channel row_bias is a conv bias folded into the norm: the mean subtraction removes
+        # it, its gradient is identically zero and is reported as None (a summation of dx, as the
+        # unfused graph does, returns rounding noise around that zero)
+        d_row_bias = torch.empty_like(row_bias) if ctx.has_row_bias and row_bias.dim() != 1 else None
         dy = dy.contiguous()
         c = x.shape[1]
         dx = torch.empty_like(x)
@@ -146,16 +149,24 @@ class _FusedBNReLU:
     def _init_fused(self, relu):
         self.fuse_relu = bool(relu)
 
-    def forward(self, x, row_bias=None, pre_partial=None):
+    def forward(self, x, row_bias=None, pre_partial=None, chan_bias=None):
         """``row_bias`` (B, C, K), optional: normalise ``x + row_bias[..., None]`` for
         ``x`` (B, C, K, G) without materialising the sum (G a power of two in 4..256).
         ``pre_partial`` (C, nslice, 2), optional: (sum, sum of squares) partials of x left by
-        its producer (native training path only; ignored otherwise)."""
+        its producer (native training path only; ignored otherwise).
+        ``chan_bias`` (C), optional: the bias of the convolution that produced ``x``: normalise
+        ``x + chan_bias`` with the sum formed in registers (same rounding as the separate add)."""
         backend = backend_for(x)  # raises for CPU tensors without an injected back end
         native = (backend.name == 'hip' and self.training and x.dtype == torch.float32
                   and self.affine and self.track_running_stats and self.momentum is not None)
         native_eval = self._native_eval(x, backend)
-        if row_bias is not None:
+        if chan_bias is not None:
+            assert row_bias is None and pre_partial is None
+            if native or native_eval:
+                row_bias = chan_bias
+            else:
+                x = x + chan_bias.view(1, -1, *([1] * (x.dim() - 2)))
+        elif row_bias is not None:
             g = x.shape[-1]
             if not ((native or native_eval) and x.dim() == 4 and 4 <= g <= 256 and g & (g - 1) == 0):
                 x, row_bias = x + row_bias.unsqueeze(-1), None

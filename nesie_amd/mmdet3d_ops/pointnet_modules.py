@@ -193,6 +193,11 @@ class ConvModule(nn.Module):
             # (parts, C, 2) -> the norm kernels' (C, slices, 2) layout: a 1 MB transpose
             x = self.norm(y.view(B, w2.shape[0], *x.shape[2:]),
                           pre_partial=part.permute(1, 0, 2).contiguous())
+        elif (self.with_norm and self.conv.bias is not None
+              and isinstance(self.norm, (FusedBNReLU1d, FusedBNReLU2d))):
+            # the bias add moves into the norm's own passes (a launch and a tensor round trip
+            # less; same values), and its identically-zero gradient is not summed up
+            x = self.norm(pointwise_conv(x, self.conv.weight), chan_bias=self.conv.bias)
         else:
             x = self.conv(x)
             if self.with_norm:

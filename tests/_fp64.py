@@ -5,6 +5,7 @@ Test infrastructure only."""
 import torch
 
 import oracle
+from tests import _small
 
 
 def _f32(t):
@@ -83,4 +84,4 @@ def train_step_fp64(model32, pts, boxes, labels, noise=None):
         losses = model.forward_train(pts.double(), None, gt, None)
         model.parse_losses(losses).backward()
     return ({k: float(v.detach().sum()) for k, v in losses.items()},
-            {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            _small.grads_of(model))

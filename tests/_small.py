@@ -40,9 +40,30 @@ def train_step_losses(model, pts, boxes, labels):
     losses = model.forward_train(pts, None, gt, None)
     total = model.parse_losses(losses)
     total.backward()
-    return ({k: v.detach().cpu() for k, v in losses.items()},
-            {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()
-             if p.grad is not None})
+    return ({k: v.detach().cpu() for k, v in losses.items()}, grads_of(model, cpu=True))
+
+
+def norm_fed_biases(model):
+    """Names of the convolution biases that feed a batch norm (VoteModule / BaseConvBboxHead build
+    their ConvModules with bias=True AND a norm).  The norm's mean subtraction removes such a bias:
+    its gradient is identically zero.  The unfused graph still sums dx over the batch and gets
+    the rounding residue of that zero; the native path folds the add into the norm kernels and
+    reports no gradient (``FlatTrainState.collect`` zero-fills it)."""
+    from nesie_amd.mmdet3d_ops import ConvModule
+    return {f'{name}.conv.bias' for name, m in model.named_modules()
+            if isinstance(m, ConvModule) and m.with_norm and m.conv.bias is not None}
+
+
+def grads_of(model, cpu=False):
+    """{name: gradient} of the parameters the loss reached; a norm-fed conv bias without a
+    gradient counts as reached with gradient zero (see ``norm_fed_biases``)."""
+    zero = norm_fed_biases(model)
+    out = {}
+    for n, p in model.named_parameters():
+        g = p.grad if p.grad is not None else (torch.zeros_like(p) if n in zero else None)
+        if g is not None:
+            out[n] = g.detach().cpu().clone() if cpu else g.detach().clone()
+    return out
 
 
 from oracle.forcing import ForcedSampler, force_vote_sampling  # noqa: E402,F401

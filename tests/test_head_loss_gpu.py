@@ -29,7 +29,7 @@ def _run(model, pts, gt, fused, weights=None):
         sum(losses[k] * w[k] for k in losses).backward()
         return ({k: v.detach().clone() for k, v in losses.items()},
                 {k: v.grad.detach().clone() for k, v in keep.items()},
-                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+                _small.grads_of(model))
     finally:
         head_loss.ENABLED = True
 

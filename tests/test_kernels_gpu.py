@@ -247,6 +247,45 @@ def test_fused_bn_row_bias_matches_materialised_sum(hip_device, shape):
     torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (3, 37, 250), (2, 128, 256), (4, 32, 30, 16)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_fused_bn_folds_a_conv_bias(hip_device, shape, relu):
+    """norm(x, chan_bias=b) -- the bias of the convolution in front, added inside the norm's own
+    passes -- vs the same kernels on the materialised x + b: the sum is rounded once in both, so
+    outputs, running statistics and input gradients are bit-equal; the bias gets no gradient (its
+    true gradient is zero: the materialised form returns the rounding residue of sum(dx)).
+    Training and evaluation mode, with and without p % 4 == 0."""
+    import copy
+    from nesie_amd.mmdet3d_ops.norm import FusedBNReLU1d, FusedBNReLU2d
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = torch.randn(shape, generator=g).to(hip_device)
+    cb = (torch.randn(C, generator=g) * 2.0 + 0.3).to(hip_device)
+    go = torch.randn(shape, generator=g).to(hip_device)
+    cls = FusedBNReLU1d if len(shape) == 3 else FusedBNReLU2d
+    a = cls(C, relu=relu).to(hip_device)
+    with torch.no_grad():
+        a.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        a.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    b = copy.deepcopy(a)
+    view = (1, C) + (1,) * (len(shape) - 2)
+    x1, c1 = x.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    y1 = a(x1, chan_bias=c1)
+    y1.backward(go)
+    x2, c2 = x.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    y2 = b(x2 + c2.view(view))
+    y2.backward(go)
+    assert torch.equal(y1, y2)
+    assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+    assert torch.equal(x1.grad, x2.grad)
+    assert torch.equal(a.weight.grad, b.weight.grad) and torch.equal(a.bias.grad, b.bias.grad)
+    assert c1.grad is None
+    assert c2.grad.abs().max().item() <= 1e-4 * go.abs().sum().item()  # the residue of a zero
+    a.eval(); b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(x, chan_bias=cb), b(x + cb.view(view)))
+
+
 def _blend_case(k, segs, g, c, seed, b=2, m=300):
     gen = torch.Generator().manual_seed(seed)
     n = k * segs * g

@@ -197,8 +197,7 @@ def _semi_step(model, device, oracle_kernels=None):
                                      [True, False, False], meta_s, meta_t, rows)
         model.parse_losses(losses).backward()
     del model.get_pseudo_labels
-    grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()
-             if p.grad is not None}
+    grads = _small.grads_of(model, cpu=True)
     return {k: v.detach().cpu() for k, v in losses.items()}, grads, picks
 
 
