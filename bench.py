@@ -281,7 +281,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
     main = torch.cuda.current_stream(device)
 
-    from nesie_amd.votenet.backbone import index_tree_like, index_tree_tensors as flat, pack_tensors
+    from nesie_amd.votenet.backbone import (copy_tensors, index_tree_like,
+                                            index_tree_tensors as flat, pack_tensors)
 
     semi_like = workload in ('semi', 'saqe')
     # weight-independent work of a step: the backbone's index chain(s) and, for the supervised
@@ -294,7 +295,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     def assemble_next():
         ids_next.copy_((ids_next + batch) % resident)
         p_, g_ = scenes.assemble_batch(ids_next, num_points=NUM_POINTS, noise=noise)
-        torch._foreach_copy_([pts_next] + gt_parts(gt_next), [p_] + gt_parts(g_))
+        copy_tensors([pts_next] + gt_parts(gt_next), [p_] + gt_parts(g_))
 
     def input_only_work():
         if scenes is not None:
@@ -350,7 +351,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         g_idx = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_idx, stream=side, **mode):
             fresh, fresh_votes = input_only_work()
-            torch._foreach_copy_(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
+            copy_tensors(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
         ready, copied = torch.cuda.Event(), torch.cuda.Event()
         stage('input graph captured')
         with torch.cuda.stream(side):
@@ -363,7 +364,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
             main.wait_event(ready)                       # this step's indices are complete
             arena_cur.copy_(arena_next)
             if scenes is not None:                       # ... and so is this step's batch
-                torch._foreach_copy_([pts] + gt_parts(gt), [pts_next] + gt_parts(gt_next))
+                copy_tensors([pts] + gt_parts(gt), [pts_next] + gt_parts(gt_next))
             copied.record(main)
             side.wait_event(copied)
             with torch.cuda.stream(side):                # next step's index chain, overlapped

@@ -103,10 +103,14 @@ class HipKernels(_BNPoolMixin):
         hit = cls._spatial_index.get(xyz.device)
         if hit is None:
             return None
-        ref, version, shape, ws, stream = hit
+        ref, version, shape, ws, stream, capturing = hit
+        # an entry made while a graph was being captured describes that graph's static buffers:
+        # replays rewrite them without touching the version counter, so eager code must not
+        # trust it (and vice versa)
         same = (ref.data_ptr() == xyz.data_ptr() and ref._version == version
                 and xyz._version == version and shape == (b, n) and ref.dtype == xyz.dtype
-                and stream == _stream(xyz))
+                and stream == _stream(xyz)
+                and capturing == torch.cuda.is_current_stream_capturing())
         return ws if same else None
 
     def furthest_point_sampling_wrapper(self, b, n, m, xyz, temp, idx):
@@ -121,8 +125,9 @@ class HipKernels(_BNPoolMixin):
                 _lib.call("nesie_furthest_point_sampling_ws", b, n, m, _ptr(xyz),
                           _ptr(temp), _ptr(idx), _ptr(ws), need, _stream(xyz))
                 if lib.nesie_fps_leaves_index(b, n):
-                    HipKernels._spatial_index[xyz.device] = (xyz, xyz._version, (b, n), ws,
-                                                             _stream(xyz))
+                    HipKernels._spatial_index[xyz.device] = (
+                        xyz, xyz._version, (b, n), ws, _stream(xyz),
+                        torch.cuda.is_current_stream_capturing())
             else:
                 _lib.call("nesie_furthest_point_sampling_wrapper", b, n, m, _ptr(xyz),
                           _ptr(temp), _ptr(idx), _stream(xyz))

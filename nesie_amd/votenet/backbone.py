@@ -154,3 +154,17 @@ def pack_tensors(tensors):
         views.append(v)
         off += slot
     return views, arena
+
+
+def copy_tensors(dst, src):
+    """``dst[i].copy_(src[i])`` for lists of mixed dtypes as one multi-tensor launch per dtype:
+    ``torch._foreach_copy_`` over a mixed list falls back to one device-to-device copy per tensor
+    (32 blit launches for one index set)."""
+    groups = {}
+    for d, s in zip(dst, src):
+        groups.setdefault((d.dtype, s.dtype), ([], []))
+        groups[(d.dtype, s.dtype)][0].append(d)
+        groups[(d.dtype, s.dtype)][1].append(s)
+    for ds, ss in groups.values():
+        torch._foreach_copy_(ds, ss)
+

@@ -33,6 +33,8 @@ for ev in prof.events():
     site = ' < '.join(n.replace('autograd::engine::evaluate_function: ', 'bwd ') for n in chain[:3])
     frames = [f for f in (ev.stack or []) if f.startswith('nesie_amd/') or f.startswith('bench.py')]
     site = (site + ' @ ' if site else 'py ') + (frames[0] if frames else '?')
+    if 'emcpy' in names or 'copyBuffer' in names:
+        site = '[memcpy] ' + site
     a = acc[(ev.name, site[:150])]
     a[0] += len(ev.kernels); a[1] += k_us
 rows = sorted(acc.items(), key=lambda kv: -kv[1][1])
