@@ -261,17 +261,22 @@ def batched_heads(heads, x):
     stacked = iter(fused_mlp.stack_groups(groups))          # one multi-tensor copy for all of them
     weights = {id(layers[0]): next(stacked) for layers in convs}
     biases = {id(layers[0]): next(stacked) for layers in convs if layers[0].bias is not None}
-    for layers in zip(*heads):
+    steps = [layers for layers in zip(*heads) if not isinstance(layers[0], nn.Identity)]
+    held = None   # a conv bias waiting for the norm layer behind it
+    for i, layers in enumerate(steps):
         first = layers[0]
-        if isinstance(first, nn.Identity):
-            continue
         if isinstance(first, PointwiseConv1d):
             x = torch.matmul(weights[id(first)].unsqueeze(0), x)               # (S, Co, Ci) stacks
             if first.bias is not None:
-                x = x + biases[id(first)].view(1, S, -1, 1)
+                if i + 1 < len(steps) and isinstance(steps[i + 1][0], FusedBNReLU1d):
+                    # added inside the norm's passes (same values); no gradient: it is zero
+                    held = biases[id(first)].reshape(-1)
+                else:
+                    x = x + biases[id(first)].view(1, S, -1, 1)
         elif isinstance(first, FusedBNReLU1d):
             C, P = x.shape[2], x.shape[3]
-            x = _stacked_bn(layers, x.reshape(B, S * C, P)).view(B, S, C, P)
+            x = _stacked_bn(layers, x.reshape(B, S * C, P), row_bias=held).view(B, S, C, P)
+            held = None
         else:
             raise TypeError(f'batched_heads: unsupported layer {type(first).__name__}')
     return x

@@ -49,9 +49,19 @@ def norm_fed_biases(model):
     its gradient is identically zero.  The unfused graph still sums dx over the batch and gets
     the rounding residue of that zero; the native path folds the add into the norm kernels and
     reports no gradient (``FlatTrainState.collect`` zero-fills it)."""
-    from nesie_amd.mmdet3d_ops import ConvModule
-    return {f'{name}.conv.bias' for name, m in model.named_modules()
-            if isinstance(m, ConvModule) and m.with_norm and m.conv.bias is not None}
+    from torch import nn
+    from nesie_amd.mmdet3d_ops import ConvModule, PointwiseConv1d
+    from nesie_amd.mmdet3d_ops.norm import FusedBNReLU1d
+    names = {f'{name}.conv.bias' for name, m in model.named_modules()
+             if isinstance(m, ConvModule) and m.with_norm and m.conv.bias is not None}
+    # the score heads: nn.Sequential(conv, norm, Identity, conv, norm, Identity, conv)
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Sequential):
+            kids = [(k, c) for k, c in m.named_children() if not isinstance(c, nn.Identity)]
+            for (k, c), (_, nxt) in zip(kids, kids[1:]):
+                if isinstance(c, PointwiseConv1d) and c.bias is not None and isinstance(nxt, FusedBNReLU1d):
+                    names.add(f'{name}.{k}.bias')
+    return names
 
 
 def grads_of(model, cpu=False):
