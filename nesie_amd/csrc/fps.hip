@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(
   }
   __syncthreads();
   float x1 = sx[0], y1 = sy[0], z1 = sz[0];
-  if (tid == 0) idx[0] = 0;
+  int my_pick = 0;  // idx[0] = 0
   for (int r = 1; r < m; ++r) {
     // invalid slots hold tp = 0 / klo = 0: their key (0, 0) loses to every real key
     unsigned long long best = 0ull;
@@ -174,16 +174,22 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(
     unsigned wv, wl_;
     wave_argmax(bl != 0u, bv, bl, wv, wl_);
     unsigned gl = wl_;
-    if (NW > 1) {
+    if constexpr (NW > 1) {
       if (lane == 0) { red_v[r & 1][wave] = wv; red_l[r & 1][wave] = wl_; }
       __syncthreads();
       const unsigned cv = red_v[r & 1][lane & (NW - 1)], cl = red_l[r & 1][lane & (NW - 1)];
-      unsigned gv;
-      wave_argmax(cl != 0u, cv, cl, gv, gl);
+      group_argmax<NW>(cl != 0u, cv, cl, gl);  // NW candidates replicated over the lanes
     }
     const int old = k_of_key_lo(gl, L);
     x1 = sx[old]; y1 = sy[old]; z1 = sz[old];  // LDS broadcast, no global read
-    if (tid == 0) idx[r] = old;
+    // thread (r mod BLOCK) keeps round r's pick; stored BLOCK rounds at a time (no global store
+    // inside the dependent rounds)
+    my_pick = tid == (r & (BLOCK - 1)) ? old : my_pick;
+    if ((r & (BLOCK - 1)) == BLOCK - 1) idx[(r & ~(BLOCK - 1)) + tid] = my_pick;
+  }
+  if (((m - 1) & (BLOCK - 1)) != BLOCK - 1) {
+    const int base = (m - 1) & ~(BLOCK - 1);
+    if (base + tid <= m - 1) idx[base + tid] = my_pick;
   }
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
