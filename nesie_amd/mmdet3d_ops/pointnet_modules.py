@@ -31,7 +31,7 @@ class _PointwiseConvFn(torch.autograd.Function):
     For P >= 32768 the reduction is cut into S = 16 chunks per scene, evaluated as one
     strided-batched GEMM per scene over views (no copies), and the partials are summed."""
 
-    SPLIT_MIN_P, SPLIT, FOLD_MAX_P = 32768, 16, 2048
+    SPLIT_MIN_P, SPLIT, FOLD_MAX_P = 32768, 16, 1023
 
     @staticmethod
     def forward(ctx, x3, w2):
@@ -62,9 +62,12 @@ class _PointwiseConvFn(torch.autograd.Function):
                                    x3[b].view(ci, S, pc).permute(1, 2, 0)) for b in range(B)]
                 dw = torch.stack(parts).sum((0, 1))
             elif B > 1 and P <= _PointwiseConvFn.FOLD_MAX_P and dy.is_cuda:
-                # short rows (proposal-level layers, P = 256 .. 2048): B GEMMs with K = P each
+                # short rows (proposal-level layers, P = 256 .. 512): B GEMMs with K = P each
                 # are latency-bound (4 TFLOP/s measured); one GEMM over the folded B * P axis
-                # costs two small transposing copies and runs an order of magnitude faster
+                # costs two small transposing copies and runs an order of magnitude faster.
+                # From P = 1024 (seed-level layers) the B GEMMs + sum win again: the folded
+                # product has so few output tiles that it runs on 8..48 workgroups
+                # (tools/debug/wgrad_paths.py, inside a replayed graph: 16-27 vs 33-43 us)
                 ci = x3.shape[1]
                 dw = torch.mm(dy.transpose(0, 1).reshape(co, B * P),
                               x3.transpose(0, 1).reshape(ci, B * P).t())
