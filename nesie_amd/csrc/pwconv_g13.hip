@@ -1,0 +1,3 @@
+// pw_fwd_kernel<65, 8, 1, 32, *, *>: half-size operand tiles, two workgroups per CU (pwconv_fwd.h)
+#include "pwconv_fwd.h"
+PW_GEOM_DEF(65, 8, 1, 32)

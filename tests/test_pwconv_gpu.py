@@ -35,6 +35,9 @@ CASES = [  # nb, ng, k, cout, p
     (4, 1, 256, 128, 512), (12, 6, 256, 128, 256), (4, 2, 128, 256, 256), (2, 1, 64, 64, 1024),
     (2, 1, 64, 128, 512), (2, 1, 131, 128, 256), (2, 1, 259, 128, 192), (2, 1, 128, 128, 384),
     (3, 1, 100, 200, 256), (2, 1, 128, 64, 256), (2, 1, 256, 256, 128), (2, 1, 260, 90, 64),
+    # odd multiples of the half-size tiles (32 positions at K > 132, 64 below)
+    (2, 1, 256, 128, 96), (2, 1, 128, 128, 192), (2, 1, 131, 64, 192), (2, 1, 100, 40, 320),
+    (3, 1, 259, 200, 160),
 ]
 
 
@@ -165,11 +168,11 @@ def test_row_bias_bias_and_transposed_weights():
 def test_unsupported_shapes_are_refused_not_miscomputed():
     hip = _hip()
     assert not hip.pw_supported(300, 128, 512) and not hip.pw_supported(128, 300, 512)
-    assert not hip.pw_supported(256, 128, 96)
-    x = torch.randn(1, 256, 96, device=_dev())
+    assert not hip.pw_supported(256, 128, 80)        # positions must fill whole 32-wide tiles
+    x = torch.randn(1, 256, 80, device=_dev())
     w = torch.randn(1, 128, 256, device=_dev())
     with pytest.raises(RuntimeError):
-        hip.pw_layer_forward(x, w, y=torch.empty(1, 128, 96, device=_dev()))
+        hip.pw_layer_forward(x, w, y=torch.empty(1, 128, 80, device=_dev()))
 
 
 def test_norm_backward_from_the_raw_output():
