@@ -380,6 +380,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         comm.launch(0, e_bb)
         comm.wait()
         stage('forward/backward graphs replayed')
+        if hasattr(opt, 'sync_hyper'):
+            opt.sync_hyper()         # a scheduler's new lr / wd reaches the captured update
         g2.replay()
         stage('update graph replayed')
         return loss_out
@@ -409,6 +411,45 @@ def cpu_baseline(sample_batch, steps):
                        f'PyTorch-CPU dense ops, {dt:.2f} s/step')
 
 
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start N fresh child
+    processes of this script -- one rank per GPU, the torchrun environment contract (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT) -- BEFORE this process has made
+    any GPU call (it never makes one: it only waits; a process that has touched the GPU must not
+    exec or fork workers on this pool).  Rank 0's stdout (the ONE JSON line) and every rank's
+    stderr pass through; the exit code is the first non-zero child code.  The reference gets its
+    ranks from ``train.py --launcher`` -> ``mmdet.apis.train_detector`` (train.py:71-74, 131-136)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:           # a free rendezvous port
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                LOCAL_WORLD_SIZE=str(n))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # host threads per rank: the box's cores shared between the ranks
+    base['OMP_NUM_THREADS'] = str(max(1, host_cores() // n))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for pr in procs:
+            code = pr.wait()
+            rc = rc or code
+            if code:                         # one rank failed: the others would wait for it forever
+                for other in procs:
+                    if other.poll() is None:
+                        other.terminate()
+    except KeyboardInterrupt:
+        for pr in procs:
+            pr.terminate()
+        rc = 130
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -429,8 +470,15 @@ def main():
                     help='0 to skip the CPU-vs-HIP loss check that precedes the timing (N = 1 only)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare `python bench.py --gpus N`: this process becomes the launcher of N ranks
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank, world, local = dp.init_distributed()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; run '
+              f'`python bench.py --gpus {args.gpus}` (it starts its own ranks) or launch '
+              f'{args.gpus} ranks', file=sys.stderr)
+        sys.exit(2)
     # (several ranks may share a device only in the gloo rehearsal, see dp.init_distributed)
     device = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)

@@ -119,6 +119,14 @@ int nesie_flat_adamw_step(long long n, float *param, float *grad, float *exp_avg
                           float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
                           float eps, float weight_decay, float max_norm, float *grad_norm_out,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The same step with the learning rate and the weight decay read from DEVICE memory at execution
+ * time (hyper = [lr, weight_decay]): a launch captured in a hipGraph then follows the step-decay
+ * schedule of the reference configs (pretrain-010.py:112-114, lr x 0.1 at epochs 24 / 32) without
+ * being re-captured -- the scheduler rewrites the two floats between replays. */
+int nesie_flat_adamw_step_dev(long long n, float *param, float *grad, float *exp_avg,
+                              float *exp_avg_sq, float *step, const float *hyper, float beta1,
+                              float beta2, float eps, float max_norm, float *grad_norm_out,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

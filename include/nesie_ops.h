@@ -367,6 +367,11 @@ int nesie_side_decode_backward(int b, int k, int bins, const float *reg, const f
  * bias = beta - mean * scale (what torch.nn.BatchNorm{1,2}d.eval() + nn.ReLU compute for the
  * ConvModules of point_sa_module.py:277-289 / side_pooling_module.py:346-358 at test time).
  * row_bias / group as in nesie_bn_relu_forward. */
+/* coef [C,4] of an evaluation-mode BatchNorm from its parameters and running statistics (gamma /
+ * beta may be NULL); one launch, recomputed per call (torch.nn.BatchNorm.eval() folds the same
+ * numbers inside its kernel on every call). */
+int nesie_bn_eval_coef(int c, const float *gamma, const float *beta, const float *running_mean,
+                       const float *running_var, float eps, float *coef, void *stream);
 int nesie_affine_relu_forward(int b, int c, long long p, const float *x, const float *coef,
                               int relu, const float *row_bias, int group, float *y,
                               void *stream);

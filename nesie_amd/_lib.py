@@ -35,6 +35,7 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _I, _P],
     "nesie_side_decode_forward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_side_decode_backward": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nesie_bn_eval_coef": [_I, _P, _P, _P, _P, _F, _P, _P],
     "nesie_affine_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _I, _P, _I, _P, _P],
     "nesie_affine_relu_maxpool_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_aligned_3d_nms": [_I, _I, _P, _P, _P, _P, _F, _P, _P, _P],
@@ -86,6 +87,8 @@ SIGNATURES = {
     "nesie_side_prob_stats": [_I, _I, _I, _I, _P, _P, _P],
     "nesie_flat_adamw_step": [ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _P,
                               ctypes.c_size_t, _P],
+    "nesie_flat_adamw_step_dev": [ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P,
+                                  ctypes.c_size_t, _P],
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P],

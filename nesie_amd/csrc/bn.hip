@@ -719,6 +719,35 @@ extern "C" int nesie_bn_relu_maxpool_backward(int b, int c, int m, int ns,
 }
 
 // ---- evaluation mode -----------------------------------------------------------------------
+// coef[c] = (gamma / sqrt(var + eps), beta - mean * scale, 0, 0): the folded running statistics,
+// recomputed per call (one launch) -- the statistics are written by kernels through raw pointers
+// and the parameters through the flat optimiser vector, so no host-side cache key can see them change
+__global__ __launch_bounds__(256) void bn_eval_coef_kernel(int c, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ var, float eps,
+                                                           float4 *__restrict__ coef) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  float scale = rsqrtf(var[i] + eps);
+  if (gamma) scale = scale * gamma[i];
+  float shift = -mean[i] * scale;
+  if (beta) shift = shift + beta[i];
+  coef[i] = make_float4(scale, shift, 0.f, 0.f);
+}
+
+extern "C" int nesie_bn_eval_coef(int c, const float *gamma, const float *beta,
+                                  const float *running_mean, const float *running_var, float eps,
+                                  float *coef, void *stream) {
+  const char *W = "bn_eval_coef";
+  NESIE_REQUIRE(c >= 0, W);
+  if (c == 0) return NESIE_OK;
+  NESIE_REQUIRE(running_mean && running_var && coef && ((uintptr_t)coef & 15) == 0, W);
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, c,
+                     gamma, beta, running_mean, running_var, eps, (float4 *)coef);
+  return check_launch(W);
+}
+
 extern "C" int nesie_affine_relu_forward(int b, int c, long long p, const float *x,
                                          const float *coef, int relu, const float *row_bias,
                                          int group, float *y, void *stream) {

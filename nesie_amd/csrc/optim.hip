@@ -36,7 +36,11 @@ __global__ __launch_bounds__(OPT_BLOCK) void sumsq_partials_kernel(long long n, 
 __global__ __launch_bounds__(OPT_BLOCK) void adamw_clip_kernel(
     long long n, float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
     float *__restrict__ v, const float *__restrict__ part, const float *__restrict__ step,
-    float lr, float beta1, float beta2, float eps, float wd, float max_norm, float *__restrict__ norm_out) {
+    float lr, float beta1, float beta2, float eps, float wd, float max_norm, float *__restrict__ norm_out,
+    const float *__restrict__ hyper) {
+  // hyper (optional, device): [lr, weight_decay] read at execution time, so that a captured
+  // launch follows a learning-rate schedule without being re-captured
+  if (hyper) { lr = hyper[0]; wd = hyper[1]; }
   __shared__ float sh[OPT_BLOCK / 64];
   __shared__ float coef_s;
   // total squared norm: OPT_PARTS partials, 4 per thread, then the block tree (same everywhere)
@@ -77,12 +81,11 @@ using namespace nesie;
 
 extern "C" size_t nesie_flat_adamw_workspace_bytes(void) { return OPT_PARTS * sizeof(float); }
 
-extern "C" int nesie_flat_adamw_step(long long n, float *param, float *grad, float *exp_avg,
-                                     float *exp_avg_sq, float *step, float lr, float beta1,
-                                     float beta2, float eps, float weight_decay, float max_norm,
-                                     float *grad_norm_out, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
-  const char *W = "flat_adamw_step";
+static int flat_adamw_impl(const char *W, long long n, float *param, float *grad, float *exp_avg,
+                           float *exp_avg_sq, float *step, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, const float *hyper, float max_norm,
+                           float *grad_norm_out, void *workspace, size_t workspace_bytes,
+                           void *stream) {
   NESIE_REQUIRE(n >= 0, W);
   if (n == 0) return NESIE_OK;
   NESIE_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && workspace, W);
@@ -93,6 +96,27 @@ extern "C" int nesie_flat_adamw_step(long long n, float *param, float *grad, flo
   const int blocks = (int)((n + 4095) / 4096 < 1024 ? (n + 4095) / 4096 : 1024);
   hipLaunchKernelGGL(adamw_clip_kernel, dim3(blocks), dim3(OPT_BLOCK), 0, s, n, param, grad, exp_avg,
                      exp_avg_sq, part, step, lr, beta1, beta2, eps, weight_decay, max_norm,
-                     grad_norm_out);
+                     grad_norm_out, hyper);
   return check_launch(W);
+}
+
+extern "C" int nesie_flat_adamw_step(long long n, float *param, float *grad, float *exp_avg,
+                                     float *exp_avg_sq, float *step, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, float max_norm,
+                                     float *grad_norm_out, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+  return flat_adamw_impl("flat_adamw_step", n, param, grad, exp_avg, exp_avg_sq, step, lr, beta1,
+                         beta2, eps, weight_decay, nullptr, max_norm, grad_norm_out, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int nesie_flat_adamw_step_dev(long long n, float *param, float *grad, float *exp_avg,
+                                         float *exp_avg_sq, float *step, const float *hyper,
+                                         float beta1, float beta2, float eps, float max_norm,
+                                         float *grad_norm_out, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  const char *W = "flat_adamw_step_dev";
+  NESIE_REQUIRE(n == 0 || hyper, W);
+  return flat_adamw_impl(W, n, param, grad, exp_avg, exp_avg_sq, step, 0.f, beta1, beta2, eps, 0.f,
+                         hyper, max_norm, grad_norm_out, workspace, workspace_bytes, stream);
 }

@@ -136,31 +136,73 @@ class FlatTrainState(FlatGradBucket):
 
 class FlatAdamW(torch.optim.Optimizer):
     """``clip_grad_norm_(max_norm)`` + ``torch.optim.AdamW`` over ``FlatTrainState.flat_param`` as
-    two launches of ``nesie_flat_adamw_step`` (capture-safe: the step count is a device scalar,
-    the clip coefficient never visits the host).  State keys are torch's (``step``, ``exp_avg``,
-    ``exp_avg_sq``), so ``checkpoint.per_parameter_optimizer_state`` applies unchanged."""
+    two launches of ``nesie_flat_adamw_step_dev``.  Capture-safe: the step count, the learning
+    rate and the weight decay live in device memory and the clip coefficient never visits the
+    host, so a step captured in a hipGraph follows an LR schedule -- the scheduler writes
+    ``param_groups[0]['lr']`` as usual and ``sync_hyper()`` (called by ``step()``, and by whoever
+    replays a captured step) carries a changed value to the device.  betas / eps / max_norm are
+    launch constants (the reference never schedules them).  State keys are torch's (``step``,
+    ``exp_avg``, ``exp_avg_sq``), so ``checkpoint.per_parameter_optimizer_state`` applies
+    unchanged."""
 
     def __init__(self, flat_param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  max_norm=None):
         super().__init__([flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_norm = max_norm
         self.grad_norm = None      # device scalar: the un-clipped global norm of the last step
+        self.hyper = None          # device (2,): [lr, weight_decay] as the kernels read them
+        self._hyper_host = None
+
+    def sync_hyper(self):
+        """Device copy of (lr, weight_decay) <- ``param_groups[0]`` when they differ from what was
+        last written.  Must not be called while a graph is being captured with a changed value
+        (the write is a host-to-device copy); ``step()`` calls it, so an eager step needs nothing."""
+        group = self.param_groups[0]
+        p = group['params'][0]
+        want = (float(group['lr']), float(group['weight_decay']))
+        if self.hyper is None or self.hyper.device != p.device:
+            self.hyper = torch.tensor(want, dtype=torch.float32, device=p.device)
+            self._hyper_host = want
+        elif want != self._hyper_host:
+            assert not (p.is_cuda and torch.cuda.is_current_stream_capturing()), \
+                'the learning rate changed inside a graph capture: call sync_hyper() before it'
+            self.hyper.copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = want
+        return self.hyper
+
+    def _device_state(self, p):
+        """Adam state of the flat parameter, created on first use and NORMALISED after a
+        ``load_state_dict``: ``Optimizer.load_state_dict`` leaves ``step`` on the CPU (it only
+        moves it for capturable / fused groups) and checkpoints store it as a CPU scalar
+        (checkpoint.per_parameter_optimizer_state); the kernels need a float32 device scalar."""
+        st = self.state[p]
+        if not st:
+            st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st['exp_avg'] = torch.zeros_like(p)
+            st['exp_avg_sq'] = torch.zeros_like(p)
+        step = st['step']
+        if not torch.is_tensor(step):
+            step = torch.tensor(float(step))
+        if step.device != p.device or step.dtype != torch.float32 or step.dim() != 0:
+            st['step'] = step.detach().reshape(()).to(device=p.device, dtype=torch.float32)
+        for k in ('exp_avg', 'exp_avg_sq'):
+            if st[k].device != p.device or st[k].dtype != p.dtype or not st[k].is_contiguous():
+                st[k] = st[k].to(device=p.device, dtype=p.dtype).contiguous()
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
         from .kernels import backend_for
         group = self.param_groups[0]
         p = group['params'][0]
-        st = self.state[p]
-        if not st:
-            st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
-            st['exp_avg'] = torch.zeros_like(p)
-            st['exp_avg_sq'] = torch.zeros_like(p)
+        st = self._device_state(p)
         if self.grad_norm is None:
             self.grad_norm = torch.zeros((), dtype=torch.float32, device=p.device)
+        hyper = self.sync_hyper()
         backend_for(p).flat_adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], st['step'],
                                        group['lr'], group['betas'], group['eps'],
-                                       group['weight_decay'], self.max_norm, self.grad_norm)
+                                       group['weight_decay'], self.max_norm, self.grad_norm,
+                                       hyper=hyper)
 
 
 def backward_head(total, boundary, early_params):

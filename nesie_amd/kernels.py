@@ -93,10 +93,14 @@ class HipKernels(_BNPoolMixin):
 
     # The bucket-pruned FPS kernel leaves the scene spatially sorted in its scratch; the ball
     # query that follows on the SAME coordinates (every set-abstraction module samples and then
-    # groups one cloud) can use it as an index.  The entry keeps the coordinate tensor alive, so
-    # its address cannot be handed to another tensor while the entry exists, and records its
-    # version counter, so an in-place change invalidates it.  One entry per device.
+    # groups one cloud) can use it as an index.  The hand-over is scoped: an entry is recorded
+    # only inside ``spatial_index_scope()`` -- one set-abstraction forward -- and dropped when the
+    # scope ends, so a ball query somewhere else can never meet the index of an earlier scene
+    # (a buffer refilled by a kernel, a memcpy or a graph replay keeps its address AND its
+    # version counter).  Inside the scope the entry keeps the coordinate tensor alive and still
+    # records address, version, shape, stream and capture state.  One entry per device.
     _spatial_index = {}
+    _index_scope_depth = 0
 
     @classmethod
     def _index_for(cls, xyz, b, n):
@@ -124,7 +128,7 @@ class HipKernels(_BNPoolMixin):
                 ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
                 _lib.call("nesie_furthest_point_sampling_ws", b, n, m, _ptr(xyz),
                           _ptr(temp), _ptr(idx), _ptr(ws), need, _stream(xyz))
-                if lib.nesie_fps_leaves_index(b, n):
+                if HipKernels._index_scope_depth > 0 and lib.nesie_fps_leaves_index(b, n):
                     HipKernels._spatial_index[xyz.device] = (
                         xyz, xyz._version, (b, n), ws, _stream(xyz),
                         torch.cuda.is_current_stream_capturing())
@@ -288,6 +292,16 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_side_decode_backward", b, k, bins, _ptr(reg), _ptr(probs),
                       _ptr(scale), _ptr(sign), opt(d_surface), opt(d_bbox), _ptr(d_reg),
                       _ptr(d_agg), _stream(reg))
+
+    def bn_eval_coef(self, gamma, beta, running_mean, running_var, eps, coef):
+        """coef (C,4) <- (gamma / sqrt(var + eps), beta - mean * scale, 0, 0); one launch."""
+        _check(running_mean, running_var, coef); _f32(running_mean, running_var, coef)
+        c = running_mean.numel()
+        assert tuple(coef.shape) == (c, 4) and coef.is_contiguous()
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(coef.device):
+            _lib.call("nesie_bn_eval_coef", c, opt(gamma), opt(beta), _ptr(running_mean),
+                      _ptr(running_var), float(eps), _ptr(coef), _stream(coef))
 
     def affine_relu_forward(self, x, coef, relu, y, row_bias=None):
         """Evaluation-mode norm: y = relu?(coef[c,0] * (x + row_bias) + coef[c,1]); x, y (B,C,*)."""
@@ -794,14 +808,26 @@ class HipKernels(_BNPoolMixin):
         return out
 
     def flat_adamw_step(self, param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay,
-                        max_norm, grad_norm_out=None):
+                        max_norm, grad_norm_out=None, hyper=None):
         """clip_grad_norm_(max_norm) + AdamW over flat vectors, in place (nesie_flat_adamw_step);
-        ``step`` is a float32 device scalar that the call increments."""
+        ``step`` is a float32 device scalar that the call increments.  ``hyper`` (2,) device
+        float32 = [lr, weight_decay]: read at execution time instead of the host values
+        (nesie_flat_adamw_step_dev: a captured launch follows the schedule)."""
         _check(param, grad, exp_avg, exp_avg_sq, step); _f32(param, grad, exp_avg, exp_avg_sq, step)
         n = param.numel()
         assert grad.numel() == n == exp_avg.numel() == exp_avg_sq.numel() and step.numel() == 1
         need = _lib.load().nesie_flat_adamw_workspace_bytes()
         ws = torch.empty(need, dtype=torch.uint8, device=param.device)
+        if hyper is not None:
+            _check(hyper); _f32(hyper)
+            assert hyper.numel() == 2 and hyper.is_contiguous()
+            with torch.cuda.device(param.device):
+                _lib.call("nesie_flat_adamw_step_dev", n, _ptr(param), _ptr(grad), _ptr(exp_avg),
+                          _ptr(exp_avg_sq), _ptr(step), _ptr(hyper), float(betas[0]),
+                          float(betas[1]), float(eps), float(max_norm or 0.0),
+                          0 if grad_norm_out is None else _ptr(grad_norm_out), _ptr(ws), need,
+                          _stream(param))
+            return
         with torch.cuda.device(param.device):
             _lib.call("nesie_flat_adamw_step", n, _ptr(param), _ptr(grad), _ptr(exp_avg),
                       _ptr(exp_avg_sq), _ptr(step), float(lr), float(betas[0]), float(betas[1]),
@@ -988,6 +1014,20 @@ def backend_for(tensor):
 
 def injected_backend():
     return _injected
+
+
+@contextlib.contextmanager
+def spatial_index_scope():
+    """One sample-then-group pass over ONE coordinate tensor (a set-abstraction forward): the
+    spatial index the FPS kernel leaves behind may serve the ball queries inside this block and
+    nothing after it."""
+    HipKernels._index_scope_depth += 1
+    try:
+        yield
+    finally:
+        HipKernels._index_scope_depth -= 1
+        if HipKernels._index_scope_depth == 0:
+            HipKernels._spatial_index.clear()
 
 
 @contextlib.contextmanager

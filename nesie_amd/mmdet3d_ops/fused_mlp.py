@@ -388,12 +388,19 @@ class MiniHeadFn(Function):
         B, S, H0, P = c0.shape
         half = w3.shape[1]
         G = ctx.G
-        if dc is None:
+        owned = dc is None
+        if owned:
             dc = c0.new_zeros(B, S, half, P)
-        dc = dc.contiguous()
-        if dg is not None:   # the pooled gradient joins the dense one at the arg-max, in place
+        if dg is not None:
+            # the pooled gradient joins the dense one at the arg-max -- in a buffer of our OWN:
+            # autograd does not hand a backward ownership of its incoming gradients (the same
+            # tensor may be another consumer's gradient, a hook's or a retained one)
+            if not owned:
+                dc = dc.clone(memory_format=torch.contiguous_format)
             dcv = dc.view(B, S, half, P // G, G)
             backend.group_max_pool_backward_add(dg.contiguous(), arg, dcv)
+        else:
+            dc = dc.contiguous()
         x0 = c0.view(B * S, H0, P)
         dcf = dc.view(B * S, half, P)
         dw3 = None

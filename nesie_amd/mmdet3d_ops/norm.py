@@ -135,6 +135,18 @@ def eval_coefficients(weight, bias, running_mean, running_var, eps):
     return torch.stack([scale, shift, zero, zero], dim=1).contiguous()
 
 
+def stacked_eval_coef(layers):
+    """(S*C, 4) evaluation coefficients of S same-width norm layers stacked along the channel
+    axis: every layer's launch fills its own slice (no concatenation)."""
+    if len(layers) == 1:
+        return layers[0].eval_coef()
+    c = layers[0].num_features
+    table = layers[0].running_mean.new_empty(len(layers) * c, 4)
+    for i, l in enumerate(layers):
+        l.eval_coef(out=table[i * c:(i + 1) * c])
+    return table
+
+
 def affine_relu_eval(x, coef, relu, row_bias=None):
     x = x.contiguous()
     y = torch.empty_like(x)
@@ -184,19 +196,22 @@ class _FusedBNReLU:
         return F.relu(y) if self.fuse_relu else y
 
 
-    def eval_coef(self):
-        """(C,4) = (scale, shift, 0, 0) of this layer in evaluation mode, cached until a
-        parameter or running statistic changes (six small launches otherwise, per call)."""
-        key = (self.running_mean.data_ptr(), self.running_mean._version, self.running_var._version,
-               None if self.weight is None else self.weight._version,
-               None if self.bias is None else self.bias._version, self.running_mean.device)
-        hit = getattr(self, '_eval_coef_cache', None)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, eval_coefficients(self.weight, self.bias, self.running_mean,
-                                              self.running_var, self.eps))
-            self._eval_coef_cache = hit
-        return hit[1]
+    def eval_coef(self, out=None):
+        """(C,4) = (scale, shift, 0, 0) of this layer in evaluation mode, recomputed on every call
+        by one native launch (``nesie_bn_eval_coef``).  NOT cached: the running statistics are
+        written by the training kernels through raw pointers, the parameters through the flat
+        optimiser vector and the EMA swap through ``.data`` copies -- none of which moves a
+        tensor version counter, so a cache keyed on them served stale coefficients in any
+        train -> eval -> train -> eval loop and across ``EMATeacher.swap``.  ``out`` (C,4),
+        optional: a slice of a stacked table to fill in place."""
+        c = self.num_features
+        coef = self.running_mean.new_empty(c, 4) if out is None else out
+        with torch.no_grad():
+            backend_for(self.running_mean).bn_eval_coef(
+                None if self.weight is None else self.weight.detach(),
+                None if self.bias is None else self.bias.detach(),
+                self.running_mean, self.running_var, self.eps, coef)
+        return coef
 
     def _native_eval(self, x, backend):
         return (backend.name == 'hip' and not self.training and self.track_running_stats

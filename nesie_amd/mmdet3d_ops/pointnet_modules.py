@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from ..kernels import backend_for
+from ..kernels import backend_for, spatial_index_scope
 from . import fused_mlp
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
@@ -291,12 +291,17 @@ class BasePointSAModule(nn.Module):
         """The weight-independent half of forward(): FPS indices, sampled centres and the
         ball-query indices of every scale.  A training loop can run this for the NEXT batch
         on a side stream while the current step computes (see bench.py)."""
-        new_xyz, indices = self._sample_points(points_xyz, None, None, None)
-        group_idx = [g.ball_indices(points_xyz, new_xyz) for g in self.groupers]
+        with spatial_index_scope():   # FPS hands its sorted scene to the ball queries below
+            new_xyz, indices = self._sample_points(points_xyz, None, None, None)
+            group_idx = [g.ball_indices(points_xyz, new_xyz) for g in self.groupers]
         group_csr = [inverted_index(i, points_xyz.shape[1]) for i in group_idx]
         return dict(indices=indices, new_xyz=new_xyz, group_idx=group_idx, group_csr=group_csr)
 
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None, precomputed=None):
+        with spatial_index_scope():   # FPS hands its sorted scene to this forward's ball queries
+            return self._forward(points_xyz, features, indices, target_xyz, precomputed)
+
+    def _forward(self, points_xyz, features, indices, target_xyz, precomputed):
         new_features_list = []
         if precomputed is not None:
             new_xyz, indices = precomputed['new_xyz'], precomputed['indices']

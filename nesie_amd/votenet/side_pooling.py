@@ -103,7 +103,7 @@ def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     from ..mmdet3d_ops import norm as _norm
     first = layers[0]
     if not first.training:   # evaluation: one scale / bias pass over the stacked channels
-        coef = torch.cat([l.eval_coef() for l in layers]) if len(layers) > 1 else first.eval_coef()
+        coef = _norm.stacked_eval_coef(layers)
         return _norm.affine_relu_eval(x, coef, first.fuse_relu, row_bias)
     pack = stacked_running_stats(layers)
     rm, rv = pack[0], pack[1]
@@ -210,8 +210,8 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     gamma0, beta0, w3, w, b3, gamma1, beta1, w4, *b4 = fused_mlp.stack_groups(groups)
     evaluating = not bn0s[0].training
     backend = backend_for(c0)
-    if evaluating:   # test path: the cached folded running statistics are the operand transforms
-        coef0 = torch.cat([l.eval_coef() for l in bn0s]) if S > 1 else bn0s[0].eval_coef()
+    if evaluating:   # test path: the folded running statistics are the operand transforms
+        coef0 = _norm.stacked_eval_coef(bn0s)
         c, g, _ = fused_mlp.mini_head_kernels(backend, c0.reshape(B, S, H, K * G).contiguous(),
                                                coef0, w3, G)
     else:
@@ -226,7 +226,7 @@ def fused_mini_pointnets(nets, c0, c0_stats):
         + torch.matmul(w_l, b3.unsqueeze(-1)).view(1, S, H2, 1)
     if evaluating:
         y, _ = fused_mlp.mini_tail_first(backend, c, small.contiguous(), w_l, G)
-        coef1 = torch.cat([l.eval_coef() for l in bn1s]) if S > 1 else bn1s[0].eval_coef()
+        coef1 = _norm.stacked_eval_coef(bn1s)
         out, _ = fused_mlp.mini_tail_second(backend, y, coef1, w4, G)
     else:
         out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w_l,

@@ -136,3 +136,46 @@ def test_flat_optimizer_state_is_saved_in_the_per_parameter_form_and_back(tmp_pa
         o.step()
     for pa, pc in zip(a.parameters(), c.parameters()):
         torch.testing.assert_close(pa, pc, rtol=1e-5, atol=1e-7)
+
+
+def test_fresh_flat_adamw_normalises_a_loaded_step_count(tmp_path):
+    """dp.FlatAdamW (the optimiser bench.py's GPU path uses) resumed from a checkpoint BEFORE its
+    first step: ``Optimizer.load_state_dict`` leaves ``step`` wherever the checkpoint had it (a
+    CPU scalar, possibly float64 or a python number); the kernels need a float32 0-dim tensor on
+    the parameter's device.  A stub back end stands in for the HIP library and checks exactly
+    that (the GPU tier repeats it with the real kernels)."""
+    import copy
+
+    from nesie_amd import checkpoint as ck
+    from nesie_amd import dp, kernels
+
+    class Stub:
+        name = 'stub'
+        seen = []
+
+        def flat_adamw_step(self, param, grad, m, v, step, lr, betas, eps, wd, max_norm,
+                            grad_norm_out=None, hyper=None):
+            assert torch.is_tensor(step) and step.dim() == 0 and step.dtype == torch.float32
+            assert step.device == param.device and m.device == param.device
+            assert hyper is not None and hyper.dtype == torch.float32 and hyper.numel() == 2
+            self.seen.append((float(step), float(hyper[0]), float(hyper[1])))
+            step += 1
+
+    torch.manual_seed(8)
+    a = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    ref = torch.optim.AdamW(a.parameters(), lr=3e-3, weight_decay=0.02)
+    a(torch.randn(5, 4)).sum().backward()
+    ref.step()
+    want = ref.state_dict()
+    want['state'][0]['step'] = torch.tensor(1.0, dtype=torch.float64)   # as some writers store it
+    b = copy.deepcopy(a)
+    state = dp.FlatTrainState(b.parameters())
+    opt = dp.FlatAdamW(state.flat_param, lr=1.0, weight_decay=0.0, max_norm=10.0)
+    ck.load_per_parameter_optimizer_state(opt, state, want)
+    with kernels.use_backend(Stub()):
+        opt.step()
+        opt.param_groups[0]['lr'] = 3e-4          # a scheduler's decay reaches the device copy
+        opt.step()
+    assert Stub.seen[0][0] == 1.0 and Stub.seen[1][0] == 2.0
+    assert abs(Stub.seen[0][1] - 3e-3) < 1e-9 and abs(Stub.seen[1][1] - 3e-4) < 1e-9
+    assert abs(Stub.seen[0][2] - 0.02) < 1e-9

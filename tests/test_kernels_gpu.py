@@ -128,12 +128,22 @@ def test_ball_query_over_the_fps_index_matches_the_full_scan(oracle_kernels, hip
     assert _lib.load().nesie_fps_leaves_index(b, n) == 1
     xyz_cpu = _cases.cloud(11 + n + m, b, n, **kw)
     xyz = xyz_cpu.to(hip_device)
-    picks = ops.furthest_point_sample(xyz, m)
-    centres = torch.gather(xyz, 1, picks.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-    centres[:, -1] += 100.0  # an empty ball
     back = kernels.backend_for(xyz)
-    assert back._index_for(xyz, b, n) is not None
-    got = ops.ball_query(min_r, r, ns, xyz, centres)
+    # outside a scope FPS leaves nothing behind: a later ball query cannot meet a stale index
+    ops.furthest_point_sample(xyz, m)
+    assert back._index_for(xyz, b, n) is None and not back._spatial_index
+    with kernels.spatial_index_scope():   # the hand-over of one set-abstraction forward
+        picks = ops.furthest_point_sample(xyz, m)
+        centres = torch.gather(xyz, 1, picks.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        centres[:, -1] += 100.0  # an empty ball
+        assert back._index_for(xyz, b, n) is not None
+        got = ops.ball_query(min_r, r, ns, xyz, centres)
+        # an in-place change of the cloud retires the index inside the scope too
+        keep = xyz.clone()
+        xyz.add_(0.25)
+        assert back._index_for(xyz, b, n) is None
+        xyz.copy_(keep)
+    assert not back._spatial_index        # ... and the scope's end drops it
     full = torch.zeros_like(got)
     _lib.call("nesie_ball_query_wrapper", b, n, m, min_r, r, ns, centres.data_ptr(),
               xyz.data_ptr(), full.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -142,9 +152,8 @@ def test_ball_query_over_the_fps_index_matches_the_full_scan(oracle_kernels, hip
         want = ops.ball_query(min_r, r, ns, xyz_cpu, centres.cpu())
     eq(got, want)
     assert (got[:, -1] == 0).all()
-    # an in-place change of the cloud retires the index: the full scan answers for the new cloud
+    # a refilled buffer (same address) outside the scope: the full scan answers for the new cloud
     xyz.add_(0.25)
-    assert back._index_for(xyz, b, n) is None
     moved = ops.ball_query(min_r, r, ns, xyz, centres + 0.25)
     with kernels.use_backend(oracle_kernels):
         want_moved = ops.ball_query(min_r, r, ns, xyz.cpu(), (centres + 0.25).cpu())
@@ -808,3 +817,127 @@ def test_flat_adamw_with_clipping_matches_torch(hip_device):
     assert float(st_a['step']) == float(st_b['step']) == 5
     torch.testing.assert_close(st_a['exp_avg'], st_b['exp_avg'], rtol=1e-5, atol=1e-8)
     torch.testing.assert_close(st_a['exp_avg_sq'], st_b['exp_avg_sq'], rtol=1e-5, atol=1e-10)
+
+
+def test_captured_flat_adamw_follows_a_learning_rate_change(hip_device):
+    """lr and weight decay are read from device memory (nesie_flat_adamw_step_dev): a step
+    captured in a hipGraph at lr = 8e-3 and replayed after the scheduler set lr = 8e-4 (the
+    reference's step decay, pretrain-010.py:112-114) applies 8e-4 -- compared with eager
+    torch.optim.AdamW whose param_group was changed the same way."""
+    from nesie_amd import dp
+    g = torch.Generator(device=hip_device).manual_seed(5)
+    n = 70_001
+    p0 = torch.randn(n, device=hip_device, generator=g)
+    a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    opt_a = dp.FlatAdamW(a, lr=8e-3, weight_decay=0.01, max_norm=10.0)
+    opt_b = torch.optim.AdamW([b], lr=8e-3, weight_decay=0.01)
+    grads = [torch.randn(n, device=hip_device, generator=g) for _ in range(4)]
+    static_g = torch.zeros(n, device=hip_device)
+    a.grad = grads[0].clone()
+    b.grad = grads[0].clone()
+    torch.nn.utils.clip_grad_norm_([b], 10.0)
+    opt_a.step()                       # eager: creates the state, loads the library
+    opt_b.step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        a.grad.copy_(static_g)
+        opt_a.step()
+    for it, grad in enumerate(grads[1:]):
+        if it == 1:                    # the scheduler's decay between two replays
+            for o in (opt_a, opt_b):
+                o.param_groups[0]['lr'] = 8e-4
+                o.param_groups[0]['weight_decay'] = 0.02
+        static_g.copy_(grad)
+        opt_a.sync_hyper()
+        graph.replay()
+        b.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([b], 10.0)
+        opt_b.step()
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=1e-7, msg=str(it))
+    assert float(opt_a.state[a]['step']) == 4
+
+
+def test_fresh_flat_adamw_resumes_from_its_own_checkpoint(hip_device, tmp_path):
+    """save -> load into a FRESH dp.FlatAdamW (never stepped) -> step: Optimizer.load_state_dict
+    leaves ``step`` on the CPU; FlatAdamW normalises it to the float32 device scalar the kernels
+    read.  The resumed optimiser then takes the same step as the original."""
+    import copy
+
+    from nesie_amd import checkpoint as ck
+    from nesie_amd import dp
+    torch.manual_seed(6)
+    m1 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3)).to(hip_device)
+    s1 = dp.FlatTrainState(m1.parameters())
+    o1 = dp.FlatAdamW(s1.flat_param, lr=1e-2, weight_decay=0.05, max_norm=10.0)
+    xs = [torch.randn(7, 6, device=hip_device) for _ in range(3)]
+
+    def one(model, st, opt, x):
+        st.begin()
+        model(x).square().sum().backward()
+        st.collect()
+        opt.step()
+    for x in xs[:2]:
+        one(m1, s1, o1, x)
+    path = ck.save_reference_checkpoint(m1, tmp_path, 1, 2, optimizer=o1, flat_state=s1)[0]
+    m2 = copy.deepcopy(m1)
+    saved = torch.load(path, weights_only=False)
+    m2.load_state_dict(saved['state_dict'])
+    s2 = dp.FlatTrainState(m2.parameters())
+    o2 = dp.FlatAdamW(s2.flat_param, lr=1.0, weight_decay=0.0, max_norm=10.0)
+    ck.load_per_parameter_optimizer_state(o2, s2, saved['optimizer'])
+    assert o2.param_groups[0]['lr'] == 1e-2
+    one(m1, s1, o1, xs[2])
+    one(m2, s2, o2, xs[2])
+    st2 = o2.state[s2.flat_param]
+    assert st2['step'].is_cuda and st2['step'].dtype == torch.float32 and float(st2['step']) == 3
+    for pa, pb in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-6, atol=1e-8)
+
+
+def test_eval_coefficients_follow_native_training_steps_and_the_teacher_swap(hip_device):
+    """eval -> one native training step (running statistics written by the kernels through raw
+    pointers, parameters through the flat optimiser vector) -> eval again: the second evaluation
+    must use the NEW folded statistics (a cache keyed on tensor version counters served the first
+    ones).  Same around EMATeacher.swap(), which copies through ``.data``."""
+    from nesie_amd import dp
+    from nesie_amd.mmdet3d_ops import norm as N
+    torch.manual_seed(7)
+    bn = N.FusedBNReLU2d(24).to(hip_device)
+    flat = dp.FlatTrainState(bn.parameters())
+    opt = dp.FlatAdamW(flat.flat_param, lr=0.1, weight_decay=0.0)
+    x = torch.randn(4, 24, 32, 16, device=hip_device) * 3 + 1
+
+    def reference():
+        return N.eval_coefficients(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    for it in range(3):
+        bn.eval()
+        with torch.no_grad():
+            got = bn.eval_coef().clone()
+            y = bn(x)
+        want = reference()
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7, msg=f'eval {it}')
+        torch.testing.assert_close(
+            y, torch.relu(x * want[:, 0].view(1, -1, 1, 1) + want[:, 1].view(1, -1, 1, 1)),
+            rtol=1e-5, atol=1e-5)
+        bn.train()
+        flat.begin()
+        bn(x).square().mean().backward()      # native forward: running stats by raw pointer
+        flat.collect()
+        opt.step()                            # parameters through the flat vector
+    # teacher swap: parameters replaced through .data copies
+    model = torch.nn.Module()
+    model.bn = bn
+    from nesie_amd.votenet.semi import EMATeacher
+    teacher = EMATeacher(model)
+    with torch.no_grad():
+        bn.weight.mul_(3.0)
+    bn.eval()
+    with torch.no_grad():
+        student = bn.eval_coef().clone()
+        teacher.swap()
+        swapped = bn.eval_coef().clone()
+        torch.testing.assert_close(swapped, reference(), rtol=1e-6, atol=1e-7)
+        teacher.swap()
+        torch.testing.assert_close(bn.eval_coef(), student, rtol=0, atol=0)
+    assert (swapped[:, 0] - student[:, 0]).abs().max() > 1e-3

@@ -366,6 +366,33 @@ def test_two_rank_step_rehearsal_on_one_gpu():
     assert res['scaling'] == 'weak' and res['value'] > 0 and 'cpu_baseline' not in res
 
 
+@pytest.mark.parametrize('workload,batch', [('pretrain', 8), ('semi', 3)])
+def test_bare_bench_command_starts_its_own_ranks(workload, batch):
+    """The driver's command form, ``python bench.py --gpus N`` with WORLD_SIZE unset: the process
+    starts N fresh ranks itself (before it touches the GPU) and rank 0 prints the one line with
+    the world size and the collective back end.  Two ranks share this GPU, so gloo stands in for
+    RCCL (NESIE_DIST_BACKEND)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['NESIE_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
+         '1', '--cpu-baseline', '0', '--workload', workload, '--batch', str(batch)],
+        env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['world_size'] == 2
+    assert res['config']['collective_backend'] == 'gloo'
+    assert res['config']['global_batch'] == 2 * batch and res['value'] > 0
+
+
 def test_stream_first_layer_equals_the_gemm_path(hip_device):
     """ConvModule's skinny-first-layer path (streaming MFMA kernel + statistics epilogue feeding
     the norm) against the plain conv -> norm path: outputs, running statistics, gradients."""

@@ -16,6 +16,30 @@ def _flat(grads, names):
     return torch.cat([grads[n].flatten().double().cpu() for n in names])
 
 
+# Per-parameter gradient bound against the fp64 referee: the HIP path's error (largest entry,
+# relative to the tensor's largest gradient) may be at most 1.5 x the CPU oracle path's own error,
+# with a floor of 1e-3.  Tensors that need more are listed BY NAME with the bound they get and why
+# (nothing else is excused: a broken single tensor fails).
+# reduced model: the MiniPointNets' BatchNorms normalise over 2 x 32 proposals -- near-constant
+# channels whose variance is of the order of fp32 rounding; their weight gradients sit up to
+# 3.1e-3 (HIP) / 3.4e-2 (CPU oracle path) from fp64 depending on the summation order
+SMALL_MODEL_SLACK = {r'bbox_head\.grid_conv\.mlps_before\.\d\.(first|second)_conv\.\d\.': 5e-3}
+FULL_SIZE_SLACK = {}
+
+
+def _check_per_parameter(worst, slack):
+    import re
+    bad = []
+    for e_gpu, e_cpu, n in worst:
+        bound = max(1.5 * e_cpu, 1e-3)
+        for pat, extra in slack.items():
+            if re.search(pat, n):
+                bound = max(bound, extra)
+        if e_gpu > bound:
+            bad.append((n, f'{e_gpu:.3e}', f'cpu {e_cpu:.3e}', f'bound {bound:.3e}'))
+    assert not bad, bad
+
+
 def test_gradients_are_as_close_to_fp64_as_the_cpu_path(oracle_kernels, hip_device):
     """The referee for gradients is an fp64 evaluation of the same model (tests/_fp64.py: fp32
     index decisions, fp64 values).  The HIP path must be no farther from it than the fp32 CPU
@@ -56,8 +80,7 @@ def test_gradients_are_as_close_to_fp64_as_the_cpu_path(oracle_kernels, hip_devi
         worst.append((e_gpu, e_cpu, n))
     worst.sort(reverse=True)
     print('worst per-parameter errors (gpu, cpu):', worst[:4])
-    for e_gpu, e_cpu, n in worst:   # (an index decision of the fp64 leg can differ from both)
-        assert e_gpu <= 1.5 * e_cpu + 2e-2, (n, e_gpu, e_cpu)
+    _check_per_parameter(worst, SMALL_MODEL_SLACK)
 
 
 def test_full_size_step_losses_and_gradients_match_the_cpu_oracle(oracle_kernels, hip_device):
@@ -104,8 +127,7 @@ def test_full_size_step_losses_and_gradients_match_the_cpu_oracle(oracle_kernels
     # a 3-NN or ball-membership decision can still flip on a 1e-7 coordinate difference (in
     # either fp32 leg: the CPU oracle path sits 1e-1 off on one MiniPointNet for this seed), so
     # per parameter the bound is relative to the CPU leg's own error
-    for e_gpu, e_cpu, n in worst:
-        assert e_gpu <= 1.5 * e_cpu + 2e-2, (n, e_gpu, e_cpu)
+    _check_per_parameter(worst, FULL_SIZE_SLACK)
 
 
 def test_full_size_eval_forward_matches_the_cpu_oracle(oracle_kernels, hip_device):
@@ -145,10 +167,13 @@ def test_full_size_eval_forward_matches_the_cpu_oracle(oracle_kernels, hip_devic
         assert torch.equal(lg.cpu(), lc)
 
 
-def _semi_pair(kind, obj_bias=2.3, cls_bias=0.9):
+def _semi_pair(kind, obj_bias=2.3, cls_bias=0.9, full=False):
+    """Student/teacher detector of ``kind``; ``full`` = the BASELINE configuration
+    (nesie / saqe_votenet_scannet_cfg as they stand: 40 000-point backbone, 256 proposals),
+    otherwise the reduced model of tests/_small.py."""
     from nesie_amd.votenet import semi
-    cfg = _small.small_cfg()
-    if kind == 'saqe':
+    cfg = None if full else _small.small_cfg()
+    if kind == 'saqe' and not full:
         from nesie_amd.votenet.detector import saqe_votenet_scannet_cfg
         scfg = saqe_votenet_scannet_cfg()
         cfg['bbox_head'].update(angle_loss=scfg['bbox_head']['angle_loss'],
@@ -165,17 +190,24 @@ def _semi_pair(kind, obj_bias=2.3, cls_bias=0.9):
         if kind == 'saqe':   # VoteNetSAQE filters on the quality head's objectness (last 2 of 38)
             model.bbox_head.grid_conv.mlps_head[6][6].bias[37] += obj_bias
     model.teacher.resync()
-    model.bbox_head.jitter_noise = _small.fixed_noise(3, 32)
-    _small.force_vote_sampling(model, 'semi-' + kind)   # student + teacher picks of the first leg
+    model.train()
+    model.bbox_head.jitter_noise = _small.fixed_noise(3, model.bbox_head.num_proposal)
+    # student + teacher picks of the first leg
+    _small.force_vote_sampling(model, 'semi-' + kind + ('-full' if full else ''))
     return model
 
 
-def _semi_step(model, device, oracle_kernels=None):
+def _semi_step(model, device, oracle_kernels=None, full=False):
     from contextlib import nullcontext
 
     from nesie_amd.votenet import semi
-    model.init_label_state(12, 108, device)
-    pts, boxes, labels = _small.small_batch(batch=3, n=2048)
+    if full:
+        from nesie_amd.scenes import make_batch
+        model.init_label_state(120, 1081, device)
+        pts, boxes, labels = make_batch(4242, 3, 40000)
+    else:
+        model.init_label_state(12, 108, device)
+        pts, boxes, labels = _small.small_batch(batch=3, n=2048)
     g = torch.Generator().manual_seed(1)
     meta_t = semi.AugMeta.random(3, device, g, strong=False)
     meta_s = semi.AugMeta.random(3, device, g, strong=True)
@@ -228,6 +260,44 @@ def test_student_teacher_step_matches_the_cpu_oracle(oracle_kernels, hip_device,
     w, g = _flat(want_g, names), _flat(got_g, names)
     rel = ((g - w).norm() / w.norm()).item()
     print(f'{kind}: pseudo boxes {int(v.sum())}, flat gradient rel. L2 {rel:.3e}')
+    assert rel < 5e-3, rel
+
+
+@pytest.mark.parametrize('kind,obj_bias', [('saqe', 1.3), ('nesie', 1.7)])
+def test_full_size_student_teacher_step_matches_the_cpu_oracle(oracle_kernels, hip_device, kind,
+                                                               obj_bias):
+    """BASELINE configs[4] (``VoteNetSAQE``, saqe-votenet-scannet-train) and configs[3]
+    (``VoteNetNesie``) at FULL size: 3 scenes (1 labeled : 2 unlabeled) x 40 000 points, the
+    whole configured model -- for SAQE the 27-points-per-side grids, the 128-wide MiniPointNets
+    and the 996-wide global quality head (votenet_saqe.py:69-127, saqe_head.py:331-521,
+    quelity_estimation_module.py).  HIP path vs the CPU oracle path on the same weights,
+    inputs, jitter and replayed vote picks: the teacher's pseudo-label decisions (validity,
+    classes, class histogram) exact, boxes and every loss term (13 for SAQE, 12 for Nesie)
+    within 1e-4, the student's flat gradient within 5e-3.  The teacher's biases are set so
+    that the filters pass SOME proposals (15-27 of 256 per scene on the CPU leg)."""
+    model = _semi_pair(kind, obj_bias=obj_bias, cls_bias=0.75, full=True)
+    gmodel = copy.deepcopy(model).to(hip_device)
+    want_l, want_g, want_p = _semi_step(model, torch.device('cpu'), oracle_kernels, full=True)
+    got_l, got_g, got_p = _semi_step(gmodel, hip_device, full=True)
+    v = want_p['valid']
+    per_scene = v.sum(1)
+    assert int(per_scene.min()) > 0 and int(per_scene.max()) < v.shape[1], per_scene  # the filter decides
+    assert torch.equal(got_p['valid'], v)
+    assert torch.equal(got_p['labels'][v], want_p['labels'][v])
+    torch.testing.assert_close(got_p['boxes'][v], want_p['boxes'][v], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got_p['quality'][v], want_p['quality'][v], rtol=1e-3, atol=1e-3)
+    assert torch.equal(gmodel.state.ulb_list.cpu(), model.state.ulb_list)
+    assert torch.equal(gmodel.state.ulb_flag.cpu(), model.state.ulb_flag)
+    assert set(got_l) == set(want_l) and len(want_l) == (13 if kind == 'saqe' else 12)
+    for k in want_l:
+        assert float(want_l[k].sum()) > 0, k   # every term is live
+        torch.testing.assert_close(got_l[k], want_l[k], rtol=1e-4, atol=1e-5, msg=k)
+    names = sorted(want_g)
+    assert set(got_g) == set(names)
+    w, g = _flat(want_g, names), _flat(got_g, names)
+    rel = ((g - w).norm() / w.norm()).item()
+    print(f'{kind} full size: pseudo boxes per scene {per_scene.tolist()}, '
+          f'flat gradient rel. L2 {rel:.3e}')
     assert rel < 5e-3, rel
 
 
@@ -337,8 +407,9 @@ def test_three_graph_replays_equal_eager_per_tensor_steps(hip_device):
     assert gaps[0][0] < 1e-2, gaps[:6]
 
 
-def test_semi_graph_replays_with_ema_equal_eager_per_tensor_steps(hip_device):
-    """Student/teacher step (configs[3] shapes, 3 scenes): g2 also holds the EMA update and the
-    pseudo-label state lives in the graph: three replays."""
-    gaps = _replays_vs_eager(hip_device, 'semi', 3, 3)
+@pytest.mark.parametrize('workload', ['semi', 'saqe'])
+def test_semi_graph_replays_with_ema_equal_eager_per_tensor_steps(hip_device, workload):
+    """Student/teacher step (configs[3] / configs[4] shapes, 3 scenes x 40 000 points): g2 also
+    holds the EMA update and the pseudo-label state lives in the graph: three replays."""
+    gaps = _replays_vs_eager(hip_device, workload, 3, 3)
     assert gaps[0][0] < 1e-2, gaps[:6]

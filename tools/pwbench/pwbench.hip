@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void ownstream_kernel(float *buf, long long *t
 // not waited for inside the loop (pure issue cost).  1 global_load_dwordx4, 2 ds_write_b128,
 // 3 global_load_lds_dwordx4, 4 global_store_dwordx4, 5 global_store_dword, 6 ds_read2st64_b32,
 // 7 ds_read_b128, 8 v_pk_fma_f32 x2, 9 s_waitcnt lgkmcnt(15)
-template <int WHAT>
+template <int WHAT, int EVERY = 1>
 __global__ __launch_bounds__(256) void issue_kernel(float *buf, long long *times, int iters) {
   extern __shared__ __attribute__((aligned(16))) float shd[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void issue_kernel(float *buf, long long *times
       if (u & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a1, 0, 0, 0); else a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a0, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       const unsigned go = (unsigned)(((i * 8 + u) & 7) * 1024 + lane * 16);
+      if (u % EVERY != 0) continue;
       if (WHAT == 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ld[u]) : "v"(go), "s"(src) : "memory");
       if (WHAT == 2) asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(ld[u]) : "memory");
       if (WHAT == 3) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(go), "s"(src), "s"(lw) : "memory", "m0");
@@ -185,10 +186,15 @@ __global__ __launch_bounds__(256) void issue_kernel(float *buf, long long *times
       if (WHAT == 7) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[u]) : "v"(la));
       if (WHAT == 8) { pk = __builtin_elementwise_fma(pk, r2, r2); r2 = __builtin_elementwise_fma(r2, pk, pk); }
       if (WHAT == 9) asm volatile("s_waitcnt lgkmcnt(15)");
+      // conflict-free address patterns (lane * 4 / lane * 8): WHAT 6's lane * 16 is a 4-way bank conflict for 4-byte reads
+      if (WHAT == 10) asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:4" : "=v"(r2) : "v"(lw + lane * 4));
+      if (WHAT == 11) asm volatile("ds_read_b64 %0, %1" : "=v"(r2) : "v"(lw + lane * 8));
+      if (WHAT == 12) asm volatile("ds_read_b32 %0, %1" : "=v"(r2[0]) : "v"(lw + lane * 4));
+      if (WHAT == 13) asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:64" : "=v"(ld[u]) : "v"(lw + lane * 8));
       __builtin_amdgcn_sched_barrier(0);
     }
     if (WHAT == 1 || WHAT == 3 || WHAT == 4 || WHAT == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (WHAT == 2 || WHAT == 6 || WHAT == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (WHAT == 2 || WHAT == 6 || WHAT == 7 || WHAT >= 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   const long long t1 = __builtin_amdgcn_s_memtime();
   float sink = a0[0] + a1[0] + r2[0] + pk[0];
@@ -245,6 +251,16 @@ int main(int argc, char **argv) {
     run(issue_kernel<7>, "ds_read_b128");
     run(issue_kernel<8>, "2 x v_pk_fma_f32");
     run(issue_kernel<9>, "s_waitcnt lgkmcnt(15)");
+    run(issue_kernel<1, 8>, "global_load_dwordx4, one per 8 MFMAs");
+    run(issue_kernel<4, 8>, "global_store_dwordx4, one per 8 MFMAs");
+    run(issue_kernel<4, 4>, "global_store_dwordx4, one per 4 MFMAs");
+    run(issue_kernel<5, 8>, "global_store_dword, one per 8 MFMAs");
+    run(issue_kernel<2, 8>, "ds_write_b128, one per 8 MFMAs");
+    run(issue_kernel<2, 4>, "ds_write_b128, one per 4 MFMAs");
+    run(issue_kernel<10>, "ds_read2st64_b32 conflict-free");
+    run(issue_kernel<11>, "ds_read_b64 conflict-free");
+    run(issue_kernel<12>, "ds_read_b32 conflict-free");
+    run(issue_kernel<13>, "ds_read2_b64 conflict-free");
     return 0;
   }
   if (mode == 11) {
