@@ -8,22 +8,16 @@
 
 namespace nesie {
 // launchers of the built geometries (pwconv_g*.hip; with -DPW_DEV, tools/pwbench: defined below)
-PW_GEOM_DECL(16, 4, 2, 256)
-PW_GEOM_DECL(16, 8, 1, 128)
-PW_GEOM_DECL(32, 4, 2, 128)
-PW_GEOM_DECL(32, 8, 1, 128)
-PW_GEOM_DECL(32, 8, 1, 64)
-PW_GEOM_DECL(33, 8, 1, 64)
-PW_GEOM_DECL(64, 8, 1, 32)
-PW_GEOM_DECL(65, 8, 1, 32)
-PW_GEOM_DECL(32, 4, 2, 64)
-PW_GEOM_DECL(33, 4, 2, 64)
-PW_GEOM_DECL(33, 4, 2, 128)
-PW_GEOM_DECL(33, 8, 1, 128)
-PW_GEOM_DECL(64, 4, 2, 64)
-PW_GEOM_DECL(64, 8, 1, 64)
-PW_GEOM_DECL(65, 4, 2, 64)
-PW_GEOM_DECL(65, 8, 1, 64)
+// (K sub-tile / 16, sub-tiles along K, row waves, column waves, 16-row sets per wave)
+PW_GEOM_DECL(4, 1, 4, 1, 1)    // K <= 64,  Cout <= 64   (HBM-bound: small workgroups, up to four per CU)
+PW_GEOM_DECL(4, 1, 4, 1, 2)    // K <= 64,  Cout <= 128
+PW_GEOM_DECL(4, 1, 8, 1, 1)    // K <= 64,  Cout <= 128  (A/B: NESIE_PW_K64=8)
+PW_GEOM_DECL(8, 1, 4, 1, 1)    // K <= 128, Cout <= 64
+PW_GEOM_DECL(8, 1, 8, 1, 1)    // K <= 128, Cout <= 128
+PW_GEOM_DECL(9, 1, 8, 1, 1)    // K <= 144
+PW_GEOM_DECL(8, 2, 8, 1, 1)    // K <= 256
+PW_GEOM_DECL(9, 2, 8, 1, 1)    // K <= 288
+PW_GEOM_DECL(8, 4, 8, 1, 1)    // K <= 512
 
 // Chan merge of the per-wave partials -> (scale, bias, mean, invstd) + running statistics.
 // One 64-thread block per channel (channel index runs over ng * cout: stacked layers).
@@ -103,33 +97,40 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(
 }
 
 // tile geometry of a (K, Cout) layer
-struct PwGeom { int kq, wr, wc, pt, nhalf, per_cu; };
+struct PwGeom { int kt16, kh, wr, wc, rw, pt, nhalf, per_cu; };
 
 static bool pw_geometry(int k, int cout, PwGeom *o) {
-  const int kq = k <= 64 ? 16 : k <= 128 ? 32 : k <= 132 ? 33 : k <= 256 ? 64 : k <= 260 ? 65 : 0;
-  if (!kq || cout < 1 || cout > 256) return false;
-  o->kq = kq;
-  o->nhalf = cout > 128 ? 2 : 1;                 // 128-row workgroups
-  o->wr = cout <= 64 ? 4 : 8;
-  o->wc = o->wr == 4 ? 2 : 1;                    // 8 waves
-  // 64 KB operand tiles (32 KB at K <= 64): PT x padded K x 4 bytes
-  o->pt = kq == 16 ? (o->wc == 2 ? 256 : 128) : kq <= 33 ? 128 : 64;
-  o->per_cu = 1;
-  // Half-size operand tiles (32 KB instead of 64 KB) and twice the workgroups: two workgroups
-  // share a CU, so one's barrier / staging / epilogue phases sit under the other's MFMAs.  The
-  // per-launch time is unchanged (+-1 %), the step is 0.38 ms shorter (15.93 -> 15.54 ms): the
-  // gain is in the launch boundaries, where a 256-workgroup grid drains and refills the chip in
-  // lock step.  NESIE_PW_HALF (A/B switch, default 15): bit 0: K <= 132 x 8 row waves, bit 1:
-  // K <= 260 x 8 row waves, bit 2: K <= 64 (same tile, two per CU), bit 3: K <= 132 x 4 row waves.
-  static const int half = [] { const char *e = getenv("NESIE_PW_HALF"); return e ? atoi(e) : 15; }();
-  if ((half & 1) && (kq == 32 || kq == 33) && o->wr == 8) { o->pt = 64; o->per_cu = 2; }
-  if ((half & 2) && (kq == 64 || kq == 65) && o->wr == 8) { o->pt = 32; o->per_cu = 2; }
-  if ((half & 4) && kq == 16 && o->pt == 128) o->per_cu = 2;
-  if ((half & 8) && (kq == 32 || kq == 33) && o->wr == 4) { o->pt = 64; o->per_cu = 2; }
+  if (k < 1 || cout < 1 || cout > 256) return false;
+  if (k <= 64) { o->kt16 = 4; o->kh = 1; }
+  else if (k <= 128) { o->kt16 = 8; o->kh = 1; }
+  else if (k <= 144) { o->kt16 = 9; o->kh = 1; }
+  else if (k <= 256) { o->kt16 = 8; o->kh = 2; }
+  else if (k <= 288) { o->kt16 = 9; o->kh = 2; }
+  else if (k > 384 && k <= 512) { o->kt16 = 8; o->kh = 4; }   // (288, 384] would leave sub-tile 3 empty
+  else return false;
+  // K > 64 (MFMA-bound): 8 waves x 16 rows, 64-position tiles, <= 128 VGPRs: two workgroups per
+  // CU.  K <= 64 (HBM-bound, SA1): 4-wave workgroups, up to four per CU.  Cout > 128: two
+  // 128-row workgroups per tile.  Measured and rejected in round 3 (tools/pwbench):
+  // 32 rows per wave in 4-wave workgroups, one 256-row workgroup of 32-row waves, a
+  // two-team ping-pong workgroup.
+  o->nhalf = cout > 128 ? 2 : 1;
+  if (o->kt16 == 4) {
+    static const int k64 = [] { const char *e = getenv("NESIE_PW_K64"); return e ? atoi(e) : 4; }();
+    o->wr = 4; o->wc = 1; o->rw = cout <= 64 ? 1 : 2;
+    if (k64 == 8 && cout > 64) { o->wr = 8; o->rw = 1; }                       // A/B switch
+  } else if (cout <= 64 && o->kt16 == 8 && o->kh == 1) {
+    o->wr = 4; o->wc = 1; o->rw = 1;
+  } else {
+    o->wr = 8; o->wc = 1; o->rw = 1;
+  }
+  o->pt = 64 * o->wc;
+  o->per_cu = pw_per_cu(o->kt16, o->kh, o->wr * o->wc, o->wc, o->rw);
+  static const int one = [] { const char *e = getenv("NESIE_PW_ONE_PER_CU"); return e ? atoi(e) : 0; }();
+  if (one) o->per_cu = 1;   // A/B switch: 256-workgroup grids
   return true;
 }
 
-static size_t pw_lds_bytes(const PwGeom &g) { return (size_t)2 * 4 * g.kq * g.pt * sizeof(float); }
+static size_t pw_lds_bytes(const PwGeom &g) { return (size_t)2 * 16 * g.kt16 * g.pt * sizeof(float); }
 
 }  // namespace nesie
 
@@ -144,20 +145,25 @@ extern "C" int nesie_pw_supported(int k, int cout, long long p) {
   return pw_geometry(k, cout, &g) && p % g.pt == 0 && (long long)(k > cout ? k : cout) * p < (1ll << 30) ? 1 : 0;
 }
 
-// number of statistic slots per weight group a forward launch writes
-extern "C" int nesie_pw_stat_slots(int nb, int ng, int k, int cout, long long p) {
-  PwGeom g;
-  if (!pw_geometry(k, cout, &g) || ng < 1) return 0;
+// workgroups per weight group of a launch
+static int pw_groups(const PwGeom &g, int nb, int ng, long long p) {
   const long long tiles = (long long)(nb / ng) * cdiv(p, g.pt);
   long long nwg = 256 * g.per_cu / (ng * g.nhalf);
   if (nwg < 1) nwg = 1;
   if (nwg > tiles) nwg = tiles;
-  return (int)nwg * g.wc;
+  return (int)nwg;
+}
+
+// number of statistic slots per weight group a forward launch writes
+extern "C" int nesie_pw_stat_slots(int nb, int ng, int k, int cout, long long p) {
+  PwGeom g;
+  if (!pw_geometry(k, cout, &g) || ng < 1) return 0;
+  return pw_groups(g, nb, ng, p) * g.wc;
 }
 
 #ifdef PW_DEV   // single-translation-unit development build (tools/pwbench): two geometries
-PW_GEOM_DEF(64, 8, 1, 64)
-PW_GEOM_DEF(32, 8, 1, 128)
+PW_GEOM_DEF(8, 2, 8, 1, 1)
+PW_GEOM_DEF(8, 1, 8, 1, 1)
 #endif
 
 static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long long p,
@@ -216,25 +222,20 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
 #endif
   a.tiles_per_batch = cdiv(p, g.pt);
   a.nslots = nesie_pw_stat_slots(nb, ng, k, cout, p);
-  a.nwg_g = a.nslots / g.wc;
+  a.nwg_g = pw_groups(g, nb, ng, p);
   a.nhalf = g.nhalf;
   const int grid = a.nwg_g * ng * g.nhalf;
   const size_t lds = pw_lds_bytes(g);
   hipStream_t s = (hipStream_t)stream;
   int st = NESIE_ERR_UNSUPPORTED;
-#define G(KQ, WR, WC, PT) \
-  if (g.kq == KQ && g.wr == WR) st = PW_GEOM_NAME(KQ, WR, WC, PT)(a, epi, pg, grid, lds, s)
+#define G(KT16, KH, WR, WC, RW)                                                          \
+  if (g.kt16 == KT16 && g.kh == KH && g.wr == WR && g.wc == WC && g.rw == RW)            \
+  st = PW_GEOM_NAME(KT16, KH, WR, WC, RW)(a, epi, pg, grid, lds, s)
 #ifdef PW_DEV
-  G(64, 8, 1, 64); G(32, 8, 1, 128);
+  G(8, 2, 8, 1, 1); G(8, 1, 8, 1, 1);
 #else
-  G(16, 4, 2, 256); G(16, 8, 1, 128);
-#define GP(KQ, WR, WC, PT) \
-  if (g.kq == KQ && g.wr == WR && g.pt == PT) st = PW_GEOM_NAME(KQ, WR, WC, PT)(a, epi, pg, grid, lds, s)
-  GP(32, 4, 2, 128); GP(32, 8, 1, 128); GP(32, 8, 1, 64); GP(32, 4, 2, 64);
-  GP(33, 8, 1, 64); GP(33, 4, 2, 64); GP(64, 8, 1, 32); GP(65, 8, 1, 32);
-  if (g.kq == 33 && g.pt == 128) { G(33, 4, 2, 128); G(33, 8, 1, 128); }
-  if ((g.kq == 64 || g.kq == 65) && g.pt == 64) { G(64, 4, 2, 64); G(64, 8, 1, 64); G(65, 4, 2, 64); G(65, 8, 1, 64); }
-#undef GP
+  G(4, 1, 4, 1, 1); G(4, 1, 4, 1, 2); G(4, 1, 8, 1, 1); G(8, 1, 4, 1, 1); G(8, 1, 8, 1, 1);
+  G(9, 1, 8, 1, 1); G(8, 2, 8, 1, 1); G(9, 2, 8, 1, 1); G(8, 4, 8, 1, 1);
 #endif
 #undef G
   if (st != NESIE_OK) {

@@ -1,52 +1,69 @@
 // Pointwise (1x1) convolution layers of the grouped per-seed MLPs on the fp32 matrix cores of
 // gfx950: the shared MLPs of the set-abstraction stack (reference mmdet3d/ops/pointnet_modules/
 // point_sa_module.py:277-289 built from mmcv ConvModule(Conv2d 1x1, BN2d, ReLU), pooled at
-// :136-158) and the quality head's MiniPointNets (models/dense_heads/side_pooling_module.py:
-// 343-370).
+// :136-158), the quality head's MiniPointNets (models/dense_heads/side_pooling_module.py:343-370)
+// and the 1-D per-seed / per-proposal stacks (vote_module.py:65-74, reliable_conv_bbox_module.py:
+// 112-141, point_fp_module.py:31-37).
 //
 //     Y[n] = W[n % ng] . act(X[n])        X[n] (K x P) and Y[n] (Cout x P) row-major, positions
 //                                         contiguous (NCHW as it stands: no transposes)
 //     act(v) = max(scale[k] * v + bias[k], lo)   the PREVIOUS layer's folded BatchNorm + ReLU
 //
-// What shapes the kernel: on gfx950 an fp32 MFMA holds its SIMD's instruction issue for its whole
-// duration -- no instruction of the same wave or of the SIMD's other waves overlaps it
-// (tools/pwbench modes 10 / 11: an MFMA stream starves its partner wave of VALU, SALU, LDS and
-// VMEM issue alike, s_setprio or not; k extra instructions behind an MFMA of the same wave cost
-// their full issue time).  Matrix-pipe utilisation is therefore
-//     MFMA cycles / (MFMA cycles + issue cycles of EVERYTHING else on the SIMD)
-// and the design minimises the instruction count per MFMA rather than trying to hide it:
+// What shapes the kernel (tools/pwbench, modes 10-12, re-measured in round 3): on gfx950 an fp32
+// MFMA holds its SIMD's instruction issue for its whole 32 cycles.  A second wave on the SIMD gets
+// NO issue slot while the first streams MFMAs (its VALU / SALU / LDS / VMEM stream finishes after
+// the MFMA wave has ended), and every instruction a wave puts between its own MFMAs costs its
+// issue time in full: a conflict-free LDS read ~7 cycles WHATEVER its width (b32, b64, 2 x b32,
+// b128 alike), a global_load_dwordx4 ~5, a dense VALU instruction ~3, a packed fp32 fma ~13.
+// Matrix-pipe utilisation is therefore
+//     MFMA cycles / (MFMA cycles + issue cycles of everything else + cycles in which NO wave of
+//                    the SIMD has an instruction to issue)
+// and the design (a) minimises the instruction COUNT per MFMA and (b) keeps a burst of loads from
+// ever standing between a wave and its MFMAs:
 //   * weight-stationary: a persistent workgroup owns a run of (n, position-tile) tiles of one
-//     weight group; wave wr keeps 16 rows of W in registers for the whole launch (K/4 VGPRs);
+//     weight group; a wave keeps 16 (RW = 1) or 32 (RW = 2) rows of W in registers for the whole
+//     launch;
+//   * ONE ds_read_b128 FEEDS FOUR MFMAs (eight at RW = 2).  The operand tile sits in LDS as it
+//     sits in memory, [k][position]; lane (l16, quad) reads X[4 kk + quad][64 b + 4 l16 .. + 3]
+//     -- four CONSECUTIVE POSITIONS of one k -- and hands component e to MFMA e, whose 16 "rows"
+//     are then the positions 64 b + 4 i + e.  Any bijection between MFMA rows and positions is a
+//     valid GEMM; this one makes the operand fetch a quarter of the instructions of a
+//     one-value-per-lane fetch (round 2: ds_read2st64_b32, two values per instruction) and is
+//     bank-conflict-free without a swizzle (row pitch = 64 words: the 16-lane groups of a b128
+//     read cover all 64 banks);
 //   * v_mfma_f32_16x16x4_f32 computes the TRANSPOSED block D[position][channel] (A = X^T
-//     fragment, B = W^T fragment: the same register contents, swapped operands), so a lane ends
-//     with 4 CONSECUTIVE positions of one output channel: the block is stored with ONE
-//     global_store_dwordx4 per lane on a scalar tile base + a per-lane 32-bit offset computed
-//     once per launch (a lane of the untransposed block holds 4 channels x 1 position: 4 dword
-//     stores and 4x the statistics state);
-//   * X tiles are K rows x PT positions = 64 KB, two LDS buffers.  Tile t+1 is loaded
-//     HBM -> registers (global_load_dwordx4 on scalar base + constant per-lane offsets, no
-//     address arithmetic) at the top of iteration t, rides out the MFMAs of tile t, gets the
-//     previous layer's BatchNorm + ReLU applied IN REGISTERS (packed fma, once per element,
-//     coefficients of the thread's fixed rows held in registers) and is written to the other
-//     buffer: one barrier per tile, no LDS round trip for the transform;
-//   * operand fetch (lane l: X[4 kk + (l >> 4)][pos + (l & 15)]) = 4 rows x 16 consecutive
-//     words; odd rows are stored with their 64-byte halves swapped so rows r and r+1 sit on
-//     disjoint bank halves: conflict-free ds_read2st64_b32 (two k-steps per instruction),
-//     issued a group ahead with counted lgkmcnt waits (explicit instructions: left to itself
-//     hipcc sinks the reads to their uses and every MFMA pair waits out an LDS round trip);
-//   * Cout = 256 runs as two workgroups of 128 rows (the operand tile is fetched twice, the
-//     second time from L2 / Infinity Cache) so every geometry is 8 waves of 16 rows;
+//     fragment, B = W^T fragment), so with that bijection a lane ends with 16 CONSECUTIVE positions
+//     (16 quad .. + 15) of one output channel: per-channel statistics, the 16-position pooling
+//     group and the row bias are lane-local, and the block leaves as four 16-byte stores;
+//   * K is walked in sub-tiles of KT = 64 / 128 / 144 rows x PT = 64 WC positions (32 KB at
+//     128 x 64): K <= 144 is one sub-tile, K <= 288 two, with the accumulators carried across.
+//     Two LDS buffers; 64 KB per workgroup at K <= 128, so two workgroups share a CU where the
+//     registers allow it (<= 128 VGPRs; tools/isa_regs.py prints the table);
+//   * the loads of sub-tile s + 2 are issued INSIDE the MFMA loop of sub-tile s (its last third), one
+//     global_load_dwordx4 at a time right behind the LDS write that frees its registers (the
+//     write moves sub-tile s + 1, loaded during s - 1, into the other buffer, with the previous
+//     layer's BatchNorm + ReLU applied in registers on the way).  A load has a whole sub-tile
+//     (>= 4096 MFMA cycles) to arrive, the memory system sees a steady stream instead of one
+//     burst per barrier (round 2 issued a tile's loads in one block behind the barrier: with every
+//     CU doing so at once the issue itself stalled for 3 000 - 5 000 cycles per tile, pwbench
+//     stamps), and one barrier per sub-tile remains;
+//   * staging slots are addressed by a wave-uniform base (SGPR) + ONE per-lane offset register,
+//     LDS offsets are immediates; rows beyond K are never loaded: their LDS rows are zeroed once
+//     (they meet zero weights), a partly valid slot re-reads row K - 1;
 //   * epilogue straight from the accumulators: optional output-side row bias / channel bias,
 //     the raw conv output, this layer's own BatchNorm statistics as per-wave SHIFTED sums
 //     (count, shift, sum(y - shift), sum((y - shift)^2): no E[x^2] - E[x]^2 cancellation;
-//     merged in fp64 by pw_stats_finalize_kernel with Chan's formula), and the max / min over
-//     each group of 16 or 32 consecutive positions with the position of each (pooling tail).
-// The K x P operand is read once (twice at Cout = 256), Y written once (or never, for a pooled
-// tail): 2 tensor passes per layer where conv + statistics + normalise cost 5.
+//     merged in fp64 by pw_stats_finalize_kernel with Chan's formula), the max / min over each
+//     group of 16 or 32 consecutive positions with the position of each (pooling tail), and for
+//     input-gradient launches the two sums of the BatchNorm backward.
+// The K x P operand is read once, Y written once (or never, for a pooled tail): 2 tensor passes
+// per layer where conv + statistics + normalise cost 5.  Cout = 256 at K <= 144 is ONE workgroup
+// of 8 waves x 32 rows (round 2 ran two 128-row workgroups that each staged the tile).
 // (this header: the kernel template and its per-geometry launcher; every geometry is instantiated
 // in a translation unit of its own, pwconv_g*.hip, so that the library builds in parallel)
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -67,21 +84,18 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-// two words 256 * (U1 - U0) bytes apart in one instruction (offsets in units of 256 bytes)
-template <int U0, int U1>
-__device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
-  static_assert(U0 >= 0 && U1 < 256, "ds_read2st64 reach");
-  f32x2 v;
-  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(U0), "n"(U1));
-  return v;
-}
-
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 reach");
   f32x4 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_b128(unsigned addr, f32x4 v) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_write_b128 reach");
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
 // 16 bytes per lane from sbase (wave-uniform) + voff (per-lane byte offset).  A plain load: the
@@ -91,17 +105,15 @@ __device__ __forceinline__ f32x4 load16_saddr(unsigned voff, const void *sbase) 
   return *(const f32x4 *)((const char *)sbase + voff);
 }
 
-// *(float4 *)(sbase + voff + IMM) = v
+// *(float4 *)(sbase + voff + IMM) = v.  A PLAIN store, like the loads: the compiler's vmcnt
+// bookkeeping must see it.  (Round 2 and the first round-3 build issued the stores from inline asm:
+// invisible to the wait-count pass, so the counted `s_waitcnt vmcnt(N)` in front of the next
+// staging write -- N = the loads issued after the one needed -- also waited for the epilogue's
+// four stores, which are YOUNGER than those loads but were not in the count: every tile began by
+// sitting out a store acknowledgement from HBM.)
 template <int IMM>
-__device__ __forceinline__ void store16_saddr(unsigned voff, f32x4 v, const void *sbase) {
-  // the trailing s_nop: a store of more than 64 bits needs wait states before its data VGPRs
-  // are overwritten, and the hazard recognizer does not look inside asm
-  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void vm_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+__device__ __forceinline__ void store16_saddr(unsigned voff, f32x4 v, void *sbase) {
+  *(f32x4 *)((char *)sbase + voff + IMM) = v;
 }
 
 template <int N>
@@ -131,7 +143,7 @@ struct PwFwd {
   float *pool_max, *pool_min; uint8_t *arg_max, *arg_min;  // (nb, cout, p / PG)
   const float *bn_z; long long bnz_bs;     // PW_BNRED: raw conv output Z (nb, cout, p) ...
   const float *bn_coef; float *bn_part;    // ... its [ng * cout][4] (scale, bias, mean, invstd); [ng * cout][nslots][2]
-  int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout (128 rows each)
+  int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -143,23 +155,47 @@ struct PwFwd {
     a.stamps[2 * 24 * 8 + 2 * (which)] = __builtin_amdgcn_s_memtime();       \
     a.stamps[2 * 24 * 8 + 2 * (which) + 1] = __builtin_amdgcn_s_memrealtime(); \
   }
+// per-workgroup wall clock (100 MHz): entry, loop start, loop end, after the last store
+#define STAMP_WG(which)                                                                    \
+  if (a.stamps && threadIdx.x == 0 && blockIdx.x < 1024)                                    \
+    a.stamps[512 + blockIdx.x * 4 + (which)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define STAMP(slot)
 #define STAMP_CLK(which)
+#define STAMP_WG(which)
 #endif
 
-// KQ = padded K / 4; WR x WC waves (16 output rows each x PT / WC positions); PT positions
-// per tile; EPI = epilogue / prologue flags; PG = pooling granule (16 or 32)
-template <int KQ, int WR, int WC, int PT, int EPI, int PG>
-__global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
-  constexpr int NW = WR * WC, NT = NW * 64, KPAD = 4 * KQ, NBLK = PT / 16 / WC;
-  constexpr int TILE = KPAD * PT, CPR = PT / 4;          // floats per buffer, 16-byte chunks per row
-  constexpr int NX = (KPAD * CPR + NT - 1) / NT;         // staged chunks per thread and tile
-  constexpr bool EVEN = KPAD * CPR == NX * NT;           // every staging slot is a real chunk
-  constexpr int CROWS = WR * 16;                         // output rows per workgroup
-  static_assert(NBLK >= 1 && PT % (16 * WC) == 0 && PT >= 32 && CPR % 8 == 0, "tile");
-  static_assert(!(EPI & PW_POOL) || PG == 16 || NBLK % 2 == 0, "a 32-position pool needs block pairs");
+// workgroups per CU the launch is sized for: limited by the two LDS buffers (160 KB per CU) and
+// capped so that each wave keeps a register budget that fits its W rows (512 / waves per SIMD)
+constexpr int pw_per_cu(int kt16, int kh, int nw, int wc, int rw) {
+  const int lds = 2 * 16 * kt16 * 64 * wc * 4;
+  int n = 160 * 1024 / lds;
+  const int cap = nw == 4 ? (kt16 * kh * rw <= 8 ? 4 : 2) : (kt16 * kh * rw <= 9 ? 2 : 1);
+  return n < cap ? n : cap;
+}
+// ... and the matching minimum waves per SIMD for __launch_bounds__
+constexpr int pw_min_waves(int kt16, int kh, int nw, int wc, int rw) {
+  return pw_per_cu(kt16, kh, nw, wc, rw) * nw / 4;
+}
+
+// KT16 = rows of a K sub-tile / 16; KH = sub-tiles along K; WR x WC waves, each RW x 16 output
+// rows x 64 positions of a PT = 64 WC position tile; EPI = epilogue / prologue flags; PG = pooling
+// granule (16 or 32)
+// RAGGED: some output rows of some wave lie beyond Cout (Cout not a multiple of the workgroup's
+// rows): every per-row access is guarded.  The common case has no guards and no branches.
+template <int KT16, int KH, int WR, int WC, int RW, int EPI, int PG, bool RAGGED>
+__global__ __launch_bounds__(WR *WC * 64, pw_min_waves(KT16, KH, WR *WC, WC, RW))
+void pw_fwd_kernel(const PwFwd a) {
+  constexpr int NW = WR * WC, NT = NW * 64, KT = 16 * KT16, KQ = KT / 4, PT = 64 * WC;
+  constexpr int TILE = KT * PT, CPR = PT / 4;            // floats per buffer, 16-byte chunks per row
+  constexpr int NCH = KT * CPR;                          // chunks of a sub-tile
+  constexpr int NX = (NCH + NT - 1) / NT;                // staging slots per thread
+  constexpr bool EVEN = NCH == NX * NT;
+  constexpr int ROWSTEP = NT / CPR;                      // rows between two slots of a thread
+  constexpr int CROWS = WR * RW * 16;                    // output rows per workgroup
+  static_assert(NT % CPR == 0 && (PG == 16 || PG == 32), "tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  STAMP_WG(0)
 
   const int tid = threadIdx.x, lane = tid & 63, quad = lane >> 4, l16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,355 +205,442 @@ __global__ __launch_bounds__(WR *WC * 64) void pw_fwd_kernel(const PwFwd a) {
   const int g = (blockIdx.x / a.nhalf) % a.ng, rank = blockIdx.x / (a.nhalf * a.ng);
   const int k = a.k;
   const int c0 = half * CROWS;                           // first output row of this workgroup
-  const int cout = a.cout, crows = cout - c0 < CROWS ? cout - c0 : CROWS;
+  const int cout = a.cout;
   const long long p = a.p;
 
-  // staging slots of this thread: chunk c = i * NT + tid -> row c / CPR, 16-byte column c % CPR.
-  // goff: byte offset from the tile's first word; lw: LDS byte offset inside a buffer (odd rows
-  // carry their 64-byte halves swapped); (sc, bi): the row's BatchNorm coefficients.
-  unsigned goff[NX], lw[NX];
-  bool okslot[NX];
-  f32x2 sc[(EPI & PW_AFFINE) ? NX : 1], bi[(EPI & PW_AFFINE) ? NX : 1];
+  // ---- staging: slot i of a thread = rows SR(i) + tid / CPR of the sub-tile, 16-byte column
+  // tid % CPR, SR(i) = i ROWSTEP (a ragged last slot starts at KT - ROWSTEP instead and overlaps
+  // its predecessor: every thread is active in every slot, no execution masks).  The loop body
+  // is STRAIGHT-LINE code: no slot is skipped and nothing is branched around, so that the
+  // compiler's wait-count pass can count the loads and stores in flight exactly (behind a branch
+  // it falls back to `s_waitcnt vmcnt(0)` in front of every staging write and every re-load,
+  // which made each tile sit out the previous tile's store acknowledgements).
+  //  * sub-tiles kh < KH - 1 are whole (the host picks KH = ceil(K / KT)): wave-uniform base +
+  //    ONE per-lane offset register;
+  //  * the last sub-tile may end inside a slot: per-slot per-lane offsets with the row clamped to
+  //    K - 1 (the copies of row K - 1 land in pad rows of the LDS tile and meet zero weights);
+  //  * past the workgroup's last tile the loads read one harmless cache line of tile 0 and the
+  //    writes fill a buffer nobody reads.
+  const int srow = tid / CPR, scol = tid % CPR;
+  auto slot_row = [](int i) constexpr { return (EVEN || i + 1 < NX) ? i * ROWSTEP : KT - ROWSTEP; };
+  const unsigned voff0 = (unsigned)(((size_t)srow * p + scol * 4) * 4);
+  unsigned voff_last[NX];                                 // last sub-tile: rows clamped to K - 1
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int c = i * NT + tid;
-    const int row = c / CPR, cp = c % CPR;
-    const bool ok = (EVEN || c < KPAD * CPR) && row < k;
-    okslot[i] = ok;
-    goff[i] = ok ? (unsigned)(((size_t)row * p + cp * 4) * 4) : 0u;   // invalid slots re-read word 0
-    lw[i] = (unsigned)((row * PT + ((cp ^ ((row & 1) << 2)) * 4)) * 4);
-    if (EPI & PW_AFFINE) {
-      const float s0 = ok ? a.in_coef[((size_t)g * k + row) * 4] : 0.f;
-      const float b0 = ok ? a.in_coef[((size_t)g * k + row) * 4 + 1] : 0.f;
-      sc[i] = (f32x2){s0, s0};
-      bi[i] = (f32x2){b0, b0};
-    }
+    int row = (KH - 1) * KT + slot_row(i) + srow;
+    row = row < k ? row : k - 1;
+    voff_last[i] = (unsigned)(((size_t)(row - (KH - 1) * KT) * p + scol * 4) * 4);
   }
-  // this wave's 16 rows of W, for the whole launch (lane: row l16, k = 4 kk + quad)
-  float wreg[KQ];
-  {
-    const int m = wr * 16 + l16;
-    const float *wg = a.w + (size_t)g * a.w_gs + (size_t)(c0 + m) * a.w_rs;
+  const unsigned lw0 = lds_addr(lds) + (unsigned)((srow * PT + scol * 4) * 4);
+
+  // this wave's rows of W, for the whole launch: lane (l16, quad) holds W[m][kh KT + 4 kk + quad]
+  float wreg[RW][KH * KQ];
 #pragma unroll
-    for (int kk = 0; kk < KQ; ++kk) {
+  for (int rw = 0; rw < RW; ++rw) {
+    const int m = c0 + (wr * RW + rw) * 16 + l16;
+    const float *wg = a.w + (size_t)g * a.w_gs + (size_t)m * a.w_rs;
+#pragma unroll
+    for (int kk = 0; kk < KH * KQ; ++kk) {
       const int kx = 4 * kk + quad;
-      wreg[kk] = (m < crows && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
+      wreg[rw][kk] = (m < cout && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
     }
   }
-  const bool all_k = __builtin_amdgcn_readfirstlane(k == KPAD ? 1 : 0) != 0;
+  // (scale, bias) of the previous layer's folded BatchNorm for the rows of every staging slot
+  float2 cof[(EPI & PW_AFFINE) ? KH : 1][(EPI & PW_AFFINE) ? NX : 1];
+  if (EPI & PW_AFFINE) {
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        int row = kh * KT + slot_row(i) + srow;
+        row = row < k ? row : k - 1;
+        cof[kh][i] = *(const float2 *)(a.in_coef + ((size_t)g * k + row) * 4);
+      }
+  }
   const int tpb = a.tiles_per_batch, nwg = a.nwg_g;
   const int ntiles = (a.nb / a.ng) * tpb;
 
-  // The launch-time loads (W, coefficients) are waited for HERE: left alone, the compiler puts
-  // their vmcnt(0) in front of the first use inside the tile loop, where it also drains the
-  // operand loads that were just issued for the next tile.
+  // The launch-time loads (W) are waited for HERE: left alone, the compiler puts their vmcnt(0)
+  // in front of the first use inside the tile loop, where it also drains the operand loads.
 #pragma unroll
-  for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(wreg[kk]));
+  for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+    for (int kk = 0; kk < KH * KQ; ++kk) asm volatile("" : "+v"(wreg[rw][kk]));
   if (EPI & PW_AFFINE) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(sc[i]), "+v"(bi[i]));
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(cof[kh][i].x), "+v"(cof[kh][i].y));
   }
 
-  // Tiles are whole (the host requires p % PT == 0): the loads of a tile are a straight line of
-  // NX instructions with no branch between issue and first use.
-  f32x4 stg[NX];
-  auto load_tile = [&](int n, long long p0) {
-    const float *xb = a.x + (size_t)n * a.x_bs + p0;                  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < NX; ++i) stg[i] = load16_saddr(goff[i], xb);
+  // ---- the stream of sub-tiles this workgroup stages: (tile, kh) in execution order
+  struct Cursor { int t, q, r, kh; };                    // tile index, (batch of the group, tile of the batch), sub-tile
+  const int dq = nwg / tpb, dr = nwg % tpb;
+  auto advance = [&](Cursor &c) {
+    if (KH > 1 && c.kh + 1 < KH) { ++c.kh; return; }
+    c.kh = 0;
+    c.t += nwg; c.q += dq; c.r += dr;
+    if (c.r >= tpb) { c.r -= tpb; ++c.q; }
   };
-  // previous layer's BatchNorm + ReLU in registers (packed fma; the backward's mask test uses
-  // the same fused form), then into the LDS buffer
-  auto write_chunk = [&](auto ic, float *buf) {
+  f32x4 stg[NX];
+  // loads of slot i of sub-tile c (kh compile-time) into its staging registers; `live` false:
+  // the sub-tile does not exist, read the first words of the tensor instead
+  auto load_slot = [&](auto ic, auto khc, const Cursor &c, bool live) {
+    constexpr int i = decltype(ic)::value, kh = decltype(khc)::value;
+    const float *xb = a.x + (size_t)(g + a.ng * c.q) * a.x_bs + (size_t)c.r * PT + (size_t)(kh * KT) * p;
+    if constexpr (kh < KH - 1) {
+      const float *xs = live ? xb + (size_t)slot_row(i) * p : a.x;   // wave-uniform
+      stg[i] = load16_saddr(live ? voff0 : 0u, xs);
+    } else {
+      stg[i] = load16_saddr(live ? voff_last[i] : 0u, live ? xb : a.x);
+    }
+  };
+  // previous layer's BatchNorm + ReLU in registers, then into LDS buffer `buf` (0 / 1)
+  auto write_slot = [&](auto ic, auto khc, int buf) {
     constexpr int i = decltype(ic)::value;
     f32x4 q = stg[i];
-    if (!(EVEN && all_k)) q = okslot[i] ? q : (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (EPI & PW_AFFINE) {
-      const f32x2 lo = __builtin_elementwise_fma((f32x2){q[0], q[1]}, sc[i], bi[i]);
-      const f32x2 hi = __builtin_elementwise_fma((f32x2){q[2], q[3]}, sc[i], bi[i]);
-      q[0] = fmaxf(lo[0], a.in_lo); q[1] = fmaxf(lo[1], a.in_lo);
-      q[2] = fmaxf(hi[0], a.in_lo); q[3] = fmaxf(hi[1], a.in_lo);
+    if constexpr ((EPI & PW_AFFINE) != 0) {
+      const float2 co = cof[decltype(khc)::value][i];
+      const float lo = a.in_lo;
+      q[0] = fmaxf(__builtin_fmaf(q[0], co.x, co.y), lo);
+      q[1] = fmaxf(__builtin_fmaf(q[1], co.x, co.y), lo);
+      q[2] = fmaxf(__builtin_fmaf(q[2], co.x, co.y), lo);
+      q[3] = fmaxf(__builtin_fmaf(q[3], co.x, co.y), lo);
     }
-    if (EVEN || (i * NT + tid) < KPAD * CPR) *(f32x4 *)((char *)buf + lw[i]) = q;
-  };
-  auto write_tile = [&](float *buf) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      f32x4 q = stg[i];
-      if (!(EVEN && all_k)) q = okslot[i] ? q : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (EPI & PW_AFFINE) {
-        const f32x2 lo = __builtin_elementwise_fma((f32x2){q[0], q[1]}, sc[i], bi[i]);
-        const f32x2 hi = __builtin_elementwise_fma((f32x2){q[2], q[3]}, sc[i], bi[i]);
-        q[0] = fmaxf(lo[0], a.in_lo); q[1] = fmaxf(lo[1], a.in_lo);
-        q[2] = fmaxf(hi[0], a.in_lo); q[3] = fmaxf(hi[1], a.in_lo);
-      }
-      if (EVEN || (i * NT + tid) < KPAD * CPR) *(f32x4 *)((char *)buf + lw[i]) = q;
-    }
+    lds_write_b128<slot_row(i) * PT * 4>(lw0 + (unsigned)(buf * TILE * 4), q);
   };
 
-  // statistics state: a lane holds ONE channel (row c0 + 16 wr + l16) x 4 positions per block
-  float s1 = 0.f, s2 = 0.f, shift = 0.f;
-  int nblk_done = 0;
-  const int q0 = wc * NBLK * 16;              // this wave's first position inside a tile
-  const int m = c0 + wr * 16 + l16;           // this lane's output channel
-  // byte offset of (row m, position q0 + 4 quad) from the tile's first output word
-  const unsigned roff = (unsigned)(((size_t)m * p + q0 + 4 * quad) * 4);
+  // statistics state: a lane holds ONE channel per row set (row c0 + 16 (wr RW + rw) + l16) and 16
+  // consecutive positions of it per tile
+  float s1[RW], s2[RW], shift[RW];
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw) s1[rw] = s2[rw] = shift[rw] = 0.f;
+  int ntile_done = 0;
+  // Which 16-byte chunk of an operand row a lane fetches decides which output positions it ends
+  // with.  PERM (every variant without a pooled tail): lane l16 fetches chunk 4 (l16 % 4) + l16 / 4,
+  // so accumulator (e, r) of lane (channel, quad) is position 16 r + 4 quad + e and the r-th
+  // 16-byte store of the four quads of a channel is one contiguous 64-byte segment (with the
+  // identity order a lane owns 16 consecutive positions and every store instruction writes 64
+  // separate 16-byte pieces: the epilogue's eight stores then took 2 000 - 4 000 cycles per tile,
+  // pwbench stamps).  Pooled tails keep the identity order: position 16 quad + 4 r + e, the lane's 16
+  // values ARE a pooling group.
+  constexpr bool PERM = !(EPI & PW_POOL);
+  constexpr int RS = PERM ? 16 : 4;           // positions between accumulator registers r and r + 1
+  const int q0 = wc * 64 + (PERM ? 4 : 16) * quad;   // this lane's first position inside a tile
+  // byte offset of (row m, position q0) from the tile's first output word, per row set
+  unsigned roff[RW];
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw)
+    roff[rw] = (unsigned)(((size_t)(c0 + (wr * RW + rw) * 16 + l16) * p + q0) * 4);
 
   // PW_BNRED: the raw output Z of the layer whose activation gradient this launch produces, at
-  // this lane's output elements (loaded ahead of the MFMAs of the tile), and the two sums
-  f32x4 zv[(EPI & PW_BNRED) ? NBLK : 1];
-  float r0 = 0.f, r1 = 0.f;
-  float4 zc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI & PW_BNRED) {
-    if (m < cout) zc = *(const float4 *)(a.bn_coef + ((size_t)g * cout + m) * 4);
-    asm volatile("" : "+v"(zc.x), "+v"(zc.y), "+v"(zc.z), "+v"(zc.w));
+  // this lane's output elements (loaded ahead of the MFMAs of the tile's last sub-tile), and the sums
+  f32x4 zv[(EPI & PW_BNRED) ? RW : 1][4];
+  float r0[RW], r1[RW];
+  float4 zc[RW];
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw) {
+    r0[rw] = r1[rw] = 0.f;
+    zc[rw] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI & PW_BNRED) {
+      const int m = c0 + (wr * RW + rw) * 16 + l16;
+      if (!RAGGED || m < cout) zc[rw] = *(const float4 *)(a.bn_coef + ((size_t)g * cout + m) * 4);
+      asm volatile("" : "+v"(zc[rw].x), "+v"(zc[rw].y), "+v"(zc[rw].z), "+v"(zc[rw].w));
+    }
   }
+  auto row_ok = [&](int rw) { return !RAGGED || c0 + (wr * RW + rw) * 16 + l16 < cout; };
   auto load_z = [&](int n, long long p0) {
     const float *zt = a.bn_z + (size_t)n * a.bnz_bs + p0;   // wave-uniform
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j)
-      zv[j] = m < cout ? load16_saddr(roff + 64u * j, zt) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rw = 0; rw < RW; ++rw) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        zv[rw][r] = row_ok(rw) ? load16_saddr(roff[rw] + 4u * RS * r, zt) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // output-side additions: the channel bias once, the row bias of a tile at the top of its last
+  // sub-tile (a load inside the epilogue would be waited for on the spot)
+  float cbias[RW], rbias[RW][4];
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw) {
+    cbias[rw] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rbias[rw][r] = 0.f;
+    if (EPI & PW_BIAS) {
+      if (row_ok(rw)) cbias[rw] = a.bias[g * cout + c0 + (wr * RW + rw) * 16 + l16];
+      asm volatile("" : "+v"(cbias[rw]));
+    }
+  }
+  auto load_row_bias = [&](int n, long long p0) {
+    const size_t cols = (size_t)(p >> a.rb_shift);
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // (groups of >= 64 positions: four loads of one word)
+        const size_t col = (size_t)((p0 + q0 + RS * r) >> a.rb_shift);
+        rbias[rw][r] = row_ok(rw) ? a.row_bias[((size_t)n * cout + c0 + (wr * RW + rw) * 16 + l16) * cols + col] : 0.f;
+      }
   };
 
-  f32x4 acc[NBLK];
+  // accumulators: acc[rw][e][r] = Y[row set rw][position q0 + RS r + e]
+  f32x4 acc[RW][4];
   auto epilogue = [&](int n, long long p0) {
-    constexpr bool full = true;   // p % PT == 0
     float *ytile = a.y + (size_t)n * a.y_bs + p0;        // wave-uniform
-    static_for<0, NBLK>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (full || p0 + q0 + 16 * j < p) {
-        if (EPI & PW_ROWBIAS) {
-          if (m < cout) {
-            const float rb = a.row_bias[((size_t)n * cout + m) * (size_t)(p >> a.rb_shift) +
-                                        ((p0 + q0 + 16 * j) >> a.rb_shift)];
-            acc[j] += (f32x4){rb, rb, rb, rb};
-          }
-        }
-        if (EPI & PW_BIAS) {
-          if (m < cout) { const float bs = a.bias[g * cout + m]; acc[j] += (f32x4){bs, bs, bs, bs}; }
-        }
-        if (EPI & PW_STORE) {
-          if (m < cout) store16_saddr<64 * j>(roff, acc[j], ytile);
-        }
-        if (EPI & PW_BNRED) {
+    static_for<0, RW>([&](auto rwc) {
+      constexpr int rw = decltype(rwc)::value;
+      const int m = c0 + (wr * RW + rw) * 16 + l16;
+      if (EPI & (PW_ROWBIAS | PW_BIAS)) {
+        f32x4 add;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float z = zv[j][r];
-            const float gg = __builtin_fmaf(z, zc.x, zc.y) > 0.f ? acc[j][r] : 0.f;
-            r0 += gg;
-            r1 += gg * ((z - zc.z) * zc.w);
-          }
-        }
-        if (EPI & PW_STATS) {
-          if (nblk_done == 0) shift = __shfl(acc[j][0], l16, 64);   // first value of the channel
-          ++nblk_done;
+        for (int r = 0; r < 4; ++r)
+          add[r] = ((EPI & PW_ROWBIAS) ? rbias[rw][r] : 0.f) + ((EPI & PW_BIAS) ? cbias[rw] : 0.f);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float d = acc[j][r] - shift;
-            s1 += d;
-            s2 += d * d;
+        for (int e = 0; e < 4; ++e) acc[rw][e] += add;
+      }
+      if (EPI & PW_STORE) {
+        if (row_ok(rw)) {
+          static_for<0, 4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            store16_saddr<4 * RS * r>(roff[rw], (f32x4){acc[rw][0][r], acc[rw][1][r], acc[rw][2][r], acc[rw][3][r]}, ytile);
+          });
+        }
+      }
+      if (EPI & PW_BNRED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = zv[rw][r][e];
+            const float gg = __builtin_fmaf(z, zc[rw].x, zc[rw].y) > 0.f ? acc[rw][e][r] : 0.f;
+            r0[rw] += gg;
+            r1[rw] += gg * ((z - zc[rw].z) * zc[rw].w);
+          }
+      }
+      if (EPI & PW_STATS) {
+        const float first = __shfl(acc[rw][0][0], l16, 64);   // first value of the channel
+        shift[rw] = ntile_done == 0 ? first : shift[rw];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = acc[rw][e][r] - shift[rw];
+            s1[rw] += d;
+            s2[rw] += d * d;
+          }
+      }
+      if (EPI & PW_POOL) {
+        // the lane's 16 values ARE one 16-position group (position 4 r + e inside it); a
+        // 32-position group is the lane pair (quad, quad ^ 1): both lanes end with the pair's
+        // extremum and both store it (the same bytes to the same place: no execution mask)
+        const size_t prow = (size_t)(p / PG);
+        const size_t pcol = (size_t)((p0 + q0) / PG);
+#pragma unroll
+        for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
+          float ev = acc[rw][0][0];
+          int at = 0;
+#pragma unroll
+          for (int u = 1; u < 16; ++u) {            // ascending position: the first extremum wins
+            const float v = acc[rw][u % 4][u / 4];
+            const bool better = mm ? v < ev : v > ev;
+            at = better ? u : at;
+            ev = better ? v : ev;
+          }
+          if (PG == 32) {
+            at += 16 * (quad & 1);
+            const float oe = __shfl_xor(ev, 16, 64);
+            const int oa = __shfl_xor(at, 16, 64);
+            const bool take = (mm ? oe < ev : oe > ev) || (oe == ev && oa < at);
+            ev = take ? oe : ev;
+            at = take ? oa : at;
+          }
+          if (row_ok(rw)) {
+            const size_t o = ((size_t)n * cout + m) * prow + pcol;
+            (mm ? a.pool_min : a.pool_max)[o] = ev;
+            (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)at;
           }
         }
       }
     });
-    if (EPI & PW_POOL) {
-      // a group = PG consecutive positions = PG / 16 blocks x (4 quads x 4 registers)
-      const size_t prow = (size_t)(p / PG);
-      static_for<0, NBLK / (PG / 16)>([&](auto jc) {
-        constexpr int j = decltype(jc)::value * (PG / 16);
-        if (full || p0 + q0 + 16 * j < p) {
-          const size_t pcol = (size_t)((p0 + q0 + 16 * j) / PG);
-#pragma unroll
-          for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
-            // per lane: best of its 4 (8) values, smallest position on ties
-            float e = acc[j][0];
-            int at = 4 * quad;
-#pragma unroll
-            for (int u = 1; u < 4 * (PG / 16); ++u) {
-              const float v = acc[j + u / 4][u % 4];
-              const bool better = mm ? v < e : v > e;
-              at = better ? 16 * (u / 4) + 4 * quad + u % 4 : at;
-              e = better ? v : e;
-            }
-            // across the 4 quads (lanes l16, l16 + 16, + 32, + 48)
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-              const float oe = __shfl_xor(e, off, 64);
-              const int oa = __shfl_xor(at, off, 64);
-              const bool take = (mm ? oe < e : oe > e) || (oe == e && oa < at);
-              e = take ? oe : e;
-              at = take ? oa : at;
-            }
-            if (quad == 0 && m < cout) {
-              const size_t o = ((size_t)n * cout + m) * prow + pcol;
-              (mm ? a.pool_min : a.pool_max)[o] = e;
-              (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)at;
-            }
-          }
-        }
-      });
-    }
+    if (EPI & PW_STATS) ++ntile_done;
   };
 
-  // ---- main loop: one barrier per tile; b0 holds tile t, tile t+1 is staged through registers
-  // into b1 behind the MFMAs of tile t
-  float *b0 = lds, *b1 = lds + TILE;
-  // tile coordinates advance incrementally: tile t = (batch tq of the group, tile tr of the batch)
-  const int dq = nwg / tpb, dr = nwg % tpb;
-  auto advance = [&](int &q, int &r) {
-    q += dq; r += dr;
-    if (r >= tpb) { r -= tpb; ++q; }
-  };
-  int t = rank;
-  int tq = rank / tpb, tr = rank % tpb;          // tile t
-  int nq = tq, nr = tr;                          // tile t + 1
-  advance(nq, nr);
-  __syncthreads();                               // LDS zero fill
-  if (t < ntiles) {
-    load_tile(g + a.ng * tq, (long long)tr * PT);
-    write_tile(b0);
-  }
+  // ---- pipeline prologue: sub-tile 0 -> buffer 0, sub-tile 1 -> staging registers
+  Cursor cur{rank, rank / tpb, rank % tpb, 0};           // the sub-tile being multiplied
+  Cursor nxt = cur;                                       // the sub-tile in the staging registers
+  using KH0 = std::integral_constant<int, 0>;
+  using KH1 = std::integral_constant<int, (KH > 1 ? 1 : 0)>;   // sub-tile 1 is (tile 0, kh 1) or (tile 1, kh 0)
+  static_for<0, NX>([&](auto ic) { load_slot(ic, KH0{}, cur, cur.t < ntiles); });
+  static_for<0, NX>([&](auto ic) { write_slot(ic, KH0{}, 0); });
+  advance(nxt);
+  static_for<0, NX>([&](auto ic) { load_slot(ic, KH1{}, nxt, nxt.t < ntiles); });
+  Cursor ld = nxt;                                        // the sub-tile the next loads fetch
+  advance(ld);
+  int buf = 0;
   int iter = 0;
   (void)iter;
   STAMP_CLK(0)
-  for (; t < ntiles; t += nwg, ++iter) {
-    STAMP(0)
-    lgkm_wait<0>();          // this thread's ds_writes of tile t
-    __builtin_amdgcn_s_barrier();
-    STAMP(1)
-    const bool more = t + nwg < ntiles;
-#ifdef PW_INTERLEAVE
-    const float *nxb = a.x + (size_t)(g + a.ng * nq) * a.x_bs + (long long)nr * PT;   // uniform
-#else
-    if (EPI & PW_BNRED) load_z(g + a.ng * tq, (long long)tr * PT);   // older than the operand loads
-    if (more) load_tile(g + a.ng * nq, (long long)nr * PT);
-#endif
-    STAMP(2)
-    const int n = g + a.ng * tq;
-    const long long p0 = (long long)tr * PT;
-    constexpr bool do_mfma = true;
-    if (do_mfma) {
-      // ---- MFMA loop: NBLK blocks of 16 positions, K in groups of GK quads; the LDS reads of
-      // group gi + 1 are issued before the MFMAs of group gi, counted lgkmcnt waits
-      constexpr int GK = NBLK >= 8 ? 2 : 4, NGRP = (KQ + GK - 1) / GK, UPK = PT / 16;   // 256-byte units per kk
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // lane address: row quad (odd rows: halves swapped), position q0 + 16 j + l16
-      unsigned xa[NBLK];
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j)
-        xa[j] = lds_addr(b0) + (unsigned)(quad * PT + ((q0 + 16 * j + l16) ^ ((quad & 1) << 4))) * 4u;
-      f32x2 bq[2][NBLK][GK / 2];
-      auto load_group = [&](auto gic) {
-        constexpr int gi = decltype(gic)::value;
-        static_for<0, GK / 2>([&](auto ic) {
-          constexpr int i = decltype(ic)::value, kk = gi * GK + 2 * i;
-          if constexpr (kk < KQ) {
-            // kk + 1 == KQ (odd KQ): the second word is a dummy re-read of kk
-            constexpr int k1 = kk + 1 < KQ ? kk + 1 : kk;
-            static_for<0, NBLK>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              if constexpr (k1 * UPK < 256)
-                bq[gi & 1][j][i] = lds_read2st64<kk * UPK, k1 * UPK>(xa[j]);
-              else   // beyond the 8-bit reach (the odd tail of K = 132 / 260): rebased by 64 KB
-                bq[gi & 1][j][i] = lds_read2st64<kk * UPK - 256, k1 * UPK - 256>(xa[j] + 65536u);
-            });
-          }
+  STAMP_WG(1)
+  // lane address of the operand fetch: row quad, positions 64 wc + 4 chunk .. + 3
+  const int chunk = PERM ? 4 * (l16 & 3) + (l16 >> 2) : l16;
+  const unsigned xa0 = lds_addr(lds) + (unsigned)((quad * PT + 64 * wc + 4 * chunk) * 4);
+  // one K sub-tile on the matrix cores: KQ groups of 4 k, PF operand reads in flight; `stage(kk)`
+  // runs behind the MFMAs of group kk
+  constexpr int PF = 2;
+  auto mfma_subtile = [&](auto khc, int bufsel, auto &&stage) {
+    constexpr int kh = decltype(khc)::value;
+    const unsigned xa = xa0 + (unsigned)(bufsel * TILE * 4);
+    f32x4 frag[PF + 1];
+    auto read_frag = [&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int off = kk * 4 * PT * 4;
+      if constexpr (off < 65536) frag[kk % (PF + 1)] = lds_read_b128<off>(xa);
+      else frag[kk % (PF + 1)] = lds_read_b128<off - 65536>(xa + 65536u);
+    };
+    static_for<0, PF>([&](auto kc) { if constexpr (decltype(kc)::value < KQ) read_frag(kc); });
+    static_for<0, KQ>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      // (LDS operations complete in order: waiting for all but the PF youngest reads also waits for
+      // a staging ds_write issued in between, which is harmless -- it is older than those reads)
+      if constexpr (kk + PF < KQ) {
+        read_frag(std::integral_constant<int, kk + PF>{});
+        lgkm_wait<PF>();
+      } else {
+        lgkm_wait<(KQ - 1 - kk)>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        static_for<0, RW>([&](auto rwc) {
+          constexpr int rw = decltype(rwc)::value;
+          // D[position][channel] += X^T[position][k] . W^T[k][channel]
+          acc[rw][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[kk % (PF + 1)][e], wreg[rw][kh * KQ + kk], acc[rw][e], 0, 0, 0);
         });
-      };
-      load_group(std::integral_constant<int, 0>{});
-      static_for<0, NGRP>([&](auto gic) {
-        constexpr int gi = decltype(gic)::value;
-        if constexpr (gi + 1 < NGRP) {
-          load_group(std::integral_constant<int, gi + 1>{});
-          constexpr int nk = KQ - (gi + 1) * GK < GK ? KQ - (gi + 1) * GK : GK;
-          lgkm_wait<((nk + 1) / 2) * NBLK>();
-        } else {
-          lgkm_wait<0>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, GK>([&](auto ic) {
-          constexpr int i = decltype(ic)::value, kk = gi * GK + i;
-          if constexpr (kk < KQ) {
-            static_for<0, NBLK>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              // D[position][channel] += X^T[position][k] . W^T[k][channel]
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[gi & 1][j][i / 2][i & 1], wreg[kk], acc[j], 0, 0, 0);
-            });
-          }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef PW_INTERLEAVE
-        if (more) {
-          constexpr int H = NGRP / 2;
-          static_for<0, NX>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr ((i * H) / NX == gi) stg[i] = load16_saddr(goff[i], nxb);
-            if constexpr (H + (i * (NGRP - H)) / NX == gi) write_chunk(ic, b1);
-          });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       });
-    }
-    STAMP(3)
-#ifndef PW_INTERLEAVE
-    if (more) write_tile(b1);   // waits for the loads of tile t + 1 (issued before the MFMAs)
-#endif
-    STAMP(4)
-    if (do_mfma) epilogue(n, p0);
-    STAMP(5)
-    tq = nq; tr = nr;
-    advance(nq, nr);
-    float *const tb = b0; b0 = b1; b1 = tb;
+      __builtin_amdgcn_sched_barrier(0);
+      stage(kkc);
+    });
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[rw][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  for (; cur.t < ntiles; ++iter) {
+    const int n = g + a.ng * cur.q;
+    const long long p0 = (long long)cur.r * PT;
+    static_for<0, KH>([&](auto khc) {
+      constexpr int kh = decltype(khc)::value;
+      STAMP(0)
+      lgkm_wait<0>();          // this thread's ds_writes of the sub-tile
+      __builtin_amdgcn_s_barrier();
+      STAMP(1)
+      const bool have2 = ld.t < ntiles;
+      if ((EPI & PW_BNRED) && kh == KH - 1) load_z(n, p0);
+      if ((EPI & PW_ROWBIAS) && kh == KH - 1) load_row_bias(n, p0);
+      if (kh == 0) zero_acc();
+      // Staging sits in the LAST part of the loop (slot i at kk = S0 + 2 i).  The wait-count pass
+      // cannot count loads and stores on one counter (mixed event types: it waits for vmcnt(0)), so
+      // the first staging write of a sub-tile also waits for the previous tile's stores and this
+      // tile's Z / row-bias loads: placed here they are S0 x 128 RW MFMA cycles old and have
+      // landed, while the operand loads it really needs are a whole sub-tile old.
+      constexpr int S0 = KQ - 2 - 2 * NX;
+      static_assert(S0 >= 0, "staging slots do not fit the K loop");
+      mfma_subtile(khc, buf, [&](auto kkc) {
+        constexpr int kk = decltype(kkc)::value;
+        if constexpr (kk >= S0 && (kk - S0) % 2 == 0 && (kk - S0) / 2 < NX) {
+          constexpr int i = (kk - S0) / 2;
+          // the sub-tile after this one has kh + 1 (mod KH), the one after that kh + 2 (mod KH)
+          write_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 1) % KH>{}, buf ^ 1);
+          load_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 2) % KH>{}, ld, have2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      STAMP(2)
+      if (kh == KH - 1) epilogue(n, p0);
+      STAMP(3)
+      cur = nxt;
+      nxt = ld;
+      advance(ld);
+      buf ^= 1;
+    });
   }
   STAMP_CLK(1)
+  STAMP_WG(2)
   if (EPI & PW_BNRED) {
     const int slot = rank * WC + wc;
-    r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64);
-    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);
-    if (quad == 0 && m < cout)
-      *(float2 *)(a.bn_part + (((size_t)g * cout + m) * a.nslots + slot) * 2) = make_float2(r0, r1);
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw) {
+      const int m = c0 + (wr * RW + rw) * 16 + l16;
+      float t0 = r0[rw], t1 = r1[rw];
+      t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64);
+      t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
+      if (quad == 0 && m < cout)
+        *(float2 *)(a.bn_part + (((size_t)g * cout + m) * a.nslots + slot) * 2) = make_float2(t0, t1);
+    }
   }
   if (EPI & PW_STATS) {
-    // one partial per wave: (count, shift, sum, sum of squares) of its 16 channels; the four
-    // quads hold different positions of the same channel
+    // one partial per wave and row set: (count, shift, sum, sum of squares) of its 16 channels;
+    // the four quads hold different positions of the same channel
     const int slot = rank * WC + wc;
-    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-    if (quad == 0 && m < cout) {
-      float4 o;
-      o.x = (float)nblk_done * 16.f;
-      o.y = shift;
-      o.z = s1; o.w = s2;
-      *(float4 *)(a.stat_part + (((size_t)g * a.nslots + slot) * cout + m) * 4) = o;
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw) {
+      const int m = c0 + (wr * RW + rw) * 16 + l16;
+      float t1 = s1[rw], t2 = s2[rw];
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (quad == 0 && m < cout) {
+        float4 o;
+        o.x = (float)ntile_done * 64.f;
+        o.y = shift[rw];
+        o.z = t1; o.w = t2;
+        *(float4 *)(a.stat_part + (((size_t)g * a.nslots + slot) * cout + m) * 4) = o;
+      }
     }
   }
 }
 
 // ---- per-geometry launcher: picks the built prologue / epilogue combination -----------------
-template <int KQ, int WR, int WC, int PT>
+template <int KT16, int KH, int WR, int WC, int RW>
 static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, hipStream_t s) {
-#define GO(E, G)                                                                              \
+  const bool ragged = a.cout % (WR * RW * 16) != 0;
+#define GO1(E, G, R)                                                                          \
   do {                                                                                        \
-    auto kern = pw_fwd_kernel<KQ, WR, WC, PT, E, G>;                                          \
+    auto kern = pw_fwd_kernel<KT16, KH, WR, WC, RW, E, G, R>;                                 \
     static bool attr = false;                                                                 \
     if (!attr) {                                                                              \
       (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                    \
       attr = true;                                                                            \
+      if (getenv("NESIE_PW_OCCUPANCY")) { /* residency report (tools/pw_occupancy.py) */     \
+        int nblk = -1;                                                                        \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, kern, WR * WC * 64, lds);   \
+        hipFuncAttributes fa;                                                                 \
+        (void)hipFuncGetAttributes(&fa, (const void *)kern);                                  \
+        fprintf(stderr, "pw_fwd_kernel<%d,%d,%d,%d,%d,%d,%d,%d>: %d VGPRs, %zu B LDS, %d workgroups/CU (occupancy API), grid %d\n", \
+                KT16, KH, WR, WC, RW, E, G, (int)R, fa.numRegs, lds, nblk, grid);             \
+      }                                                                                       \
     }                                                                                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WR *WC * 64), lds, s, a);                       \
     return NESIE_OK;                                                                          \
+  } while (0)
+  // GO: built for whole and ragged Cout; GOW: whole only (a ragged Cout there is an error)
+#define GO(E, G)                                                                              \
+  do {                                                                                        \
+    if (ragged) GO1(E, G, true); else GO1(E, G, false);                                       \
+  } while (0)
+#define GOW(E, G)                                                                             \
+  do {                                                                                        \
+    if (!ragged) GO1(E, G, false);                                                            \
   } while (0)
 #ifdef PW_DEV   // tools/pwbench development build: a few instantiations per geometry
   if (epi == PW_STORE) GO(PW_STORE, 16);
   if (epi == (PW_STORE | PW_BNRED)) GO(PW_STORE | PW_BNRED, 16);
   if (epi == (PW_AFFINE | PW_STORE | PW_STATS)) GO(PW_AFFINE | PW_STORE | PW_STATS, 16);
   if (epi == (PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
-    GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
+    GOW(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
   if (epi == (PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
-    GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
+    GOW(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
   set_error("dev build");
   return NESIE_ERR_UNSUPPORTED;
 #else
@@ -526,35 +649,39 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
   // the prologue / epilogue combinations the step uses
   if (aff) {
     if (base == PW_STORE) GO(PW_AFFINE | PW_STORE, 16);
+    if (base == (PW_STORE | PW_BIAS)) GO(PW_AFFINE | PW_STORE | PW_BIAS, 16);
     if (base == (PW_STORE | PW_STATS)) GO(PW_AFFINE | PW_STORE | PW_STATS, 16);
-    if (base == (PW_STORE | PW_POOL) && pg == 16) GO(PW_AFFINE | PW_STORE | PW_POOL, 16);
-    if (base == PW_POOL && pg == 16) GO(PW_AFFINE | PW_POOL, 16);
+    if (base == (PW_STORE | PW_POOL) && pg == 16) GOW(PW_AFFINE | PW_STORE | PW_POOL, 16);
+    if (base == PW_POOL && pg == 16) GOW(PW_AFFINE | PW_POOL, 16);
     if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
-      GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
-    if (base == (PW_STORE | PW_POOL) && pg == 32) GO(PW_AFFINE | PW_STORE | PW_POOL, 32);
-    if (base == PW_POOL && pg == 32) GO(PW_AFFINE | PW_POOL, 32);
+      GOW(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
+    if (base == (PW_STORE | PW_POOL) && pg == 32) GOW(PW_AFFINE | PW_STORE | PW_POOL, 32);
+    if (base == PW_POOL && pg == 32) GOW(PW_AFFINE | PW_POOL, 32);
     if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
-      GO(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
+      GOW(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
   } else {
     if (base == PW_STORE) GO(PW_STORE, 16);
+    if (base == (PW_STORE | PW_BIAS)) GO(PW_STORE | PW_BIAS, 16);
     if (base == (PW_STORE | PW_BNRED)) GO(PW_STORE | PW_BNRED, 16);
     if (base == (PW_STORE | PW_STATS)) GO(PW_STORE | PW_STATS, 16);
-    if (base == (PW_STORE | PW_STATS | PW_ROWBIAS)) GO(PW_STORE | PW_STATS | PW_ROWBIAS, 16);
+    if (base == (PW_STORE | PW_STATS | PW_ROWBIAS)) GOW(PW_STORE | PW_STATS | PW_ROWBIAS, 16);
   }
   set_error("pw_layer_forward: epilogue combination 0x%x (pool group %d) is not built", epi, pg);
   return NESIE_ERR_UNSUPPORTED;
 #endif
 #undef GO
+#undef GOW
+#undef GO1
 }
 
-#define PW_GEOM_NAME(KQ, WR, WC, PT) pw_launch_##KQ##_##WR##_##WC##_##PT
-#define PW_GEOM_DECL(KQ, WR, WC, PT) \
-  int PW_GEOM_NAME(KQ, WR, WC, PT)(const PwFwd &a, int epi, int pg, int grid, size_t lds, hipStream_t s);
-#define PW_GEOM_DEF(KQ, WR, WC, PT)                                                             \
+#define PW_GEOM_NAME(KT16, KH, WR, WC, RW) pw_launch_##KT16##_##KH##_##WR##_##WC##_##RW
+#define PW_GEOM_DECL(KT16, KH, WR, WC, RW) \
+  int PW_GEOM_NAME(KT16, KH, WR, WC, RW)(const PwFwd &a, int epi, int pg, int grid, size_t lds, hipStream_t s);
+#define PW_GEOM_DEF(KT16, KH, WR, WC, RW)                                                        \
   namespace nesie {                                                                             \
-  int PW_GEOM_NAME(KQ, WR, WC, PT)(const PwFwd &a, int epi, int pg, int grid, size_t lds,       \
-                                   hipStream_t s) {                                             \
-    return pw_launch_epi<KQ, WR, WC, PT>(a, epi, pg, grid, lds, s);                             \
+  int PW_GEOM_NAME(KT16, KH, WR, WC, RW)(const PwFwd &a, int epi, int pg, int grid, size_t lds, \
+                                         hipStream_t s) {                                       \
+    return pw_launch_epi<KT16, KH, WR, WC, RW>(a, epi, pg, grid, lds, s);                       \
   }                                                                                             \
   }
 

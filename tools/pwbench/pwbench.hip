@@ -230,6 +230,10 @@ int main(int argc, char **argv) {
       {8, 1, 128, 256, 4096, 16, "SA4 128->256"},
       {8, 1, 256, 256, 1024, 16, "FP 256->256"},
   };
+  if (const char *e = getenv("PW_SHAPE")) {   // PW_SHAPE="nb ng k cout p g": one custom shape, index 0
+    Shape c{}; long long pp = 0;
+    if (sscanf(e, "%d %d %d %d %lld %d", &c.nb, &c.ng, &c.k, &c.cout, &pp, &c.g) == 6) { c.p = pp; c.what = "custom"; shapes.insert(shapes.begin(), c); }
+  }
   if (mode == 12) {
     float *buf; long long *tm; CK(hipMalloc(&buf, (size_t)(1 << 24) * 4 * 2)); CK(hipMalloc(&tm, 256 * 8 * 8));
     CK(hipMemset(buf, 0, (size_t)(1 << 24) * 4 * 2));
@@ -367,8 +371,9 @@ int main(int argc, char **argv) {
                                       dw + (size_t)g * s.cout * s.k, s.k, 0, &zero,
                                       dy2 + (size_t)g * s.cout * s.p, (int)s.p, (long long)s.ng * s.cout * s.p, s.nb / s.ng);
     };
+    const long long xbs = getenv("PW_XSTRIDE0") ? 0 : (long long)s.k * s.p;   // every batch reads X[0]: operand from cache
     auto own = [&](const float *coef, int relu, float *y, float *part, int pg, int pmin) {
-      int st = nesie_pw_layer_forward(s.nb, s.ng, s.k, s.cout, s.p, dx, (long long)s.k * s.p, dw, (long long)s.cout * s.k,
+      int st = nesie_pw_layer_forward(s.nb, s.ng, s.k, s.cout, s.p, dx, xbs, dw, (long long)s.cout * s.k,
                                       s.k, 1, coef, relu, nullptr, 0, nullptr, y, (long long)s.cout * s.p, part, pg, pmin,
                                       dpmax, dpmin, damax, damin, 0);
       if (st) { printf("nesie error %d: %s\n", st, nesie_last_error()); exit(1); }
@@ -376,14 +381,24 @@ int main(int argc, char **argv) {
 #ifdef PW_STAMP
     if (mode == 7 || mode == 8) {
       extern long long *g_pw_stamps;
-      long long *dst; CK(hipMalloc(&dst, (2 * 24 * 8 + 4) * 8)); CK(hipMemset(dst, 0, (2 * 24 * 8 + 4) * 8));
+      const size_t NST = 512 + 1024 * 4;
+      long long *dst; CK(hipMalloc(&dst, NST * 8)); CK(hipMemset(dst, 0, NST * 8));
       for (int rep = 0; rep < 400; ++rep) own(mode == 8 ? dcoef : nullptr, 1, dy, mode == 8 ? dpart : nullptr, 0, 0);
       g_pw_stamps = dst;
       own(mode == 8 ? dcoef : nullptr, 1, dy, mode == 8 ? dpart : nullptr, 0, 0);
       CK(hipDeviceSynchronize());
       g_pw_stamps = nullptr;
-      std::vector<long long> hs(2 * 24 * 8 + 4);
+      std::vector<long long> hs(NST);
       CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+      {  // per-workgroup wall clock (10 ns ticks), relative to the earliest entry
+        long long t0 = -1; int nwgs = 0;
+        for (int b = 0; b < 1024; ++b) if (hs[512 + b * 4]) { ++nwgs; if (t0 < 0 || hs[512 + b * 4] < t0) t0 = hs[512 + b * 4]; }
+        long long mx[3] = {0, 0, 0}, mn[3] = {1ll << 60, 1ll << 60, 1ll << 60}; double av[3] = {0, 0, 0};
+        for (int b = 0; b < 1024; ++b) if (hs[512 + b * 4]) for (int k = 0; k < 3; ++k) {
+          const long long v = hs[512 + b * 4 + k] - t0; mx[k] = v > mx[k] ? v : mx[k]; mn[k] = v < mn[k] ? v : mn[k]; av[k] += (double)v / nwgs; }
+        printf("%d workgroups; us since the first entry (min / mean / max): entry %.2f %.2f %.2f | loop start %.2f %.2f %.2f | loop end %.2f %.2f %.2f\n", nwgs,
+               mn[0] * .01, av[0] * .01, mx[0] * .01, mn[1] * .01, av[1] * .01, mx[1] * .01, mn[2] * .01, av[2] * .01, mx[2] * .01);
+      }
       printf("in-kernel clock: %lld shader cycles over %lld ticks of the 100 MHz counter = %.3f GHz\n", hs[2 * 24 * 8 + 2] - hs[2 * 24 * 8],
              hs[2 * 24 * 8 + 3] - hs[2 * 24 * 8 + 1], 0.1 * (double)(hs[2 * 24 * 8 + 2] - hs[2 * 24 * 8]) / (double)(hs[2 * 24 * 8 + 3] - hs[2 * 24 * 8 + 1]));
       const char *nm[8] = {"top", "waited", "barrier", "issued", "xform", "late-epi", "mfma", "epi"};
@@ -401,6 +416,7 @@ int main(int argc, char **argv) {
     }
 #endif
     if (mode == 1) { printf("%s plain %.4f ms\n", s.what, timeit([&]() { own(nullptr, 0, dy, nullptr, 0, 0); })); continue; }
+    if (mode == 13) { printf("%s pool-only (no Y store) %.4f ms\n", s.what, timeit([&]() { own(dcoef, 1, nullptr, nullptr, 16, 0); })); continue; }
     if (mode == 2) { printf("%s fused %.4f ms\n", s.what, timeit([&]() { own(dcoef, 1, dy, dpart, 0, 0); })); continue; }
     if (mode == 3) { printf("%s rocblas %.4f ms\n", s.what, timeit(roc)); continue; }
     const float t_roc = timeit(roc);
