@@ -203,6 +203,104 @@ __global__ __launch_bounds__(256) void issue_kernel(float *buf, long long *times
   if (sink == 123.456f) buf[0] = sink;
 }
 
+// Pipeline-sharing probe (mode 14): every wave runs T "tiles" = NM fp32 MFMAs on register operands
+// followed by NS 16-byte-per-lane stores of its accumulators (no LDS, no barrier: the waves are
+// independent pipelines).  How do two such waves share a SIMD?  POLICY: 0 equal priority,
+// 1 waves 4-7 at s_setprio 1 throughout, 2 priority 3 around the stores, 3 priority 3 around the
+// MFMAs, 4 waves 4-7 start half a tile late (one epilogue + half a loop of s_sleep), 5 = 2 + 4.
+// active = waves per workgroup that work (4: one per SIMD, 8: two per SIMD).
+template <int NM, int NS, int POLICY>
+__global__ __launch_bounds__(512) void pipe_probe_kernel(float *buf, long long *times, int tiles, int active) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave >= active) return;
+  f32x4_t acc[8];
+  for (int c = 0; c < 8; ++c) acc[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float a = 1.f + lane * 1e-3f, b = 2.f;
+  float *dst = buf + ((size_t)blockIdx.x * 8 + wave) * (size_t)tiles * NS * 256 + lane * 4;
+  if (POLICY == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((POLICY == 4 || POLICY == 5) && wave >= 4)
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);       // ~ 4 x 8k cycles? (64 clocks per unit)
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    if (POLICY == 3) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int i = 0; i < NM / 8; ++i)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+    if (POLICY == 3) __builtin_amdgcn_s_setprio(0);
+    if (POLICY == 2 || POLICY == 5) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) *(f32x4_t *)(dst + ((size_t)t * NS + i) * 256) = acc[i % 8];
+    if (POLICY == 2 || POLICY == 5) __builtin_amdgcn_s_setprio(0);
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) { times[(blockIdx.x * 8 + wave) * 2] = t0; times[(blockIdx.x * 8 + wave) * 2 + 1] = t1; }
+}
+
+// The same probe with the layer kernel's OUTPUT ADDRESSING (mode 15): a 128-row x P tensor per batch,
+// a tile = 64 positions; lane (l16, quad) of wave w stores rows 32 w + l16 (+ 16), 16 bytes at
+// position 4 quad (+ 16 r), i.e. every store instruction writes 16 rows x 64 contiguous bytes, rows
+// P * 4 bytes apart.  LOADS > 0: also LOADS 16-byte-per-lane loads per tile in the operand pattern
+// (rows P * 4 bytes apart, 256 contiguous bytes per row), consumed by a dummy ds_write.
+// LSPREAD: the loads are issued one per NM / 8 / LOADS groups of 8 MFMAs instead of in one burst at
+// the top; SSPREAD: the previous tile's stores (from a copy of the accumulators) are issued one per
+// group inside the MFMA loop instead of in one burst behind it.
+template <int NM, int LOADS, bool LSPREAD, bool SSPREAD>
+__global__ __launch_bounds__(256) void pipe_addr_kernel(float *out, const float *in, long long *times, int tiles, int P, int ntile_total) {
+  __shared__ float sink[4096];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l16 = lane & 15, quad = lane >> 4;
+  f32x4_t acc[8], old[8];
+  for (int c = 0; c < 8; ++c) acc[c] = old[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float a = 1.f + lane * 1e-3f, b = 2.f;
+  const int tpb = P / 64;
+  f32x4_t ld[LOADS > 0 ? LOADS : 1];
+  float *dprev = out;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    const int tix = (blockIdx.x + t * gridDim.x) % ntile_total;
+    const int n = tix / tpb, col = tix % tpb;
+    const float *src = in + (size_t)n * 128 * P + (size_t)col * 64;
+    float *dst = out + (size_t)n * 128 * P + (size_t)col * 64;
+    if (!LSPREAD) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i)   // thread (row = 16 i + tid / 16, 16-byte column tid % 16)
+        ld[i] = *(const f32x4_t *)(src + (size_t)(16 * i + (threadIdx.x >> 4)) * P + (threadIdx.x & 15) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NM / 8; ++i) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (LSPREAD && LOADS > 0 && i % (NM / 8 / (LOADS > 0 ? LOADS : 1)) == 0 && i / (NM / 8 / (LOADS > 0 ? LOADS : 1)) < LOADS) {
+        const int li = i / (NM / 8 / (LOADS > 0 ? LOADS : 1));
+        ld[li] = *(const f32x4_t *)(src + (size_t)(16 * li + (threadIdx.x >> 4)) * P + (threadIdx.x & 15) * 4);
+      }
+      if (SSPREAD && i % 4 == 2 && i / 4 < 8) {
+        const int si = i / 4;
+        *(f32x4_t *)(dprev + (size_t)(32 * wave + 16 * (si / 4) + l16) * P + 4 * quad + 16 * (si % 4)) = old[si];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) *(f32x4_t *)&sink[((threadIdx.x * 4 + i * 1024) & 4095)] = ld[i];
+    if (SSPREAD) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) old[c] = acc[c];
+      dprev = dst;
+    } else {
+#pragma unroll
+      for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *(f32x4_t *)(dst + (size_t)(32 * wave + 16 * rw + l16) * P + 4 * quad + 16 * r) = acc[rw * 4 + r];
+    }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) { times[(blockIdx.x * 4 + wave) * 2] = t0; times[(blockIdx.x * 4 + wave) * 2 + 1] = t1; }
+  if (sink[lane] == 123.456f) out[0] = old[0][0];
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static uint32_t rng = 12345;
@@ -233,6 +331,58 @@ int main(int argc, char **argv) {
   if (const char *e = getenv("PW_SHAPE")) {   // PW_SHAPE="nb ng k cout p g": one custom shape, index 0
     Shape c{}; long long pp = 0;
     if (sscanf(e, "%d %d %d %d %lld %d", &c.nb, &c.ng, &c.k, &c.cout, &pp, &c.g) == 6) { c.p = pp; c.what = "custom"; shapes.insert(shapes.begin(), c); }
+  }
+  if (mode == 14) {
+    const int tiles = 24;
+    float *buf; long long *tm;
+    CK(hipMalloc(&buf, (size_t)256 * 8 * tiles * 8 * 256 * 4 + 4096)); CK(hipMalloc(&tm, 256 * 16 * 8));
+    auto run = [&](auto kern, int active, const char *nm) {
+      CK(hipMemset(tm, 0, 256 * 16 * 8));
+      for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, buf, tm, tiles, active);
+      CK(hipDeviceSynchronize());
+      std::vector<long long> h(256 * 16);
+      CK(hipMemcpy(h.data(), tm, h.size() * 8, hipMemcpyDeviceToHost));
+      // workgroup 7: waves 0 and 4 (SIMD partners); span = first start to last end over its waves
+      const long long *q = &h[7 * 16];
+      long long lo = q[0], hi = q[1];
+      for (int w = 0; w < active; ++w) { if (q[2 * w] < lo) lo = q[2 * w]; if (q[2 * w + 1] > hi) hi = q[2 * w + 1]; }
+      const double mf = (double)tiles * 256 * 32 * (active / 4);   // MFMA cycles per SIMD
+      printf("%-58s %d waves: wave0 %7lld cyc, wave4 %7lld cyc, span %7lld = %.0f per tile and SIMD-wave, matrix pipe %.0f %%\n", nm, active,
+             q[1] - q[0], active > 4 ? q[9] - q[8] : 0ll, hi - lo, (double)(hi - lo) / tiles / (active / 4), 100.0 * mf / (hi - lo));
+    };
+    run(pipe_probe_kernel<256, 8, 0>, 4, "256 MFMA + 8 stores");
+    run(pipe_probe_kernel<256, 0, 0>, 4, "256 MFMA + 0 stores");
+    run(pipe_probe_kernel<256, 8, 0>, 8, "256 MFMA + 8 stores, equal priority");
+    run(pipe_probe_kernel<256, 0, 0>, 8, "256 MFMA + 0 stores, equal priority");
+    run(pipe_probe_kernel<256, 8, 1>, 8, "256 MFMA + 8 stores, waves 4-7 at priority 1");
+    run(pipe_probe_kernel<256, 8, 2>, 8, "256 MFMA + 8 stores, priority 3 around the stores");
+    run(pipe_probe_kernel<256, 8, 3>, 8, "256 MFMA + 8 stores, priority 3 around the MFMAs");
+    run(pipe_probe_kernel<256, 8, 4>, 8, "256 MFMA + 8 stores, waves 4-7 start late");
+    run(pipe_probe_kernel<256, 8, 5>, 8, "256 MFMA + 8 stores, late start + priority 3 around stores");
+    run(pipe_probe_kernel<128, 4, 0>, 8, "128 MFMA + 4 stores, equal priority");
+    run(pipe_probe_kernel<128, 4, 2>, 8, "128 MFMA + 4 stores, priority 3 around the stores");
+    return 0;
+  }
+  if (mode == 15) {
+    const int P = 8192, nb = 48, tiles = 24;
+    float *out, *in; long long *tm;
+    CK(hipMalloc(&out, (size_t)nb * 128 * P * 4)); CK(hipMalloc(&in, (size_t)nb * 128 * P * 4)); CK(hipMalloc(&tm, 256 * 8 * 8));
+    CK(hipMemset(in, 0, (size_t)nb * 128 * P * 4));
+    auto run = [&](auto kern, const char *nm) {
+      for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, out, in, tm, tiles, P, nb * P / 64);
+      CK(hipDeviceSynchronize());
+      std::vector<long long> h(256 * 8);
+      CK(hipMemcpy(h.data(), tm, h.size() * 8, hipMemcpyDeviceToHost));
+      printf("%-50s wave0 %7lld cyc = %.0f per tile (256 MFMAs = 8192)\n", nm, h[7 * 8 + 1] - h[7 * 8], (double)(h[7 * 8 + 1] - h[7 * 8]) / tiles);
+    };
+    run(pipe_addr_kernel<256, 0, false, false>, "8 stores (burst), no loads");
+    run(pipe_addr_kernel<256, 8, false, false>, "8 loads (burst at top) + 8 stores (burst)");
+    run(pipe_addr_kernel<256, 8, true, false>, "8 loads (spread) + 8 stores (burst)");
+    run(pipe_addr_kernel<256, 8, false, true>, "8 loads (burst at top) + 8 stores (spread, next tile)");
+    run(pipe_addr_kernel<256, 8, true, true>, "8 loads (spread) + 8 stores (spread, next tile)");
+    run(pipe_addr_kernel<256, 0, false, true>, "no loads, 8 stores (spread, next tile)");
+    run(pipe_addr_kernel<256, 8, true, false>, "again: 8 loads (spread) + 8 stores (burst)");
+    return 0;
   }
   if (mode == 12) {
     float *buf; long long *tm; CK(hipMalloc(&buf, (size_t)(1 << 24) * 4 * 2)); CK(hipMalloc(&tm, 256 * 8 * 8));
