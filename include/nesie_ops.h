@@ -462,11 +462,15 @@ int nesie_pw_dgrad_bn_reduce(int nb, int ng, int k, int cout, long long p, const
                              float *bn_part, void *stream);
 /* stat_part -> coef[ch][4] = (scale, bias, mean, invstd), scale = gamma * invstd, bias = beta -
  * mean * scale (fp64, Chan's merge of the shifted partials), running statistics updated like
- * torch.nn.BatchNorm2d in training mode.  channels = ng * cout (stacked layers). */
+ * torch.nn.BatchNorm2d in training mode.  channels = ng * cout (stacked layers).
+ * chan_bias [channels] or NULL: the bias of a convolution in FRONT of the norm (mmcv ConvModule
+ * with bias=True and a norm, vote_module.py:65-74).  The layer kernel leaves it out -- the mean
+ * subtraction cancels it in every normalised value and its gradient is identically zero -- and
+ * only the running mean, which tracks the biased output, gets it added here. */
 int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,
                             const float *gamma, const float *beta, float *running_mean,
                             float *running_var, float momentum, float eps, float *coef,
-                            void *stream);
+                            const float *chan_bias, void *stream);
 /* Pooling tail: combine the group / pool_group partial extrema of every group of `group`
  * positions; with coef (this layer's BatchNorm) the value is relu?(scale * ext + bias) of the
  * extremum the sign of the scale selects (= max over the group of the normalised activation).

@@ -24,7 +24,7 @@ PW_GEOM_DECL(8, 4, 8, 1, 1)    // K <= 512
 __global__ __launch_bounds__(64) void pw_stats_finalize_kernel(
     int cout, int nslots, const float *__restrict__ part, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *running_mean, float *running_var, float momentum,
-    float eps, float *__restrict__ coef) {
+    float eps, float *__restrict__ coef, const float *__restrict__ chan_bias) {
   const int ch = blockIdx.x, g = ch / cout, m = ch % cout;
   const float4 *pp = (const float4 *)part + ((size_t)g * nslots) * cout + m;
   double n = 0.0, sm = 0.0;
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(64) void pw_stats_finalize_kernel(
   const double var = n > 0.0 ? m2 / n : 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
   if (running_mean) {
-    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+    // chan_bias: the bias of the convolution in front of the norm.  The layer kernel never adds
+    // it (the mean subtraction removes it from every normalised value); the running mean of the
+    // biased output differs from the unbiased one by exactly the bias
+    const double shown = mean + (chan_bias ? (double)chan_bias[ch] : 0.0);
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * shown);
     const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
     running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
   }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(
 struct PwGeom { int kt16, kh, wr, wc, rw, pt, nhalf, per_cu; };
 
 static bool pw_geometry(int k, int cout, PwGeom *o) {
-  if (k < 1 || cout < 1 || cout > 256) return false;
+  if (k < 1 || cout < 1 || cout > 512) return false;
   if (k <= 64) { o->kt16 = 4; o->kh = 1; }
   else if (k <= 128) { o->kt16 = 8; o->kh = 1; }
   else if (k <= 144) { o->kt16 = 9; o->kh = 1; }
@@ -113,7 +117,7 @@ static bool pw_geometry(int k, int cout, PwGeom *o) {
   // 128-row workgroups per tile.  Measured and rejected in round 3 (tools/pwbench):
   // 32 rows per wave in 4-wave workgroups, one 256-row workgroup of 32-row waves, a
   // two-team ping-pong workgroup.
-  o->nhalf = cout > 128 ? 2 : 1;
+  o->nhalf = (cout + 127) / 128;   // 128-row workgroups per tile
   if (o->kt16 == 4) {
     static const int k64 = [] { const char *e = getenv("NESIE_PW_K64"); return e ? atoi(e) : 4; }();
     o->wr = 4; o->wc = 1; o->rw = cout <= 64 ? 1 : 2;
@@ -281,13 +285,14 @@ extern "C" int nesie_pw_dgrad_bn_reduce(int nb, int ng, int k, int cout, long lo
 extern "C" int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,
                                        const float *gamma, const float *beta,
                                        float *running_mean, float *running_var, float momentum,
-                                       float eps, float *coef, void *stream) {
+                                       float eps, float *coef, const float *chan_bias,
+                                       void *stream) {
   const char *W = "pw_stats_finalize";
   NESIE_REQUIRE(channels >= 1 && cout >= 1 && channels % cout == 0 && nslots >= 1, W);
   NESIE_REQUIRE(stat_part && coef && (running_mean == nullptr) == (running_var == nullptr), W);
   hipLaunchKernelGGL(pw_stats_finalize_kernel, dim3(channels), dim3(64), 0, (hipStream_t)stream,
                      cout, nslots, stat_part, gamma, beta, running_mean, running_var, momentum,
-                     eps, coef);
+                     eps, coef, chan_bias);
   return check_launch(W);
 }
 

@@ -915,17 +915,19 @@ class HipKernels(_BNPoolMixin):
         return out
 
     def pw_stats_finalize(self, stat_part, gamma, beta, running_mean, running_var, momentum, eps,
-                          coef):
+                          coef, chan_bias=None):
         """(ng, slots, Cout, 4) shifted partials -> coef (ng*Cout, 4) = (scale, bias, mean,
-        invstd); running statistics (ng*Cout) updated in place (or None)."""
+        invstd); running statistics (ng*Cout) updated in place (or None).  chan_bias (ng*Cout):
+        bias of the convolution in front of the norm, added to the running mean only."""
         _check(stat_part, coef); _f32(stat_part, coef)
         ng, nslots, cout, _ = stat_part.shape
         assert tuple(coef.shape) == (ng * cout, 4)
+        assert chan_bias is None or (chan_bias.numel() == ng * cout and chan_bias.is_contiguous())
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
         with torch.cuda.device(coef.device):
             _lib.call("nesie_pw_stats_finalize", ng * cout, cout, nslots, _ptr(stat_part), opt(gamma),
                       opt(beta), opt(running_mean), opt(running_var), float(momentum), float(eps),
-                      _ptr(coef), _stream(coef))
+                      _ptr(coef), opt(chan_bias), _stream(coef))
 
     def pw_pool_finish(self, ng, p, group, pool_group, pool_out, coef, relu, pooled, argmax):
         """partial extrema (NB, C, P / pool_group) -> pooled (NB, C, P / group) float,

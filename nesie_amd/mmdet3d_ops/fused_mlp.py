@@ -18,6 +18,8 @@ re-derived with the same fused multiply-add the forward's operand load used).
 Same function as the module-by-module path (which stays the CPU checker's and serves shapes the
 kernels are not built for); differences are fp32 summation order and fma-vs-mul/add rounding.
 """
+import os as _os
+
 import torch
 from torch.autograd import Function
 
@@ -294,6 +296,23 @@ class StackGroups(Function):
         return tuple(out)
 
 
+class CatRows(Function):
+    """Same-width 2-D tensors (rows_i, C) -> their row concatenation (sum rows_i, C) filled by one
+    multi-tensor copy; the gradient goes back as row slices.  1-D tensors concatenate likewise."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        rows = [t.shape[0] for t in tensors]
+        out = tensors[0].new_empty(sum(rows), *tensors[0].shape[1:])
+        torch._foreach_copy_(list(out.split(rows, 0)), [t.detach() for t in tensors])
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
 def stack_groups(groups):
     """[[t_0 .. t_{S-1}], ...] -> [stacked (S, ...) per group]; S = 1 needs no copy at all."""
     if len(groups[0]) == 1:
@@ -476,3 +495,210 @@ def mini_pointnets_fused_supported(backend, c0, c0_part, G):
     B, S, H0, P = c0.shape[0], c0.shape[1], c0.shape[2], c0.shape[3] * c0.shape[4]
     return (c0_part.numel() > 0 and backend.pw_supported(H0, H0 // 2, P)
             and backend.pw_supported(H0 // 2, H0, P))
+
+
+# ---- 1-D per-seed / per-proposal stacks ----------------------------------------------------------
+# VoteModule (vote_module.py:65-74, 85-147), the prediction head's trunk and its three output
+# convolutions (reliable_conv_bbox_module.py:112-141, 144-177), the feature-propagation MLPs
+# (point_fp_module.py:31-37) and the quality head's score heads (side_pooling_module.py:55-78, 318):
+# chains of Conv1d(1x1) [-> BatchNorm1d -> ReLU] over (B, C, P) with P = 256 .. 1024.  The reference
+# runs them op by op; here a chain is ONE autograd function on the layer kernel, like the
+# set-abstraction stacks: per layer one forward launch (previous norm + ReLU folded into the operand
+# load, this layer's statistics from the accumulators), and in the backward one input-gradient
+# launch with the norm reduction, one weight-gradient launch and one norm apply pass.
+
+class Stack1dLayer:
+    """Static description of one layer: ``bias`` (the conv has one), ``bn`` = None or
+    (running_mean, running_var, momentum, eps) (-> conv, BatchNorm, ReLU)."""
+
+    def __init__(self, bias, bn):
+        self.bias, self.bn = bool(bias), bn
+
+
+class Stack1dFn(Function):
+    """x (NB, C0, P), batch n uses weight group n % S.  Layers l = 0 .. L-1:
+    y_l = W_l . a_{l-1} (+ bias_l), a_l = relu(bn_l(y_l)) for a layer with a norm, a_l = y_l
+    without.  Returns a_{L-1}.  Tensors after ``layers``: per layer W (S, Cout, Cin), then bias
+    (S * Cout) if the conv has one, then gamma, beta (S * Cout) if it has a norm.
+
+    A conv bias in FRONT of a norm is never added: the mean subtraction removes it from every
+    normalised value; the running mean gets it (``pw_stats_finalize(chan_bias=)``) and its
+    gradient -- identically zero -- is reported as None."""
+
+    @staticmethod
+    def forward(ctx, x, layers, S, *tensors):
+        backend = backend_for(x)
+        x = x.contiguous()
+        NB, c0, P = x.shape
+        ts = list(tensors)
+        per_layer, pos = [], 0
+        for lay in layers:
+            w = ts[pos]; pos += 1
+            b = None
+            if lay.bias:
+                b = ts[pos]; pos += 1
+            gamma = beta = None
+            if lay.bn is not None:
+                gamma, beta = ts[pos], ts[pos + 1]; pos += 2
+            per_layer.append((w, b, gamma, beta))
+        src, coef = x, None
+        ys, coefs = [], []
+        for lay, (w, b, gamma, beta) in zip(layers, per_layer):
+            cout = w.shape[1]
+            y = x.new_empty(NB, cout, P)
+            if lay.bn is not None:
+                rm, rv, momentum, eps = lay.bn
+                part = x.new_empty(S, backend.pw_stat_slots(NB, S, w.shape[2], cout, P), cout, 4)
+                backend.pw_layer_forward(src, w, ng=S, in_coef=coef, in_relu=True, y=y, stat_part=part)
+                coef = x.new_empty(S * cout, 4)
+                backend.pw_stats_finalize(part, gamma, beta, rm, rv, momentum, eps, coef,
+                                          chan_bias=None if b is None else b.detach().contiguous())
+            else:
+                backend.pw_layer_forward(src, w, ng=S, in_coef=coef, in_relu=True, y=y,
+                                         bias=None if b is None else b.detach().contiguous())
+                coef = None
+            ys.append(y)
+            coefs.append(coef)
+            src = y
+        out = ys[-1]
+        if layers[-1].bn is not None:      # the last activation is somebody's input: materialise it
+            cl = out.shape[1]
+            act = torch.empty_like(out)
+            backend.affine_relu_forward(out.view(NB // S, S * cl, P), coefs[-1], True,
+                                        act.view(NB // S, S * cl, P))
+            out = act
+        ctx.layers, ctx.S, ctx.n_tensors = layers, S, len(tensors)
+        ctx.save_for_backward(x, *ys, *[c for c in coefs if c is not None], *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        layers, S = ctx.layers, ctx.S
+        L = len(layers)
+        sv = list(ctx.saved_tensors)
+        x, ys = sv[0], sv[1:1 + L]
+        ncoef = sum(1 for lay in layers if lay.bn is not None)
+        coef_list = sv[1 + L:1 + L + ncoef]
+        ts = sv[1 + L + ncoef:]
+        coefs, ci_ = [], 0
+        for lay in layers:
+            if lay.bn is not None:
+                coefs.append(coef_list[ci_]); ci_ += 1
+            else:
+                coefs.append(None)
+        per_layer, pos, slots = [], 0, []
+        for lay in layers:
+            sl = {'w': pos}
+            w = ts[pos]; pos += 1
+            b = gamma = beta = None
+            if lay.bias:
+                sl['b'] = pos; b = ts[pos]; pos += 1
+            if lay.bn is not None:
+                sl['g'] = pos; gamma, beta = ts[pos], ts[pos + 1]; pos += 2
+            per_layer.append((w, b, gamma, beta))
+            slots.append(sl)
+        backend = backend_for(dout)
+        NB, c0, P = x.shape
+        B = NB // S
+        grads = [None] * ctx.n_tensors
+        need = ctx.needs_input_grad
+        dout = dout.contiguous()
+        # gradient of the last layer's RAW output
+        w, b, gamma, beta = per_layer[-1]
+        cl = ys[-1].shape[1]
+        if layers[-1].bn is not None:
+            coef = coefs[-1]
+            dz = torch.empty_like(ys[-1])
+            dgamma, dbeta = dout.new_empty(S * cl), dout.new_empty(S * cl)
+            backend.bn_relu_backward(dout.view(B, S * cl, P), ys[-1].view(B, S * cl, P), None, gamma, beta,
+                                     coef[:, 2].contiguous(), coef[:, 3].contiguous(), coef, True,
+                                     dz.view(B, S * cl, P), dgamma, dbeta)
+            grads[slots[-1]['g']], grads[slots[-1]['g'] + 1] = dgamma, dbeta
+        else:
+            dz = dout
+            if b is not None and need[3 + slots[-1]['b']]:
+                grads[slots[-1]['b']] = dz.view(B, S * cl, P).sum((0, 2)) 
+        dx = None
+        for l in range(L - 1, -1, -1):
+            w = per_layer[l][0]
+            cout, cin = w.shape[1], w.shape[2]
+            src = x if l == 0 else ys[l - 1]
+            src_coef = None if l == 0 else coefs[l - 1]
+            if need[3 + slots[l]['w']]:
+                grads[slots[l]['w']] = _wgrad(backend, dz, src, src_coef, ng=S)
+            if l == 0:
+                if need[0]:
+                    if backend.pw_supported(cout, cin, P):
+                        dx = dz.new_empty(NB, cin, P)
+                        backend.pw_layer_forward(dz, w.transpose(1, 2), ng=S, y=dx)
+                    else:
+                        dx = torch.matmul(w.transpose(1, 2).unsqueeze(0), dz.view(B, S, cout, P)).view(NB, cin, P)
+                break
+            # gradient of the previous layer's activation, then through its norm + ReLU
+            pw, pb, pgamma, pbeta = per_layer[l - 1]
+            da = dz.new_empty(NB, cin, P)
+            part = backend.pw_dgrad_bn_reduce(dz, w.transpose(1, 2), ys[l - 1], coefs[l - 1], da, ng=S)
+            dzp = torch.empty_like(da)
+            dgamma, dbeta = dz.new_empty(S * cin), dz.new_empty(S * cin)
+            backend.bn_relu_backward_apply(da.view(B, S * cin, P), ys[l - 1].view(B, S * cin, P), pgamma,
+                                           None, coefs[l - 1], part, dzp.view(B, S * cin, P), dgamma, dbeta)
+            grads[slots[l - 1]['g']], grads[slots[l - 1]['g'] + 1] = dgamma, dbeta
+            dz = dzp
+        return (dx, None, None) + tuple(grads)
+
+
+# A/B switch (NESIE_STACK1D, default 15): bit 0 vote module, 1 prediction head, 2 feature
+# propagation, 3 score heads -- which chains run through Stack1dFn
+import os as _os
+STACK1D_MASK = int(_os.environ.get('NESIE_STACK1D', '15'))
+VOTE, PRED, FPROP, HEADS = 1, 2, 4, 8
+
+
+def stack1d_supported(backend, x, shapes, norms, S=1, which=15):
+    """True when ``Stack1dFn`` serves the chain: ``shapes`` = [(Cin, Cout), ...], ``norms`` = the
+    norm layer (or None) behind each conv; native training BatchNorm1d/2d with a folded ReLU,
+    fp32, every forward and input-gradient product inside the built tiles, only the LAST layer
+    may come without a norm."""
+    from .norm import FusedBNReLU1d, FusedBNReLU2d
+    if not ENABLED or backend.name != 'hip' or x.dtype != torch.float32 or not torch.is_grad_enabled() \
+            or not (STACK1D_MASK & which):
+        return False
+    P = x.shape[-1] if x.dim() == 3 else x.numel() // (x.shape[0] * x.shape[1])
+    for i, ((cin, cout), norm) in enumerate(zip(shapes, norms)):
+        if norm is None:
+            if i != len(shapes) - 1:
+                return False
+        elif not (isinstance(norm, (FusedBNReLU1d, FusedBNReLU2d)) and norm.fuse_relu and norm.training
+                  and norm.affine and norm.track_running_stats and norm.momentum is not None):
+            return False
+        if not backend.pw_supported(cin, cout, P):
+            return False
+        if i > 0 and not backend.pw_supported(cout, cin, P):
+            return False
+    return True
+
+
+def stack1d(x, convs, norms, S=1, weights=None, biases=None, gammas=None, betas=None, stats=None):
+    """Run a conv / norm chain through ``Stack1dFn``.  ``convs`` / ``norms``: one module (or, for
+    S > 1, a list of S structurally identical modules) per layer; norms[i] None = plain conv.
+    ``weights`` etc.: pre-stacked tensors for S > 1 (see side_pooling.batched_heads)."""
+    from . import norm as _norm
+    layers, tensors = [], []
+    for i, (conv, norm) in enumerate(zip(convs, norms)):
+        first_conv = conv[0] if isinstance(conv, (list, tuple)) else conv
+        first_norm = norm[0] if isinstance(norm, (list, tuple)) else norm
+        w = weights[i] if weights is not None else first_conv.weight.flatten(1).unsqueeze(0)
+        tensors.append(w)
+        has_bias = first_conv.bias is not None
+        if has_bias:
+            tensors.append(biases[i] if biases is not None else first_conv.bias)
+        bn = None
+        if first_norm is not None:
+            tensors += [gammas[i] if gammas is not None else first_norm.weight,
+                        betas[i] if betas is not None else first_norm.bias]
+            rm, rv = stats[i] if stats is not None else (first_norm.running_mean, first_norm.running_var)
+            bn = (rm, rv, first_norm.momentum, first_norm.eps)
+            for n in (norm if isinstance(norm, (list, tuple)) else [norm]):
+                _norm.count_batch(n.num_batches_tracked)
+        layers.append(Stack1dLayer(has_bias, bn))
+    return Stack1dFn.apply(x, tuple(layers), S, *tensors)

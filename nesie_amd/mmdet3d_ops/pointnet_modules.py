@@ -387,6 +387,13 @@ class PointFPModule(nn.Module):
             idx, weight, csr = taps if taps is not None else self.interpolation_taps(target, source)
             spread = three_interpolate(source_feats, idx, weight, csr)
         joined = spread if target_feats is None else torch.cat([spread, target_feats], dim=1)
+        layers = list(self.mlps)
+        if all(isinstance(l, ConvModule) and l.act_fused for l in layers):
+            shapes = [(l.conv.in_channels, l.conv.out_channels) for l in layers]
+            norms = [l.norm for l in layers]
+            if fused_mlp.stack1d_supported(backend_for(joined), joined, shapes, norms, which=fused_mlp.FPROP):
+                # the shared MLP as one fused chain on the layer kernel (point_fp_module.py:31-37)
+                return fused_mlp.stack1d(joined, [l.conv for l in layers], norms)
         return self.mlps(joined.unsqueeze(-1)).squeeze(-1)
 
 

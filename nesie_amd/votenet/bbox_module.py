@@ -52,7 +52,33 @@ class ReliableConvBboxHead(nn.Module):
                            act_cfg=self.act_cfg, bias=self.bias, inplace=True))
         return layers
 
+    def _fused(self, feats):
+        """The shared trunk as ONE fused chain on the layer kernel (``fused_mlp.Stack1dFn``); the class,
+        side-distribution and heading convolutions stay three small products on its output
+        (reliable_conv_bbox_module.py:144-177).  None when the chain is not served (evaluation,
+        CPU checker, configured branch convs).
+        (Round 3 also ran the three output convolutions as one stacked 220-row layer inside the
+        chain.  Values and gradients matched, but a step captured in a hipGraph with that layer
+        aborted on replay while every launch of it replays fine on its own
+        (tools/debug/graph_ops.py, graph_bisect.py); not understood, so not shipped.)"""
+        from ..kernels import backend_for
+        from ..mmdet3d_ops import fused_mlp
+        if (len(self.cls_conv_channels) or len(self.bbox_conv_channels) or len(self.heading_conv_channels)
+                or len(self.shared_conv_channels) == 0):
+            return None
+        trunk = list(self.shared_convs)
+        shapes = [(m.conv.in_channels, m.conv.out_channels) for m in trunk]
+        norms = [m.norm for m in trunk]
+        if not all(m.act_fused for m in trunk) or \
+                not fused_mlp.stack1d_supported(backend_for(feats), feats, shapes, norms, which=fused_mlp.PRED):
+            return None
+        x = fused_mlp.stack1d(feats, [m.conv for m in trunk], norms)
+        return self.conv_cls(x), torch.cat((self.conv_bbox(x), self.conv_heading(x)), dim=1)
+
     def forward(self, feats):
+        fused = self._fused(feats)
+        if fused is not None:
+            return fused
         x = self.shared_convs(feats) if len(self.shared_conv_channels) > 0 else feats
         x_cls = self.cls_convs(x) if len(self.cls_conv_channels) > 0 else x
         cls_score = self.conv_cls(x_cls)

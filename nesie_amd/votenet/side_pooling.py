@@ -262,6 +262,9 @@ def batched_heads(heads, x):
     weights = {id(layers[0]): next(stacked) for layers in convs}
     biases = {id(layers[0]): next(stacked) for layers in convs if layers[0].bias is not None}
     steps = [layers for layers in zip(*heads) if not isinstance(layers[0], nn.Identity)]
+    fused = _heads_as_stack(heads, x, steps, weights, biases)
+    if fused is not None:
+        return fused
     held = None   # a conv bias waiting for the norm layer behind it
     for i, layers in enumerate(steps):
         first = layers[0]
@@ -280,6 +283,45 @@ def batched_heads(heads, x):
         else:
             raise TypeError(f'batched_heads: unsupported layer {type(first).__name__}')
     return x
+
+
+def _heads_as_stack(heads, x, steps, weights, biases):
+    """The S stacked heads as ONE fused chain on the layer kernel (``fused_mlp.Stack1dFn``, weight
+    group = head): conv -> norm -> ReLU pairs followed by a plain conv.  None when not served."""
+    from ..mmdet3d_ops import fused_mlp
+    B, S, cin, P = x.shape
+    convs, norms = [], []
+    i = 0
+    while i < len(steps):
+        if not isinstance(steps[i][0], PointwiseConv1d):
+            return None
+        convs.append(steps[i])
+        if i + 1 < len(steps) and isinstance(steps[i + 1][0], FusedBNReLU1d):
+            norms.append(steps[i + 1])
+            i += 2
+        else:
+            norms.append(None)
+            i += 1
+    shapes = [(c[0].in_channels, c[0].out_channels) for c in convs]
+    if not fused_mlp.stack1d_supported(backend_for(x), x.reshape(B * S, cin, P), shapes,
+                                       [None if n is None else n[0] for n in norms], S, which=fused_mlp.HEADS):
+        return None
+    bn_groups = [g for n in norms if n is not None for g in ([l.weight for l in n], [l.bias for l in n])]
+    stacked = iter(fused_mlp.stack_groups(bn_groups)) if bn_groups else iter(())
+    gammas, betas, stats = [], [], []
+    for n in norms:
+        if n is None:
+            gammas.append(None); betas.append(None); stats.append(None)
+        else:
+            gammas.append(next(stacked).reshape(-1)); betas.append(next(stacked).reshape(-1))
+            pack = stacked_running_stats(list(n))
+            stats.append((pack[0], pack[1]))
+    w = [weights[id(c[0])] for c in convs]
+    b = [biases[id(c[0])].reshape(-1) if c[0].bias is not None else None for c in convs]
+    y = fused_mlp.stack1d(x.reshape(B * S, cin, P), [list(c) for c in convs],
+                          [None if n is None else list(n) for n in norms], S=S, weights=w, biases=b,
+                          gammas=gammas, betas=betas, stats=stats)
+    return y.view(B, S, y.shape[1], P)
 
 
 def heads_batchable(heads, x):
@@ -535,5 +577,9 @@ class SidePooling(nn.Module):
                                              c0_stats=bbox_stats)
         else:
             bbox_feats = self.mlps_before[6](bbox_feats)
-        end_points[f'{prefix}iou_scores'] = self.mlps_head[6](bbox_feats).transpose(2, 1)
+        if heads_batchable([self.mlps_head[6]], bbox_feats):     # (one head: the same fused chain)
+            iou = batched_heads([self.mlps_head[6]], bbox_feats.unsqueeze(1)).squeeze(1)
+        else:
+            iou = self.mlps_head[6](bbox_feats)
+        end_points[f'{prefix}iou_scores'] = iou.transpose(2, 1)
         return end_points

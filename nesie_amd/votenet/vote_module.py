@@ -35,6 +35,19 @@ class VoteModule(nn.Module):
         from .head_loss import new_ticket
         self.register_buffer('_loss_ticket', new_ticket(), persistent=False)
 
+    def _vote_stack(self, seed_feats):
+        """conv_out(vote_conv(x)): the Hough-voting MLP (vote_module.py:65-74) -- on the HIP back end
+        in training one fused chain on the layer kernel (``fused_mlp.Stack1dFn``), else layer by layer."""
+        from ..kernels import backend_for
+        from ..mmdet3d_ops import fused_mlp
+        convs = [m.conv for m in self.vote_conv] + [self.conv_out]
+        norms = [m.norm for m in self.vote_conv] + [None]
+        shapes = [(c.in_channels, c.out_channels) for c in convs]
+        if all(m.act_fused for m in self.vote_conv) and \
+                fused_mlp.stack1d_supported(backend_for(seed_feats), seed_feats, shapes, norms, which=fused_mlp.VOTE):
+            return fused_mlp.stack1d(seed_feats, convs, norms)
+        return self.conv_out(self.vote_conv(seed_feats))
+
     def forward(self, seed_points, seed_feats):
         """seed_points (B, N, 3), seed_feats (B, C, N) -> vote_points (B, N*V, 3), vote_feats
         (B, C, N*V), offset (B, 3, N*V); vote v of seed n sits at column n*V + v."""
@@ -44,7 +57,7 @@ class VoteModule(nn.Module):
             seed_points, seed_feats = seed_points[:, :self.num_points], seed_feats[..., :self.num_points]
         B, C, N = seed_feats.shape
         V = self.vote_per_seed
-        raw = self.conv_out(self.vote_conv(seed_feats)).view(B, V, self.per_vote, N)
+        raw = self._vote_stack(seed_feats).view(B, V, self.per_vote, N)
         # one split: its backward is one concatenation (two slices cost two zero fills + an add)
         shift, residual = raw.split([3, self.per_vote - 3], dim=2) if self.with_res_feat \
             else (raw, None)                                              # (B, V, 3, N), (B, V, C, N)

@@ -169,7 +169,7 @@ def test_row_bias_bias_and_transposed_weights():
 
 def test_unsupported_shapes_are_refused_not_miscomputed():
     hip = _hip()
-    assert not hip.pw_supported(300, 128, 512) and not hip.pw_supported(128, 300, 512)
+    assert not hip.pw_supported(300, 128, 512) and not hip.pw_supported(128, 600, 512)
     assert not hip.pw_supported(600, 128, 512)
     assert not hip.pw_supported(256, 128, 80)        # positions must fill whole 64-wide tiles
     x = torch.randn(1, 256, 80, device=_dev())

@@ -20,7 +20,8 @@ int nesie_pw_layer_forward(int nb, int ng, int k, int cout, long long p, const f
 int nesie_pw_stat_slots(int nb, int ng, int k, int cout, long long p);
 int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,
                             const float *gamma, const float *beta, float *running_mean,
-                            float *running_var, float momentum, float eps, float *coef, void *stream);
+                            float *running_var, float momentum, float eps, float *coef,
+                            const float *chan_bias, void *stream);
 const char *nesie_last_error(void);
 }
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -600,7 +601,7 @@ int main(int argc, char **argv) {
     }
     // fused: affine + relu prologue, store + stats epilogue
     const float t_fused = timeit([&]() { own(dcoef, 1, dy, dpart, 0, 0); });
-    nesie_pw_stats_finalize(s.ng * s.cout, s.cout, slots, dpart, nullptr, nullptr, nullptr, nullptr, 0.1f, 1e-5f, dcoef_out, 0);
+    nesie_pw_stats_finalize(s.ng * s.cout, s.cout, slots, dpart, nullptr, nullptr, nullptr, nullptr, 0.1f, 1e-5f, dcoef_out, nullptr, 0);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hy.data(), dy, ye * 4, hipMemcpyDeviceToHost));
     std::vector<float> hco((size_t)s.ng * s.cout * 4);
