@@ -76,4 +76,4 @@ def grads_of(model, cpu=False):
     return out
 
 
-from oracle.forcing import ForcedSampler, force_vote_sampling  # noqa: E402,F401
+from oracle.forcing import ForcedSampler, force_grid_taps, force_vote_sampling  # noqa: E402,F401
