@@ -29,6 +29,10 @@ from ..kernels import backend_for
 # Tests flip this to obtain the module-by-module evaluation of the same network on the device.
 ENABLED = True
 
+# addresses of gradient buffers a backward of this file has freshly allocated and is returning
+# (ownership hand-over between MiniTailFn.backward and MiniHeadFn.backward, see there)
+_FRESH_GRADS = set()
+
 
 def _wgrad(backend, dy, x, x_coef, ng=1):
     """dW (ng, Cout, Cin) = sum over n % ng == g of dy[n] @ act(x[n])^T; act = relu(scale * x +
@@ -407,8 +411,12 @@ class MiniHeadFn(Function):
         B, S, H0, P = c0.shape
         half = w3.shape[1]
         G = ctx.G
-        owned = dc is None
-        if owned:
+        # (MiniTailFn.backward hands over a buffer it has just allocated and registers its address:
+        # that one is ours to write into; anything else is copied first)
+        owned = dc is None or (dc.is_contiguous() and dc._base is None and dc.data_ptr() in _FRESH_GRADS)
+        if dc is not None:
+            _FRESH_GRADS.discard(dc.data_ptr())
+        if dc is None:
             dc = c0.new_zeros(B, S, half, P)
         if dg is not None:
             # the pooled gradient joins the dense one at the arg-max -- in a buffer of our OWN:
@@ -485,6 +493,7 @@ class MiniTailFn(Function):
             dwl = _wgrad(backend, dyf, cf, None, ng=S)
         dc = torch.empty_like(c)
         backend.pw_layer_forward(dyf, wl.transpose(1, 2), ng=S, y=dc.view(B * S, half, P))
+        _FRESH_GRADS.add(dc.data_ptr())     # nobody else holds this gradient buffer
         return dc, dsmall, None, None, dwl, dgamma, dbeta, dw4
 
 
