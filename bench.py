@@ -83,10 +83,15 @@ class KernelTimer:
 
 
 class GemmTimer:
-    """HIP-event timing + FLOP count of every launch of one matrix-core entry point."""
+    """HIP-event timing + FLOP and algorithmic-byte count of every launch of one matrix-core
+    entry point.  ``flops(*args, **kw)`` -> (flop, bytes, positions): launches over >= BIG
+    positions (nb * p) are the grouped per-seed MLPs (set-abstraction stacks, MiniPointNets);
+    the rest are the 1-D per-seed / per-proposal chains (P = 256 .. 1024 per scene)."""
+
+    BIG = 32768
 
     def __init__(self, backend, method, flops):
-        self.events, self.flop, self.enabled = [], [], False
+        self.events, self.work, self.enabled = [], [], False
         inner = getattr(backend, method)
 
         def wrapped(*args, **kw):
@@ -98,14 +103,17 @@ class GemmTimer:
             r = inner(*args, **kw)
             e.record()
             self.events.append((s, e))
-            self.flop.append(flops(*args, **kw))
+            self.work.append(flops(*args, **kw))
             return r
         setattr(backend, method, wrapped)
 
-    def totals(self):
-        """(launches, ms, flop) summed over the recorded launches."""
-        ts = [s.elapsed_time(e) for s, e in self.events]
-        return len(ts), sum(ts), float(sum(self.flop))
+    def totals(self, big=True):
+        """(launches, ms, flop, bytes) summed over the recorded launches of one size class."""
+        n = ms = fl = by = 0.0
+        for (s, e), (f, b, pos) in zip(self.events, self.work):
+            if (pos >= self.BIG) == big:
+                n += 1; ms += s.elapsed_time(e); fl += f; by += b
+        return n, ms, fl, by
 
 
 def parity_gate(device):
@@ -517,13 +525,21 @@ def main():
     bn_bwd_timer = KernelTimer(hip, 'bn_relu_backward', lambda dy, *_: dy.numel() == mid)
     # the matrix-core family: every launch of the layer kernel (forward products and, on the
     # transposed weight view, input gradients) and of the weight-gradient kernel
+    # -> (flop, algorithmic HBM bytes, positions): operands read once, results written once
     def fwd_flop(x, w, **kw):
-        return 2.0 * x.shape[0] * x.shape[1] * w.shape[1] * x.shape[2]
+        nb, k, p = x.shape
+        co = w.shape[1]
+        out = nb * co * p * 4 if kw.get('y') is not None else 0
+        return 2.0 * nb * k * co * p, nb * k * p * 4 + out, nb * p
 
     def wgrad_flop(dy, x, dw, **kw):
-        return 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] * dy.shape[2]
-    def dgrad_flop(dy, w, *a, **kw):
-        return 2.0 * dy.shape[0] * dy.shape[1] * w.shape[1] * dy.shape[2]
+        nb, co, p = dy.shape
+        return 2.0 * nb * co * x.shape[1] * p, nb * (co + x.shape[1]) * p * 4, nb * p
+
+    def dgrad_flop(dy, w, z, z_coef, da, **kw):   # + the raw output Z of the norm-backward reduction
+        nb, k, p = dy.shape
+        co = w.shape[1]
+        return 2.0 * nb * k * co * p, nb * (k + 2 * co) * p * 4, nb * p
     gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
                    GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop))
     bn_apply_timer = KernelTimer(hip, 'bn_relu_backward_apply', lambda dy, *_: dy.numel() == mid)
@@ -610,19 +626,33 @@ def main():
         # ---- the dominant family: the grouped per-seed MLP GEMMs on the fp32 matrix cores.
         # achieved = algorithmic FLOPs (2 * batches * K * Cout * positions per launch) / HIP-event
         # time, summed over every launch of the family in the un-captured steps.
-        n_l, ms_l, fl_l = (a + b for a, b in zip(gemm_timers[0].totals(), gemm_timers[2].totals()))
-        n_w, ms_w, fl_w = gemm_timers[1].totals()
+        n_l, ms_l, fl_l, by_l = (a + b for a, b in zip(gemm_timers[0].totals(), gemm_timers[2].totals()))
+        n_w, ms_w, fl_w, by_w = gemm_timers[1].totals()
         if n_l + n_w:
             tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             per_step = lambda v: v / eager_steps  # noqa: E731
+            # HBM bytes of the family as rocprofv3 counted them (separate --pmc FETCH_SIZE / WRITE_SIZE
+            # passes of this command, gfx950 fetch correction applied): produced by
+            # tools/make_r03_profiles.py, LOADED here, never measured inside this run
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
+            if os.path.exists(tpath) and args.workload == 'pretrain' and args.batch == 8:
+                t = json.load(open(tpath))
+                traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
+                           'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w),
+                           'largest_launch_over_algorithmic': t.get('largest_launch_over_algorithmic'),
+                           'source': 'profiles/r03_pmc_hbm_traffic.json', 'measured_in_run': False}
             out['roofline'] = {
                 'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients, with the operand '
                           'normalisation / statistics / pooling / norm-backward reduction epilogues) + '
-                          'nesie::pw_wgrad_kernel: the 1x1-conv layers of the SA stacks and the '
-                          'MiniPointNets, fp32 MFMA (v_mfma_f32_16x16x4_f32)',
+                          'nesie::pw_wgrad_kernel on the grouped per-seed MLPs: the 1x1-conv layers of the '
+                          'SA stacks and the MiniPointNets (>= 32768 positions per launch), fp32 MFMA '
+                          '(v_mfma_f32_16x16x4_f32)',
                 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf / MFMA_F32_PEAK_TFLOPS,
-                'traffic': None,   # HBM bytes of this family: profiles/r02_pmc_hbm_traffic.txt
+                'traffic': traffic,
+                'algorithmic_bytes_per_step': per_step(by_l + by_w),
+                'algorithmic_hbm_gbs': (by_l + by_w) / ((ms_l + ms_w) * 1e-3) / 1e9,
                 'launches_per_step': per_step(n_l + n_w),
                 'family_ms_per_step': per_step(ms_l + ms_w),
                 'avg_launch_ms': (ms_l + ms_w) / (n_l + n_w),
@@ -631,11 +661,20 @@ def main():
                                  'tflops': fl_l / (ms_l * 1e-3) / 1e12 if ms_l else None},
                 'wgrad_kernel': {'launches_per_step': per_step(n_w), 'ms_per_step': per_step(ms_w),
                                  'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None}}
+            # the same kernels on the 1-D per-seed / per-proposal chains (vote module, prediction
+            # trunk, feature propagation, score heads): 8 x 256 .. 1024 positions, launch-bound
+            sn, sms, sfl, _ = (a + b + c for a, b, c in zip(*(t.totals(big=False) for t in gemm_timers)))
+            if sn:
+                out['roofline_small_layers'] = {
+                    'kernel': 'the same kernels on the 1-D chains (fused_mlp.Stack1dFn): P = 256 .. 1024 '
+                              'positions per scene, one or two tiles per workgroup',
+                    'bound': 'latency', 'launches_per_step': per_step(sn), 'ms_per_step': per_step(sms),
+                    'avg_launch_us': 1e3 * sms / sn, 'tflops': sfl / (sms * 1e-3) / 1e12}
             # the same FLOPs against the whole step (everything that is not a GEMM counts as lost)
-            step_tf = per_step(fl_l + fl_w) / (ms_per_step * 1e-3) / 1e12
+            step_tf = per_step(fl_l + fl_w + sfl) / (ms_per_step * 1e-3) / 1e12
             out['roofline_step'] = {'bound': 'mfma', 'achieved': step_tf, 'peak': MFMA_F32_PEAK_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': step_tf / MFMA_F32_PEAK_TFLOPS,
-                                    'native_gemm_flop_per_step': per_step(fl_l + fl_w)}
+                                    'native_gemm_flop_per_step': per_step(fl_l + fl_w + sfl)}
         else:
             out['roofline'] = None
         out['roofline_streaming'] = [e for e in (
@@ -646,13 +685,17 @@ def main():
                     bn_bwd_timer.mean_ms(), 5, mid * 4),
             _stream('nesie::bn_bwd_apply_kernel<relu> from the input-gradient kernel\'s partials '
                     '(B,64,2048,64): read da, z; write dz', bn_apply_timer.mean_ms(), 3, mid * 4)) if e]
+        rounds = 2047
         out['roofline_latency_bound'] = {
-            'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048: 2047 dependent rounds; '
-                      'longest single launch, overlapped with the previous step on a side '
-                      'stream in graph mode)',
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': None,
-            'avg_launch_ms': fps_ms, 'algorithmic_bytes_per_launch': alg_bytes}
+            'kernel': 'nesie::fps_pruned_kernel<16> (D-FPS 40000->2048: 2047 DEPENDENT rounds, one '
+                      '1024-thread workgroup per scene; longest single launch, overlapped with the '
+                      'previous step on a side stream in graph mode)',
+            'bound': 'latency', 'achieved': fps_ms * 1e3 / rounds if fps_ms else None,
+            'unit': 'us/round', 'rounds': rounds, 'avg_launch_ms': fps_ms,
+            # what a round re-reads: one 20-byte record per bucket test (625 buckets) + the ~12 active
+            # buckets of 64 points x 16 B from L2 + their running minima from LDS
+            'on_chip_bytes_per_round': 625 * 20 + 12 * 64 * (16 + 4),
+            'compulsory_hbm_bytes_per_launch': alg_bytes, 'peak': None, 'frac': None, 'traffic': None}
         if gate is not None:
             out['parity_gate'] = gate
         if args.cpu_baseline and world == 1:

@@ -170,7 +170,7 @@ struct PwFwd {
 constexpr int pw_per_cu(int kt16, int kh, int nw, int wc, int rw) {
   const int lds = 2 * 16 * kt16 * 64 * wc * 4;
   int n = 160 * 1024 / lds;
-  const int cap = nw == 4 ? (kt16 * kh * rw <= 8 ? 4 : 2) : (kt16 * kh * rw <= 9 ? 2 : 1);
+  const int cap = nw == 4 ? (kt16 * kh * rw <= 4 ? 4 : 2) : (kt16 * kh * rw <= 8 ? 2 : 1);
   return n < cap ? n : cap;
 }
 // ... and the matching minimum waves per SIMD for __launch_bounds__
@@ -322,9 +322,10 @@ void pw_fwd_kernel(const PwFwd a) {
   // 16-byte store of the four quads of a channel is one contiguous 64-byte segment (with the
   // identity order a lane owns 16 consecutive positions and every store instruction writes 64
   // separate 16-byte pieces: the epilogue's eight stores then took 2 000 - 4 000 cycles per tile,
-  // pwbench stamps).  Pooled tails keep the identity order: position 16 quad + 4 r + e, the lane's 16
-  // values ARE a pooling group.
-  constexpr bool PERM = !(EPI & PW_POOL);
+  // pwbench stamps).  A pooled tail WITHOUT a store keeps the identity order: position 16 quad + 4 r + e,
+  // the lane's 16 values ARE a pooling group; with a store the four quads of a channel share every
+  // group and reduce it with two cross-lane exchanges.
+  constexpr bool PERM = !(EPI & PW_POOL) || (EPI & PW_STORE);   // (a pooled tail that stores nothing keeps lane-local groups)
   constexpr int RS = PERM ? 16 : 4;           // positions between accumulator registers r and r + 1
   const int q0 = wc * 64 + (PERM ? 4 : 16) * quad;   // this lane's first position inside a tile
   // byte offset of (row m, position q0) from the tile's first output word, per row set
@@ -429,34 +430,87 @@ void pw_fwd_kernel(const PwFwd a) {
           }
       }
       if (EPI & PW_POOL) {
-        // the lane's 16 values ARE one 16-position group (position 4 r + e inside it); a
-        // 32-position group is the lane pair (quad, quad ^ 1): both lanes end with the pair's
-        // extremum and both store it (the same bytes to the same place: no execution mask)
         const size_t prow = (size_t)(p / PG);
-        const size_t pcol = (size_t)((p0 + q0) / PG);
+        if constexpr (!PERM) {
+          // the lane's 16 values ARE one 16-position group (position 4 r + e inside it); a
+          // 32-position group is the lane pair (quad, quad ^ 1): both lanes end with the pair's
+          // extremum and both store it (the same bytes to the same place: no execution mask)
+          const size_t pcol = (size_t)((p0 + q0) / PG);
 #pragma unroll
-        for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
-          float ev = acc[rw][0][0];
-          int at = 0;
+          for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
+            float ev = acc[rw][0][0];
+            int at = 0;
 #pragma unroll
-          for (int u = 1; u < 16; ++u) {            // ascending position: the first extremum wins
-            const float v = acc[rw][u % 4][u / 4];
-            const bool better = mm ? v < ev : v > ev;
-            at = better ? u : at;
-            ev = better ? v : ev;
+            for (int u = 1; u < 16; ++u) {            // ascending position: the first extremum wins
+              const float v = acc[rw][u % 4][u / 4];
+              const bool better = mm ? v < ev : v > ev;
+              at = better ? u : at;
+              ev = better ? v : ev;
+            }
+            if (PG == 32) {
+              at += 16 * (quad & 1);
+              const float oe = __shfl_xor(ev, 16, 64);
+              const int oa = __shfl_xor(at, 16, 64);
+              const bool take = (mm ? oe < ev : oe > ev) || (oe == ev && oa < at);
+              ev = take ? oe : ev;
+              at = take ? oa : at;
+            }
+            if (row_ok(rw)) {
+              const size_t o = ((size_t)n * cout + m) * prow + pcol;
+              (mm ? a.pool_min : a.pool_max)[o] = ev;
+              (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)at;
+            }
           }
-          if (PG == 32) {
-            at += 16 * (quad & 1);
-            const float oe = __shfl_xor(ev, 16, 64);
-            const int oa = __shfl_xor(at, 16, 64);
-            const bool take = (mm ? oe < ev : oe > ev) || (oe == ev && oa < at);
-            ev = take ? oe : ev;
-            at = take ? oa : at;
-          }
-          if (row_ok(rw)) {
-            const size_t o = ((size_t)n * cout + m) * prow + pcol;
-            (mm ? a.pool_min : a.pool_max)[o] = ev;
-            (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)at;
+        } else {
+          // accumulator (e, r) is position 16 r + 4 quad + e: group gi = r (PG 16) or r / 2 (PG 32)
+          // is spread over the channel's four quads.  Local extremum first (ascending position: the
+          // first one wins), then two exchanges (lanes 16 and 32 apart); afterwards every quad
+          // holds every group's result and quad gi stores group gi (PG 32: quads 2, 3 repeat 0, 1)
+          constexpr int NG = 64 / PG, RPG = PG / 16;           // groups per 64 positions, registers r per group
+          const size_t pcol = (size_t)((p0 + 64 * wc) / PG) + (PG == 16 ? quad : (quad & 1));
+#pragma unroll
+          for (int mm = 0; mm < ((EPI & PW_POOLMIN) ? 2 : 1); ++mm) {
+            float ev[NG];
+            int at[NG];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+              ev[gi] = acc[rw][0][gi * RPG];
+              at[gi] = 4 * quad;
+#pragma unroll
+              for (int u = 1; u < 4 * RPG; ++u) {
+                const int rr = u / 4, e = u % 4;
+                const float v = acc[rw][e][gi * RPG + rr];
+                const bool better = mm ? v < ev[gi] : v > ev[gi];
+                at[gi] = better ? 16 * rr + 4 * quad + e : at[gi];
+                ev[gi] = better ? v : ev[gi];
+              }
+            }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+              float oe[NG];
+              int oa[NG];
+#pragma unroll
+              for (int gi = 0; gi < NG; ++gi) { oe[gi] = __shfl_xor(ev[gi], off, 64); oa[gi] = __shfl_xor(at[gi], off, 64); }
+#pragma unroll
+              for (int gi = 0; gi < NG; ++gi) {
+                const bool take = (mm ? oe[gi] < ev[gi] : oe[gi] > ev[gi]) || (oe[gi] == ev[gi] && oa[gi] < at[gi]);
+                ev[gi] = take ? oe[gi] : ev[gi];
+                at[gi] = take ? oa[gi] : at[gi];
+              }
+            }
+            float sev = ev[0];
+            int sat = at[0];
+            const int mine = PG == 16 ? quad : (quad & 1);
+#pragma unroll
+            for (int gi = 1; gi < NG; ++gi) {
+              sev = mine == gi ? ev[gi] : sev;
+              sat = mine == gi ? at[gi] : sat;
+            }
+            if (row_ok(rw)) {
+              const size_t o = ((size_t)n * cout + m) * prow + pcol;
+              (mm ? a.pool_min : a.pool_max)[o] = sev;
+              (mm ? a.arg_min : a.arg_max)[o] = (uint8_t)sat;
+            }
           }
         }
       }

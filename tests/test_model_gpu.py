@@ -17,9 +17,13 @@ def test_small_model_losses_and_grads_match_cpu_oracle(oracle_kernels, hip_devic
     model.train_cfg['neg_distance_thr'] = 1.5
     pts, boxes, labels = _small.small_batch()
     model.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
+    # discrete decisions on PREDICTED coordinates (vote sampling, grid taps) are replayed from the
+    # CPU leg: a last-bit difference may legitimately flip them (oracle/forcing.py)
+    _small.force_vote_sampling(model, 'nesie-small')
+    _small.force_grid_taps(model, 'nesie-small')
+    gmodel = copy.deepcopy(model).to(hip_device)
     with kernels.use_backend(oracle_kernels):
         want_l, want_g = _small.train_step_losses(model, pts, boxes, labels)
-    gmodel = copy.deepcopy(model).to(hip_device)
     got_l, got_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
     for k in want_l:  # north_star tolerance: 1e-4 for fp32 losses
         assert want_l[k].item() > 0, k
@@ -167,9 +171,13 @@ def test_saqe_model_losses_match_cpu_oracle(oracle_kernels, hip_device):
     model = build_saqe_votenet(cfg)
     pts, boxes, labels = _small.small_batch()
     model.bbox_head.jitter_noise = _small.fixed_noise(2, 32)
+    # discrete decisions on PREDICTED coordinates (vote sampling, grid taps) are replayed from the
+    # CPU leg: a last-bit difference may legitimately flip them (oracle/forcing.py)
+    _small.force_vote_sampling(model, 'saqe-small')
+    _small.force_grid_taps(model, 'saqe-small')
+    gmodel = copy.deepcopy(model).to(hip_device)
     with kernels.use_backend(oracle_kernels):
         want_l, want_g = _small.train_step_losses(model, pts, boxes, labels)
-    gmodel = copy.deepcopy(model).to(hip_device)
     got_l, got_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
     assert set(want_l) == {'vote_loss', 'objectness_loss', 'semantic_loss', 'center_loss',
                            'surface_loss', 'angle_loss', 'angle_pred_loss', 'iou_loss',

