@@ -10,27 +10,33 @@ from nesie_amd.votenet import build_nesie_votenet
 from nesie_amd.votenet import semi
 
 
-# names the reference's modules produce (point_sa_module.py:277-289,
-# side_pooling_module.py:55-78,346-358, simi_teacher_hook.py:39-52)
-REFERENCE_KEYS = [
-    'backbone.SA_modules.0.mlps.0.layer0.conv.weight',
-    'backbone.SA_modules.0.mlps.0.layer0.bn.weight',
-    'backbone.SA_modules.0.mlps.0.layer0.bn.running_mean',
-    'backbone.SA_modules.3.mlps.0.layer2.bn.num_batches_tracked',
-    'backbone.FP_modules.1.mlps.layer1.conv.weight',
-    'bbox_head.vote_module.vote_conv.0.conv.weight',
-    'bbox_head.vote_module.conv_out.bias',
-    'bbox_head.vote_aggregation.mlps.0.layer0.conv.weight',
-    'bbox_head.grid_conv.mlps_before.3.first_conv.0.weight',
-    'bbox_head.grid_conv.mlps_before.6.second_conv.3.bias',
-    'bbox_head.grid_conv.mlps_head.0.4.running_var',
-]
+# {key: shape} of the state_dict the REFERENCE's own classes produce (PointNet2SASSG, PointSAModule,
+# PointFPModule, NesieHead, point_sa_module.py:277-289, side_pooling_module.py:55-78,346-358) and the
+# buffers its EMA hook registers (simi_teacher_hook.py:39-52), dumped by
+# tests/golden/make_checkpoint_keys.py from the reference's files loaded by path
+def _reference_keys():
+    import json
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'reference_state_dict_keys.json')
+    return json.load(open(path))
 
 
-def test_state_dict_uses_the_reference_names():
-    keys = set(build_nesie_votenet().state_dict().keys())
-    for k in REFERENCE_KEYS:
-        assert k in keys, k
+def test_state_dict_has_exactly_the_reference_names_and_shapes():
+    ref = _reference_keys()['state_dict']
+    assert len(ref) == 375
+    mine = {k: list(v.shape) for k, v in build_nesie_votenet().state_dict().items()}
+    assert sorted(mine) == sorted(ref)
+    assert list(mine) == [k for k in mine if k in ref]
+    for k, shape in ref.items():
+        assert mine[k] == shape, (k, mine[k], shape)
+
+
+def test_ema_buffers_have_the_reference_hook_names_and_shapes():
+    ref = _reference_keys()
+    model = semi.build_nesie_votenet_semi()
+    mine = {k: list(v.shape) for k, v in model.state_dict().items() if k.startswith('ema_')}
+    assert mine == ref['ema_buffers']
+    rest = {k: list(v.shape) for k, v in model.state_dict().items() if not k.startswith('ema_')}
+    assert rest == ref['state_dict']            # the semi-supervised detector adds nothing else
 
 
 def test_reference_envelope_round_trip(tmp_path):
