@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
 
   unsigned goff[NX], lw[NX];
   bool okslot[NX];
-  f32x2 sc[AFF ? NX : 1], bi[AFF ? NX : 1];
+  float sc[AFF ? NX : 1], bi[AFF ? NX : 1];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int c = i * NT + tid;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     if (AFF) {
       const float s0 = (ok && !isdy) ? x_coef[((size_t)g * ci + r) * 4] : 0.f;
       const float b0 = (ok && !isdy) ? x_coef[((size_t)g * ci + r) * 4 + 1] : 0.f;
-      sc[i] = (f32x2){s0, s0};
-      bi[i] = (f32x2){b0, b0};
+      sc[i] = s0;
+      bi[i] = b0;
     }
   }
   if (AFF) {
@@ -64,26 +64,41 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(sc[i]), "+v"(bi[i]));
   }
   const bool all_rows = __builtin_amdgcn_readfirstlane((co == CO16 * 16 && ci == CI16 * 16) ? 1 : 0) != 0;
-  const long long tpb = p / PT;
-  const long long ntiles = (long long)(nb / ng) * tpb;
+  // tiles (batch of the group, 32 positions) in 32-bit arithmetic (the host checks the count): a
+  // 64-bit division per tile was 130 instructions of the loop
+  const int tpb = (int)(p / PT);
+  const int ntiles = (nb / ng) * tpb;
 
-  f32x4 stg[NX];
-  auto load_tile = [&](long long t) {
-    const int n = g + ng * (int)(t / tpb);
-    const long long p0 = (t % tpb) * PT;
+  // TWO tiles in flight in registers: the loads of tile t + 2 are issued at the top of tile t and
+  // written to LDS at the bottom of tile t + 1, i.e. 1.5 - 2 tile times (6 000 - 16 000 cycles with
+  // the SIMD's two waves taking turns on the matrix pipe) later; with one tile in flight the wave
+  // that gets the pipe first waited for HBM at the bottom of every tile (14 000 cycles per tile for
+  // 8 192 of MFMA: 57 % utilisation).  Loads are unconditional (past the end: the last tile again),
+  // so the wait in front of a write is a counted vmcnt(NX), not a drain.
+  f32x4 stg[2][NX];
+  auto load_tile = [&](auto sc_, int t) {
+    constexpr int S = decltype(sc_)::value;
+    t = t < ntiles ? t : ntiles - 1;
+    const int n = g + ng * (t / tpb);
+    const long long p0 = (long long)(t % tpb) * PT;
     const float *dyb = dy + (size_t)n * dy_bs + p0, *xb = x + (size_t)n * x_bs + p0;   // uniform
 #pragma unroll
-    for (int i = 0; i < NX; ++i) stg[i] = load16_saddr(goff[i], i < DYSLOTS ? dyb : xb);
+    for (int i = 0; i < NX; ++i) {
+      // (opaque copy: the zero-extension of the offset must stay in this block, or instruction
+      // selection sees a hoisted 64-bit register pair and drops the scalar-base addressing form)
+      unsigned o = goff[i];
+      asm volatile("" : "+v"(o));
+      stg[S][i] = load16_saddr(o, i < DYSLOTS ? dyb : xb);
+    }
   };
-  auto write_tile = [&](float *buf) {
+  auto write_tile = [&](auto sc_, float *buf) {
+    constexpr int S = decltype(sc_)::value;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      f32x4 q = stg[i];
+      f32x4 q = stg[S][i];
       if (AFF && i >= DYSLOTS) {
-        const f32x2 lo = __builtin_elementwise_fma((f32x2){q[0], q[1]}, sc[i], bi[i]);
-        const f32x2 hi = __builtin_elementwise_fma((f32x2){q[2], q[3]}, sc[i], bi[i]);
-        q[0] = fmaxf(lo[0], x_lo); q[1] = fmaxf(lo[1], x_lo);
-        q[2] = fmaxf(hi[0], x_lo); q[3] = fmaxf(hi[1], x_lo);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = fmaxf(__builtin_fmaf(q[e], sc[i], bi[i]), x_lo);
       }
       if (!(EVEN && all_rows)) q = okslot[i] ? q : (f32x4){0.f, 0.f, 0.f, 0.f};
       if (EVEN || (i * NT + tid) < ROWS * CPR) *(f32x4 *)((char *)buf + lw[i]) = q;
@@ -97,36 +112,38 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float *b0 = lds, *b1 = lds + TILE;
-  long long t = rank;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  int t = rank;
   if (t < ntiles) {
-    load_tile(t);
-    write_tile(b0);
+    load_tile(S0{}, t);
+    write_tile(S0{}, b0);
+    load_tile(S0{}, t + nwg_g);           // stg[0] = tile t + 1 ...
   }
-  for (; t < ntiles; t += nwg_g) {
+  // one tile: barrier, loads of the tile after next into the set `LD`, MFMAs of the tile in
+  // b0, the set `WR` (next tile, loaded one tile ago) to b1
+  auto tile = [&](auto ldc, auto wrc) {
     lgkm_wait<0>();
     __builtin_amdgcn_s_barrier();
-    const bool more = t + nwg_g < ntiles;
-    if (more) load_tile(t + nwg_g);
+    load_tile(ldc, t + 2 * nwg_g);
     // lane (l16 = row inside its block, quad): positions 16 pg + 4 quad .. + 3
     const unsigned la = lds_addr(b0) + (unsigned)(((wm * MB * 16 + l16) * PITCH + 4 * quad) * 4);
     const unsigned lb = lds_addr(b0) + (unsigned)(((CO16 * 16 + wn * NB * 16 + l16) * PITCH + 4 * quad) * 4);
-    f32x4 fa[2][MB], fb[2][NB];
-    auto load_frags = [&](auto pgc) {
+    // ONE set of fragment registers (the second position group is read behind the MFMAs of the
+    // first: its LDS latency is covered by the SIMD's other wave; two sets + two staging sets
+    // spilled)
+    f32x4 fa[MB], fb[NB];
+    static_for<0, 2>([&](auto pgc) {
       constexpr int pg = decltype(pgc)::value;
       static_for<0, MB>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        fa[pg][i] = lds_read_b128<(i * 16 * PITCH + 16 * pg) * 4>(la);
+        fa[i] = lds_read_b128<(i * 16 * PITCH + 16 * pg) * 4>(la);
       });
       static_for<0, NB>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        fb[pg][j] = lds_read_b128<(j * 16 * PITCH + 16 * pg) * 4>(lb);
+        fb[j] = lds_read_b128<(j * 16 * PITCH + 16 * pg) * 4>(lb);
       });
-    };
-    load_frags(std::integral_constant<int, 0>{});
-    load_frags(std::integral_constant<int, 1>{});
-    static_for<0, 2>([&](auto pgc) {
-      constexpr int pg = decltype(pgc)::value;
-      if constexpr (pg == 0) lgkm_wait<MB + NB>(); else lgkm_wait<0>();
+      lgkm_wait<0>();
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, 4>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -134,15 +151,21 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
           constexpr int i = decltype(ic)::value;
           static_for<0, NB>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pg][i][c], fb[pg][j][c], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
           });
         });
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (more) write_tile(b1);
+    write_tile(wrc, b1);     // (after the last tile: a copy of it that nobody reads)
     float *const tb = b0; b0 = b1; b1 = tb;
+    t += nwg_g;
+  };
+  while (t + nwg_g < ntiles) {     // pairs (the staging sets swap roles); no exit from the middle:
+    tile(S1{}, S0{});              // the accumulators stay in place
+    tile(S0{}, S1{});
   }
+  if (t < ntiles) tile(S1{}, S0{});
   // partial[(g * nwg + rank)][co][ci]: lane (quad, l16) holds rows 4 quad + r, column l16
   float *dst = partial + ((size_t)g * nwg_g + rank) * co * ci;
 #pragma unroll
@@ -224,6 +247,7 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
   NESIE_REQUIRE(workspace_bytes >= nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p), W);
   NESIE_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (dy_bstride & 3) == 0 && (x_bstride & 3) == 0, W);
   NESIE_REQUIRE((long long)(co > ci ? co : ci) * p < (1ll << 30), W);
+  NESIE_REQUIRE((long long)(nb / ng) * (p / 32) < (1ll << 30), W);     // (32-bit tile cursor)
   const int nwg = pw_wgrad_nwg(nb, ng, p);
   float *partial = (float *)workspace;
   const float lo = x_relu ? 0.f : -__builtin_inff();
