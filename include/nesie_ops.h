@@ -486,7 +486,9 @@ int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, i
  * autograd computes for ConvModule (point_sa_module.py:277-289) with the normalised activation
  * recomputed on load.  dy[n] (co, p) at dy + n*dy_bstride, x[n] (ci, p) at x + n*x_bstride;
  * dw (ng, co, ci); partials are added in a fixed order (bitwise reproducible).
- * workspace = nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p). */
+ * Supported: co <= 256, 9 <= ci <= 1024, p % 32 == 0; a layer wider than one workgroup's
+ * accumulators (co <= 128: ci > 320; co > 128: ci > 128) runs as column blocks of dw, one
+ * launch each.  workspace = nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p). */
 int nesie_pw_wgrad_supported(int co, int ci, long long p);
 size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p);
 int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,

@@ -24,8 +24,8 @@ namespace nesie {
 template <int CO16, int CI16, int WM, int WN, bool AFF>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     int nb, int ng, int co, int ci, long long p, const float *__restrict__ dy, long long dy_bs,
-    const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, float x_lo,
-    float *__restrict__ partial, int nwg_g) {
+    const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
+    float x_lo, float *__restrict__ partial, int nwg_g) {
   constexpr int MB = CO16 / WM, NB = CI16 / WN, PT = 32, PITCH = PT + 4, CPR = PT / 4;
   constexpr int ROWS = (CO16 + CI16) * 16, NT = 512;
   constexpr int NX = (ROWS * CPR + NT - 1) / NT;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     goff[i] = ok ? (unsigned)(((size_t)r * p + cp * 4) * 4) : 0u;
     lw[i] = (unsigned)((row * PITCH + cp * 4) * 4);
     if (AFF) {
-      const float s0 = (ok && !isdy) ? x_coef[((size_t)g * ci + r) * 4] : 0.f;
-      const float b0 = (ok && !isdy) ? x_coef[((size_t)g * ci + r) * 4 + 1] : 0.f;
+      const float s0 = (ok && !isdy) ? x_coef[((size_t)g * coef_gs + r) * 4] : 0.f;
+      const float b0 = (ok && !isdy) ? x_coef[((size_t)g * coef_gs + r) * 4 + 1] : 0.f;
       sc[i] = s0;
       bi[i] = b0;
     }
@@ -180,9 +180,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
 }
 
 // dw[g][i] = sum over the nparts partials of group g, in a fixed order
+// (a launch covers the ci columns [col0, col0 + ci) of dw (ng, co, ld): wide layers run as column blocks)
 __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int nparts,
                                                                const float *__restrict__ partial,
-                                                               float *__restrict__ dw) {
+                                                               float *__restrict__ dw, int ci, int ld,
+                                                               int col0, int co) {
   __shared__ float sh[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane, g = blockIdx.y;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
     float tt = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) tt += sh[w][lane];
-    dw[(size_t)g * total + i] = tt;
+    dw[((size_t)g * co + i / ci) * ld + col0 + i % ci] = tt;
   }
 }
 
@@ -217,15 +219,20 @@ static int pw_wgrad_nwg(int nb, int ng, long long p) {
 
 }  // namespace nesie
 
+// widest column block one launch covers (the whole co x block product sits in one workgroup's
+// accumulators): wider layers run as several column blocks, each re-reading dY
+static int pw_wgrad_block(int co, int ci) {
+  if (co <= 128) return ci <= 320 ? ci : 256;
+  return ci <= 128 ? ci : 128;
+}
+
 extern "C" int nesie_pw_wgrad_supported(int co, int ci, long long p) {
-  return p % 32 == 0 && ci >= 9 &&
-                 ((co <= 64 && ci <= 64) || (co <= 128 && ci <= 320) || (co <= 256 && ci <= 128))
-             ? 1 : 0;
+  return p % 32 == 0 && ci >= 9 && co <= 256 && ci <= 1024 ? 1 : 0;
 }
 
 extern "C" size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p) {
   if (nb <= 0 || ng <= 0 || p <= 0) return 0;
-  return (size_t)ng * pw_wgrad_nwg(nb, ng, p) * co * ci * sizeof(float);
+  return (size_t)ng * pw_wgrad_nwg(nb, ng, p) * co * pw_wgrad_block(co, ci) * sizeof(float);
 }
 
 extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
@@ -261,8 +268,8 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         attr = true;                                                                             \
       }                                                                                          \
-      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, ci, p, dy,         \
-                         dy_bstride, x, x_bstride, x_coef, lo, partial, nwg);                    \
+      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,         \
+                         dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg);                   \
     } else {                                                                                     \
       auto kern = pw_wgrad_kernel<CO16, CI16, WM, WN, false>;                                    \
       static bool attr = false;                                                                  \
@@ -270,20 +277,26 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         attr = true;                                                                             \
       }                                                                                          \
-      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, ci, p, dy,         \
-                         dy_bstride, x, x_bstride, x_coef, lo, partial, nwg);                    \
+      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,         \
+                         dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg);                   \
     }                                                                                            \
   } while (0)
-  if (co <= 64 && ci <= 64) L(4, 4, 2, 4);
-  else if (co <= 128 && ci <= 64) L(8, 4, 4, 2);
-  else if (co <= 128 && ci <= 128) L(8, 8, 2, 4);
-  else if (co <= 128 && ci <= 192) L(8, 12, 2, 4);
-  else if (co <= 128 && ci <= 256) L(8, 16, 2, 4);
-  else if (co <= 128 && ci <= 320) L(8, 20, 2, 4);
-  else L(16, 8, 4, 2);
+  const int block = pw_wgrad_block(co, ci);
+  for (int c0 = 0; c0 < ci; c0 += block) {     // column blocks [c0, c0 + cw) of dw; same stream: the
+    const int cw = ci - c0 < block ? ci - c0 : block;   // workspace is free again when the next one starts
+    const float *xc = x + (size_t)c0 * p;
+    const float *cc = x_coef ? x_coef + (size_t)c0 * 4 : nullptr;
+    if (co <= 64 && cw <= 64) L(4, 4, 2, 4);
+    else if (co <= 128 && cw <= 64) L(8, 4, 4, 2);
+    else if (co <= 128 && cw <= 128) L(8, 8, 2, 4);
+    else if (co <= 128 && cw <= 192) L(8, 12, 2, 4);
+    else if (co <= 128 && cw <= 256) L(8, 16, 2, 4);
+    else if (co <= 128) L(8, 20, 2, 4);
+    else L(16, 8, 4, 2);
+    const int total = co * cw;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(total, 64), ng), dim3(1024), 0, s, total, nwg,
+                       partial, dw, cw, ci, c0, co);
+  }
 #undef L
-  const int total = co * ci;
-  hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(total, 64), ng), dim3(1024), 0, s, total, nwg,
-                     partial, dw);
   return check_launch(W);
 }

@@ -34,12 +34,20 @@ ENABLED = True
 _FRESH_GRADS = set()
 
 
+# Layers wider than one workgroup's accumulators (the 1-D chains' 256 x 256 / 256 x 512 at 8 x 1024
+# positions) run in nesie_pw_wgrad as column blocks, one launch + one partial reduction each; at
+# these sizes (one 32-position tile per workgroup, 32 MB of partials per block) a transposed copy +
+# one rocBLAS GEMM is faster: 553 / 557 vs 548 / 548 scenes/s, same-box A/B.  NESIE_WGRAD_WIDE=1
+# selects the native column blocks.
+WIDE_WGRAD = _os.environ.get('NESIE_WGRAD_WIDE', '0') != '0'
+
+
 def _wgrad(backend, dy, x, x_coef, ng=1):
     """dW (ng, Cout, Cin) = sum over n % ng == g of dy[n] @ act(x[n])^T; act = relu(scale * x +
     bias) when x_coef (ng * Cin, 4)."""
     nb, co, p = dy.shape
     ci = x.shape[1]
-    if backend.pw_wgrad_supported(co, ci, p):
+    if backend.pw_wgrad_supported(co, ci, p) and (WIDE_WGRAD or (ci <= 320 if co <= 128 else ci <= 128)):
         dw = dy.new_empty(ng, co, ci)
         backend.pw_wgrad(dy, x, dw, ng=ng, x_coef=x_coef, x_relu=True)
         return dw

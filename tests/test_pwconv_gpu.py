@@ -266,7 +266,10 @@ def test_weight_gradient_wide_shapes_and_strided_batches(cout, cin):
 
 @pytest.mark.parametrize('nb,ng,co,ci,p', [(6, 3, 128, 256, 256), (4, 1, 256, 128, 512), (4, 2, 128, 128, 256),
                                            (2, 1, 128, 131, 512), (2, 1, 128, 259, 256), (2, 1, 64, 64, 1024),
-                                           (2, 1, 128, 64, 512), (3, 1, 100, 70, 96), (2, 1, 40, 33, 64)])
+                                           (2, 1, 128, 64, 512), (3, 1, 100, 70, 96), (2, 1, 40, 33, 64),
+                                           # wide layers: column blocks of one launch each
+                                           (4, 2, 256, 256, 256), (2, 1, 256, 512, 128), (2, 1, 256, 259, 64),
+                                           (4, 2, 128, 515, 64), (2, 1, 200, 300, 96)])
 def test_layer_weight_gradient_matches_fp64(nb, ng, co, ci, p):
     """nesie_pw_wgrad: sum over batches and positions of dy . act(x)^T per weight group, with the
     activation recomputed on load, on batch-strided operands."""
