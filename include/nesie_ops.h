@@ -496,6 +496,24 @@ int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
                    const float *x_coef, int x_relu, float *dw, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* The same weight gradient fused with the BatchNorm + ReLU backward that PRODUCES its dY operand
+ * (replaces nesie_bn_relu_backward_apply + nesie_pw_wgrad for a conv -> BatchNorm -> ReLU layer of
+ * ConvModule, point_sa_module.py:277-289): da (nb, co, p) is the gradient of relu(bn(z)), z the raw
+ * conv output (both at n*z_bstride), z_coef [ng*co][4] the layer's folded forward coefficients
+ * (scale, shift, mean, invstd), part [(ng*co) * nslots * 2] the (sum g, sum g zhat) partials the
+ * input-gradient launch that produced da left (nesie_pw_dgrad_bn_reduce).  Tiles of (da, z) are
+ * turned into dz = gamma invstd (g - mean(g) - zhat mean(g zhat)), g = da [fma(z, scale, shift) > 0],
+ * on their way into LDS: dz is the MFMA operand and is written once (dz may be da) for the
+ * input-gradient launch that follows; dgamma, dbeta [ng*co] are written.  coef_ws: ng*co*8 floats.
+ * Supported where one launch owns every column of dw (nesie_pw_wgrad_bn_supported). */
+int nesie_pw_wgrad_bn_supported(int co, int ci, long long p);
+int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
+                               const float *z, long long z_bstride, const float *z_coef,
+                               const float *gamma, const float *part, int nslots, const float *x,
+                               long long x_bstride, const float *x_coef, int x_relu, float *dz,
+                               float *dw, float *dgamma, float *dbeta, float *coef_ws,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* The layer kernel for skinny HBM-bound first layers (cin <= 64, cout <= 128): W stays in
  * LDS / registers and every wave streams its own 32-position columns straight from global
  * memory into the MFMA operand registers (no LDS tile, no barrier in the main loop).

@@ -91,6 +91,9 @@ SIGNATURES = {
                                   ctypes.c_size_t, _P],
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
+    "nesie_pw_wgrad_bn_backward": [_I, _I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P,
+                                   _P, _I, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P,
+                                   ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "nesie_pw_pool_finish": [_I, _I, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P,
                              _P],
@@ -136,6 +139,8 @@ def load():
     lib.nesie_mlp_stream_partials.restype = ctypes.c_longlong
     lib.nesie_pw_wgrad_supported.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_supported.restype = _I
+    lib.nesie_pw_wgrad_bn_supported.argtypes = [_I, _I, ctypes.c_longlong]
+    lib.nesie_pw_wgrad_bn_supported.restype = _I
     lib.nesie_pw_wgrad_workspace_bytes.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_flat_adamw_workspace_bytes.argtypes = []

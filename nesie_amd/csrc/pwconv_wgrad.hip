@@ -21,11 +21,21 @@ using namespace nesie;
 // 4 banks apart.
 namespace nesie {
 
-template <int CO16, int CI16, int WM, int WN, bool AFF>
+// BNB: dY is not given but formed on load from the gradient `dy` = dA of relu(bn(Z)) and the raw
+// conv output Z (`bnz`, same layout) with the finished reduction coefficients bnb[g*co + r] =
+// (scale, shift of the forward's fused multiply-add: mask = fma(z, scale, shift) > 0; a, mean, d1, e0):
+//     dZ = a g + (e0 - (z - mean) d1),  g = mask ? dA : 0,  d1 = a invstd mean(g zhat),  e0 = -a mean(g)
+// (= gamma invstd (g - mean(g) - zhat mean(g zhat)), the BatchNorm + ReLU backward's apply pass,
+// nesie_bn_relu_backward_apply) -- used as the MFMA operand AND written to `dz` for the
+// input-gradient launch that follows, so the separate apply pass over (dA, Z) -> dZ disappears.
+// dz may be dy itself: a tile's words are read once, by the workgroup that owns the tile, before
+// it writes them.
+template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     int nb, int ng, int co, int ci, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
-    float x_lo, float *__restrict__ partial, int nwg_g) {
+    float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
+    const float *__restrict__ bnb, float *dz) {
   constexpr int MB = CO16 / WM, NB = CI16 / WN, PT = 32, PITCH = PT + 4, CPR = PT / 4;
   constexpr int ROWS = (CO16 + CI16) * 16, NT = 512;
   constexpr int NX = (ROWS * CPR + NT - 1) / NT;
@@ -42,6 +52,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   unsigned goff[NX], lw[NX];
   bool okslot[NX];
   float sc[AFF ? NX : 1], bi[AFF ? NX : 1];
+  float zsc[BNB ? DYSLOTS : 1], zbi[BNB ? DYSLOTS : 1], za[BNB ? DYSLOTS : 1], zmu[BNB ? DYSLOTS : 1], zd1[BNB ? DYSLOTS : 1], ze0[BNB ? DYSLOTS : 1];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int c = i * NT + tid;
@@ -58,6 +69,13 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       sc[i] = s0;
       bi[i] = b0;
     }
+    if constexpr (BNB) {
+      if (i < DYSLOTS) {
+        const float *cf = bnb + ((size_t)g * co + (ok ? r : 0)) * 8;
+        zsc[i] = cf[0]; zbi[i] = cf[1]; za[i] = cf[2]; zmu[i] = cf[3]; zd1[i] = cf[4]; ze0[i] = cf[5];
+        asm volatile("" : "+v"(zsc[i]), "+v"(zbi[i]), "+v"(za[i]), "+v"(zmu[i]), "+v"(zd1[i]), "+v"(ze0[i]));
+      }
+    }
   }
   if (AFF) {
 #pragma unroll
@@ -69,33 +87,50 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   const int tpb = (int)(p / PT);
   const int ntiles = (nb / ng) * tpb;
 
-  // TWO tiles in flight in registers: the loads of tile t + 2 are issued at the top of tile t and
-  // written to LDS at the bottom of tile t + 1, i.e. 1.5 - 2 tile times (6 000 - 16 000 cycles with
-  // the SIMD's two waves taking turns on the matrix pipe) later; with one tile in flight the wave
-  // that gets the pipe first waited for HBM at the bottom of every tile (14 000 cycles per tile for
-  // 8 192 of MFMA: 57 % utilisation).  Loads are unconditional (past the end: the last tile again),
-  // so the wait in front of a write is a counted vmcnt(NX), not a drain.
-  f32x4 stg[2][NX];
-  auto load_tile = [&](auto sc_, int t) {
-    constexpr int S = decltype(sc_)::value;
+  // Register staging, ONE set: the loads of tile t + 2 are issued right behind the LDS write of
+  // tile t + 1 at the bottom of tile t and are waited for at the bottom of tile t + 1 -- a full
+  // tile time (8 000 - 11 000 cycles: the SIMD's two waves take turns on the matrix pipe) later.
+  // (Issued at the TOP of the tile they were waited for at its bottom, i.e. after only the wave's
+  // own 4 096 MFMA cycles for the wave that gets the pipe first: it sat out HBM latency in every
+  // tile, 14 000 cycles per tile for 8 192 of MFMA.)  Loads are unconditional (past the end: the
+  // last tile again); nothing younger than the awaited loads is in flight at the wait.
+  f32x4 stg[NX], stz[BNB ? DYSLOTS : 1];
+  size_t pend = 0;           // (batch, position) word offset of the tile in the staging registers
+  bool pend_ok = false;      // ... and whether it is a tile of this workgroup (not the repeat past the end)
+  auto load_tile = [&](int t) {
+    pend_ok = t < ntiles;
     t = t < ntiles ? t : ntiles - 1;
     const int n = g + ng * (t / tpb);
     const long long p0 = (long long)(t % tpb) * PT;
-    const float *dyb = dy + (size_t)n * dy_bs + p0, *xb = x + (size_t)n * x_bs + p0;   // uniform
+    pend = (size_t)n * dy_bs + p0;
+    const float *dyb = dy + pend, *xb = x + (size_t)n * x_bs + p0;   // uniform
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       // (opaque copy: the zero-extension of the offset must stay in this block, or instruction
       // selection sees a hoisted 64-bit register pair and drops the scalar-base addressing form)
       unsigned o = goff[i];
       asm volatile("" : "+v"(o));
-      stg[S][i] = load16_saddr(o, i < DYSLOTS ? dyb : xb);
+      stg[i] = load16_saddr(o, i < DYSLOTS ? dyb : xb);
+      if constexpr (BNB) {
+        if (i < DYSLOTS) stz[i] = load16_saddr(o, bnz + pend);
+      }
     }
   };
-  auto write_tile = [&](auto sc_, float *buf) {
-    constexpr int S = decltype(sc_)::value;
+  auto write_tile = [&](float *buf) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      f32x4 q = stg[S][i];
+      f32x4 q = stg[i];
+      if constexpr (BNB) {
+        if (i < DYSLOTS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zz = stz[i][e];
+            const float gg = __builtin_fmaf(zz, zsc[i], zbi[i]) > 0.f ? q[e] : 0.f;
+            q[e] = __builtin_fmaf(za[i], gg, __builtin_fmaf(zmu[i] - zz, zd1[i], ze0[i]));
+          }
+          if (pend_ok && okslot[i]) *(f32x4 *)((char *)(dz + pend) + goff[i]) = q;
+        }
+      }
       if (AFF && i >= DYSLOTS) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[e] = fmaxf(__builtin_fmaf(q[e], sc[i], bi[i]), x_lo);
@@ -112,26 +147,20 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float *b0 = lds, *b1 = lds + TILE;
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
   int t = rank;
   if (t < ntiles) {
-    load_tile(S0{}, t);
-    write_tile(S0{}, b0);
-    load_tile(S0{}, t + nwg_g);           // stg[0] = tile t + 1 ...
+    load_tile(t);
+    write_tile(b0);
+    load_tile(t + nwg_g);
   }
-  // one tile: barrier, loads of the tile after next into the set `LD`, MFMAs of the tile in
-  // b0, the set `WR` (next tile, loaded one tile ago) to b1
-  auto tile = [&](auto ldc, auto wrc) {
+  for (; t < ntiles; t += nwg_g) {
     lgkm_wait<0>();
     __builtin_amdgcn_s_barrier();
-    load_tile(ldc, t + 2 * nwg_g);
     // lane (l16 = row inside its block, quad): positions 16 pg + 4 quad .. + 3
     const unsigned la = lds_addr(b0) + (unsigned)(((wm * MB * 16 + l16) * PITCH + 4 * quad) * 4);
     const unsigned lb = lds_addr(b0) + (unsigned)(((CO16 * 16 + wn * NB * 16 + l16) * PITCH + 4 * quad) * 4);
     // ONE set of fragment registers (the second position group is read behind the MFMAs of the
-    // first: its LDS latency is covered by the SIMD's other wave; two sets + two staging sets
-    // spilled)
+    // first: its LDS latency is covered by the SIMD's other wave)
     f32x4 fa[MB], fb[NB];
     static_for<0, 2>([&](auto pgc) {
       constexpr int pg = decltype(pgc)::value;
@@ -157,15 +186,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    write_tile(wrc, b1);     // (after the last tile: a copy of it that nobody reads)
+    write_tile(b1);          // tile t + 1 (after the last tile: a copy of it that nobody reads)
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(t + 2 * nwg_g);
     float *const tb = b0; b0 = b1; b1 = tb;
-    t += nwg_g;
-  };
-  while (t + nwg_g < ntiles) {     // pairs (the staging sets swap roles); no exit from the middle:
-    tile(S1{}, S0{});              // the accumulators stay in place
-    tile(S0{}, S1{});
   }
-  if (t < ntiles) tile(S1{}, S0{});
   // partial[(g * nwg + rank)][co][ci]: lane (quad, l16) holds rows 4 quad + r, column l16
   float *dst = partial + ((size_t)g * nwg_g + rank) * co * ci;
 #pragma unroll
@@ -210,8 +235,12 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
   }
 }
 
-static int pw_wgrad_nwg(int nb, int ng, long long p) {
-  long long nwg = 256 / ng;
+// workgroups per weight group: one per CU; TWO per CU where a block's tiles (<= 74 KB of LDS) and
+// registers (<= 128) allow it (NESIE_WGRAD_PER_CU=1: A/B switch)
+static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw) {
+  static const int per_cu_max = getenv("NESIE_WGRAD_PER_CU") ? atoi(getenv("NESIE_WGRAD_PER_CU")) : 2;
+  const int per_cu = (co <= 128 && cw <= 128 && per_cu_max >= 2) ? 2 : 1;
+  long long nwg = 256 * per_cu / ng;
   const long long tiles = (long long)(nb / ng) * (p / 32);
   if (nwg > tiles) nwg = tiles;
   return nwg < 1 ? 1 : (int)nwg;
@@ -232,16 +261,49 @@ extern "C" int nesie_pw_wgrad_supported(int co, int ci, long long p) {
 
 extern "C" size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p) {
   if (nb <= 0 || ng <= 0 || p <= 0) return 0;
-  return (size_t)ng * pw_wgrad_nwg(nb, ng, p) * co * pw_wgrad_block(co, ci) * sizeof(float);
+  return (size_t)ng * pw_wgrad_nwg(nb, ng, p, co, pw_wgrad_block(co, ci)) * co * pw_wgrad_block(co, ci) * sizeof(float);
 }
 
-extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
-                              long long dy_bstride, const float *x, long long x_bstride,
-                              const float *x_coef, int x_relu, float *dw, void *workspace,
-                              size_t workspace_bytes, void *stream) {
-  const char *W = "pw_wgrad";
+namespace nesie {
+// bnb[c] = (scale, shift, a, mean, d1, e0, -, -) of channel c = g * co + r from the reduction
+// partials the input-gradient launch left (partial[(c * nslots + i) * 2 + {0, 1}] = sum g, sum g zhat),
+// the layer's folded forward coefficients z_coef[c] = (scale, shift, mean, invstd) and gamma;
+// dgamma / dbeta written on the way (fp64 sums, as bn_bwd_finalize in bn.hip)
+__global__ __launch_bounds__(64) void pw_bnb_coef_kernel(int channels, int nslots, double count,
+                                                         const float *__restrict__ part,
+                                                         const float *__restrict__ z_coef,
+                                                         const float *__restrict__ gamma,
+                                                         float *__restrict__ bnb, float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta) {
+  const int c = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < nslots; i += 64) {
+    s0 += (double)part[((size_t)c * nslots + i) * 2];
+    s1 += (double)part[((size_t)c * nslots + i) * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
+  }
+  if (threadIdx.x == 0) {
+    const float invstd = z_coef[c * 4 + 3];
+    const float a = (float)((gamma ? (double)gamma[c] : 1.0) * (double)invstd);
+    const float k1 = (float)(s0 / count), k2 = (float)(s1 / count);
+    float *o = bnb + (size_t)c * 8;
+    o[0] = z_coef[c * 4 + 0]; o[1] = z_coef[c * 4 + 1]; o[2] = a; o[3] = z_coef[c * 4 + 2];
+    o[4] = a * invstd * k2; o[5] = -a * k1; o[6] = 0.f; o[7] = 0.f;
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
+  }
+}
+
+static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long long p, const float *dy,
+                           long long dy_bstride, const float *x, long long x_bstride,
+                           const float *x_coef, int x_relu, float *dw, void *workspace,
+                           size_t workspace_bytes, const float *bnz, const float *bnb, float *dz,
+                           hipStream_t s) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && ci >= 1 && p >= 0 && dw, W);
-  hipStream_t s = (hipStream_t)stream;
   if (nb == 0 || p == 0) {
     (void)hipMemsetAsync(dw, 0, (size_t)ng * co * ci * sizeof(float), s);
     return NESIE_OK;
@@ -255,33 +317,29 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
   NESIE_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (dy_bstride & 3) == 0 && (x_bstride & 3) == 0, W);
   NESIE_REQUIRE((long long)(co > ci ? co : ci) * p < (1ll << 30), W);
   NESIE_REQUIRE((long long)(nb / ng) * (p / 32) < (1ll << 30), W);     // (32-bit tile cursor)
-  const int nwg = pw_wgrad_nwg(nb, ng, p);
+  const int block = pw_wgrad_block(co, ci);
+  // (the fused norm backward writes dZ while it forms it: one launch must own every column)
+  NESIE_REQUIRE(!bnb || (bnz && dz && block == ci && (((uintptr_t)bnz | (uintptr_t)dz) & 15) == 0), W);
+  const int nwg = pw_wgrad_nwg(nb, ng, p, co, block);
   float *partial = (float *)workspace;
   const float lo = x_relu ? 0.f : -__builtin_inff();
-#define L(CO16, CI16, WM, WN)                                                                    \
+#define LK(CO16, CI16, WM, WN, AFF, BNB)                                                         \
   do {                                                                                           \
     const size_t lds = (size_t)2 * (CO16 + CI16) * 16 * 36 * sizeof(float);                      \
-    if (x_coef) {                                                                                \
-      auto kern = pw_wgrad_kernel<CO16, CI16, WM, WN, true>;                                     \
-      static bool attr = false;                                                                  \
-      if (!attr) {                                                                               \
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        attr = true;                                                                             \
-      }                                                                                          \
-      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,         \
-                         dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg);                   \
-    } else {                                                                                     \
-      auto kern = pw_wgrad_kernel<CO16, CI16, WM, WN, false>;                                    \
-      static bool attr = false;                                                                  \
-      if (!attr) {                                                                               \
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        attr = true;                                                                             \
-      }                                                                                          \
-      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,         \
-                         dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg);                   \
+    auto kern = pw_wgrad_kernel<CO16, CI16, WM, WN, AFF, BNB>;                                   \
+    static bool attr = false;                                                                    \
+    if (!attr) {                                                                                 \
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr = true;                                                                               \
     }                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,           \
+                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz);       \
   } while (0)
-  const int block = pw_wgrad_block(co, ci);
+#define L(CO16, CI16, WM, WN)                                                                    \
+  do {                                                                                           \
+    if (bnb) { if (x_coef) LK(CO16, CI16, WM, WN, true, true); else LK(CO16, CI16, WM, WN, false, true); } \
+    else { if (x_coef) LK(CO16, CI16, WM, WN, true, false); else LK(CO16, CI16, WM, WN, false, false); }   \
+  } while (0)
   for (int c0 = 0; c0 < ci; c0 += block) {     // column blocks [c0, c0 + cw) of dw; same stream: the
     const int cw = ci - c0 < block ? ci - c0 : block;   // workspace is free again when the next one starts
     const float *xc = x + (size_t)c0 * p;
@@ -298,5 +356,42 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
                        partial, dw, cw, ci, c0, co);
   }
 #undef L
+#undef LK
   return check_launch(W);
+}
+}  // namespace nesie
+
+extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
+                              long long dy_bstride, const float *x, long long x_bstride,
+                              const float *x_coef, int x_relu, float *dw, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  return pw_wgrad_launch("pw_wgrad", nb, ng, co, ci, p, dy, dy_bstride, x, x_bstride, x_coef, x_relu, dw,
+                         workspace, workspace_bytes, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nesie_pw_wgrad_bn_supported(int co, int ci, long long p) {
+  return nesie_pw_wgrad_supported(co, ci, p) && pw_wgrad_block(co, ci) == ci ? 1 : 0;
+}
+
+extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
+                                          const float *z, long long z_bstride, const float *z_coef,
+                                          const float *gamma, const float *part, int nslots,
+                                          const float *x, long long x_bstride, const float *x_coef,
+                                          int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
+                                          float *coef_ws, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+  const char *W = "pw_wgrad_bn_backward";
+  NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (nb == 0 || p == 0) {
+    if (dgamma) (void)hipMemsetAsync(dgamma, 0, (size_t)ng * co * sizeof(float), s);
+    if (dbeta) (void)hipMemsetAsync(dbeta, 0, (size_t)ng * co * sizeof(float), s);
+    return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
+                           workspace_bytes, nullptr, nullptr, nullptr, s);
+  }
+  NESIE_REQUIRE(da && z && z_coef && part && dz && coef_ws && nb % ng == 0, W);
+  hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
+                     (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
+  return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
+                         workspace_bytes, z, coef_ws, dz, s);
 }

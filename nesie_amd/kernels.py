@@ -632,6 +632,41 @@ class HipKernels(_BNPoolMixin):
                       0 if x_coef is None else _ptr(x_coef), int(bool(x_relu)), _ptr(dw), _ptr(ws),
                       need, _stream(dy))
 
+    def pw_wgrad_bn_supported(self, co, ci, p):
+        return bool(_lib.load().nesie_pw_wgrad_bn_supported(int(co), int(ci), int(p)))
+
+    def pw_wgrad_bn_backward(self, da, z, z_coef, gamma, part, x, dz, dw, dgamma, dbeta, ng=1,
+                             x_coef=None, x_relu=True):
+        """The BatchNorm + ReLU backward's apply pass fused into the weight gradient it feeds
+        (nesie_pw_wgrad_bn_backward): da (NB, co, P) gradient of relu(bn(z)), z raw conv output,
+        z_coef (ng*co, 4), part (ng*co, slots, 2) from ``pw_dgrad_bn_reduce``; x (NB, ci, P) the
+        layer's input with its own folded norm x_coef.  Writes dz (may be da), dw (ng, co, ci),
+        dgamma, dbeta (ng*co)."""
+        _f32(da, z, x, dz, dw, dgamma, dbeta); _check(z_coef, part, dz); _f32(z_coef, part)
+        nb, co, p = da.shape
+        ci = x.shape[1]
+        assert da.is_cuda and tuple(z.shape) == (nb, co, p) == tuple(dz.shape) and x.shape[0] == nb
+        assert x.shape[2] == p and nb % ng == 0 and da.is_contiguous() and z.is_contiguous()
+        assert dw.is_contiguous() and dw.numel() == ng * co * ci
+        assert x.stride(2) == 1 and x.stride(1) == p
+        assert tuple(z_coef.shape) == (ng * co, 4) and part.dim() == 3 and part.shape[0] == ng * co
+        assert dgamma.numel() == ng * co == dbeta.numel()
+        if gamma is not None:
+            _check(gamma); _f32(gamma)
+        if x_coef is not None:
+            _check(x_coef); _f32(x_coef)
+            assert tuple(x_coef.shape) == (ng * ci, 4)
+        lib = _lib.load()
+        need = lib.nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p)
+        with torch.cuda.device(da.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=da.device)
+            cws = torch.empty(ng * co, 8, dtype=torch.float32, device=da.device)
+            _lib.call("nesie_pw_wgrad_bn_backward", nb, ng, co, ci, p, _ptr(da), _ptr(z), co * p,
+                      _ptr(z_coef), 0 if gamma is None else _ptr(gamma), _ptr(part), part.shape[1],
+                      _ptr(x), x.stride(0) if nb > 1 else ci * p, 0 if x_coef is None else _ptr(x_coef),
+                      int(bool(x_relu)), _ptr(dz), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _ptr(cws),
+                      _ptr(ws), need, _stream(da))
+
     @staticmethod
     def conv_wgrad_supported(cout, cin):
         return (cout <= 128 and cin <= 288) or (cout <= 256 and cin <= 128)

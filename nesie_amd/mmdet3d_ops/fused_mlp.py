@@ -73,6 +73,33 @@ def _wgrad(backend, dy, x, x_coef, ng=1):
     return torch.stack(out)
 
 
+# NESIE_FOLD_NORM_BWD=0: A/B switch -- the BatchNorm + ReLU backward's apply pass runs as its own
+# launch (nesie_bn_relu_backward_apply) in front of the weight gradient instead of inside it
+FOLD_NORM_BWD = _os.environ.get('NESIE_FOLD_NORM_BWD', '1') != '0'
+
+
+def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1):
+    """The backward of relu(bn(z)) given da (its gradient) and the reduction partials the
+    input-gradient launch left, and the weight gradient dz . act(src)^T of the conv that produced z:
+    -> (dz, dw | None, dgamma, dbeta).  One launch where the layer kernel's weight gradient serves
+    the shape (``nesie_pw_wgrad_bn_backward``: dz is formed on the operand load and written over
+    da), the apply pass + ``_wgrad`` otherwise."""
+    nb, co, p = da.shape
+    ci = src.shape[1]
+    dgamma, dbeta = da.new_empty(ng * co), da.new_empty(ng * co)
+    if FOLD_NORM_BWD and need_w and backend.pw_wgrad_bn_supported(co, ci, p):
+        dw = da.new_empty(ng, co, ci)
+        backend.pw_wgrad_bn_backward(da, z, coef, gamma, part, src, da, dw, dgamma, dbeta, ng=ng,
+                                     x_coef=src_coef)
+        return da, dw, dgamma, dbeta
+    dz = torch.empty_like(da)
+    b = nb // ng
+    backend.bn_relu_backward_apply(da.view(b, ng * co, p), z.view(b, ng * co, p), gamma, None, coef, part,
+                                   dz.view(b, ng * co, p), dgamma, dbeta)
+    dw = _wgrad(backend, dz, src, src_coef, ng=ng) if need_w else None
+    return dz, dw, dgamma, dbeta
+
+
 class SAStackFn(Function):
     """x (B, C0, M, ns) -> max_ns relu(bn_L(conv_L(... relu(bn_1(conv_1(x)))))) (B, C_L, M).
     ``fixed_lead`` = number of leading input channels that are inputs of the step (grouped
@@ -148,13 +175,21 @@ class SAStackFn(Function):
                                          dy.view(B, cl, M, ns), dgamma, dbeta)
         grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dgamma, dbeta
         dx = None
+        pending = None          # (da, part) of the layer whose norm backward has not been applied yet
         for l in range(L - 1, -1, -1):
             w = params[3 * l]
             cout, cin = w.shape[0], w.shape[1]
             w2 = w.reshape(cout, cin)
             src = x3 if l == 0 else ys[l - 1]
             src_coef = None if l == 0 else coefs[l - 1]
-            if ctx.needs_input_grad[3 + 3 * l]:
+            need_w = ctx.needs_input_grad[3 + 3 * l]
+            if pending is not None:     # norm backward of this layer, with its weight gradient
+                dy, dw, dgamma, dbeta = _norm_backward_wgrad(backend, pending[0], ys[l], params[3 * l + 1],
+                                                             coefs[l], pending[1], src, src_coef, need_w)
+                grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+                if dw is not None:
+                    grads[3 * l] = dw.view_as(w)
+            elif need_w:
                 grads[3 * l] = _wgrad(backend, dy, src, src_coef).view_as(w)
             if l == 0:
                 if ctx.needs_input_grad[0]:
@@ -172,15 +207,10 @@ class SAStackFn(Function):
                     else:
                         dx = torch.bmm(w2.t().unsqueeze(0).expand(B, -1, -1), dy)
                 break
-            # gradient of the previous layer's activation, then through its BatchNorm + ReLU
+            # gradient of the previous layer's activation (+ the reduction of its norm backward)
             da = dy.new_empty(B, cin, P)
             part = backend.pw_dgrad_bn_reduce(dy, w2.t().unsqueeze(0), ys[l - 1], coefs[l - 1], da)
-            dyp = torch.empty_like(da)
-            dgamma, dbeta = g.new_empty(cin), g.new_empty(cin)
-            backend.bn_relu_backward_apply(da, ys[l - 1], params[3 * (l - 1) + 1], None,
-                                           coefs[l - 1], part, dyp, dgamma, dbeta)
-            grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dgamma, dbeta
-            dy = dyp
+            pending = (da, part)
         if dx is not None:
             dx = dx.view(B, c0, M, ns)
         return (dx, None, None) + tuple(grads)
@@ -636,12 +666,20 @@ class Stack1dFn(Function):
             if b is not None and need[3 + slots[-1]['b']]:
                 grads[slots[-1]['b']] = dz.view(B, S * cl, P).sum((0, 2)) 
         dx = None
+        pending = None          # (da, part) of the layer whose norm backward has not been applied yet
         for l in range(L - 1, -1, -1):
             w = per_layer[l][0]
             cout, cin = w.shape[1], w.shape[2]
             src = x if l == 0 else ys[l - 1]
             src_coef = None if l == 0 else coefs[l - 1]
-            if need[3 + slots[l]['w']]:
+            need_w = need[3 + slots[l]['w']]
+            if pending is not None:     # norm backward of this layer, with its weight gradient
+                dz, dw, dgamma, dbeta = _norm_backward_wgrad(backend, pending[0], ys[l], per_layer[l][2], coefs[l],
+                                                             pending[1], src, src_coef, need_w, ng=S)
+                grads[slots[l]['g']], grads[slots[l]['g'] + 1] = dgamma, dbeta
+                if dw is not None:
+                    grads[slots[l]['w']] = dw
+            elif need_w:
                 grads[slots[l]['w']] = _wgrad(backend, dz, src, src_coef, ng=S)
             if l == 0:
                 if need[0]:
@@ -651,16 +689,10 @@ class Stack1dFn(Function):
                     else:
                         dx = torch.matmul(w.transpose(1, 2).unsqueeze(0), dz.view(B, S, cout, P)).view(NB, cin, P)
                 break
-            # gradient of the previous layer's activation, then through its norm + ReLU
-            pw, pb, pgamma, pbeta = per_layer[l - 1]
+            # gradient of the previous layer's activation (+ the reduction of its norm backward)
             da = dz.new_empty(NB, cin, P)
             part = backend.pw_dgrad_bn_reduce(dz, w.transpose(1, 2), ys[l - 1], coefs[l - 1], da, ng=S)
-            dzp = torch.empty_like(da)
-            dgamma, dbeta = dz.new_empty(S * cin), dz.new_empty(S * cin)
-            backend.bn_relu_backward_apply(da.view(B, S * cin, P), ys[l - 1].view(B, S * cin, P), pgamma,
-                                           None, coefs[l - 1], part, dzp.view(B, S * cin, P), dgamma, dbeta)
-            grads[slots[l - 1]['g']], grads[slots[l - 1]['g'] + 1] = dgamma, dbeta
-            dz = dzp
+            pending = (da, part)
         return (dx, None, None) + tuple(grads)
 
 

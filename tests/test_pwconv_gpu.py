@@ -294,6 +294,59 @@ def test_layer_weight_gradient_matches_fp64(nb, ng, co, ci, p):
         assert (dw.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('nb,ng,co,ci,p,in_place', [(6, 3, 128, 256, 256, False), (4, 1, 256, 128, 512, True),
+                                                     (4, 2, 128, 128, 256, True), (2, 1, 64, 67, 1024, False),
+                                                     (3, 1, 100, 70, 96, True), (2, 1, 128, 320, 128, False)])
+def test_weight_gradient_fused_with_the_norm_backward(nb, ng, co, ci, p, in_place):
+    """nesie_pw_wgrad_bn_backward = nesie_bn_relu_backward_apply + nesie_pw_wgrad in one pass over
+    (dA, Z): dZ (written, optionally over dA), dW, dgamma, dbeta against float64."""
+    hip = _hip()
+    assert hip.pw_wgrad_bn_supported(co, ci, p)
+    g = torch.Generator(device=_dev()).manual_seed(co + 7 * ci + ng)
+    da = torch.randn(nb, co, p, device=_dev(), generator=g)
+    z = torch.randn(nb, co, p, device=_dev(), generator=g) * 1.5 + 0.7
+    x_all = torch.randn(nb, ci + 3, p, device=_dev(), generator=g)
+    x = x_all[:, 3:]
+    gamma = torch.randn(ng * co, device=_dev(), generator=g)
+    beta = torch.randn(ng * co, device=_dev(), generator=g) * 0.3
+    xcoef = torch.rand(ng * ci, 4, device=_dev(), generator=g) + 0.5
+    xcoef[:, 1] -= 1.0
+    grp = torch.arange(nb, device=_dev()) % ng
+    # the layer's own forward statistics and folded coefficients, per weight group
+    zd = z.double().view(nb // ng, ng, co, p)
+    mean = zd.mean((0, 3))
+    invstd = (zd.var((0, 3), unbiased=False) + 1e-5).rsqrt()                 # (ng, co)
+    scale = gamma.double().view(ng, co) * invstd
+    shift = beta.double().view(ng, co) - mean * scale
+    zcoef = torch.stack([scale, shift, mean, invstd], -1).view(ng * co, 4).float().contiguous()
+    zc = zcoef.double().view(ng, co, 4)
+    mask = (torch.addcmul(zcoef[:, 1].view(ng, co)[grp].unsqueeze(-1), z, zcoef[:, 0].view(ng, co)[grp].unsqueeze(-1)) > 0)
+    gg = torch.where(mask, da, torch.zeros_like(da)).double()
+    zhat = (z.double() - zc[grp][:, :, 2:3]) * zc[grp][:, :, 3:4]
+    s0 = gg.view(nb // ng, ng, co, p).sum((0, 3))
+    s1 = (gg * zhat).view(nb // ng, ng, co, p).sum((0, 3))
+    n = nb // ng * p
+    a = gamma.double().view(ng, co) * zc[:, :, 3]
+    dz_ref = a[grp].unsqueeze(-1) * (gg - (s0 / n)[grp].unsqueeze(-1) - zhat * (s1 / n)[grp].unsqueeze(-1))
+    part = torch.stack([s0, s1], -1).view(ng * co, 1, 2).float().contiguous()   # one slot per channel
+    for use_coef in (True, False):
+        xd = x.double()
+        if use_coef:
+            c = xcoef.double().view(ng, ci, 4)[grp]
+            xd = (xd * c[:, :, 0:1] + c[:, :, 1:2]).clamp_min(0)
+        dw_ref = torch.bmm(dz_ref, xd.transpose(1, 2)).view(nb // ng, ng, co, ci).sum(0)
+        src = da.clone()
+        dz = src if in_place else torch.empty_like(da)
+        dw = torch.empty(ng, co, ci, device=_dev())
+        dgamma, dbeta = torch.empty(ng * co, device=_dev()), torch.empty(ng * co, device=_dev())
+        hip.pw_wgrad_bn_backward(src, z, zcoef, gamma, part, x, dz, dw, dgamma, dbeta, ng=ng,
+                                 x_coef=xcoef if use_coef else None)
+        assert (dz.double() - dz_ref).abs().max().item() < 2e-5 * dz_ref.abs().max().item()
+        assert (dw.double() - dw_ref).abs().max().item() < 1e-4 * dw_ref.abs().max().item()
+        torch.testing.assert_close(dgamma.double(), s1.view(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(dbeta.double(), s0.view(-1), rtol=1e-5, atol=1e-4)
+
+
 def _sa_module(c_in, mlp, ns):
     from nesie_amd.mmdet3d_ops import PointSAModule
     torch.manual_seed(0)

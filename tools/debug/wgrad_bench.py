@@ -37,3 +37,38 @@ for nb, ng, co, ci, p, aff in [(48, 6, 128, 256, 8192, True), (48, 6, 256, 128, 
         want[n % ng] += dy[n].double() @ a.t()
     err = float((dw.double() - want).abs().max() / want.abs().max())
     print((nb, ng, co, ci, p, aff), f'{ms:.4f} ms  {2 * nb * co * ci * p / ms / 1e9:.1f} TFLOP/s  rel err {err:.2e}')
+
+print('---- fused norm backward + weight gradient vs the two separate launches')
+for nb, ng, co, ci, p in [(48, 6, 128, 256, 8192), (48, 6, 256, 128, 8192), (8, 1, 64, 64, 131072),
+                          (8, 1, 128, 128, 65536), (8, 1, 128, 256, 32768)]:
+    g = torch.Generator(device=dev).manual_seed(1)
+    da = torch.randn(nb, co, p, device=dev, generator=g)
+    z = torch.randn(nb, co, p, device=dev, generator=g)
+    x = torch.randn(nb, ci, p, device=dev, generator=g)
+    xcoef = torch.rand(ng * ci, 4, device=dev, generator=g) + 0.5
+    zcoef = torch.rand(ng * co, 4, device=dev, generator=g) + 0.5
+    gamma = torch.randn(ng * co, device=dev, generator=g)
+    part = torch.randn(ng * co, 512, 2, device=dev, generator=g)
+    dz = torch.empty_like(da)
+    dw = torch.empty(ng, co, ci, device=dev)
+    dg, db = torch.empty(ng * co, device=dev), torch.empty(ng * co, device=dev)
+
+    def separate():
+        hip.bn_relu_backward_apply(da.view(nb // ng, ng * co, p), z.view(nb // ng, ng * co, p), gamma, None, zcoef,
+                                   part, dz.view(nb // ng, ng * co, p), dg, db)
+        hip.pw_wgrad(dz, x, dw, ng=ng, x_coef=xcoef, x_relu=True)
+
+    def fused():
+        hip.pw_wgrad_bn_backward(da, z, zcoef, gamma, part, x, dz, dw, dg, db, ng=ng, x_coef=xcoef)
+    res = []
+    for fn in (separate, fused):
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        res.append(s.elapsed_time(e) / 20)
+    print((nb, ng, co, ci, p), f'separate {res[0]:.4f} ms  fused {res[1]:.4f} ms')
