@@ -67,6 +67,25 @@ int nesie_head_loss_forward(int b, int k, int t, int c, const float *cls, const 
                             float *s_side_iou, float *s_side_pred, int *sem_pick, int *kstar,
                             float *dmin, float *partial, int *ticket, void *stream);
 
+/* The unsupervised variant (NesieHead.unsup_loss, nesie_head.py:415-509; SAQEHead.unsup_loss,
+ * saqe_head.py:706-800): the same kernel with quality (B*K, 6) = the pseudo label's six side
+ * qualities gathered per proposal (zeros for padding).  Semantic and centre terms as above; the
+ * surface term of side i is weighted box_w * quality[i], the IoU term box_w * mean(quality); the
+ * objectness, IoU-quality and side-quality terms are not part of this loss (their outputs and saved
+ * gradients are zero).  detach_sigma != 0: the uncertainties are constants (SAQE: sigma.detach()).
+ * The caller applies the reference's un_label_weight (2.0).  Outputs and scratch as above;
+ * nesie_head_loss_backward serves both. */
+int nesie_head_loss_forward_unsup(int b, int k, int t, int c, const float *cls, const float *bbox,
+                                  const float *surface, const float *side, const float *iou_s,
+                                  const float *iou, const float *quality, int detach_sigma,
+                                  const long long *obj_t, const long long *label, const float *obj_w,
+                                  const float *box_w, const float *bbox_t, const float *centre_t,
+                                  const float *valid_w, const float *config, float *loss,
+                                  float *s_cls, float *s_centre, float *s_surface, float *s_iou,
+                                  float *s_iou_s, float *s_side_surf, float *s_side_iou,
+                                  float *s_side_pred, int *sem_pick, int *kstar, float *dmin,
+                                  float *partial, int *ticket, void *stream);
+
 /* Gradient assembly: the saved per-term gradients times the incoming gradients g[7] (device) of
  * the seven terms, in the producers' layouts: d_cls (B,2+C,K), d_bbox (B,K,7) (size and yaw
  * columns zero), d_surface, d_iou (B*K), d_iou_s (B,2K,C), d_side (6,B,C,2K) which must arrive

@@ -125,7 +125,15 @@ struct HeadLoss {
   float *dmin;             // (B*T) scratch
   float *partial;          // (workgroups, 8) scratch
   int *ticket;             // zero before the first launch; the kernel leaves it zero
+  // the unsupervised variant (NesieHead.unsup_loss, nesie_head.py:415-509; SAQEHead's, saqe_head.py:706-800):
+  // quality (B*K, 6) = the pseudo label's side qualities gathered per proposal: the surface term of
+  // side i is weighted box_w * quality[i], the IoU term box_w * mean(quality); HL_UNSUP drops the
+  // objectness, IoU-quality and side-quality terms; HL_DETACH_SIGMA treats the uncertainties as
+  // constants (no gradient into the side scores)
+  const float *quality;
+  int flags;
 };
+enum { HL_UNSUP = 1, HL_DETACH_SIGMA = 2 };
 
 __device__ __forceinline__ float hl_log_clamped(float v) { return fmaxf(logf(v), -100.f); }
 
@@ -170,8 +178,9 @@ __global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
       const float e0 = expf(z0 - m), e1 = expf(z1 - m), s = e0 + e1;
       const float lse = m + logf(s);
       const float cw = y ? a.cw1 : a.cw0;
-      l_obj += a.w_obj * ((-cw * ((y ? z1 : z0) - lse)) * ow);
-      const float gsc = a.w_obj * ow * cw;
+      const bool on = !(a.flags & HL_UNSUP);
+      l_obj += on ? a.w_obj * ((-cw * ((y ? z1 : z0) - lse)) * ow) : 0.f;
+      const float gsc = on ? a.w_obj * ow * cw : 0.f;
       dzp[0] = gsc * (e0 / s - (y ? 0.f : 1.f));
       dzp[K] = gsc * (e1 / s - (y ? 1.f : 0.f));
     }
@@ -226,7 +235,16 @@ __global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
       sig_mean += sig[i];
     }
     sig_mean = sig_mean / 6.f;
+    const bool unsup = (a.flags & HL_UNSUP) != 0, keep_sigma = !(a.flags & HL_DETACH_SIGMA);
+    float qmean = 1.f;
+    if (a.quality) {
+      qmean = 0.f;
+      for (int i = 0; i < 6; ++i) qmean += a.quality[p * 6 + i];
+      qmean = qmean / 6.f;
+    }
     for (int i = 0; i < 6; ++i) {
+      const float w_box = w;                       // (the side-quality term keeps the plain weight)
+      const float w = a.quality ? w_box * a.quality[p * 6 + i] : w_box;
       const float half = 0.5f * tb[3 + i % 3];
       const float ts = i < 3 ? tb[i] - half : tb[i - 3] + half;
       const float sp = a.surface[p * 6 + i];
@@ -235,21 +253,22 @@ __global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
       const float ex = expf(-sig[i]);
       l_surf += ex * l + a.alpha * sig[i] * w;
       a.s_surface[p * 6 + i] = ex * (a.w_surf * (2.f * e) * w);
-      a.s_side_surf[p * 6 + i] = (-ex * l + a.alpha * w) * dsig_ds[i];
+      a.s_side_surf[p * 6 + i] = keep_sigma ? (-ex * l + a.alpha * w) * dsig_ds[i] : 0.f;
       // side quality: label = min(1, 4 |error|), squared error of the assigned class's score
       const float lbl = fminf(4.f * fabsf(e), 1.f);
       const float sc = a.side[(((size_t)i * a.b + bi) * C + lab) * side_k + kk];
       const float r = sc - lbl;
-      l_side += a.w_side * ((r * r) * w);
-      a.s_side_pred[p * 6 + i] = a.w_side * (2.f * r) * w;
+      l_side += unsup ? 0.f : a.w_side * ((r * r) * w_box);
+      a.s_side_pred[p * 6 + i] = unsup ? 0.f : a.w_side * (2.f * r) * w_box;
     }
     // -- IoU regression under the mean uncertainty
     {
-      const float li = a.w_iou * ((w > 0.f ? 1.f - a.iou[p] : 0.f) * w);
+      const float wq = a.quality ? w * qmean : w;
+      const float li = a.w_iou * ((wq > 0.f ? 1.f - a.iou[p] : 0.f) * wq);
       const float ex = expf(-sig_mean);
-      l_iou += ex * li + a.alpha * sig_mean * w;
-      a.s_iou[p] = ex * (a.w_iou * (w > 0.f ? -1.f : 0.f) * w);
-      const float dmean = (-ex * li + a.alpha * w) / 6.f;
+      l_iou += ex * li + a.alpha * sig_mean * wq;
+      a.s_iou[p] = ex * (a.w_iou * (wq > 0.f ? -1.f : 0.f) * wq);
+      const float dmean = keep_sigma ? (-ex * li + a.alpha * wq) / 6.f : 0.f;
       for (int i = 0; i < 6; ++i) a.s_side_iou[p * 6 + i] = dmean * dsig_ds[i];
     }
     // -- IoU prediction: quality focal loss on probabilities, plain and jittered halves
@@ -259,6 +278,10 @@ __global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
       float *dp = a.s_iou_s + row;
       const float score = hj ? a.iou_j[p] : a.iou[p];
       float acc = 0.f;
+      if (unsup) {
+        for (int j = 0; j < C; ++j) dp[j] = 0.f;
+        continue;
+      }
       for (int j = 0; j < C; ++j) {
         const float q = pr[j];
         const float den = fmaxf((1.f - q) * q, 1e-12f);
@@ -365,7 +388,8 @@ extern "C" int nesie_head_targets(int b, int k, int t, const float *agg, const f
   return check_launch(W);
 }
 
-extern "C" int nesie_head_loss_forward(
+static int head_loss_forward_impl(
+    const char *W, const float *quality, int flags,
     int b, int k, int t, int c, const float *cls, const float *bbox, const float *surface,
     const float *side, const float *iou_s, const float *iou, const float *iou_j,
     const long long *obj_t, const long long *label, const float *obj_w, const float *box_w,
@@ -374,7 +398,6 @@ extern "C" int nesie_head_loss_forward(
     float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
     float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
     void *stream) {
-  const char *W = "head_loss_forward";
   NESIE_REQUIRE(b >= 0 && k >= 1 && t >= 1 && c >= 1 && c <= HL_MAXC, W);
   if (b == 0) return NESIE_OK;
   NESIE_REQUIRE(cls && bbox && surface && side && iou_s && iou && iou_j && obj_t && label && obj_w &&
@@ -396,10 +419,44 @@ extern "C" int nesie_head_loss_forward(
   a.s_iou_s = s_iou_s; a.s_side_surf = s_side_surf; a.s_side_iou = s_side_iou;
   a.s_side_pred = s_side_pred; a.sem_pick = sem_pick; a.kstar = kstar; a.dmin = dmin;
   a.partial = partial; a.ticket = ticket;
+  a.quality = quality; a.flags = flags;
   hipLaunchKernelGGL(head_loss_nearest_kernel, dim3((b * t + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(head_loss_kernel, dim3((b * k + HL_PB - 1) / HL_PB), dim3(HL_PB), 0,
                      (hipStream_t)stream, a);
   return check_launch(W);
+}
+
+extern "C" int nesie_head_loss_forward(
+    int b, int k, int t, int c, const float *cls, const float *bbox, const float *surface,
+    const float *side, const float *iou_s, const float *iou, const float *iou_j,
+    const long long *obj_t, const long long *label, const float *obj_w, const float *box_w,
+    const float *bbox_t, const float *centre_t, const float *valid_w,
+    const float *config /* [11] */, float *loss, float *s_cls, float *s_centre,
+    float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
+    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
+    void *stream) {
+  return head_loss_forward_impl("head_loss_forward", nullptr, 0, b, k, t, c, cls, bbox, surface, side, iou_s,
+                                iou, iou_j, obj_t, label, obj_w, box_w, bbox_t, centre_t, valid_w, config,
+                                loss, s_cls, s_centre, s_surface, s_iou, s_iou_s, s_side_surf, s_side_iou,
+                                s_side_pred, sem_pick, kstar, dmin, partial, ticket, stream);
+}
+
+extern "C" int nesie_head_loss_forward_unsup(
+    int b, int k, int t, int c, const float *cls, const float *bbox, const float *surface,
+    const float *side, const float *iou_s, const float *iou, const float *quality /* (B*K, 6) */,
+    int detach_sigma, const long long *obj_t, const long long *label, const float *obj_w,
+    const float *box_w, const float *bbox_t, const float *centre_t, const float *valid_w,
+    const float *config /* [11] */, float *loss, float *s_cls, float *s_centre,
+    float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
+    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
+    void *stream) {
+  const char *W = "head_loss_forward_unsup";
+  NESIE_REQUIRE(b == 0 || quality, W);
+  return head_loss_forward_impl(W, quality, HL_UNSUP | (detach_sigma ? HL_DETACH_SIGMA : 0), b, k, t, c, cls,
+                                bbox, surface, side, iou_s, iou, iou, obj_t, label, obj_w, box_w, bbox_t,
+                                centre_t, valid_w, config, loss, s_cls, s_centre, s_surface, s_iou, s_iou_s,
+                                s_side_surf, s_side_iou, s_side_pred, sem_pick, kstar, dmin, partial, ticket,
+                                stream);
 }
 
 extern "C" int nesie_head_loss_backward(

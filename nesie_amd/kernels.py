@@ -893,11 +893,13 @@ class HipKernels(_BNPoolMixin):
                       _ptr(out['valid_weights']), _stream(agg))
         return out
 
-    def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config, ticket):
+    def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config, ticket,
+                          quality=None, detach_sigma=False):
         """The seven loss terms + their saved gradients (nesie_head_loss_forward).  cls
         (B,2+C,K), bbox (B,K,7), surface (B,K,6), side (6,B,C,2K), iou_s (B,2K,C), iou / iou_j
         (B*K); tg = head_targets(...); config = 11 python floats; ticket = a zeroed int32 scalar
-        that lives outside any graph capture (the kernel leaves it zero).  -> (loss (7,), saved dict)."""
+        that lives outside any graph capture (the kernel leaves it zero).  -> (loss (7,), saved dict).
+        quality (B*K, 6): the unsupervised variant (nesie_head_loss_forward_unsup; iou_j unused)."""
         _check(cls, bbox, surface, side, iou_s, iou, iou_j)
         _f32(cls, bbox, surface, side, iou_s, iou, iou_j)
         b, nc, k = cls.shape
@@ -916,9 +918,16 @@ class HipKernels(_BNPoolMixin):
         partial = f32((b * k + 63) // 64, 8)
         assert ticket.dtype == torch.int32 and ticket.is_cuda and ticket.numel() == 1
         cfg = (ctypes.c_float * 11)(*[float(v) for v in config])
+        if quality is not None:
+            _check(quality); _f32(quality)
+            assert quality.numel() == b * k * 6
+            head = ("nesie_head_loss_forward_unsup", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
+                    _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(quality), int(bool(detach_sigma)))
+        else:
+            head = ("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
+                    _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(iou_j))
         with torch.cuda.device(dev):
-            _lib.call("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
-                      _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(iou_j), _ptr(tg['obj_targets']),
+            _lib.call(*head, _ptr(tg['obj_targets']),
                       _ptr(tg['mask_targets']), _ptr(tg['obj_weights']), _ptr(tg['box_weights']),
                       _ptr(tg['bbox_targets']), _ptr(tg['center_targets']),
                       _ptr(tg['valid_weights']), ctypes.cast(cfg, ctypes.c_void_p), _ptr(loss),

@@ -34,11 +34,14 @@ class HeadLossFn(Function):
     and not seven zero-padded vectors)."""
 
     @staticmethod
-    def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config, ticket):
+    def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config, ticket,
+                quality=None, detach_sigma=False):
+        """quality (B, K, 6): the unsupervised variant -- semantic, centre, surface and IoU terms
+        with the pseudo labels' side qualities in the weights, the other three terms zero."""
         backend = backend_for(cls)
         loss, saved = backend.head_loss_forward(cls, bbox, surface, side_all, iou_all,
                                                 iou.reshape(-1), iou_j.reshape(-1), targets, config,
-                                                ticket)
+                                                ticket, quality=quality, detach_sigma=detach_sigma)
         ctx.saved, ctx.label, ctx.k, ctx.iou_shape = saved, targets['mask_targets'], bbox.shape[1], iou.shape
         return tuple(loss.unbind(0))
 
@@ -49,7 +52,7 @@ class HeadLossFn(Function):
         backend = backend_for(g)
         d = backend.head_loss_backward(g, ctx.label, ctx.saved, ctx.k)
         return (d['cls'], d['bbox'], d['surface'], d['side'], d['iou_s'],
-                d['iou'].view(ctx.iou_shape), None, None, None, None)
+                d['iou'].view(ctx.iou_shape), None, None, None, None, None, None)
 
 
 def config_of(head):
@@ -75,9 +78,24 @@ def config_of(head):
             q.loss_weight, sd.loss_func.loss_weight]
 
 
-def usable(head, bbox_preds):
-    """True when ``NesieHead.loss`` can take the fused path for these predictions."""
-    if not ENABLED or type(head).__name__ != 'NesieHead':
+def unsup_config_of(head):
+    """The scalars the unsupervised variant reads (semantic, centre, surface, IoU), or None."""
+    from . import losses as L
+    s, c, su, io = head.semantic_loss, head.center_loss, head.surface_loss, head.iou_loss
+    ok = (isinstance(s, L.CrossEntropyLoss) and s.reduction == 'sum' and s.class_weight is None
+          and isinstance(c, L.ChamferDistance) and c.mode == 'l2' and c.reduction == 'sum'
+          and isinstance(su, L.SurfaceLoss) and su.func_type == 'MSELoss'
+          and isinstance(io, L.IoU3DLoss))
+    if not ok:
+        return None
+    return [head.alpha, 0.0, 0.0, 0.0, s.loss_weight, c.loss_src_weight, c.loss_dst_weight,
+            su.loss_func.loss_weight, io.loss_weight, 0.0, 0.0]
+
+
+def usable(head, bbox_preds, unsup=False):
+    """True when ``NesieHead.loss`` (``unsup``: ``unsup_loss``, also of a subclass) can take the
+    fused path for these predictions."""
+    if not ENABLED or (type(head).__name__ != 'NesieHead' and not unsup):
         return False
     need = ('_cls_all', '_side_all', '_iou_all')
     if any(k not in bbox_preds for k in need):
@@ -90,7 +108,7 @@ def usable(head, bbox_preds):
     return (cls.shape[0] == B and cls.shape[2] == K and C <= 32
             and tuple(bbox_preds['_side_all'].shape) == (6, B, C, 2 * K)
             and tuple(bbox_preds['_iou_all'].shape) == (B, 2 * K, C)
-            and config_of(head) is not None)
+            and (unsup_config_of(head) if unsup else config_of(head)) is not None)
 
 
 class VoteLossFn(Function):

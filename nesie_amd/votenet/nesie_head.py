@@ -522,6 +522,8 @@ class NesieHead(nn.Module):
                 else:
                     quality.append(torch.zeros(num_proposal, 6, device=assignment.device))
             pseudo_quality_side = torch.stack(quality)
+        if head_loss.usable(self, bbox_preds, unsup=True):
+            return self._fused_unsup_loss(bbox_preds, targets, pseudo_quality_side)
         pseudo_quality_mean = pseudo_quality_side.mean(dim=-1)
 
         s2t, t2s = self.center_loss(bbox_preds['bbox_preds'][..., :3], center_targets,
@@ -554,6 +556,30 @@ class NesieHead(nn.Module):
                     unsup_center_loss=un_label_weight * unsup_center_loss,
                     unsup_iou_loss=un_label_weight * unsup_iou_loss,
                     unsup_surface_loss=un_label_weight * unsup_surface_loss)
+
+    def _fused_unsup_loss(self, bbox_preds, targets, pseudo_quality_side):
+        """The four terms in one launch (``head_loss.HeadLossFn`` with the side qualities); the
+        rotated-IoU evaluation stays."""
+        (_, _, center_targets, bbox_targets, mask_targets, _, objectness_targets,
+         objectness_weights, box_loss_weights, valid_gt_weights, _) = targets
+        boxes = bbox_preds['bbox_preds']
+        iou = cal_iou_3d(boxes, bbox_targets)                              # (B, K), with gradient
+        tg = dict(obj_targets=objectness_targets, mask_targets=mask_targets,
+                  obj_weights=objectness_weights, box_weights=box_loss_weights,
+                  bbox_targets=bbox_targets, center_targets=center_targets,
+                  valid_weights=valid_gt_weights)
+        terms = dict(zip(head_loss.TERMS, head_loss.HeadLossFn.apply(
+            bbox_preds['_cls_all'].contiguous(), boxes.contiguous(),
+            bbox_preds['surface_pred'].contiguous(), bbox_preds['_side_all'].contiguous(),
+            bbox_preds['_iou_all'].contiguous(), iou, iou.detach(), tg,
+            head_loss.unsup_config_of(self), self._loss_ticket,
+            pseudo_quality_side.to(boxes.dtype).contiguous(),
+            bool(getattr(self, '_sigma_is_constant', False)))))
+        un_label_weight = 2.0
+        return dict(unsup_semantic_loss=un_label_weight * terms['semantic_loss'],
+                    unsup_center_loss=un_label_weight * terms['center_loss'],
+                    unsup_iou_loss=un_label_weight * terms['iou_loss'],
+                    unsup_surface_loss=un_label_weight * terms['surface_loss'])
 
     # ---- targets (:511-679), batched on the device ------------------------------
     @staticmethod

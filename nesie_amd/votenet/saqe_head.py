@@ -224,9 +224,11 @@ class SAQEHead(NesieHead):
         alpha, self.alpha = self.alpha, 0.0
         sig = self._sigma
         self._sigma = lambda bp: sig(bp).detach()
+        self._sigma_is_constant = True        # (read by the fused form, NesieHead._fused_unsup_loss)
         try:
             return super().unsup_loss(bbox_preds, points, pseudo_boxes, pseudo_label, img_metas,
                                       pseudo_quality_score)
         finally:
             self.alpha = alpha
             del self._sigma
+            del self._sigma_is_constant

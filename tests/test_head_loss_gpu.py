@@ -59,6 +59,74 @@ def test_fused_loss_matches_the_module_by_module_loss(hip_device, thresholds):
     assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-4
 
 
+def _run_unsup(model, pts, boxes, labels, quality, fused):
+    head_loss.ENABLED = fused
+    try:
+        for p in model.parameters():
+            p.grad = None
+        preds = model.bbox_head(model.extract_feat(pts), 'vote')
+        keep = {}
+        for k in ('_cls_all', 'bbox_preds', 'surface_pred', '_side_all', '_iou_all'):
+            preds[k].retain_grad()
+            keep[k] = preds[k]
+        assert head_loss.usable(model.bbox_head, preds, unsup=True) == fused
+        gt = GTBatch.collate(boxes, labels, pts.device)
+        losses = model.bbox_head.unsup_loss(preds, pts, gt, None, None, quality)
+        w = dict(unsup_semantic_loss=1.3, unsup_center_loss=0.9, unsup_iou_loss=0.8, unsup_surface_loss=1.1)
+        sum(losses[k] * w[k] for k in losses).backward()
+        return ({k: v.detach().clone() for k, v in losses.items()},
+                {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v)) for k, v in keep.items()},
+                _small.grads_of(model))
+    finally:
+        head_loss.ENABLED = True
+
+
+@pytest.mark.parametrize('kind', ['nesie', 'saqe'])
+def test_fused_unsupervised_loss_matches_the_module_by_module_loss(hip_device, kind):
+    """NesieHead.unsup_loss (nesie_head.py:415-509) and SAQEHead.unsup_loss (saqe_head.py:706-800:
+    alpha 0, detached uncertainties) through nesie_head_loss_forward_unsup: the four terms, the
+    gradients at the head's outputs and every parameter gradient; pseudo labels = the ground truth
+    with seeded side qualities, one scene without any pseudo box."""
+    if kind == 'saqe':
+        from nesie_amd.votenet.detector import build_saqe_votenet, saqe_votenet_scannet_cfg
+        cfg, scfg = _small.small_cfg(), saqe_votenet_scannet_cfg()
+        cfg['bbox_head'].update(angle_loss=scfg['bbox_head']['angle_loss'],
+                                angle_pred_loss=scfg['bbox_head']['angle_pred_loss'])
+        cfg['head_type'] = 'SAQEHead'
+        torch.manual_seed(0)
+        model = build_saqe_votenet(cfg)
+        assert type(model.bbox_head).__name__ == 'SAQEHead'
+    else:
+        model = _small.small_model()
+    model = model.to(hip_device).train()
+    model.train_cfg['pos_distance_thr'], model.train_cfg['neg_distance_thr'] = 1.0, 1.5
+    model.bbox_head.train_cfg = model.train_cfg
+    pts, boxes, labels = _small.small_batch(batch=3)
+    boxes[1], labels[1] = boxes[1][:0], labels[1][:0]
+    pts = pts.to(hip_device)
+    model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(3, 32))
+    T = max(b.shape[0] for b in boxes)
+    g = torch.Generator().manual_seed(11)
+    quality = torch.zeros(3, max(T, 1), 6)
+    for i, b in enumerate(boxes):
+        quality[i, :b.shape[0]] = torch.rand(b.shape[0], 6, generator=g)
+    quality = quality.to(hip_device)
+    want = _run_unsup(model, pts, boxes, labels, quality, False)
+    got = _run_unsup(model, pts, boxes, labels, quality, True)
+    assert list(got[0]) == list(want[0]) and len(want[0]) == 4
+    for k in want[0]:
+        assert want[0][k].abs().item() > 0, k
+        torch.testing.assert_close(got[0][k], want[0][k], rtol=2e-5, atol=1e-6, msg=k)
+    for k in want[1]:
+        scale = want[1][k].abs().max().item()
+        torch.testing.assert_close(got[1][k], want[1][k], rtol=1e-4, atol=2e-5 * max(scale, 1e-6), msg=k)
+    if kind == 'saqe':      # constant uncertainties: nothing reaches the side scores
+        assert float(got[1]['_side_all'].abs().max()) == 0.0 == float(want[1]['_side_all'].abs().max())
+    flat_w = torch.cat([want[2][n].flatten() for n in sorted(want[2])]).double()
+    flat_g = torch.cat([got[2][n].flatten() for n in sorted(want[2])]).double()
+    assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-4
+
+
 def test_targets_kernel_matches_the_tensor_ops(hip_device):
     """nesie_head_targets vs get_targets' tensor-op form: indices exact, weights bit-equal."""
     model = _small.small_model().to(hip_device)
