@@ -540,8 +540,14 @@ def main():
         nb, k, p = dy.shape
         co = w.shape[1]
         return 2.0 * nb * k * co * p, nb * (k + 2 * co) * p * 4, nb * p
+    def wgrad_bn_flop(da, z, z_coef, gamma, part, x, dz, dw, *a, **kw):
+        # the weight gradient with the norm backward's apply pass inside: the SAME algorithmic FLOPs
+        # (the per-element transform is not counted); reads dA, Z, X once, writes dZ once
+        nb, co, p = da.shape
+        return 2.0 * nb * co * x.shape[1] * p, nb * (3 * co + x.shape[1]) * p * 4, nb * p
     gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
-                   GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop))
+                   GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop),
+                   GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop))
     bn_apply_timer = KernelTimer(hip, 'bn_relu_backward_apply', lambda dy, *_: dy.numel() == mid)
     timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer, bn_apply_timer) + gemm_timers
 
@@ -628,6 +634,10 @@ def main():
         # time, summed over every launch of the family in the un-captured steps.
         n_l, ms_l, fl_l, by_l = (a + b for a, b in zip(gemm_timers[0].totals(), gemm_timers[2].totals()))
         n_w, ms_w, fl_w, by_w = gemm_timers[1].totals()
+        # weight-gradient launches that also carry the BatchNorm + ReLU backward's apply pass (dZ formed
+        # on the operand load from (dA, Z) and written once): 4 tensor passes per launch instead of 2,
+        # HBM co-bound -- priced on their own below, and shown inside the family as well
+        n_wf, ms_wf, fl_wf, by_wf = gemm_timers[3].totals()
         if n_l + n_w:
             tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             per_step = lambda v: v / eager_steps  # noqa: E731
@@ -639,7 +649,7 @@ def main():
             if os.path.exists(tpath) and args.workload == 'pretrain' and args.batch == 8:
                 t = json.load(open(tpath))
                 traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
-                           'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w),
+                           'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf),   # (PMC rows include the fused weight-gradient launches)
                            'largest_launch_over_algorithmic': t.get('largest_launch_over_algorithmic'),
                            'source': 'profiles/r03_pmc_hbm_traffic.json', 'measured_in_run': False}
             out['roofline'] = {
@@ -651,8 +661,8 @@ def main():
                 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf / MFMA_F32_PEAK_TFLOPS,
                 'traffic': traffic,
-                'algorithmic_bytes_per_step': per_step(by_l + by_w),
-                'algorithmic_hbm_gbs': (by_l + by_w) / ((ms_l + ms_w) * 1e-3) / 1e9,
+                'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf),   # incl. the fused weight-gradient launches below
+                'algorithmic_hbm_gbs': (by_l + by_w + by_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e9,
                 'launches_per_step': per_step(n_l + n_w),
                 'family_ms_per_step': per_step(ms_l + ms_w),
                 'avg_launch_ms': (ms_l + ms_w) / (n_l + n_w),
@@ -660,10 +670,28 @@ def main():
                 'layer_kernel': {'launches_per_step': per_step(n_l), 'ms_per_step': per_step(ms_l),
                                  'tflops': fl_l / (ms_l * 1e-3) / 1e12 if ms_l else None},
                 'wgrad_kernel': {'launches_per_step': per_step(n_w), 'ms_per_step': per_step(ms_w),
-                                 'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None}}
+                                 'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None},
+                # the same family WITH the fused weight-gradient + norm-backward launches counted as
+                # GEMMs (their streaming half adds time but no FLOPs)
+                'with_fused_norm_backward_launches': {
+                    'launches_per_step': per_step(n_l + n_w + n_wf),
+                    'ms_per_step': per_step(ms_l + ms_w + ms_wf),
+                    'tflops': (fl_l + fl_w + fl_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e12,
+                    'frac': (fl_l + fl_w + fl_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
+            if n_wf:
+                gbs = by_wf / (ms_wf * 1e-3) / 1e9
+                out['roofline_fused_norm_backward'] = {
+                    'kernel': 'nesie::pw_wgrad_kernel<..., BNB> (nesie_pw_wgrad_bn_backward): weight gradient '
+                              'with the BatchNorm + ReLU backward apply pass on its operand load; reads dA, Z, X, '
+                              'writes dZ (replaces bn_bwd_apply_kernel + pw_wgrad_kernel: 5 tensor passes -> 4)',
+                    'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                    'launches_per_step': per_step(n_wf), 'ms_per_step': per_step(ms_wf),
+                    'avg_launch_ms': ms_wf / n_wf, 'algorithmic_bytes_per_launch': by_wf / n_wf,
+                    'tflops': fl_wf / (ms_wf * 1e-3) / 1e12}
             # the same kernels on the 1-D per-seed / per-proposal chains (vote module, prediction
             # trunk, feature propagation, score heads): 8 x 256 .. 1024 positions, launch-bound
-            sn, sms, sfl, _ = (a + b + c for a, b, c in zip(*(t.totals(big=False) for t in gemm_timers)))
+            sn, sms, sfl, _ = (sum(v) for v in zip(*(t.totals(big=False) for t in gemm_timers)))
             if sn:
                 out['roofline_small_layers'] = {
                     'kernel': 'the same kernels on the 1-D chains (fused_mlp.Stack1dFn): P = 256 .. 1024 '
@@ -671,10 +699,10 @@ def main():
                     'bound': 'latency', 'launches_per_step': per_step(sn), 'ms_per_step': per_step(sms),
                     'avg_launch_us': 1e3 * sms / sn, 'tflops': sfl / (sms * 1e-3) / 1e12}
             # the same FLOPs against the whole step (everything that is not a GEMM counts as lost)
-            step_tf = per_step(fl_l + fl_w + sfl) / (ms_per_step * 1e-3) / 1e12
+            step_tf = per_step(fl_l + fl_w + fl_wf + sfl) / (ms_per_step * 1e-3) / 1e12
             out['roofline_step'] = {'bound': 'mfma', 'achieved': step_tf, 'peak': MFMA_F32_PEAK_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': step_tf / MFMA_F32_PEAK_TFLOPS,
-                                    'native_gemm_flop_per_step': per_step(fl_l + fl_w + sfl)}
+                                    'native_gemm_flop_per_step': per_step(fl_l + fl_w + fl_wf + sfl)}
         else:
             out['roofline'] = None
         out['roofline_streaming'] = [e for e in (
