@@ -86,6 +86,46 @@ int nesie_head_loss_forward_unsup(int b, int k, int t, int c, const float *cls, 
                                   float *s_side_pred, int *sem_pick, int *kstar, float *dmin,
                                   float *partial, int *ticket, void *stream);
 
+/* The supervised terms the SAQE head shares with the Nesie head (saqe_head.py:331-703), with the
+ * head's treatment of the uncertainties: sigma_mode 1 = exp(-sigma) weights with sigma a CONSTANT
+ * (sup_loss: sigma.detach(), config alpha 0), 2 = no uncertainty weighting (loss). */
+int nesie_head_loss_forward_sigma(int sigma_mode, int b, int k, int t, int c, const float *cls,
+                                  const float *bbox, const float *surface, const float *side,
+                                  const float *iou_s, const float *iou, const float *iou_j,
+                                  const long long *obj_t, const long long *label, const float *obj_w,
+                                  const float *box_w, const float *bbox_t, const float *centre_t,
+                                  const float *valid_w, const float *config, float *loss,
+                                  float *s_cls, float *s_centre, float *s_surface, float *s_iou,
+                                  float *s_iou_s, float *s_side_surf, float *s_side_iou,
+                                  float *s_side_pred, int *sem_pick, int *kstar, float *dmin,
+                                  float *partial, int *ticket, void *stream);
+
+/* The SAQE head's ADDITIONAL supervised terms (saqe_head.py:331-521 `loss`, :524-703 `sup_loss`):
+ *   loss[0] = 0.5 (CE(R_obj) + CE(R_obj_jitter)), class- and proposal-weighted like the objectness term;
+ *   loss[1] = sum box_w * w_angle * (SmoothL1(sin th - sin th*) + SmoothL1(cos th - cos th*)), in
+ *             sup mode times exp(-angle_sigma), angle_sigma = 0.8 a^2 - 1.8 a + 1 of the rotate score
+ *             at the arg-max class (sem_pick, from the forward above), a constant;
+ *   loss[2] = (sup == 0 only) MSE of the plain and the jittered rotate score at that class against
+ *             angle_term / *box_w_max, weight box_w;
+ *   loss[3] = side-quality loss of the JITTERED proposals (label from jsurf = Bbox2Surface of the
+ *             jittered boxes, score = side[.., label class, K + k]).
+ * robj (B, 2K, 2) logits, rot (B, 2K, C) probabilities, bbox / bbox_t (B*K, 7), jsurf (B*K, 6),
+ * side (6, B, C, 2K); config: HOST array of 7 floats = objectness weight, its two class weights,
+ * angle weight, SmoothL1 beta, angle-quality weight, side weight.  s_rot must arrive zero-filled.
+ * partial (ceil(B*K / 64), 4), ticket as above.  Backward: d_robj, d_angle (B*K, for column 6 of
+ * the boxes), d_rot, d_side (zero-filled) = the saved gradients times g[4]. */
+int nesie_saqe_extra_loss_forward(int b, int k, int c, int sup, const float *robj, const float *rot,
+                                  const float *bbox, const float *bbox_t, const float *jsurf,
+                                  const float *side, const long long *obj_t, const long long *label,
+                                  const float *obj_w, const float *box_w, const float *box_w_max,
+                                  const int *sem_pick, const float *config, float *loss,
+                                  float *s_robj, float *s_angle, float *s_rot, float *s_sidej,
+                                  float *partial, int *ticket, void *stream);
+int nesie_saqe_extra_loss_backward(int b, int k, int c, const float *g, const long long *label,
+                                   const float *s_robj, const float *s_angle, const float *s_rot,
+                                   const float *s_sidej, float *d_robj, float *d_angle, float *d_rot,
+                                   float *d_side, void *stream);
+
 /* Gradient assembly: the saved per-term gradients times the incoming gradients g[7] (device) of
  * the seven terms, in the producers' layouts: d_cls (B,2+C,K), d_bbox (B,K,7) (size and yaw
  * columns zero), d_surface, d_iou (B*K), d_iou_s (B,2K,C), d_side (6,B,C,2K) which must arrive

@@ -80,6 +80,9 @@ SIGNATURES = {
     "nesie_head_targets": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nesie_head_loss_forward": [_I, _I, _I, _I] + [_P] * 30,
     "nesie_head_loss_forward_unsup": [_I, _I, _I, _I] + [_P] * 7 + [_I] + [_P] * 23,
+    "nesie_head_loss_forward_sigma": [_I, _I, _I, _I, _I] + [_P] * 30,
+    "nesie_saqe_extra_loss_forward": [_I, _I, _I, _I] + [_P] * 21,
+    "nesie_saqe_extra_loss_backward": [_I, _I, _I] + [_P] * 11,
     "nesie_head_loss_backward": [_I, _I, _I] + [_P] * 18,
     "nesie_vote_loss_forward": [_I, _I, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                 _P, _P],

@@ -133,7 +133,8 @@ struct HeadLoss {
   const float *quality;
   int flags;
 };
-enum { HL_UNSUP = 1, HL_DETACH_SIGMA = 2 };
+// HL_NO_SIGMA: no uncertainty weighting at all (SAQEHead.loss, the pre-training loss: sigma = 0)
+enum { HL_UNSUP = 1, HL_DETACH_SIGMA = 2, HL_NO_SIGMA = 4 };
 
 __device__ __forceinline__ float hl_log_clamped(float v) { return fmaxf(logf(v), -100.f); }
 
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(HL_PB) void head_loss_kernel(const HeadLoss a) {
     float sig[6], dsig_ds[6], sig_mean = 0.f;
     for (int i = 0; i < 6; ++i) {
       const float s = a.side[(((size_t)i * a.b + bi) * C + pick) * side_k + kk];
-      sig[i] = 0.8f * s * s - 1.8f * s + 1.f;
-      dsig_ds[i] = 1.6f * s - 1.8f;
+      sig[i] = (a.flags & HL_NO_SIGMA) ? 0.f : 0.8f * s * s - 1.8f * s + 1.f;
+      dsig_ds[i] = (a.flags & HL_NO_SIGMA) ? 0.f : 1.6f * s - 1.8f;
       sig_mean += sig[i];
     }
     sig_mean = sig_mean / 6.f;
@@ -363,6 +364,141 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadLossBwd a)
   }
 }
 
+// ---- the SAQE head's additional supervised terms (saqe_head.py:331-521 `loss`, :524-703 `sup_loss`) ----
+// On top of the terms head_loss_kernel evaluates (objectness on obj_scores, semantic, centre,
+// surface, IoU, IoU quality, side quality of the plain proposals):
+//   [0] 0.5 (CE(R_obj) + CE(R_obj_jitter))      objectness of the quality head, plain + jittered
+//   [1] angle: SmoothL1(sin) + SmoothL1(cos) of the heading, weight box_w (x exp(-angle_sigma) in
+//       sup_loss, angle_sigma = 0.8 a^2 - 1.8 a + 1 of the rotate score at the arg-max class, constant)
+//   [2] angle quality (loss only): MSE of the rotate score (plain + jittered, arg-max class) against
+//       angle_term / max(box_w), weight box_w
+//   [3] side quality of the JITTERED proposals: label = min(1, 4 |jittered plane - target plane|)
+// Layouts: robj (B, 2K, 2), rot (B, 2K, C) probabilities, jsurf (B, K, 6), side as in HeadLoss.
+struct SaqeExtra {
+  int b, k, c, sup;
+  const float *robj, *rot, *bbox, *bbox_t, *jsurf, *side;
+  const long long *obj_t, *label;
+  const float *obj_w, *box_w, *box_w_max;
+  const int *sem_pick;
+  float w_obj, cw0, cw1, w_angle, beta, w_apred, w_side;
+  float *loss;                 // [4]
+  float *s_robj, *s_angle, *s_rot /* zero-filled */, *s_sidej /* (B*K, 6) */;
+  float *partial;
+  int *ticket;
+};
+
+__device__ __forceinline__ float hl_smooth_l1(float d, float beta, float *grad) {
+  const float ad = fabsf(d);
+  if (ad < beta) { *grad = d / beta; return 0.5f * ad * ad / beta; }
+  *grad = d > 0.f ? 1.f : -1.f;
+  return ad - 0.5f * beta;
+}
+
+__global__ __launch_bounds__(HL_PB) void saqe_extra_kernel(const SaqeExtra a) {
+  __shared__ int last;
+  const int np = a.b * a.k, K = a.k, C = a.c;
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+  const float wmax = *a.box_w_max;
+  for (int p = blockIdx.x * HL_PB + threadIdx.x; p < np; p += gridDim.x * HL_PB) {
+    const int bi = p / K, kk = p % K;
+    const float w = a.box_w[p], ow = a.obj_w[p];
+    const int y = (int)a.obj_t[p], lab = (int)a.label[p], pick = a.sem_pick[p];
+    // -- objectness of the quality head, both halves
+    for (int hj = 0; hj < 2; ++hj) {
+      const size_t o = ((size_t)bi * 2 * K + (size_t)hj * K + kk) * 2;
+      const float z0 = a.robj[o], z1 = a.robj[o + 1];
+      const float m = fmaxf(z0, z1);
+      const float e0 = expf(z0 - m), e1 = expf(z1 - m), s = e0 + e1;
+      const float lse = m + logf(s);
+      const float cw = y ? a.cw1 : a.cw0;
+      l0 += 0.5f * (a.w_obj * ((-cw * ((y ? z1 : z0) - lse)) * ow));
+      const float gsc = 0.5f * a.w_obj * ow * cw;
+      a.s_robj[o] = gsc * (e0 / s - (y ? 0.f : 1.f));
+      a.s_robj[o + 1] = gsc * (e1 / s - (y ? 1.f : 0.f));
+    }
+    // -- heading: sin / cos smooth-L1
+    const float th = a.bbox[(size_t)p * 7 + 6], tt = a.bbox_t[(size_t)p * 7 + 6];
+    const float sp = sinf(th), cp = cosf(th);
+    float gs, gc;
+    const float ls = hl_smooth_l1(sp - sinf(tt), a.beta, &gs);
+    const float lc = hl_smooth_l1(cp - cosf(tt), a.beta, &gc);
+    const float ang = a.w_angle * (ls * w) + a.w_angle * (lc * w);
+    const size_t rrow = ((size_t)bi * 2 * K + kk) * C;
+    const float sc_rot = a.rot[rrow + pick];
+    float ex = 1.f;
+    if (a.sup) ex = expf(-(0.8f * sc_rot * sc_rot - 1.8f * sc_rot + 1.f));
+    l1 += ex * ang;
+    a.s_angle[p] = ex * (a.w_angle * w * (gs * cp - gc * sp));
+    // -- angle quality (pre-training loss only)
+    if (!a.sup) {
+      const float lbl = ang / wmax;
+      const float r0 = sc_rot - lbl;
+      const float scj = a.rot[rrow + (size_t)K * C + pick];
+      const float r1 = scj - lbl;
+      l2 += a.w_apred * ((r0 * r0) * w) + a.w_apred * ((r1 * r1) * w);
+      a.s_rot[rrow + pick] = a.w_apred * (2.f * r0) * w;
+      a.s_rot[rrow + (size_t)K * C + pick] = a.w_apred * (2.f * r1) * w;
+    }
+    // -- side quality of the jittered proposals
+    const float *tb = a.bbox_t + (size_t)p * 7;
+    const size_t side_k = (size_t)2 * K;
+    for (int i = 0; i < 6; ++i) {
+      const float half = 0.5f * tb[3 + i % 3];
+      const float ts = i < 3 ? tb[i] - half : tb[i - 3] + half;
+      const float lbl = fminf(4.f * fabsf(a.jsurf[(size_t)p * 6 + i] - ts), 1.f);
+      const float sc = a.side[(((size_t)i * a.b + bi) * C + lab) * side_k + K + kk];
+      const float r = sc - lbl;
+      l3 += a.w_side * ((r * r) * w);
+      a.s_sidej[(size_t)p * 6 + i] = a.w_side * (2.f * r) * w;
+    }
+  }
+  float v[4] = {l0, l1, l2, l3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.partial[(size_t)blockIdx.x * 4 + i] = v[i];
+    __threadfence();
+    last = atomicAdd(a.ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+    for (unsigned w = 0; w < gridDim.x; ++w) t += __builtin_nontemporal_load(a.partial + (size_t)w * 4 + threadIdx.x);
+    a.loss[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) *a.ticket = 0;
+}
+
+// gradients of the four terms in the producers' layouts; d_side (6, B, C, 2K) must arrive zero-filled
+__global__ __launch_bounds__(256) void saqe_extra_bwd_kernel(int b, int k, int c, const float *g,
+                                                             const long long *label, const float *s_robj,
+                                                             const float *s_angle, const float *s_rot,
+                                                             const float *s_sidej, float *d_robj,
+                                                             float *d_angle, float *d_rot, float *d_side) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= b * k) return;
+  const int bi = p / k, kk = p % k;
+  const float g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+  for (int hj = 0; hj < 2; ++hj) {
+    const size_t o = ((size_t)bi * 2 * k + (size_t)hj * k + kk) * 2;
+    d_robj[o] = g0 * s_robj[o];
+    d_robj[o + 1] = g0 * s_robj[o + 1];
+    const size_t r = ((size_t)bi * 2 * k + (size_t)hj * k + kk) * c;
+    for (int j = 0; j < c; ++j) d_rot[r + j] = g2 * s_rot[r + j];
+  }
+  d_angle[p] = g1 * s_angle[p];
+  const int lab = (int)label[p];
+  const size_t side_k = (size_t)2 * k;
+  for (int i = 0; i < 6; ++i)
+    d_side[(((size_t)i * b + bi) * c + lab) * side_k + k + kk] = g3 * s_sidej[(size_t)p * 6 + i];
+}
+
 }  // namespace nesie
 
 using namespace nesie;
@@ -436,6 +572,25 @@ extern "C" int nesie_head_loss_forward(
     float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
     void *stream) {
   return head_loss_forward_impl("head_loss_forward", nullptr, 0, b, k, t, c, cls, bbox, surface, side, iou_s,
+                                iou, iou_j, obj_t, label, obj_w, box_w, bbox_t, centre_t, valid_w, config,
+                                loss, s_cls, s_centre, s_surface, s_iou, s_iou_s, s_side_surf, s_side_iou,
+                                s_side_pred, sem_pick, kstar, dmin, partial, ticket, stream);
+}
+
+extern "C" int nesie_head_loss_forward_sigma(
+    int sigma_mode /* 0 as nesie_head_loss_forward, 1 constant uncertainties, 2 none */,
+    int b, int k, int t, int c, const float *cls, const float *bbox, const float *surface,
+    const float *side, const float *iou_s, const float *iou, const float *iou_j,
+    const long long *obj_t, const long long *label, const float *obj_w, const float *box_w,
+    const float *bbox_t, const float *centre_t, const float *valid_w,
+    const float *config /* [11] */, float *loss, float *s_cls, float *s_centre,
+    float *s_surface, float *s_iou, float *s_iou_s, float *s_side_surf, float *s_side_iou,
+    float *s_side_pred, int *sem_pick, int *kstar, float *dmin, float *partial, int *ticket,
+    void *stream) {
+  const char *W = "head_loss_forward_sigma";
+  NESIE_REQUIRE(sigma_mode >= 0 && sigma_mode <= 2, W);
+  const int flags = sigma_mode == 1 ? HL_DETACH_SIGMA : sigma_mode == 2 ? HL_NO_SIGMA : 0;
+  return head_loss_forward_impl(W, nullptr, flags, b, k, t, c, cls, bbox, surface, side, iou_s,
                                 iou, iou_j, obj_t, label, obj_w, box_w, bbox_t, centre_t, valid_w, config,
                                 loss, s_cls, s_centre, s_surface, s_iou, s_iou_s, s_side_surf, s_side_iou,
                                 s_side_pred, sem_pick, kstar, dmin, partial, ticket, stream);
@@ -577,5 +732,47 @@ extern "C" int nesie_vote_loss_backward(long long n3, const float *g, const floa
   NESIE_REQUIRE(g && scale && sign && d_vote, W);
   hipLaunchKernelGGL(vote_loss_bwd_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, n3, g, scale, sign, d_vote);
+  return check_launch(W);
+}
+
+// ---- the SAQE head's additional terms ---------------------------------------------------------------
+extern "C" int nesie_saqe_extra_loss_forward(
+    int b, int k, int c, int sup, const float *robj, const float *rot, const float *bbox,
+    const float *bbox_t, const float *jsurf, const float *side, const long long *obj_t,
+    const long long *label, const float *obj_w, const float *box_w, const float *box_w_max,
+    const int *sem_pick, const float *config /* [7] */, float *loss, float *s_robj, float *s_angle,
+    float *s_rot, float *s_sidej, float *partial, int *ticket, void *stream) {
+  const char *W = "saqe_extra_loss_forward";
+  NESIE_REQUIRE(b >= 0 && k >= 1 && c >= 1 && c <= HL_MAXC, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(robj && rot && bbox && bbox_t && jsurf && side && obj_t && label && obj_w && box_w &&
+                    box_w_max && sem_pick && config && loss && s_robj && s_angle && s_rot && s_sidej &&
+                    partial && ticket, W);
+  NESIE_REQUIRE((long long)b * k < (1 << 22), W);
+  SaqeExtra a;
+  a.b = b; a.k = k; a.c = c; a.sup = sup;
+  a.robj = robj; a.rot = rot; a.bbox = bbox; a.bbox_t = bbox_t; a.jsurf = jsurf; a.side = side;
+  a.obj_t = obj_t; a.label = label; a.obj_w = obj_w; a.box_w = box_w; a.box_w_max = box_w_max;
+  a.sem_pick = sem_pick;
+  a.w_obj = config[0]; a.cw0 = config[1]; a.cw1 = config[2]; a.w_angle = config[3]; a.beta = config[4];
+  a.w_apred = config[5]; a.w_side = config[6];
+  a.loss = loss; a.s_robj = s_robj; a.s_angle = s_angle; a.s_rot = s_rot; a.s_sidej = s_sidej;
+  a.partial = partial; a.ticket = ticket;
+  hipLaunchKernelGGL(saqe_extra_kernel, dim3((b * k + HL_PB - 1) / HL_PB), dim3(HL_PB), 0,
+                     (hipStream_t)stream, a);
+  return check_launch(W);
+}
+
+extern "C" int nesie_saqe_extra_loss_backward(int b, int k, int c, const float *g, const long long *label,
+                                              const float *s_robj, const float *s_angle,
+                                              const float *s_rot, const float *s_sidej, float *d_robj,
+                                              float *d_angle, float *d_rot, float *d_side /* zero-filled */,
+                                              void *stream) {
+  const char *W = "saqe_extra_loss_backward";
+  NESIE_REQUIRE(b >= 0 && k >= 1 && c >= 1 && c <= HL_MAXC, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(g && label && s_robj && s_angle && s_rot && s_sidej && d_robj && d_angle && d_rot && d_side, W);
+  hipLaunchKernelGGL(saqe_extra_bwd_kernel, dim3((b * k + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     b, k, c, g, label, s_robj, s_angle, s_rot, s_sidej, d_robj, d_angle, d_rot, d_side);
   return check_launch(W);
 }

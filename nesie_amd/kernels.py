@@ -894,7 +894,7 @@ class HipKernels(_BNPoolMixin):
         return out
 
     def head_loss_forward(self, cls, bbox, surface, side, iou_s, iou, iou_j, tg, config, ticket,
-                          quality=None, detach_sigma=False):
+                          quality=None, detach_sigma=False, sigma_mode=0):
         """The seven loss terms + their saved gradients (nesie_head_loss_forward).  cls
         (B,2+C,K), bbox (B,K,7), surface (B,K,6), side (6,B,C,2K), iou_s (B,2K,C), iou / iou_j
         (B*K); tg = head_targets(...); config = 11 python floats; ticket = a zeroed int32 scalar
@@ -923,6 +923,9 @@ class HipKernels(_BNPoolMixin):
             assert quality.numel() == b * k * 6
             head = ("nesie_head_loss_forward_unsup", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
                     _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(quality), int(bool(detach_sigma)))
+        elif sigma_mode:      # the SAQE head's supervised losses: constant (1) or no (2) uncertainties
+            head = ("nesie_head_loss_forward_sigma", int(sigma_mode), b, k, t, c, _ptr(cls), _ptr(bbox),
+                    _ptr(surface), _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(iou_j))
         else:
             head = ("nesie_head_loss_forward", b, k, t, c, _ptr(cls), _ptr(bbox), _ptr(surface),
                     _ptr(side), _ptr(iou_s), _ptr(iou), _ptr(iou_j))
@@ -936,6 +939,46 @@ class HipKernels(_BNPoolMixin):
                       _ptr(sv['side_pred']), _ptr(sv['sem_pick']), _ptr(kstar), _ptr(dmin),
                       _ptr(partial), _ptr(ticket), _stream(cls))
         return loss, sv
+
+    def saqe_extra_forward(self, robj, rot, bbox, bbox_t, jsurf, side, tg, sem_pick, config, sup,
+                           ticket):
+        """The SAQE head's additional supervised terms (nesie_saqe_extra_loss_forward): robj
+        (B,2K,2), rot (B,2K,C), bbox / bbox_t (B,K,7), jsurf (B,K,6), side (6,B,C,2K); sem_pick from
+        ``head_loss_forward``; config = 7 python floats.  -> (loss (4,), saved dict)."""
+        _check(robj, rot, bbox, bbox_t, jsurf, side, sem_pick); _f32(robj, rot, bbox, bbox_t, jsurf, side)
+        b, k2, c = rot.shape
+        k = k2 // 2
+        assert tuple(robj.shape) == (b, k2, 2) and tuple(side.shape) == (6, b, c, k2) and len(config) == 7
+        assert bbox.numel() == b * k * 7 == bbox_t.numel() and jsurf.numel() == b * k * 6
+        dev = rot.device
+        f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)  # noqa: E731
+        sv = dict(robj=f32(b, k2, 2), angle=f32(b * k), rot=torch.zeros(b, k2, c, dtype=torch.float32, device=dev),
+                  sidej=f32(b * k, 6))
+        loss, partial = f32(4), f32((b * k + 63) // 64, 4)
+        wmax = tg['box_weights'].max().reshape(1)
+        cfg = (ctypes.c_float * 7)(*[float(v) for v in config])
+        with torch.cuda.device(dev):
+            _lib.call("nesie_saqe_extra_loss_forward", b, k, c, int(bool(sup)), _ptr(robj), _ptr(rot),
+                      _ptr(bbox), _ptr(bbox_t), _ptr(jsurf), _ptr(side), _ptr(tg['obj_targets']),
+                      _ptr(tg['mask_targets']), _ptr(tg['obj_weights']), _ptr(tg['box_weights']),
+                      _ptr(wmax), _ptr(sem_pick), ctypes.cast(cfg, ctypes.c_void_p), _ptr(loss),
+                      _ptr(sv['robj']), _ptr(sv['angle']), _ptr(sv['rot']), _ptr(sv['sidej']),
+                      _ptr(partial), _ptr(ticket), _stream(rot))
+        return loss, sv
+
+    def saqe_extra_backward(self, g, label, sv, k):
+        """g (4,) -> dict(robj, angle (B*K), rot, side (6,B,C,2K))."""
+        _check(g, label); _f32(g)
+        b, k2, c = sv['rot'].shape
+        dev = g.device
+        out = dict(robj=torch.empty_like(sv['robj']), angle=torch.empty_like(sv['angle']),
+                   rot=torch.empty_like(sv['rot']),
+                   side=torch.zeros(6, b, c, k2, dtype=torch.float32, device=dev))
+        with torch.cuda.device(dev):
+            _lib.call("nesie_saqe_extra_loss_backward", b, k, c, _ptr(g), _ptr(label), _ptr(sv['robj']),
+                      _ptr(sv['angle']), _ptr(sv['rot']), _ptr(sv['sidej']), _ptr(out['robj']),
+                      _ptr(out['angle']), _ptr(out['rot']), _ptr(out['side']), _stream(g))
+        return out
 
     def head_loss_backward(self, g, label, sv, k):
         """g (7,) incoming gradients (device) -> dict(cls, bbox, surface, iou, iou_s, side) in the

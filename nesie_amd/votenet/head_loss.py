@@ -35,24 +35,29 @@ class HeadLossFn(Function):
 
     @staticmethod
     def forward(ctx, cls, bbox, surface, side_all, iou_all, iou, iou_j, targets, config, ticket,
-                quality=None, detach_sigma=False):
+                quality=None, detach_sigma=False, sigma_mode=0):
         """quality (B, K, 6): the unsupervised variant -- semantic, centre, surface and IoU terms
         with the pseudo labels' side qualities in the weights, the other three terms zero."""
         backend = backend_for(cls)
         loss, saved = backend.head_loss_forward(cls, bbox, surface, side_all, iou_all,
                                                 iou.reshape(-1), iou_j.reshape(-1), targets, config,
-                                                ticket, quality=quality, detach_sigma=detach_sigma)
+                                                ticket, quality=quality, detach_sigma=detach_sigma,
+                                                sigma_mode=sigma_mode)
         ctx.saved, ctx.label, ctx.k, ctx.iou_shape = saved, targets['mask_targets'], bbox.shape[1], iou.shape
+        if sigma_mode:          # (the SAQE extras read the arg-max classes)
+            ctx.mark_non_differentiable(saved['sem_pick'])
+            return tuple(loss.unbind(0)) + (saved['sem_pick'],)
         return tuple(loss.unbind(0))
 
     @staticmethod
     def backward(ctx, *gs):
+        gs = gs[:7]
         ref = next(g for g in gs if g is not None)
         g = torch.stack([gi if gi is not None else torch.zeros_like(ref) for gi in gs])
         backend = backend_for(g)
         d = backend.head_loss_backward(g, ctx.label, ctx.saved, ctx.k)
         return (d['cls'], d['bbox'], d['surface'], d['side'], d['iou_s'],
-                d['iou'].view(ctx.iou_shape), None, None, None, None, None, None)
+                d['iou'].view(ctx.iou_shape), None, None, None, None, None, None, None)
 
 
 def config_of(head):
@@ -109,6 +114,65 @@ def usable(head, bbox_preds, unsup=False):
             and tuple(bbox_preds['_side_all'].shape) == (6, B, C, 2 * K)
             and tuple(bbox_preds['_iou_all'].shape) == (B, 2 * K, C)
             and (unsup_config_of(head) if unsup else config_of(head)) is not None)
+
+
+SAQE_TERMS = ('r_objectness_loss', 'angle_loss', 'angle_pred_loss', 'side_jitter_loss')
+
+
+class SaqeExtraFn(Function):
+    """(robj, rot, bbox, side_all) -> the SAQE head's four additional supervised terms
+    (``nesie_saqe_extra_loss_forward``), ``sup`` = the semi-supervised stage's form."""
+
+    @staticmethod
+    def forward(ctx, robj, rot, bbox, side_all, bbox_t, jsurf, targets, sem_pick, config, sup, ticket):
+        backend = backend_for(rot)
+        loss, saved = backend.saqe_extra_forward(robj, rot, bbox, bbox_t, jsurf, side_all, targets,
+                                                 sem_pick, config, sup, ticket)
+        ctx.saved, ctx.label, ctx.k, ctx.bshape = saved, targets['mask_targets'], bbox.shape[1], bbox.shape
+        return tuple(loss.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        g = torch.stack([gi if gi is not None else torch.zeros_like(ref) for gi in gs])
+        d = backend_for(g).saqe_extra_backward(g, ctx.label, ctx.saved, ctx.k)
+        d_bbox = d['angle'].new_zeros(ctx.bshape)
+        d_bbox[..., 6] = d['angle'].view(ctx.bshape[:2])
+        return (d['robj'], d['rot'], d_bbox, d['side'], None, None, None, None, None, None, None)
+
+
+def saqe_config_of(head):
+    """(base 11 scalars with alpha 0, the 7 scalars of the extras) of the shipped SAQE configuration,
+    or None."""
+    from . import losses as L
+    base = config_of(head)
+    al, ap = getattr(head, 'angle_loss', None), getattr(head, 'angle_pred_loss', None)
+    if base is None or not (isinstance(al, L.SmoothL1Loss) and isinstance(ap, L.MSELoss)
+                            and ap.reduction == 'sum'):
+        return None
+    o, sd = head.objectness_loss, head.side_loss
+    base = [0.0] + base[1:]
+    return base, [o.loss_weight, o.class_weight[0], o.class_weight[1], al.loss_weight, al.beta,
+                  ap.loss_weight, sd.loss_func.loss_weight]
+
+
+def saqe_usable(head, bbox_preds):
+    """True when ``SAQEHead.loss`` / ``sup_loss`` can take the fused path."""
+    if not ENABLED or type(head).__name__ != 'SAQEHead':
+        return False
+    if any(k not in bbox_preds for k in ('_cls_all', '_side_all', '_iou_all', '_rot_all', '_robj_all')):
+        return False
+    cls = bbox_preds['_cls_all']
+    if backend_for(cls).name != 'hip' or cls.dtype != torch.float32:
+        return False
+    B, K = bbox_preds['bbox_preds'].shape[:2]
+    C = cls.shape[1] - 2
+    return (cls.shape[0] == B and cls.shape[2] == K and C <= 32
+            and tuple(bbox_preds['_side_all'].shape) == (6, B, C, 2 * K)
+            and tuple(bbox_preds['_iou_all'].shape) == (B, 2 * K, C)
+            and tuple(bbox_preds['_rot_all'].shape) == (B, 2 * K, C)
+            and tuple(bbox_preds['_robj_all'].shape) == (B, 2 * K, 2)
+            and saqe_config_of(head) is not None)
 
 
 class VoteLossFn(Function):

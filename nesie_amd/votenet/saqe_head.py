@@ -99,6 +99,7 @@ class SAQEHead(NesieHead):
         results['rotate_scores_jitter'] = rot[:, k:]
         results['rotate_scores'] = rot[:, :k]
         robj = results['R_obj_scores']
+        results['_rot_all'], results['_robj_all'] = rot, robj       # for the fused loss kernels
         results['R_obj_scores_jitter'] = robj[:, k:]
         results['R_obj_scores'] = robj[:, :k]
         return results
@@ -178,10 +179,63 @@ class SAQEHead(NesieHead):
         out['side_loss'] = self._side_terms(bbox_preds, label_cls, cat, probs, surface_weight)
         return out, surface, iou, angle, box_loss_weights, targets_b
 
+    def _fused_supervised(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, sem, ins, sup,
+                          ret_target, vote_targets=None):
+        """``loss`` (sup False) / ``sup_loss`` (True) with every per-proposal term in two launches:
+        the terms shared with the Nesie head through ``head_loss.HeadLossFn`` (no / constant
+        uncertainties) and the SAQE head's own through ``head_loss.SaqeExtraFn``; the vote term and
+        the two rotated-IoU evaluations stay."""
+        from . import head_loss
+        targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, sem, ins, bbox_preds,
+                                   vote_targets=vote_targets)
+        (vote_targets, vote_target_masks, center_targets, bbox_targets, mask_targets,
+         valid_gt_masks, objectness_targets, objectness_weights, box_loss_weights,
+         valid_gt_weights, assignment) = targets
+        vote_loss = self.vote_module.get_loss(
+            bbox_preds['seed_points'], bbox_preds['vote_points'], bbox_preds['seed_indices'],
+            vote_target_masks, vote_targets)
+        boxes = bbox_preds['bbox_preds'].contiguous()
+        iou = cal_iou_3d(boxes, bbox_targets)                              # (B, K), with gradient
+        iou_jitter = cal_iou_3d(bbox_preds['jitter_bbox_preds'], bbox_targets).detach()
+        tg = dict(obj_targets=objectness_targets, mask_targets=mask_targets,
+                  obj_weights=objectness_weights, box_weights=box_loss_weights,
+                  bbox_targets=bbox_targets, center_targets=center_targets,
+                  valid_weights=valid_gt_weights)
+        base_cfg, extra_cfg = head_loss.saqe_config_of(self)
+        side_all = bbox_preds['_side_all'].contiguous()
+        out = head_loss.HeadLossFn.apply(
+            bbox_preds['_cls_all'].contiguous(), boxes, bbox_preds['surface_pred'].contiguous(),
+            side_all, bbox_preds['_iou_all'].contiguous(), iou, iou_jitter, tg, base_cfg,
+            self._loss_ticket, None, False, 1 if sup else 2)
+        base, sem_pick = dict(zip(head_loss.TERMS, out[:7])), out[7]
+        extra = dict(zip(head_loss.SAQE_TERMS, head_loss.SaqeExtraFn.apply(
+            bbox_preds['_robj_all'].contiguous(), bbox_preds['_rot_all'].contiguous(), boxes, side_all,
+            bbox_targets.contiguous(), bbox_preds['jitter_surface_preds'].detach().contiguous(), tg,
+            sem_pick, extra_cfg, sup, self._loss_ticket)))
+        losses = dict(vote_loss=vote_loss,
+                      objectness_loss=base['objectness_loss'] + extra['r_objectness_loss'],
+                      center_loss=base['center_loss'], semantic_loss=base['semantic_loss'],
+                      iou_pred_loss=base['iou_pred_loss'],
+                      side_loss=base['side_loss'] + extra['side_jitter_loss'])
+        if sup:
+            losses.update(surface_loss=base['surface_loss'], angle_loss=extra['angle_loss'],
+                          iou_loss=base['iou_loss'])
+        else:
+            losses.update(surface_loss=base['surface_loss'], iou_loss=base['iou_loss'],
+                          angle_loss=extra['angle_loss'], angle_pred_loss=extra['angle_pred_loss'])
+        if ret_target:
+            losses['targets'] = bbox_targets.view_as(boxes)
+        return losses
+
     # ---- pre-training loss (:331-521) ------------------------------------------------------
     def loss(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
              pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None, ret_target=False,
              vote_targets=None):
+        from . import head_loss
+        if head_loss.saqe_usable(self, bbox_preds):
+            return self._fused_supervised(bbox_preds, points, gt_bboxes_3d, gt_labels_3d,
+                                          pts_semantic_mask, pts_instance_mask, False, ret_target,
+                                          vote_targets)
         out, surface, iou, angle, blw, targets_b = self._common(
             bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask, pts_instance_mask,
             vote_targets=vote_targets)
@@ -204,6 +258,10 @@ class SAQEHead(NesieHead):
     def sup_loss(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
                  pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None,
                  ret_target=False):
+        from . import head_loss
+        if head_loss.saqe_usable(self, bbox_preds):
+            return self._fused_supervised(bbox_preds, points, gt_bboxes_3d, gt_labels_3d,
+                                          pts_semantic_mask, pts_instance_mask, True, ret_target)
         out, surface, iou, angle, blw, targets_b = self._common(
             bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask, pts_instance_mask)
         sigma = self._sigma(bbox_preds)

@@ -127,6 +127,69 @@ def test_fused_unsupervised_loss_matches_the_module_by_module_loss(hip_device, k
     assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-4
 
 
+def _saqe_model(hip_device):
+    from nesie_amd.votenet.detector import build_saqe_votenet, saqe_votenet_scannet_cfg
+    cfg, scfg = _small.small_cfg(), saqe_votenet_scannet_cfg()
+    cfg['bbox_head'].update(angle_loss=scfg['bbox_head']['angle_loss'],
+                            angle_pred_loss=scfg['bbox_head']['angle_pred_loss'])
+    cfg['head_type'] = 'SAQEHead'
+    torch.manual_seed(0)
+    model = build_saqe_votenet(cfg).to(hip_device).train()
+    assert type(model.bbox_head).__name__ == 'SAQEHead'
+    return model
+
+
+@pytest.mark.parametrize('which', ['loss', 'sup_loss'])
+def test_fused_saqe_supervised_losses_match_the_module_by_module_losses(hip_device, which):
+    """SAQEHead.loss (saqe_head.py:331-521) and sup_loss (:524-703) through head_loss.hip (shared
+    terms without / with constant uncertainties) + the SAQE extras kernel (quality-head objectness,
+    heading sin / cos, angle quality, jittered side quality): every term, the gradients at the
+    head's outputs and every parameter gradient, under unequal incoming gradients."""
+    model = _saqe_model(hip_device)
+    model.train_cfg['pos_distance_thr'], model.train_cfg['neg_distance_thr'] = 1.0, 1.5
+    model.bbox_head.train_cfg = model.train_cfg
+    pts, boxes, labels = _small.small_batch(batch=3)
+    for b in boxes:                      # headings that are not zero: the angle terms are alive
+        b[:, 6] = torch.linspace(-1.2, 1.4, b.shape[0])
+    pts = pts.to(hip_device)
+    gt = GTBatch.collate(boxes, labels, hip_device)
+    model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(3, 32))
+    weights = dict(vote_loss=1.0, objectness_loss=0.7, semantic_loss=1.3, center_loss=0.9, surface_loss=1.1,
+                   iou_loss=0.8, iou_pred_loss=1.2, side_loss=0.6, angle_loss=1.4, angle_pred_loss=0.5)
+    keys = ('_cls_all', 'bbox_preds', 'surface_pred', '_side_all', '_iou_all', '_rot_all', '_robj_all')
+
+    def run(fused):
+        head_loss.ENABLED = fused
+        try:
+            for p in model.parameters():
+                p.grad = None
+            preds = model.bbox_head(model.extract_feat(pts), 'vote')
+            keep = {}
+            for k in keys:
+                preds[k].retain_grad()
+                keep[k] = preds[k]
+            assert head_loss.saqe_usable(model.bbox_head, preds) == fused
+            losses = getattr(model.bbox_head, which)(preds, pts, gt, None)
+            sum(losses[k] * weights[k] for k in losses).backward()
+            return ({k: v.detach().clone() for k, v in losses.items()},
+                    {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                     for k, v in keep.items()}, _small.grads_of(model))
+        finally:
+            head_loss.ENABLED = True
+    want, got = run(False), run(True)
+    assert list(got[0]) == list(want[0])
+    assert ('angle_pred_loss' in want[0]) == (which == 'loss')
+    for k in want[0]:
+        assert want[0][k].abs().item() > 0, k
+        torch.testing.assert_close(got[0][k], want[0][k], rtol=2e-5, atol=1e-6, msg=k)
+    for k in want[1]:
+        scale = want[1][k].abs().max().item()
+        torch.testing.assert_close(got[1][k], want[1][k], rtol=1e-4, atol=2e-5 * max(scale, 1e-6), msg=k)
+    flat_w = torch.cat([want[2][n].flatten() for n in sorted(want[2])]).double()
+    flat_g = torch.cat([got[2][n].flatten() for n in sorted(want[2])]).double()
+    assert ((flat_g - flat_w).norm() / flat_w.norm()).item() < 1e-4
+
+
 def test_targets_kernel_matches_the_tensor_ops(hip_device):
     """nesie_head_targets vs get_targets' tensor-op form: indices exact, weights bit-equal."""
     model = _small.small_model().to(hip_device)
