@@ -505,6 +505,10 @@ int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
  * turned into dz = gamma invstd (g - mean(g) - zhat mean(g zhat)), g = da [fma(z, scale, shift) > 0],
  * on their way into LDS: dz is the MFMA operand and is written once (dz may be da) for the
  * input-gradient launch that follows; dgamma, dbeta [ng*co] are written.  coef_ws: ng*co*8 floats.
+ * d_row_bias (optional): the gradient of a per-group row bias that the forward added to z
+ * (nesie_pw_layer_forward's row_bias, groups of rb_group = 16 or 64 positions):
+ * d_row_bias[n][r][pos / rb_group] = sum of dz over the group; with rb_group 64 the buffer must
+ * arrive ZERO-FILLED (two partial sums per group are added atomically); requires z_bstride = co*p.
  * Supported where one launch owns every column of dw (nesie_pw_wgrad_bn_supported). */
 int nesie_pw_wgrad_bn_supported(int co, int ci, long long p);
 int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
@@ -512,7 +516,8 @@ int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, cons
                                const float *gamma, const float *part, int nslots, const float *x,
                                long long x_bstride, const float *x_coef, int x_relu, float *dz,
                                float *dw, float *dgamma, float *dbeta, float *coef_ws,
-                               void *workspace, size_t workspace_bytes, void *stream);
+                               float *d_row_bias, int rb_group, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* The layer kernel for skinny HBM-bound first layers (cin <= 64, cout <= 128): W stays in
  * LDS / registers and every wave streams its own 32-position columns straight from global

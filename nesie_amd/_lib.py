@@ -96,7 +96,7 @@ SIGNATURES = {
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_pw_wgrad_bn_backward": [_I, _I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P,
-                                   _P, _I, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P,
+                                   _P, _I, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P,
                                    ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "nesie_pw_pool_finish": [_I, _I, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P,

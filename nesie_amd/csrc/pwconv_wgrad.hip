@@ -29,13 +29,17 @@ namespace nesie {
 // nesie_bn_relu_backward_apply) -- used as the MFMA operand AND written to `dz` for the
 // input-gradient launch that follows, so the separate apply pass over (dA, Z) -> dZ disappears.
 // dz may be dy itself: a tile's words are read once, by the workgroup that owns the tile, before
-// it writes them.
+// it writes them.  d_rb (optional, BNB): gradient of a row bias that was added to Z per group of
+// rb_group (16 or 64) positions, d_rb[n][r][pos / rb_group] = sum of dZ over the group -- the 8
+// lanes that hold a row's 32 positions add their words with shuffles; a 64-group spans two tiles
+// (of different workgroups): two float atomics into a zero-filled buffer (two addends: the order
+// cannot matter).
 template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     int nb, int ng, int co, int ci, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
     float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
-    const float *__restrict__ bnb, float *dz) {
+    const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group) {
   constexpr int MB = CO16 / WM, NB = CI16 / WN, PT = 32, PITCH = PT + 4, CPR = PT / 4;
   constexpr int ROWS = (CO16 + CI16) * 16, NT = 512;
   constexpr int NX = (ROWS * CPR + NT - 1) / NT;
@@ -97,12 +101,14 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   f32x4 stg[NX], stz[BNB ? DYSLOTS : 1];
   size_t pend = 0;           // (batch, position) word offset of the tile in the staging registers
   bool pend_ok = false;      // ... and whether it is a tile of this workgroup (not the repeat past the end)
+  int pend_n = 0, pend_p0 = 0;   // ... its batch and first position
   auto load_tile = [&](int t) {
     pend_ok = t < ntiles;
     t = t < ntiles ? t : ntiles - 1;
     const int n = g + ng * (t / tpb);
     const long long p0 = (long long)(t % tpb) * PT;
     pend = (size_t)n * dy_bs + p0;
+    pend_n = n; pend_p0 = (int)p0;
     const float *dyb = dy + pend, *xb = x + (size_t)n * x_bs + p0;   // uniform
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -129,6 +135,19 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
             q[e] = __builtin_fmaf(za[i], gg, __builtin_fmaf(zmu[i] - zz, zd1[i], ze0[i]));
           }
           if (pend_ok && okslot[i]) *(f32x4 *)((char *)(dz + pend) + goff[i]) = q;
+          if (d_rb) {      // (wave-uniform)
+            float tsum = (q[0] + q[1]) + (q[2] + q[3]);
+            tsum += __shfl_xor(tsum, 1, 64);
+            tsum += __shfl_xor(tsum, 2, 64);
+            if (rb_group == 64) tsum += __shfl_xor(tsum, 4, 64);
+            const int c_ = i * NT + tid, row = c_ / CPR, cp = c_ % CPR;
+            const bool writer = rb_group == 64 ? cp == 0 : (cp & 3) == 0;
+            if (pend_ok && okslot[i] && writer) {
+              const int gsh = rb_group == 64 ? 6 : 4;
+              float *dst = d_rb + ((size_t)pend_n * co + row) * (size_t)(p >> gsh) + ((pend_p0 + 4 * cp) >> gsh);
+              if (rb_group == 64) atomicAdd(dst, tsum); else *dst = tsum;
+            }
+          }
         }
       }
       if (AFF && i >= DYSLOTS) {
@@ -302,7 +321,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
                            long long dy_bstride, const float *x, long long x_bstride,
                            const float *x_coef, int x_relu, float *dw, void *workspace,
                            size_t workspace_bytes, const float *bnz, const float *bnb, float *dz,
-                           hipStream_t s) {
+                           float *d_rb, int rb_group, hipStream_t s) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && ci >= 1 && p >= 0 && dw, W);
   if (nb == 0 || p == 0) {
     (void)hipMemsetAsync(dw, 0, (size_t)ng * co * ci * sizeof(float), s);
@@ -320,6 +339,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
   const int block = pw_wgrad_block(co, ci);
   // (the fused norm backward writes dZ while it forms it: one launch must own every column)
   NESIE_REQUIRE(!bnb || (bnz && dz && block == ci && (((uintptr_t)bnz | (uintptr_t)dz) & 15) == 0), W);
+  NESIE_REQUIRE(!d_rb || (bnb && (rb_group == 16 || rb_group == 64) && p % rb_group == 0 &&
+                          dy_bstride == (long long)co * p), W);
   const int nwg = pw_wgrad_nwg(nb, ng, p, co, block);
   float *partial = (float *)workspace;
   const float lo = x_relu ? 0.f : -__builtin_inff();
@@ -333,7 +354,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       attr = true;                                                                               \
     }                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,           \
-                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz);       \
+                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group); \
   } while (0)
 #define L(CO16, CI16, WM, WN)                                                                    \
   do {                                                                                           \
@@ -366,7 +387,7 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
                               const float *x_coef, int x_relu, float *dw, void *workspace,
                               size_t workspace_bytes, void *stream) {
   return pw_wgrad_launch("pw_wgrad", nb, ng, co, ci, p, dy, dy_bstride, x, x_bstride, x_coef, x_relu, dw,
-                         workspace, workspace_bytes, nullptr, nullptr, nullptr, (hipStream_t)stream);
+                         workspace, workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int nesie_pw_wgrad_bn_supported(int co, int ci, long long p) {
@@ -378,8 +399,8 @@ extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long l
                                           const float *gamma, const float *part, int nslots,
                                           const float *x, long long x_bstride, const float *x_coef,
                                           int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
-                                          float *coef_ws, void *workspace, size_t workspace_bytes,
-                                          void *stream) {
+                                          float *coef_ws, float *d_row_bias, int rb_group,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
   const char *W = "pw_wgrad_bn_backward";
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
   hipStream_t s = (hipStream_t)stream;
@@ -387,11 +408,11 @@ extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long l
     if (dgamma) (void)hipMemsetAsync(dgamma, 0, (size_t)ng * co * sizeof(float), s);
     if (dbeta) (void)hipMemsetAsync(dbeta, 0, (size_t)ng * co * sizeof(float), s);
     return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                           workspace_bytes, nullptr, nullptr, nullptr, s);
+                           workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, s);
   }
   NESIE_REQUIRE(da && z && z_coef && part && dz && coef_ws && nb % ng == 0, W);
   hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
                      (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
   return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                         workspace_bytes, z, coef_ws, dz, s);
+                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s);
 }

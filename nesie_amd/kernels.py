@@ -636,12 +636,13 @@ class HipKernels(_BNPoolMixin):
         return bool(_lib.load().nesie_pw_wgrad_bn_supported(int(co), int(ci), int(p)))
 
     def pw_wgrad_bn_backward(self, da, z, z_coef, gamma, part, x, dz, dw, dgamma, dbeta, ng=1,
-                             x_coef=None, x_relu=True):
+                             x_coef=None, x_relu=True, d_row_bias=None, group=0):
         """The BatchNorm + ReLU backward's apply pass fused into the weight gradient it feeds
         (nesie_pw_wgrad_bn_backward): da (NB, co, P) gradient of relu(bn(z)), z raw conv output,
         z_coef (ng*co, 4), part (ng*co, slots, 2) from ``pw_dgrad_bn_reduce``; x (NB, ci, P) the
         layer's input with its own folded norm x_coef.  Writes dz (may be da), dw (ng, co, ci),
-        dgamma, dbeta (ng*co)."""
+        dgamma, dbeta (ng*co); d_row_bias (NB, co, P / group), group 16 or 64: the gradient of the
+        per-group row bias the forward added to z (zero-filled by the caller for group 64)."""
         _f32(da, z, x, dz, dw, dgamma, dbeta); _check(z_coef, part, dz); _f32(z_coef, part)
         nb, co, p = da.shape
         ci = x.shape[1]
@@ -651,6 +652,9 @@ class HipKernels(_BNPoolMixin):
         assert x.stride(2) == 1 and x.stride(1) == p
         assert tuple(z_coef.shape) == (ng * co, 4) and part.dim() == 3 and part.shape[0] == ng * co
         assert dgamma.numel() == ng * co == dbeta.numel()
+        if d_row_bias is not None:
+            _check(d_row_bias); _f32(d_row_bias)
+            assert group in (16, 64) and d_row_bias.numel() == nb * co * (p // group)
         if gamma is not None:
             _check(gamma); _f32(gamma)
         if x_coef is not None:
@@ -665,7 +669,8 @@ class HipKernels(_BNPoolMixin):
                       _ptr(z_coef), 0 if gamma is None else _ptr(gamma), _ptr(part), part.shape[1],
                       _ptr(x), x.stride(0) if nb > 1 else ci * p, 0 if x_coef is None else _ptr(x_coef),
                       int(bool(x_relu)), _ptr(dz), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _ptr(cws),
-                      _ptr(ws), need, _stream(da))
+                      0 if d_row_bias is None else _ptr(d_row_bias), int(group), _ptr(ws), need,
+                      _stream(da))
 
     @staticmethod
     def conv_wgrad_supported(cout, cin):

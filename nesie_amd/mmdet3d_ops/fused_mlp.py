@@ -518,17 +518,26 @@ class MiniTailFn(Function):
             dw4 = _wgrad(backend, dzf, yf, coef1, ng=S)
         da = c.new_empty(B * S, H2, P)
         part = backend.pw_dgrad_bn_reduce(dzf, w4.transpose(1, 2), yf, coef1, da, ng=S)
-        dy = torch.empty_like(y)
         dgamma, dbeta = c.new_empty(S * H2), c.new_empty(S * H2)
-        dsmall = c.new_empty(B, S, H2, P // G)
-        backend.bn_relu_backward_apply(da.view(B, S * H2, P), y.view(B, S * H2, P), gamma1,
-                                       None, coef1, part, dy.view(B, S * H2, P), dgamma, dbeta,
-                                       d_row_bias=dsmall.view(B, S * H2, -1), group=G)
-        dyf = dy.view(B * S, H2, P)
         cf = c.view(B * S, half, P)
         dwl = None
-        if ctx.needs_input_grad[4]:
-            dwl = _wgrad(backend, dyf, cf, None, ng=S)
+        if (FOLD_NORM_BWD and ctx.needs_input_grad[4] and G in (16, 64)
+                and backend.pw_wgrad_bn_supported(H2, half, P)):
+            # norm backward + row-bias gradient + weight gradient in one launch (dY over da)
+            dsmall = (c.new_zeros if G == 64 else c.new_empty)(B, S, H2, P // G)
+            dwl = c.new_empty(S, H2, half)
+            backend.pw_wgrad_bn_backward(da, yf, coef1, gamma1, part, cf, da, dwl, dgamma, dbeta, ng=S,
+                                         x_coef=None, d_row_bias=dsmall.view(B * S, H2, -1), group=G)
+            dyf = da
+        else:
+            dy = torch.empty_like(y)
+            dsmall = c.new_empty(B, S, H2, P // G)
+            backend.bn_relu_backward_apply(da.view(B, S * H2, P), y.view(B, S * H2, P), gamma1,
+                                           None, coef1, part, dy.view(B, S * H2, P), dgamma, dbeta,
+                                           d_row_bias=dsmall.view(B, S * H2, -1), group=G)
+            dyf = dy.view(B * S, H2, P)
+            if ctx.needs_input_grad[4]:
+                dwl = _wgrad(backend, dyf, cf, None, ng=S)
         dc = torch.empty_like(c)
         backend.pw_layer_forward(dyf, wl.transpose(1, 2), ng=S, y=dc.view(B * S, half, P))
         _FRESH_GRADS.add(dc.data_ptr())     # nobody else holds this gradient buffer

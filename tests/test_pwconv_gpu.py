@@ -345,6 +345,18 @@ def test_weight_gradient_fused_with_the_norm_backward(nb, ng, co, ci, p, in_plac
         assert (dw.double() - dw_ref).abs().max().item() < 1e-4 * dw_ref.abs().max().item()
         torch.testing.assert_close(dgamma.double(), s1.view(-1), rtol=1e-5, atol=1e-4)
         torch.testing.assert_close(dbeta.double(), s0.view(-1), rtol=1e-5, atol=1e-4)
+    # the gradient of a per-group row bias (the forward added it to z): group sums of dz
+    for group in (16, 64):
+        if p % group:
+            continue
+        d_rb = torch.zeros(nb, co, p // group, device=_dev())
+        src = da.clone()
+        dw = torch.empty(ng, co, ci, device=_dev())
+        hip.pw_wgrad_bn_backward(src, z, zcoef, gamma, part, x, src, dw, dgamma, dbeta, ng=ng,
+                                 x_coef=None, d_row_bias=d_rb, group=group)
+        want = dz_ref.view(nb, co, p // group, group).sum(-1)
+        assert (d_rb.double() - want).abs().max().item() < 2e-5 * max(want.abs().max().item(), 1e-6)
+        assert (src.double() - dz_ref).abs().max().item() < 2e-5 * dz_ref.abs().max().item()
 
 
 def _sa_module(c_in, mlp, ns):
