@@ -256,9 +256,10 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
 
 // workgroups per weight group: one per CU; TWO per CU where a block's tiles (<= 74 KB of LDS) and
 // registers (<= 128) allow it (NESIE_WGRAD_PER_CU=1: A/B switch)
-static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw) {
+static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw, bool bnb = false) {
   static const int per_cu_max = getenv("NESIE_WGRAD_PER_CU") ? atoi(getenv("NESIE_WGRAD_PER_CU")) : 2;
-  const int per_cu = (co <= 128 && cw <= 128 && per_cu_max >= 2) ? 2 : 1;
+  // (the fused norm-backward variants need 146-150 VGPRs at 128 x 128: one workgroup per CU there)
+  const int per_cu = (co <= 128 && cw <= (bnb ? 64 : 128) && per_cu_max >= 2) ? 2 : 1;
   long long nwg = 256 * per_cu / ng;
   const long long tiles = (long long)(nb / ng) * (p / 32);
   if (nwg > tiles) nwg = tiles;
@@ -341,7 +342,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
   NESIE_REQUIRE(!bnb || (bnz && dz && block == ci && (((uintptr_t)bnz | (uintptr_t)dz) & 15) == 0), W);
   NESIE_REQUIRE(!d_rb || (bnb && (rb_group == 16 || rb_group == 64) && p % rb_group == 0 &&
                           dy_bstride == (long long)co * p), W);
-  const int nwg = pw_wgrad_nwg(nb, ng, p, co, block);
+  const int nwg = pw_wgrad_nwg(nb, ng, p, co, block, bnb != nullptr);
   float *partial = (float *)workspace;
   const float lo = x_relu ? 0.f : -__builtin_inff();
 #define LK(CO16, CI16, WM, WN, AFF, BNB)                                                         \

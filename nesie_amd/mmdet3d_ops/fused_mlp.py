@@ -70,7 +70,7 @@ def _wgrad(backend, dy, x, x_coef, ng=1):
             out.append(torch.mm(d.transpose(0, 1).reshape(co, b * p), a.transpose(0, 1).reshape(ci, b * p).t()))
         else:
             out.append(torch.bmm(d, a.transpose(1, 2)).sum(0))
-    return torch.stack(out)
+    return out[0].unsqueeze(0) if ng == 1 else torch.stack(out)
 
 
 # NESIE_FOLD_NORM_BWD=0: A/B switch -- the BatchNorm + ReLU backward's apply pass runs as its own
