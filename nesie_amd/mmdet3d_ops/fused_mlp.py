@@ -708,8 +708,8 @@ class Stack1dFn(Function):
 # A/B switch (NESIE_STACK1D, default 15): bit 0 vote module, 1 prediction head, 2 feature
 # propagation, 3 score heads -- which chains run through Stack1dFn
 import os as _os
-STACK1D_MASK = int(_os.environ.get('NESIE_STACK1D', '15'))
-VOTE, PRED, FPROP, HEADS = 1, 2, 4, 8
+STACK1D_MASK = int(_os.environ.get('NESIE_STACK1D', '31'))
+VOTE, PRED, FPROP, HEADS, PRED_OUT = 1, 2, 4, 8, 16   # (PRED_OUT: the prediction head's three output convs)
 
 
 def stack1d_supported(backend, x, shapes, norms, S=1, which=15):

@@ -54,8 +54,8 @@ class ReliableConvBboxHead(nn.Module):
 
     def _fused(self, feats):
         """The shared trunk as ONE fused chain on the layer kernel (``fused_mlp.Stack1dFn``); the class,
-        side-distribution and heading convolutions stay three small products on its output
-        (reliable_conv_bbox_module.py:144-177).  None when the chain is not served (evaluation,
+        side-distribution and heading convolutions are three single-layer launches of the same kernel
+        on its output (reliable_conv_bbox_module.py:144-177).  None when the chain is not served (evaluation,
         CPU checker, configured branch convs).
         (Round 3 also ran the three output convolutions as one stacked 220-row layer inside the
         chain.  Values and gradients matched, but a step captured in a hipGraph with that layer
@@ -73,7 +73,13 @@ class ReliableConvBboxHead(nn.Module):
                 not fused_mlp.stack1d_supported(backend_for(feats), feats, shapes, norms, which=fused_mlp.PRED):
             return None
         x = fused_mlp.stack1d(feats, [m.conv for m in trunk], norms)
-        return self.conv_cls(x), torch.cat((self.conv_bbox(x), self.conv_heading(x)), dim=1)
+
+        def out_conv(conv):     # one bias-carrying layer of the same kernel each (OUT bit of NESIE_STACK1D)
+            if fused_mlp.stack1d_supported(backend_for(x), x, [(conv.in_channels, conv.out_channels)], [None],
+                                           which=fused_mlp.PRED_OUT):
+                return fused_mlp.stack1d(x, [conv], [None])
+            return conv(x)
+        return out_conv(self.conv_cls), torch.cat((out_conv(self.conv_bbox), out_conv(self.conv_heading)), dim=1)
 
     def forward(self, feats):
         fused = self._fused(feats)
