@@ -34,7 +34,10 @@ FULL_SIZE_SLACK = {
     r'^bbox_head\.conv_pred\.shared_convs\.layer0\.(conv\.weight|bn\.bias)$': 4e-3,
     r'^bbox_head\.vote_aggregation\.mlps\.0\.layer0\.bn\.bias$': 2e-3,
     r'^backbone\.FP_modules\.0\.mlps\.layer1\.bn\.bias$': 2e-3,
-    r'^bbox_head\.grid_conv\.mlps_before\.5\.second_conv\.3\.weight$': 2e-3,
+    # (the last conv of a MiniPointNet: its gradient is a sum over the 4 x 128 arg-max positions of the
+    # 4 proposals that carry the quality head's gradient; observed 1.1e-3 .. 1.2e-3 on net 3 or 5,
+    # whichever the summation order of the day favours)
+    r'^bbox_head\.grid_conv\.mlps_before\.\d\.second_conv\.3\.weight$': 2e-3,
     # ReLU kink in the quality head.  Its whole gradient is carried by the 2 positive proposals and
     # their jittered copies (|dOut| 0.9 .. 1.4 at 4 of 1024 proposals, <= 0.013 elsewhere), i.e. by
     # 4 x 128 arg-max positions per MiniPointNet.  When one normalised activation among them sits

@@ -51,8 +51,8 @@ def main():
         f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms, on 8 CUs: hidden).",
         f"GEMM time: nesie::pw_fwd_kernel + pw_wgrad_kernel (+ conv_wgrad, mlp_stream) = {native:.2f} ms vs rocBLAS {rb:.2f} ms -> {100 * native / (native + rb):.0f} % of the GEMM time is in nesie:: kernels.",
         f"Launches per step (both streams): {calls:.0f} (round 2: 619); everything that is neither nesie:: nor rocBLAS (ATen elementwise / reduce / cat / copies / fills): {aten:.2f} ms = {100 * aten / allt:.1f} % of the summed kernel time.",
-        "The 1-D chains (vote module, prediction trunk, feature propagation, score heads) run on the layer kernel (fused_mlp.Stack1dFn): their",
-        "bn_stats / bn_apply passes are gone; rocBLAS keeps the three prediction convolutions, the blend tables and the wide weight gradients (256 x 256, 256 x 512).",
+        "The 1-D chains (vote module, prediction trunk + output convolutions, feature propagation, score heads) run on the layer kernel (fused_mlp.Stack1dFn): their",
+        "bn_stats / bn_apply passes are gone; rocBLAS keeps the blend tables, the wide weight gradients (256 x 256, 256 x 512) and the skinny coordinate rows.",
         ""]
     open(R + 'profiles/r03_bench_per_step_summary.txt', 'w').write(
         run('tools/profile_summary.py', 'profiles/r03_bench_kernel_stats.csv', str(STEPS), *hdr))
