@@ -650,7 +650,11 @@ def main():
                 t = json.load(open(tpath))
                 traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
                            'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf),   # (PMC rows include the fused weight-gradient launches)
-                           'largest_launch_over_algorithmic': t.get('largest_launch_over_algorithmic'),
+                           # the family's largest launch by bytes, counted / algorithmic (both lists' maxima:
+                           # the MiniPointNet 128 -> 256 input gradient + reduction)
+                           'largest_launch_over_algorithmic': (
+                               (t['largest_launch']['fetch_corrected_bytes'] + t['largest_launch']['write_bytes'])
+                               / max(b_ for tm in (gemm_timers[0], gemm_timers[2]) for (_, b_, _) in tm.work)),
                            'source': 'profiles/r03_pmc_hbm_traffic.json', 'measured_in_run': False}
             out['roofline'] = {
                 'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients, with the operand '

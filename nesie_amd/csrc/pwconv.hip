@@ -3,6 +3,7 @@
 // design notes are there); each tile geometry is instantiated in its own translation unit
 // (pwconv_g*.hip) and the weight-gradient kernels in pwconv_wgrad.hip, so `make -j` builds the
 // library in about a minute instead of five.
+#include <algorithm>
 #include "pwconv_fwd.h"
 #include <stdlib.h>
 
@@ -155,6 +156,13 @@ static int pw_groups(const PwGeom &g, int nb, int ng, long long p) {
   long long nwg = 256 * g.per_cu / (ng * g.nhalf);
   if (nwg < 1) nwg = 1;
   if (nwg > tiles) nwg = tiles;
+  // several row blocks per tile: a grid that is a multiple of 8 * nhalf lets the row blocks of a
+  // tile stream share an XCD (pwconv_fwd.h, xcd_map); round down when that costs < 10 % of the grid
+  if (g.nhalf > 1) {
+    const long long unit = 8 / std::__gcd((long long)8, (long long)ng);   // nwg * ng % 8 == 0
+    const long long r = nwg / unit * unit;
+    if (r > 0 && r * 10 >= nwg * 9) nwg = r;
+  }
   return (int)nwg;
 }
 
@@ -229,6 +237,8 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   a.nwg_g = pw_groups(g, nb, ng, p);
   a.nhalf = g.nhalf;
   const int grid = a.nwg_g * ng * g.nhalf;
+  static const bool xcd_on = !(getenv("NESIE_PW_XCD") && atoi(getenv("NESIE_PW_XCD")) == 0);   // A/B switch
+  a.xcd_map = (xcd_on && g.nhalf > 1 && grid % (8 * g.nhalf) == 0) ? 1 : 0;
   const size_t lds = pw_lds_bytes(g);
   hipStream_t s = (hipStream_t)stream;
   int st = NESIE_ERR_UNSUPPORTED;

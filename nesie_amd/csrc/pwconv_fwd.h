@@ -144,6 +144,7 @@ struct PwFwd {
   const float *bn_z; long long bnz_bs;     // PW_BNRED: raw conv output Z (nb, cout, p) ...
   const float *bn_coef; float *bn_part;    // ... its [ng * cout][4] (scale, bias, mean, invstd); [ng * cout][nslots][2]
   int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout
+  int xcd_map;         // the nhalf workgroups of a tile stream sit on ONE XCD (grid % (8 nhalf) == 0)
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -201,8 +202,22 @@ void pw_fwd_kernel(const PwFwd a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
   // block -> (weight group g, row half, rank inside the group)
-  const int half = blockIdx.x % a.nhalf;
-  const int g = (blockIdx.x / a.nhalf) % a.ng, rank = blockIdx.x / (a.nhalf * a.ng);
+  // Workgroups go to the 8 XCDs round-robin by block index and every XCD has its own L2.  The nhalf
+  // workgroups that walk the SAME tile stream (one per 128-row block of Cout) read the same X tiles:
+  // with consecutive block indices they sat on nhalf different XCDs and X crossed the fabric nhalf
+  // times (PMC: 807 MB fetched for 201 + 403 MB of operands at Cout = 256).  Block b = 8 slot + xcd:
+  // the row blocks of a stream are consecutive SLOTS of one XCD, start together and keep pace, so
+  // all but the first find the tile in that XCD's L2.
+  int half, sid;
+  if (a.xcd_map) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    half = slot % a.nhalf;
+    sid = xcd + 8 * (slot / a.nhalf);
+  } else {
+    half = blockIdx.x % a.nhalf;
+    sid = blockIdx.x / a.nhalf;
+  }
+  const int g = sid % a.ng, rank = sid / a.ng;
   const int k = a.k;
   const int c0 = half * CROWS;                           // first output row of this workgroup
   const int cout = a.cout;
