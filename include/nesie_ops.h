@@ -197,6 +197,21 @@ int nesie_blend_conv_runs(int n, int segs);
 int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy, int pitch, int seg_off, const int *idx, const float *weight,
                               const float *rel, float *d_table, float *d_wx, int segs,
                               int seg_len, void *stream);
+/* The same backward when the blend's output Z (B, segs, c, n/segs) is followed by a training
+ * BatchNorm + ReLU (MiniPointNet.first_conv[1:3], side_pooling_module.py:346-348): da is the
+ * gradient of relu(bn(Z)) and the norm backward's apply pass runs on the tile load with
+ * bnb [segs*c][8] from nesie_pw_bnb_coef (the partial sums come from the launch that produced da,
+ * nesie_pw_dgrad_bn_reduce) -- the pass that read (da, Z) and wrote dZ disappears. */
+int nesie_blend_conv_backward_bn(int b, int c, int m, int n, const float *da, const float *z,
+                                 const float *bnb, int pitch, int seg_off, const int *idx,
+                                 const float *weight, const float *rel, float *d_table,
+                                 float *d_wx, int segs, int seg_len, void *stream);
+/* bnb[ch] = (scale, shift, a, mean, d1, e0, -, -) of a BatchNorm + ReLU backward from the partial
+ * sums part [(channels) * nslots * 2] = (sum g, sum g zhat), the folded forward coefficients
+ * z_coef [channels][4] and gamma; count = elements per channel; dgamma / dbeta written. */
+int nesie_pw_bnb_coef(int channels, int nslots, double count, const float *part,
+                      const float *z_coef, const float *gamma, float *bnb, float *dgamma,
+                      float *dbeta, void *stream);
 
 /* nesie_blend_conv_forward (second form) followed by the training BatchNorm + ReLU of
  * MiniPointNet.first_conv[1:3] (side_pooling_module.py:346-348), fused by recomputation: the

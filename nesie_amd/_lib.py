@@ -46,6 +46,8 @@ SIGNATURES = {
     "nesie_blend_conv_forward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                  _P, _P],
     "nesie_blend_conv_backward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    "nesie_blend_conv_backward_bn": [_I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    "nesie_pw_bnb_coef": [_I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_vote_targets": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],

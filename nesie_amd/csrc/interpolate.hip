@@ -339,12 +339,18 @@ __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
 }
 
 // CPT = c / 64 channels per lane: a wave covers ALL c channels of its 16 queries.
-template <int CPT>
+// BNB: `dy` is the gradient dA of relu(bn(Z)) with Z = this blend's own output (`bnz`, same layout):
+// the BatchNorm + ReLU backward's apply pass runs on the tile load,
+//     dZ = a g + (e0 - (z - mean) d1),  g = dA [fma(z, scale, shift) > 0],
+// with bnb[sg * C + ch] = (scale, shift, a, mean, d1, e0, -, -) (pw_bnb_coef_kernel, pwconv_wgrad.hip),
+// so the separate pass that read (dA, Z) and wrote dZ for this kernel to read disappears.
+template <int CPT, bool BNB>
 __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
     const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
-    float *__restrict__ d_table, float *__restrict__ d_wx_part, int nb, int nruns) {
+    float *__restrict__ d_table, float *__restrict__ d_wx_part, int nb, int nruns,
+    const float *__restrict__ bnz, const float *__restrict__ bnb) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
@@ -357,6 +363,8 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
   const int run0 = run_i * BL_RUN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float *src = dy + ((size_t)bi * segs + sg) * C * per_seg;
+  const float *zsrc = BNB ? bnz + ((size_t)bi * segs + sg) * C * per_seg : nullptr;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);     // (wave-uniform row index: scalar loads of the coefficients)
   float *dt = d_table + (size_t)bi * m * pitch + (size_t)sg * seg_off + lane;
   float dx[CPT][3];
 #pragma unroll
@@ -380,10 +388,21 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     // 16 independent loads in flight per wave before the first LDS store
 #pragma unroll
     for (int rb = 0; rb < C / 4; rb += 16) {
-      float t16[16];
+      float t16[16], z16[BNB ? 16 : 1];
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < 16; ++u) {
         t16[u] = src[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
+        if (BNB) z16[u] = zsrc[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
+      }
+      if (BNB) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float *cf = bnb + ((size_t)sg * C + (rb + u) * 4 + wvu) * 8;      // uniform
+          const float zz = z16[u];
+          const float gg = __builtin_fmaf(zz, cf[0], cf[1]) > 0.f ? t16[u] : 0.f;
+          t16[u] = __builtin_fmaf(cf[2], gg, __builtin_fmaf(cf[3] - zz, cf[4], cf[5]));
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 16; ++u) tile[((rb + u) * 4 + wv) * (TS_Q + 1) + lane] = t16[u];
     }
@@ -836,12 +855,10 @@ extern "C" int nesie_blend_conv_runs(int n, int segs) {
   return segs >= 1 && n >= 0 ? cdiv(n / segs, BL_RUN) : 0;
 }
 
-extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy,
-                                         int pitch, int seg_off, const int *idx,
-                                         const float *weight, const float *rel,
-                                         float *d_table, float *d_wx, int segs, int seg_len,
-                                         void *stream) {
-  const char *W = "blend_conv_backward";
+static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, const float *dy,
+                                    int pitch, int seg_off, const int *idx, const float *weight,
+                                    const float *rel, float *d_table, float *d_wx, int segs,
+                                    int seg_len, const float *bnz, const float *bnb, void *stream) {
   int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
   if (st) return st;
   if (b == 0 || c == 0 || n == 0) return NESIE_OK;
@@ -856,12 +873,39 @@ extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float
   const int nruns = cdiv(per_seg, BL_RUN);
   NESIE_REQUIRE((long long)nruns * b * segs < (1ll << 31), W);
   const dim3 grid((unsigned)(nruns * b * segs));
-#define L(N) hipLaunchKernelGGL(blend_bwd_rows_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, \
-                                m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel,        \
-                                d_table, d_wx, b, nruns)
+#define L(N)                                                                                       \
+  do {                                                                                             \
+    if (bnb)                                                                                       \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, \
+                         m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
+                         b, nruns, bnz, bnb);                                                      \
+    else                                                                                           \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, \
+                         m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
+                         b, nruns, bnz, bnb);                                                      \
+  } while (0)
   if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
 #undef L
   return check_launch(W);
+}
+
+extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy,
+                                         int pitch, int seg_off, const int *idx,
+                                         const float *weight, const float *rel,
+                                         float *d_table, float *d_wx, int segs, int seg_len,
+                                         void *stream) {
+  return blend_conv_backward_impl("blend_conv_backward", b, c, m, n, dy, pitch, seg_off, idx, weight, rel,
+                                  d_table, d_wx, segs, seg_len, nullptr, nullptr, stream);
+}
+
+extern "C" int nesie_blend_conv_backward_bn(int b, int c, int m, int n, const float *da, const float *z,
+                                            const float *bnb, int pitch, int seg_off, const int *idx,
+                                            const float *weight, const float *rel, float *d_table,
+                                            float *d_wx, int segs, int seg_len, void *stream) {
+  const char *W = "blend_conv_backward_bn";
+  NESIE_REQUIRE(b == 0 || c == 0 || n == 0 || (z && bnb), W);
+  return blend_conv_backward_impl(W, b, c, m, n, da, pitch, seg_off, idx, weight, rel, d_table, d_wx, segs,
+                                  seg_len, z, bnb, stream);
 }
 
 extern "C" int nesie_three_interpolate_grad_wrapper(int b, int c, int n, int m,

@@ -417,3 +417,17 @@ extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long l
   return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
                          workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s);
 }
+
+// The reduction coefficients of a BatchNorm + ReLU backward on their own (for a consumer of dZ
+// other than the weight gradient: nesie_blend_conv_backward_bn): bnb [channels][8], dgamma, dbeta.
+extern "C" int nesie_pw_bnb_coef(int channels, int nslots, double count, const float *part,
+                                 const float *z_coef, const float *gamma, float *bnb, float *dgamma,
+                                 float *dbeta, void *stream) {
+  const char *W = "pw_bnb_coef";
+  NESIE_REQUIRE(channels >= 0 && nslots >= 1 && count > 0, W);
+  if (channels == 0) return NESIE_OK;
+  NESIE_REQUIRE(part && z_coef && bnb, W);
+  hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(channels), dim3(64), 0, (hipStream_t)stream, channels, nslots,
+                     count, part, z_coef, gamma, bnb, dgamma, dbeta);
+  return check_launch(W);
+}

@@ -428,9 +428,12 @@ class HipKernels(_BNPoolMixin):
                       _ptr(idx), _ptr(weight), opt(rel), opt(wx), _ptr(out), segs, seg_len,
                       int(out.shape[2]), c_offset, opt(stat_partial), _stream(table))
 
-    def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len):
+    def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len,
+                            bn_z=None, bnb=None):
         """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c)
-        (zeroed by the caller) and adds sum(dy x rel) into d_wx (segs, c, 3)."""
+        (zeroed by the caller) and adds sum(dy x rel) into d_wx (segs, c, 3).  bn_z / bnb: dy is
+        the gradient of relu(bn(bn_z)) and the norm backward runs on the tile load
+        (nesie_blend_conv_backward_bn; bnb (segs*c, 8) from ``pw_bnb_coef``)."""
         _check(dy, idx, weight, d_table); _f32(dy, weight, d_table); _i32(idx)
         b, m, pitch = d_table.shape
         n, c = idx.shape[1], dy.shape[2]
@@ -444,9 +447,16 @@ class HipKernels(_BNPoolMixin):
             if d_wx is not None:   # one partial per workgroup, summed here
                 runs = _lib.load().nesie_blend_conv_runs(n, segs)
                 part = torch.empty(b * runs, segs, c, 3, dtype=torch.float32, device=dy.device)
-            _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
-                      _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part), segs, seg_len,
-                      _stream(dy))
+            if bnb is not None:
+                _check(bn_z, bnb); _f32(bn_z, bnb)
+                assert tuple(bn_z.shape) == tuple(dy.shape) and tuple(bnb.shape) == (segs * c, 8)
+                _lib.call("nesie_blend_conv_backward_bn", b, c, m, n, _ptr(dy), _ptr(bn_z), _ptr(bnb),
+                          pitch, seg_off, _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part),
+                          segs, seg_len, _stream(dy))
+            else:
+                _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
+                          _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part), segs, seg_len,
+                          _stream(dy))
             if part is not None:
                 d_wx += part.sum(0)
 
@@ -631,6 +641,22 @@ class HipKernels(_BNPoolMixin):
                       dy.stride(0) if nb > 1 else co * p, _ptr(x), x.stride(0) if nb > 1 else ci * p,
                       0 if x_coef is None else _ptr(x_coef), int(bool(x_relu)), _ptr(dw), _ptr(ws),
                       need, _stream(dy))
+
+    def pw_bnb_coef(self, part, z_coef, gamma, count, dgamma, dbeta):
+        """(channels, 8) reduction coefficients of a BatchNorm + ReLU backward from the partial sums
+        part (channels, slots, 2) of ``pw_dgrad_bn_reduce`` (nesie_pw_bnb_coef); writes dgamma, dbeta."""
+        _check(part, z_coef, dgamma, dbeta); _f32(part, z_coef, dgamma, dbeta)
+        ch = part.shape[0]
+        assert part.dim() == 3 and part.shape[2] == 2 and tuple(z_coef.shape) == (ch, 4)
+        assert dgamma.numel() == ch == dbeta.numel()
+        if gamma is not None:
+            _check(gamma); _f32(gamma)
+        with torch.cuda.device(part.device):
+            bnb = torch.empty(ch, 8, dtype=torch.float32, device=part.device)
+            _lib.call("nesie_pw_bnb_coef", ch, part.shape[1], float(count), _ptr(part), _ptr(z_coef),
+                      0 if gamma is None else _ptr(gamma), _ptr(bnb), _ptr(dgamma), _ptr(dbeta),
+                      _stream(part))
+        return bnb
 
     def pw_wgrad_bn_supported(self, co, ci, p):
         return bool(_lib.load().nesie_pw_wgrad_bn_supported(int(co), int(ci), int(p)))

@@ -422,6 +422,24 @@ def mini_tail_second(backend, y, coef1, w4, G):
     return out, arg
 
 
+def _blend_producer(t):
+    """The autograd node of the ``BlendConv`` whose output ``t`` is (through view / reshape nodes
+    only), or None: such a producer takes over the backward of the norm its consumer applies
+    (interpolate.BlendConv.backward, ``pending_norm``)."""
+    node = t.grad_fn
+    for _ in range(6):
+        if node is None:
+            return None
+        name = type(node).__name__
+        if name == 'BlendConvBackward':
+            return node
+        if not any(k in name for k in ('View', 'Reshape', 'Squeeze', 'Unsqueeze', 'Alias')) \
+                or len(node.next_functions) != 1:
+            return None
+        node = node.next_functions[0][0]
+    return None
+
+
 class MiniHeadFn(Function):
     """c0 (B, S, H0, K*G) raw first-conv outputs of S stacked nets (+ their (sum, sum^2)
     partials) -> c = W3 . relu(bn0(c0)) (B, S, half, K*G) and g = max_G c (B, S, half, K)."""
@@ -429,6 +447,12 @@ class MiniHeadFn(Function):
     @staticmethod
     def forward(ctx, c0, c0_part, bufs, G, gamma0, beta0, w3):
         backend = backend_for(c0)
+        # c0 straight from the blend kernel: its backward applies this norm's backward on its tile
+        # load (no separate apply pass, no dZ tensor); the hand-over travels on the producer's node
+        ctx.blend_holder = None
+        producer = _blend_producer(c0) if (FOLD_NORM_BWD and c0.is_contiguous()) else None
+        if producer is not None:
+            ctx.blend_holder = producer.pending_norm = {}
         c0 = c0.contiguous()
         B, S, H0, P = c0.shape
         half = w3.shape[1]
@@ -474,8 +498,14 @@ class MiniHeadFn(Function):
             dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
         da0 = c0.new_empty(B * S, H0, P)
         part = backend.pw_dgrad_bn_reduce(dcf, w3.transpose(1, 2), x0, coef0, da0, ng=S)
-        dc0 = torch.empty_like(c0)
         dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
+        if ctx.blend_holder is not None:
+            # the blend's backward reads (da0, c0) and applies the norm backward itself
+            bnb = backend.pw_bnb_coef(part, coef0, gamma0, float(B) * float(P), dgamma, dbeta)
+            da0 = da0.view(B, S, H0, P)
+            ctx.blend_holder.update(z=c0, bnb=bnb, ptr=da0.data_ptr())
+            return da0, None, None, None, dgamma, dbeta, dw3
+        dc0 = torch.empty_like(c0)
         backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
                                        None, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
         return dc0, None, None, None, dgamma, dbeta, dw3

@@ -426,3 +426,43 @@ def test_stream_first_layer_equals_the_gemm_path(hip_device):
     for pa, pb in zip(a.parameters(), b.parameters()):
         scale = max(float(pb.grad.abs().max()), 1e-3)
         assert float((pa.grad - pb.grad).abs().max()) / scale < 1e-3
+
+
+def test_folded_norm_backward_matches_the_separate_apply_pass(hip_device):
+    """NESIE_FOLD_NORM_BWD on vs off on the reduced model, one training step from the same state:
+    the norm backward applied inside its consumer -- the weight gradient (SA stacks, 1-D chains,
+    MiniPointNet norm 1 with the row-bias gradient) or the blend backward (MiniPointNet norm 0,
+    handed over on the BlendConv node) -- gives the gradients of the separate apply pass."""
+    import copy
+    from nesie_amd.mmdet3d_ops import fused_mlp, interpolate
+    model = _small.small_model().to(hip_device).train()
+    pts, boxes, labels = _small.small_batch()
+    pts = pts.to(hip_device)
+    model.bbox_head.jitter_noise = tuple(t.to(hip_device) for t in _small.fixed_noise(2, 32))
+    _small.force_vote_sampling(model, 'fold')
+    _small.force_grid_taps(model, 'fold')
+    seen = []
+    real = interpolate.BlendConv.backward
+
+    def spy(ctx, dy, *rest):
+        seen.append(getattr(ctx, 'pending_norm', None) is not None and ctx.pending_norm.get('bnb') is not None)
+        return real(ctx, dy, *rest)
+    out = []
+    for fold in (False, True):
+        fused_mlp.FOLD_NORM_BWD = fold
+        interpolate.BlendConv.backward = staticmethod(spy)
+        try:
+            m = copy.deepcopy(model)
+            out.append(_small.train_step_losses(m, pts, boxes, labels))
+        finally:
+            fused_mlp.FOLD_NORM_BWD = True
+            interpolate.BlendConv.backward = staticmethod(real)
+    n = len(seen) // 2
+    assert n >= 2 and not any(seen[:n]) and all(seen[n:]), seen       # the hand-over really happened
+    (l0, g0), (l1, g1) = out
+    for k in l0:
+        torch.testing.assert_close(l1[k], l0[k], rtol=1e-6, atol=1e-7, msg=k)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        scale = max(float(g0[k].abs().max()), 1e-3 * gmax)
+        assert float((g1[k] - g0[k]).abs().max()) < 2e-4 * scale, k
