@@ -565,6 +565,13 @@ int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
                      long long dy_bstride, const float *x, long long x_bstride,
                      const float *x_coef, int x_relu, float *dw, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* The same with the BatchNorm + ReLU backward that produces dy applied on the load: da = gradient of
+ * relu(bn(z)), bnb [cout][8] from nesie_pw_bnb_coef; dz is never written (for a layer whose input
+ * needs no gradient, e.g. the first layer of SA1: nothing else reads it). */
+int nesie_conv_wgrad_bn(int b, int cout, int cin, long long p, const float *da, const float *z,
+                        long long z_bstride, const float *bnb, const float *x, long long x_bstride,
+                        const float *x_coef, int x_relu, float *dw, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

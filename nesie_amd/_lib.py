@@ -67,6 +67,8 @@ SIGNATURES = {
                                        _P, ctypes.c_size_t, _P],
     "nesie_conv_wgrad": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                          _P, _I, _P, _P, ctypes.c_size_t, _P],
+    "nesie_conv_wgrad_bn": [_I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P,
+                            ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
     "nesie_mlp_layer_forward_stream": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P,
                                        _I, _P, _P, _P],
     "nesie_mlp_stat_finalize": [_I, ctypes.c_longlong, ctypes.c_double, _P, _P, _P, _P, _P, _F,

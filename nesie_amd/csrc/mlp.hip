@@ -106,7 +106,12 @@ template <int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     int cout, int cin, long long p, long long x_bstride, long long dy_bstride, int run, int vec_ok,
     const float *__restrict__ dy, const float *__restrict__ x,
-    const float *__restrict__ x_coef, int x_relu, float *__restrict__ partial) {
+    const float *__restrict__ x_coef, int x_relu, float *__restrict__ partial,
+    const float *__restrict__ bnz, const float *__restrict__ bnb) {
+  // bnb != NULL: `dy` is the gradient dA of relu(bn(Z)), Z = `bnz` (same layout); the norm backward's
+  // apply pass runs on the load, dZ = a g + (e0 - (z - mean) d1), g = dA [fma(z, scale, shift) > 0],
+  // bnb[row] = (scale, shift, a, mean, d1, e0, -, -) (pw_bnb_coef_kernel) -- dZ is never written
+  // (nobody else reads it when the layer's input needs no gradient: the first layer of SA1).
   constexpr int MT = WM * MB * 32, NT = WN * NB * 32;  // padded Cout, Cin covered
   extern __shared__ float lds[];                      // [MT + NT][WG_P]
   float *sa = lds, *sb = lds + MT * WG_P;
@@ -116,7 +121,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const long long p0 = (long long)blockIdx.x * run;
   const long long p1 = p0 + run < p ? p0 + run : p;
   const float *dyb = dy + (size_t)bi * dy_bstride;
+  const float *zb = bnb ? bnz + (size_t)bi * dy_bstride : nullptr;
   const float *xb = x + (size_t)bi * x_bstride;
+  auto norm_bwd = [&](float4 g, float4 z, int row) {
+    const float *cf = bnb + (size_t)row * 8;
+    const float sc = cf[0], bs = cf[1], a = cf[2], mu = cf[3], d1 = cf[4], e0 = cf[5];
+    float4 r;
+    r.x = __builtin_fmaf(a, __builtin_fmaf(z.x, sc, bs) > 0.f ? g.x : 0.f, __builtin_fmaf(mu - z.x, d1, e0));
+    r.y = __builtin_fmaf(a, __builtin_fmaf(z.y, sc, bs) > 0.f ? g.y : 0.f, __builtin_fmaf(mu - z.y, d1, e0));
+    r.z = __builtin_fmaf(a, __builtin_fmaf(z.z, sc, bs) > 0.f ? g.z : 0.f, __builtin_fmaf(mu - z.z, d1, e0));
+    r.w = __builtin_fmaf(a, __builtin_fmaf(z.w, sc, bs) > 0.f ? g.w : 0.f, __builtin_fmaf(mu - z.w, d1, e0));
+    return r;
+  };
   f32x16 acc[MB][NB];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -142,7 +158,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         const int row = u * 16 + (tid >> 4) - (is_a ? 0 : MT);
         const int lim = is_a ? cout : cin;
         const int rr = row < lim ? row : lim - 1;
-        const float4 t = *(const float4 *)((is_a ? dyb : xb) + (size_t)rr * p + q);
+        float4 t = *(const float4 *)((is_a ? dyb : xb) + (size_t)rr * p + q);
+        if (is_a && bnb) t = norm_bwd(t, *(const float4 *)(zb + (size_t)rr * p + q), rr);   // (uniform test)
         v[u] = row < lim ? t : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (x_coef) {
@@ -170,13 +187,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < (is_a ? cout : cin)) {
         const float *src = (is_a ? dyb : xb) + (size_t)row * p + q;
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *zs = (is_a && bnb) ? zb + (size_t)row * p + q : nullptr;
         if (vec && q + 3 < p1) {
           v[u] = *(const float4 *)src;
+          if (zs) zz = *(const float4 *)zs;
         } else {
-          if (q < p1) v[u].x = src[0];
-          if (q + 1 < p1) v[u].y = src[1];
-          if (q + 2 < p1) v[u].z = src[2];
-          if (q + 3 < p1) v[u].w = src[3];
+          if (q < p1) { v[u].x = src[0]; if (zs) zz.x = zs[0]; }
+          if (q + 1 < p1) { v[u].y = src[1]; if (zs) zz.y = zs[1]; }
+          if (q + 2 < p1) { v[u].z = src[2]; if (zs) zz.z = zs[2]; }
+          if (q + 3 < p1) { v[u].w = src[3]; if (zs) zz.w = zs[3]; }
+        }
+        if (zs) {
+          v[u] = norm_bwd(v[u], zz, row);
+          if (q >= p1) v[u].x = 0.f;      // (positions past the run: dZ of a zero pair is e0-ish, not zero)
+          if (q + 1 >= p1) v[u].y = 0.f;
+          if (q + 2 >= p1) v[u].z = 0.f;
+          if (q + 3 >= p1) v[u].w = 0.f;
         }
         if (!is_a && x_coef) {
           const float sc = x_coef[row * 4 + 0], bs = x_coef[row * 4 + 1];
@@ -291,12 +318,10 @@ extern "C" size_t nesie_conv_wgrad_workspace_bytes(int b, int cout, int cin, lon
   return (size_t)b * runs * cout * cin * sizeof(float);
 }
 
-extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
-                                long long dy_bstride, const float *x, long long x_bstride,
-                                const float *x_coef,
-                                int x_relu, float *dw, void *workspace, size_t workspace_bytes,
-                                void *stream) {
-  const char *W = "conv_wgrad";
+static int conv_wgrad_impl(const char *W, int b, int cout, int cin, long long p, const float *dy,
+                           long long dy_bstride, const float *x, long long x_bstride,
+                           const float *x_coef, int x_relu, float *dw, void *workspace,
+                           size_t workspace_bytes, const float *bnz, const float *bnb, void *stream) {
   NESIE_REQUIRE(b >= 0 && cout >= 1 && cin >= 1 && p >= 0, W);
   NESIE_REQUIRE(dw, W);
   hipStream_t s = (hipStream_t)stream;
@@ -325,7 +350,7 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
       attr = true;                                                                               \
     }                                                                                            \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, cout, cin, p, x_bstride, dy_bstride, run,  \
-                       vec_ok, dy, x, x_coef, x_relu, partial);                                  \
+                       vec_ok, dy, x, x_coef, x_relu, partial, bnz, bnb);                        \
   } while (0)
   // (Cout/32) x (Cin/32) output blocks over 4 waves
   if (mb32 <= 2 && nb32 <= 2) L(2, 2, 1, 1);
@@ -347,6 +372,25 @@ extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const flo
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(1024), 0, s, total,
                      b * runs, partial, dw);
   return check_launch(W);
+}
+
+extern "C" int nesie_conv_wgrad(int b, int cout, int cin, long long p, const float *dy,
+                                long long dy_bstride, const float *x, long long x_bstride,
+                                const float *x_coef,
+                                int x_relu, float *dw, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+  return conv_wgrad_impl("conv_wgrad", b, cout, cin, p, dy, dy_bstride, x, x_bstride, x_coef, x_relu, dw,
+                         workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int nesie_conv_wgrad_bn(int b, int cout, int cin, long long p, const float *da, const float *z,
+                                   long long z_bstride, const float *bnb, const float *x,
+                                   long long x_bstride, const float *x_coef, int x_relu, float *dw,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+  const char *W = "conv_wgrad_bn";
+  NESIE_REQUIRE(b == 0 || p == 0 || (z && bnb), W);
+  return conv_wgrad_impl(W, b, cout, cin, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
+                         workspace_bytes, z, bnb, stream);
 }
 
 // ---- streaming form of the layer kernel for skinny layers (Cin <= 64) --------------------------

@@ -597,9 +597,10 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_iou3d_forward", n, _ptr(box1), _ptr(box2), _ptr(iou),
                       0 if jac is None else _ptr(jac), _stream(box1))
 
-    def conv_wgrad(self, dy, x, dw, x_coef=None, x_relu=False):
+    def conv_wgrad(self, dy, x, dw, x_coef=None, x_relu=False, bn_z=None, bnb=None):
         """dw (cout, cin) = sum_b dy[b] (cout, P) @ act(x[b]) (cin, P)^T on the matrix cores;
-        dy and x may be batch-strided views (each dy[b], x[b] contiguous)."""
+        dy and x may be batch-strided views (each dy[b], x[b] contiguous).  bn_z / bnb: dy is the
+        gradient of relu(bn(bn_z)) and the norm backward runs on the load (nesie_conv_wgrad_bn)."""
         _f32(dy, x, dw)
         if not (dy.is_cuda and dw.is_contiguous()):
             raise ValueError("conv_wgrad: HIP tensors, dw contiguous")
@@ -612,6 +613,14 @@ class HipKernels(_BNPoolMixin):
         need = lib.nesie_conv_wgrad_workspace_bytes(b, cout, cin, p)
         with torch.cuda.device(dy.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
+            if bnb is not None:
+                _check(bn_z, bnb); _f32(bn_z, bnb)
+                assert tuple(bn_z.shape) == tuple(dy.shape) and dy.is_contiguous() and tuple(bnb.shape) == (cout, 8)
+                _lib.call("nesie_conv_wgrad_bn", b, cout, cin, p, _ptr(dy), _ptr(bn_z), cout * p, _ptr(bnb),
+                          _ptr(x), x.stride(0) if b > 1 else cin * p,
+                          0 if x_coef is None else _ptr(x_coef), int(bool(x_relu)), _ptr(dw), _ptr(ws),
+                          need, _stream(dy))
+                return
             _lib.call("nesie_conv_wgrad", b, cout, cin, p, _ptr(dy),
                       dy.stride(0) if b > 1 else cout * p, _ptr(x),
                       x.stride(0) if b > 1 else cin * p, 0 if x_coef is None else _ptr(x_coef),

@@ -78,12 +78,14 @@ def _wgrad(backend, dy, x, x_coef, ng=1):
 FOLD_NORM_BWD = _os.environ.get('NESIE_FOLD_NORM_BWD', '1') != '0'
 
 
-def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1):
+def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1, need_dz=True):
     """The backward of relu(bn(z)) given da (its gradient) and the reduction partials the
     input-gradient launch left, and the weight gradient dz . act(src)^T of the conv that produced z:
     -> (dz, dw | None, dgamma, dbeta).  One launch where the layer kernel's weight gradient serves
     the shape (``nesie_pw_wgrad_bn_backward``: dz is formed on the operand load and written over
-    da), the apply pass + ``_wgrad`` otherwise."""
+    da), the apply pass + ``_wgrad`` otherwise.  ``need_dz`` False (the layer's input needs no
+    gradient) and a skinny input (Cin <= 8, the first layer of SA1): ``nesie_conv_wgrad_bn`` forms
+    dz on its load and never writes it -> dz None."""
     nb, co, p = da.shape
     ci = src.shape[1]
     dgamma, dbeta = da.new_empty(ng * co), da.new_empty(ng * co)
@@ -92,6 +94,11 @@ def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_
         backend.pw_wgrad_bn_backward(da, z, coef, gamma, part, src, da, dw, dgamma, dbeta, ng=ng,
                                      x_coef=src_coef)
         return da, dw, dgamma, dbeta
+    if FOLD_NORM_BWD and need_w and not need_dz and ng == 1 and ci <= 8 and backend.conv_wgrad_supported(co, ci):
+        bnb = backend.pw_bnb_coef(part, coef, gamma, float(nb) * float(p), dgamma, dbeta)
+        dw = da.new_empty(co, ci)
+        backend.conv_wgrad(da, src, dw, x_coef=src_coef, x_relu=src_coef is not None, bn_z=z, bnb=bnb)
+        return None, dw.unsqueeze(0), dgamma, dbeta
     dz = torch.empty_like(da)
     b = nb // ng
     backend.bn_relu_backward_apply(da.view(b, ng * co, p), z.view(b, ng * co, p), gamma, None, coef, part,
@@ -184,8 +191,9 @@ class SAStackFn(Function):
             src_coef = None if l == 0 else coefs[l - 1]
             need_w = ctx.needs_input_grad[3 + 3 * l]
             if pending is not None:     # norm backward of this layer, with its weight gradient
-                dy, dw, dgamma, dbeta = _norm_backward_wgrad(backend, pending[0], ys[l], params[3 * l + 1],
-                                                             coefs[l], pending[1], src, src_coef, need_w)
+                dy, dw, dgamma, dbeta = _norm_backward_wgrad(
+                    backend, pending[0], ys[l], params[3 * l + 1], coefs[l], pending[1], src, src_coef,
+                    need_w, need_dz=l > 0 or bool(ctx.needs_input_grad[0]))
                 grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
                 if dw is not None:
                     grads[3 * l] = dw.view_as(w)

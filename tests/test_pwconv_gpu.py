@@ -359,6 +359,39 @@ def test_weight_gradient_fused_with_the_norm_backward(nb, ng, co, ci, p, in_plac
         assert (src.double() - dz_ref).abs().max().item() < 2e-5 * dz_ref.abs().max().item()
 
 
+@pytest.mark.parametrize('b,cout,cin,p', [(2, 64, 4, 4096), (3, 64, 4, 1000), (2, 64, 3, 1003), (2, 128, 8, 520)])
+def test_skinny_weight_gradient_with_the_norm_backward_on_its_load(b, cout, cin, p):
+    """nesie_conv_wgrad_bn (the first layer of SA1: Cin = 4, nobody reads dZ) against float64: vector
+    interior, run edges and the scalar path for unaligned p."""
+    hip = _hip()
+    g = torch.Generator(device=_dev()).manual_seed(cout + cin + p)
+    da = torch.randn(b, cout, p, device=_dev(), generator=g)
+    z = torch.randn(b, cout, p, device=_dev(), generator=g) * 1.3 - 0.4
+    x = torch.randn(b, cin, p, device=_dev(), generator=g)
+    gamma = torch.randn(cout, device=_dev(), generator=g)
+    beta = torch.randn(cout, device=_dev(), generator=g) * 0.3
+    zd = z.double()
+    mean, invstd = zd.mean((0, 2)), (zd.var((0, 2), unbiased=False) + 1e-5).rsqrt()
+    scale = gamma.double() * invstd
+    zcoef = torch.stack([scale, beta.double() - mean * scale, mean, invstd], -1).float().contiguous()
+    mask = torch.addcmul(zcoef[:, 1].view(1, -1, 1), z, zcoef[:, 0].view(1, -1, 1)) > 0
+    gg = torch.where(mask, da, torch.zeros_like(da)).double()
+    zc = zcoef.double()
+    zhat = (zd - zc[:, 2].view(1, -1, 1)) * zc[:, 3].view(1, -1, 1)
+    s0, s1 = gg.sum((0, 2)), (gg * zhat).sum((0, 2))
+    n = b * p
+    dz = (gamma.double() * zc[:, 3]).view(1, -1, 1) * (gg - (s0 / n).view(1, -1, 1) - zhat * (s1 / n).view(1, -1, 1))
+    want = torch.bmm(dz, x.double().transpose(1, 2)).sum(0)
+    part = torch.stack([s0, s1], -1).view(cout, 1, 2).float().contiguous()
+    dgamma, dbeta = torch.empty(cout, device=_dev()), torch.empty(cout, device=_dev())
+    bnb = hip.pw_bnb_coef(part, zcoef, gamma, float(n), dgamma, dbeta)
+    dw = torch.empty(cout, cin, device=_dev())
+    hip.conv_wgrad(da, x, dw, bn_z=z, bnb=bnb)
+    assert (dw.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    torch.testing.assert_close(dgamma.double(), s1, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dbeta.double(), s0, rtol=1e-5, atol=1e-4)
+
+
 def _sa_module(c_in, mlp, ns):
     from nesie_amd.mmdet3d_ops import PointSAModule
     torch.manual_seed(0)
