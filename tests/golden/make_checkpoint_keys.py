@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Generate tests/golden/reference_state_dict_keys.json: {key: shape} of the state_dict the
-REFERENCE's own module classes produce for the Nesie-VoteNet detector, plus the buffer names its
-EMA hook registers.
+REFERENCE's own module classes produce for the Nesie-VoteNet detector AND the SAQE-VoteNet
+detector (BASELINE configs[4]: `SAQEHead` + `QualityEstimation`, saqe_head.py:90-253,
+quelity_estimation_module.py:10-285), plus the buffer names its EMA hook registers for each.
 
 Runs only in the build container (needs /root/reference).  Loaded BY PATH inside the sandbox of
 make_golden.py (third-party stand-ins only; `mmdet3d/__init__.py` never runs):
@@ -10,6 +11,7 @@ make_golden.py (third-party stand-ins only; `mmdet3d/__init__.py` never runs):
   mmdet3d/models/backbones/{base_pointnet,pointnet2_sa_ssg}.py
   mmdet3d/models/dense_heads/nesie_head.py (+ vote_module, reliable_conv_bbox_module,
       side_pooling_module), built with the reference's OWN PointSAModule as vote aggregation
+  mmdet3d/models/dense_heads/saqe_head.py (+ quelity_estimation_module), likewise
   mmdet3d/core/utils/simi_teacher_hook.py   (hooks_before_run: `ema_<name with . -> _>` buffers, :39-52)
 Only names and shapes are written -- no weights, no source.
 """
@@ -66,30 +68,46 @@ def main():
     mine_cfg = nesie_votenet_scannet_cfg()
     bcfg = {k: v for k, v in mine_cfg['backbone'].items() if k != 'type'}
 
+    saqe_mod = importlib.import_module('mmdet3d.models.dense_heads.saqe_head')
+    saqe_mod.build_sa_module = builder.build_sa_module
+    scfg = golden_inputs.saqe_head_cfg()
+    scfg['bbox_head']['grid_conv_cfg']['mean_size_arr_path'] = cfg['bbox_head']['grid_conv_cfg'][
+        'mean_size_arr_path']
+
     class Detector(nn.Module):      # single_stage.py: self.backbone, self.bbox_head
-        def __init__(self):
+        def __init__(self, head):
             super().__init__()
             self.backbone = bb.PointNet2SASSG(**bcfg)
-            self.bbox_head = ref_head_mod.NesieHead(**cfg['bbox_head'], train_cfg=cfg['train_cfg'],
-                                                    test_cfg=cfg['test_cfg'])
-    det = Detector()
-    assert type(det.bbox_head.vote_aggregation).__module__ == 'mmdet3d.ops.pointnet_modules.point_sa_module'
-    assert type(det.backbone.SA_modules[0]).__module__ == 'mmdet3d.ops.pointnet_modules.point_sa_module'
-    plain = {k: list(v.shape) for k, v in det.state_dict().items()}
+            self.bbox_head = head
+
     # the EMA hook's buffers (hooks_before_run only; update / swap are not run)
     mg._mod('mmcv.parallel', is_module_wrapper=lambda m: False)
     rn = sys.modules['mmcv.runner']
     rn.HOOKS, rn.Hook = mg.Registry('hook'), object
     mg._pkg('mmdet3d.core.utils', os.path.join(r, 'core', 'utils'))
-    hook = importlib.import_module('mmdet3d.core.utils.simi_teacher_hook').SimiTeacherHook()
-    hook.hooks_before_run(det)
-    ema = {k: list(v.shape) for k, v in det.state_dict().items() if k not in plain}
+    hook_cls = importlib.import_module('mmdet3d.core.utils.simi_teacher_hook').SimiTeacherHook
+
+    def dump(head):
+        det = Detector(head)
+        assert type(det.bbox_head.vote_aggregation).__module__ == 'mmdet3d.ops.pointnet_modules.point_sa_module'
+        assert type(det.backbone.SA_modules[0]).__module__ == 'mmdet3d.ops.pointnet_modules.point_sa_module'
+        plain = {k: list(v.shape) for k, v in det.state_dict().items()}
+        hook_cls().hooks_before_run(det)
+        ema = {k: list(v.shape) for k, v in det.state_dict().items() if k not in plain}
+        return plain, ema
+
+    plain, ema = dump(ref_head_mod.NesieHead(**cfg['bbox_head'], train_cfg=cfg['train_cfg'],
+                                             test_cfg=cfg['test_cfg']))
+    splain, sema = dump(saqe_mod.SAQEHead(**scfg['bbox_head'], train_cfg=scfg['train_cfg'],
+                                          test_cfg=scfg['test_cfg']))
     out = {'source': 'reference classes loaded by path (tests/golden/make_checkpoint_keys.py)',
            'backbone_cfg': {k: v for k, v in bcfg.items() if isinstance(v, (int, float, str, list, tuple))},
-           'state_dict': plain, 'ema_buffers': ema}
+           'state_dict': plain, 'ema_buffers': ema,
+           'saqe_state_dict': splain, 'saqe_ema_buffers': sema}
     path = os.path.join(ROOT, 'tests', 'golden', 'reference_state_dict_keys.json')
     json.dump(out, open(path, 'w'), indent=0, sort_keys=True)
-    print('wrote', path, len(plain), 'keys +', len(ema), 'ema buffers;', os.path.getsize(path), 'bytes')
+    print('wrote', path, len(plain), 'keys +', len(ema), 'ema buffers; SAQE', len(splain), '+', len(sema), ';',
+          os.path.getsize(path), 'bytes')
 
 
 if __name__ == '__main__':

@@ -39,6 +39,51 @@ def test_ema_buffers_have_the_reference_hook_names_and_shapes():
     assert rest == ref['state_dict']            # the semi-supervised detector adds nothing else
 
 
+def test_saqe_state_dict_and_ema_buffers_have_the_reference_names_and_shapes():
+    """BASELINE configs[4]: the reference's own `SAQEHead` + `QualityEstimation` module tree
+    (saqe_head.py:90-253, quelity_estimation_module.py:10-285, 365-381: one global quality head,
+    27-point side grids) and the EMA buffers its hook derives from it (simi_teacher_hook.py:39-52)."""
+    from nesie_amd.votenet.detector import build_saqe_votenet
+    ref = _reference_keys()
+    want, want_ema = ref['saqe_state_dict'], ref['saqe_ema_buffers']
+    assert len(want) == 318 and len(want_ema) == 187
+    assert want != ref['state_dict']            # a different module tree from the Nesie head's
+    mine = {k: list(v.shape) for k, v in build_saqe_votenet().state_dict().items()}
+    assert sorted(mine) == sorted(want)
+    for k, shape in want.items():
+        assert mine[k] == shape, (k, mine[k], shape)
+    model = semi.build_saqe_votenet_semi()
+    ema = {k: list(v.shape) for k, v in model.state_dict().items() if k.startswith('ema_')}
+    assert ema == want_ema
+    rest = {k: list(v.shape) for k, v in model.state_dict().items() if not k.startswith('ema_')}
+    assert rest == want
+
+
+def test_saqe_reference_envelope_round_trip(tmp_path):
+    """A checkpoint in the reference's envelope with the reference's SAQE key set (built from the
+    fixture's {key: shape}, DDP 'module.' prefix) loads strictly into the SAQE detector and the
+    semi-supervised wrapper; an `epoch_N_ema.pth` carries the teacher's weights."""
+    from nesie_amd.votenet.detector import build_saqe_votenet
+    ref = _reference_keys()
+    g = torch.Generator().manual_seed(11)
+    state = OrderedDict()
+    for k, shape in ref['saqe_state_dict'].items():
+        state['module.' + k] = (torch.zeros(shape, dtype=torch.long) if k.endswith('num_batches_tracked')
+                                else torch.rand(shape, generator=g))
+    dst = build_saqe_votenet()
+    checkpoint.load_reference_checkpoint(dst, {'meta': {'epoch': 2, 'iter': 5}, 'state_dict': state})
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, state['module.' + k]), k
+    model = semi.build_saqe_votenet_semi()
+    checkpoint.load_reference_checkpoint(model, {'meta': {}, 'state_dict': state})   # ema_* may be missing
+    model.teacher.resync()
+    paths = checkpoint.save_reference_checkpoint(model, tmp_path, epoch=2, iteration=5, ema_copy=True)
+    assert [os.path.basename(p) for p in paths] == ['epoch_2.pth', 'epoch_2_ema.pth']
+    saved = torch.load(paths[0])['state_dict']
+    assert sorted(k for k in saved if not k.startswith('ema_')) == sorted(ref['saqe_state_dict'])
+    assert sorted(k for k in saved if k.startswith('ema_')) == sorted(ref['saqe_ema_buffers'])
+
+
 def test_reference_envelope_round_trip(tmp_path):
     torch.manual_seed(0)
     src = build_nesie_votenet()
