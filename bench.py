@@ -419,13 +419,14 @@ def cpu_baseline(sample_batch, steps):
                        f'PyTorch-CPU dense ops, {dt:.2f} s/step')
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None):
     """``python bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start N fresh child
     processes of this script -- one rank per GPU, the torchrun environment contract (RANK,
     LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT) -- BEFORE this process has made
     any GPU call (it never makes one: it only waits; a process that has touched the GPU must not
     exec or fork workers on this pool).  Rank 0's stdout (the ONE JSON line) and every rank's
-    stderr pass through; the exit code is the first non-zero child code.  The reference gets its
+    stderr pass through; the exit code is the first non-zero child code, returned as soon as that
+    child has exited (the other ranks are terminated, not waited for).  The reference gets its
     ranks from ``train.py --launcher`` -> ``mmdet.apis.train_detector`` (train.py:71-74, 131-136)."""
     import socket
     import subprocess
@@ -440,20 +441,37 @@ def spawn_ranks(n, argv):
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv),
                                       env=env, stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
-        for pr in procs:
-            code = pr.wait()
-            rc = rc or code
-            if code:                         # one rank failed: the others would wait for it forever
-                for other in procs:
-                    if other.poll() is None:
-                        other.terminate()
+        # poll ALL ranks: a rank that dies during init or inside a collective leaves the others
+        # waiting in RCCL / gloo until the collective time-out, so the first non-zero exit ends the
+        # job -- terminate the rest, kill what ignores that after a grace period
+        live = list(procs)
+        while live and not rc:
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                rc = rc or code
+            if live and not rc:
+                time.sleep(0.2)
+        if rc:
+            for pr in live:
+                pr.terminate()
+            deadline = time.monotonic() + 10.0
+            for pr in live:
+                try:
+                    pr.wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    pr.wait()
     except KeyboardInterrupt:
         for pr in procs:
-            pr.terminate()
+            if pr.poll() is None:
+                pr.terminate()
         rc = 130
     return rc
 

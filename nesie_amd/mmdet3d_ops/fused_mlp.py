@@ -29,9 +29,11 @@ from ..kernels import backend_for
 # Tests flip this to obtain the module-by-module evaluation of the same network on the device.
 ENABLED = True
 
-# addresses of gradient buffers a backward of this file has freshly allocated and is returning
-# (ownership hand-over between MiniTailFn.backward and MiniHeadFn.backward, see there)
-_FRESH_GRADS = set()
+# Ownership hand-over of a freshly allocated gradient buffer between MiniTailFn.backward and
+# MiniHeadFn.backward: the producer marks the TENSOR OBJECT (an attribute, not its address -- an
+# address outlives the tensor in the caching allocator and could be handed to an unrelated gradient
+# later); whatever autograd builds from it for a second consumer is a new object without the mark.
+_OWNED_MARK = '_nesie_fresh_grad'
 
 
 # Layers wider than one workgroup's accumulators (the 1-D chains' 256 x 256 / 256 x 512 at 8 x 1024
@@ -430,22 +432,46 @@ def mini_tail_second(backend, y, coef1, w4, G):
     return out, arg
 
 
-def _blend_producer(t):
-    """The autograd node of the ``BlendConv`` whose output ``t`` is (through view / reshape nodes
-    only), or None: such a producer takes over the backward of the norm its consumer applies
-    (interpolate.BlendConv.backward, ``pending_norm``)."""
-    node = t.grad_fn
-    for _ in range(6):
-        if node is None:
-            return None
-        name = type(node).__name__
-        if name == 'BlendConvBackward':
-            return node
-        if not any(k in name for k in ('View', 'Reshape', 'Squeeze', 'Unsqueeze', 'Alias')) \
-                or len(node.next_functions) != 1:
-            return None
-        node = node.next_functions[0][0]
-    return None
+def _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3):
+    """-> (c, g, arg, coef0): the first norm's statistics from the producer's partials, then
+    ``mini_head_kernels``."""
+    B, S, H0, P = c0.shape
+    rm, rv, momentum, eps = bufs
+    coef0 = c0.new_empty(S * H0, 4)
+    backend.mlp_stat_finalize(c0_part, B * P, gamma0, beta0, rm, rv, momentum, eps, coef0,
+                              channel_major=True)
+    c, g, arg = mini_head_kernels(backend, c0, coef0, w3, G)
+    return c, g, arg, coef0
+
+
+def _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, G, need_w3):
+    """-> (da0 (B*S, H0, P) = gradient of relu(bn0(c0)), reduction partials, dw3)."""
+    B, S, H0, P = c0.shape
+    half = w3.shape[1]
+    # (MiniTailFn.backward hands over a buffer it has just allocated and marks the tensor object:
+    # that one is ours to write into; anything else is copied first)
+    owned = dc is None or (dc.is_contiguous() and dc._base is None and getattr(dc, _OWNED_MARK, False))
+    if dc is None:
+        dc = c0.new_zeros(B, S, half, P)
+    if dg is not None:
+        # the pooled gradient joins the dense one at the arg-max -- in a buffer of our OWN:
+        # autograd does not hand a backward ownership of its incoming gradients (the same
+        # tensor may be another consumer's gradient, a hook's or a retained one)
+        if not owned:
+            dc = dc.clone(memory_format=torch.contiguous_format)
+        dcv = dc.view(B, S, half, P // G, G)
+        backend.group_max_pool_backward_add(dg.contiguous(), arg, dcv)
+    else:
+        dc = dc.contiguous()
+    x0 = c0.view(B * S, H0, P)
+    dcf = dc.view(B * S, half, P)
+    dw3 = None
+    if need_w3:
+        # per-net weight gradient: the S nets are the S strided batch subsets
+        dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
+    da0 = c0.new_empty(B * S, H0, P)
+    part = backend.pw_dgrad_bn_reduce(dcf, w3.transpose(1, 2), x0, coef0, da0, ng=S)
+    return da0, part, dw3
 
 
 class MiniHeadFn(Function):
@@ -455,20 +481,8 @@ class MiniHeadFn(Function):
     @staticmethod
     def forward(ctx, c0, c0_part, bufs, G, gamma0, beta0, w3):
         backend = backend_for(c0)
-        # c0 straight from the blend kernel: its backward applies this norm's backward on its tile
-        # load (no separate apply pass, no dZ tensor); the hand-over travels on the producer's node
-        ctx.blend_holder = None
-        producer = _blend_producer(c0) if (FOLD_NORM_BWD and c0.is_contiguous()) else None
-        if producer is not None:
-            ctx.blend_holder = producer.pending_norm = {}
         c0 = c0.contiguous()
-        B, S, H0, P = c0.shape
-        half = w3.shape[1]
-        rm, rv, momentum, eps = bufs
-        coef0 = c0.new_empty(S * H0, 4)
-        backend.mlp_stat_finalize(c0_part, B * P, gamma0, beta0, rm, rv, momentum, eps, coef0,
-                                  channel_major=True)
-        c, g, arg = mini_head_kernels(backend, c0, coef0, w3, G)
+        c, g, arg, coef0 = _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3)
         ctx.G = G
         ctx.save_for_backward(c0, coef0, arg, gamma0, beta0, w3)
         ctx.mark_non_differentiable(arg)
@@ -479,44 +493,72 @@ class MiniHeadFn(Function):
         c0, coef0, arg, gamma0, beta0, w3 = ctx.saved_tensors
         backend = backend_for(c0)
         B, S, H0, P = c0.shape
-        half = w3.shape[1]
-        G = ctx.G
-        # (MiniTailFn.backward hands over a buffer it has just allocated and registers its address:
-        # that one is ours to write into; anything else is copied first)
-        owned = dc is None or (dc.is_contiguous() and dc._base is None and dc.data_ptr() in _FRESH_GRADS)
-        if dc is not None:
-            _FRESH_GRADS.discard(dc.data_ptr())
-        if dc is None:
-            dc = c0.new_zeros(B, S, half, P)
-        if dg is not None:
-            # the pooled gradient joins the dense one at the arg-max -- in a buffer of our OWN:
-            # autograd does not hand a backward ownership of its incoming gradients (the same
-            # tensor may be another consumer's gradient, a hook's or a retained one)
-            if not owned:
-                dc = dc.clone(memory_format=torch.contiguous_format)
-            dcv = dc.view(B, S, half, P // G, G)
-            backend.group_max_pool_backward_add(dg.contiguous(), arg, dcv)
-        else:
-            dc = dc.contiguous()
-        x0 = c0.view(B * S, H0, P)
-        dcf = dc.view(B * S, half, P)
-        dw3 = None
-        if ctx.needs_input_grad[6]:
-            # per-net weight gradient: the S nets are the S strided batch subsets
-            dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
-        da0 = c0.new_empty(B * S, H0, P)
-        part = backend.pw_dgrad_bn_reduce(dcf, w3.transpose(1, 2), x0, coef0, da0, ng=S)
+        da0, part, dw3 = _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, ctx.G,
+                                             ctx.needs_input_grad[6])
         dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
-        if ctx.blend_holder is not None:
-            # the blend's backward reads (da0, c0) and applies the norm backward itself
-            bnb = backend.pw_bnb_coef(part, coef0, gamma0, float(B) * float(P), dgamma, dbeta)
-            da0 = da0.view(B, S, H0, P)
-            ctx.blend_holder.update(z=c0, bnb=bnb, ptr=da0.data_ptr())
-            return da0, None, None, None, dgamma, dbeta, dw3
         dc0 = torch.empty_like(c0)
         backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
                                        None, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
         return dc0, None, None, None, dgamma, dbeta, dw3
+
+
+class BlendMiniHeadFn(Function):
+    """``interpolate.BlendConv`` (the first 1x1 conv of S MiniPointNets through the 3-NN blend,
+    side_pooling_module.py:226-243, 346-349) and ``MiniHeadFn`` as ONE autograd node:
+    (table (B, M, S*H0), wx (S, H0, 3)) -> (c, g) as MiniHeadFn.
+
+    The first norm's backward is applied by the blend backward on its tile load
+    (``nesie_blend_conv_backward_bn``): no apply pass, no dZ tensor.  That needs the blend
+    backward to see the gradient of the NORMALISED activation together with (c0, reduction
+    coefficients) -- state that must not travel through autograd as if it were a gradient (a
+    second consumer of c0, a hook or ``retain_grad`` would silently turn it into garbage).  Inside
+    one node c0 and da0 are locals: nothing else can consume, hook or accumulate into them."""
+
+    @staticmethod
+    def forward(ctx, table, wx, idx, weight, rel, segs, seg_len, bufs, G, gamma0, beta0, w3):
+        backend = backend_for(table)
+        table, wx = table.contiguous(), wx.contiguous()
+        b, m, pitch = table.shape
+        h = pitch // segs
+        n = idx.shape[1]
+        c0 = table.new_empty(b, segs, h, n // segs)
+        c0_part = table.new_empty(segs * h, b * (n // segs // 64), 2)
+        backend.blend_conv_forward(table, h, idx, weight, rel, wx, c0, segs, seg_len, h, 0,
+                                   stat_partial=c0_part)
+        c, g, arg, coef0 = _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3)
+        ctx.G, ctx.dims = G, (segs, seg_len, b, m, pitch, h)
+        ctx.save_for_backward(c0, coef0, arg, gamma0, w3, idx, weight, rel)
+        ctx.mark_non_differentiable(arg)
+        return c, g
+
+    @staticmethod
+    def backward(ctx, dc, dg):
+        c0, coef0, arg, gamma0, w3, idx, weight, rel = ctx.saved_tensors
+        segs, seg_len, b, m, pitch, h = ctx.dims
+        backend = backend_for(c0)
+        B, S, H0, P = c0.shape
+        da0, part, dw3 = _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, ctx.G,
+                                             ctx.needs_input_grad[11])
+        dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
+        d_table = c0.new_zeros(b, m, pitch)
+        d_wx = c0.new_zeros(segs, h, 3)
+        if FOLD_NORM_BWD:
+            bnb = backend.pw_bnb_coef(part, coef0, gamma0, float(B) * float(P), dgamma, dbeta)
+            backend.blend_conv_backward(da0.view(B, S, H0, P), h, idx, weight, rel, d_table, d_wx,
+                                        segs, seg_len, bn_z=c0, bnb=bnb)
+        else:       # A/B switch: the separate apply pass
+            dc0 = torch.empty_like(c0)
+            backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
+                                           None, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
+            backend.blend_conv_backward(dc0, h, idx, weight, rel, d_table, d_wx, segs, seg_len)
+        return d_table, d_wx, None, None, None, None, None, None, None, dgamma, dbeta, dw3
+
+
+def blend_mini_head_supported(backend, table, idx, segs):
+    """The blend forward leaves statistics partials (what ``BlendMiniHeadFn`` needs) for stacked
+    channel counts that are multiples of 64 over whole 64-query tiles."""
+    h, n = table.shape[2] // segs, idx.shape[1]
+    return backend.name == 'hip' and h % 64 == 0 and (n // segs) % 64 == 0
 
 
 class MiniTailFn(Function):
@@ -578,7 +620,7 @@ class MiniTailFn(Function):
                 dwl = _wgrad(backend, dyf, cf, None, ng=S)
         dc = torch.empty_like(c)
         backend.pw_layer_forward(dyf, wl.transpose(1, 2), ng=S, y=dc.view(B * S, half, P))
-        _FRESH_GRADS.add(dc.data_ptr())     # nobody else holds this gradient buffer
+        setattr(dc, _OWNED_MARK, True)      # nobody else holds this gradient buffer
         return dc, dsmall, None, None, dwl, dgamma, dbeta, dw4
 
 
@@ -617,7 +659,9 @@ class Stack1dFn(Function):
 
     A conv bias in FRONT of a norm is never added: the mean subtraction removes it from every
     normalised value; the running mean gets it (``pw_stats_finalize(chan_bias=)``) and its
-    gradient -- identically zero -- is reported as None."""
+    gradient -- identically zero -- is returned as a zero tensor, as ATen does (a None would make a
+    per-parameter optimiser skip the parameter: no weight decay on it, "unused parameter" under
+    DDP)."""
 
     @staticmethod
     def forward(ctx, x, layers, S, *tensors):
@@ -708,6 +752,8 @@ class Stack1dFn(Function):
                                      coef[:, 2].contiguous(), coef[:, 3].contiguous(), coef, True,
                                      dz.view(B, S * cl, P), dgamma, dbeta)
             grads[slots[-1]['g']], grads[slots[-1]['g'] + 1] = dgamma, dbeta
+            if 'b' in slots[-1] and need[3 + slots[-1]['b']]:
+                grads[slots[-1]['b']] = torch.zeros_like(dbeta)
         else:
             dz = dout
             if b is not None and need[3 + slots[-1]['b']]:
@@ -726,6 +772,8 @@ class Stack1dFn(Function):
                 grads[slots[l]['g']], grads[slots[l]['g'] + 1] = dgamma, dbeta
                 if dw is not None:
                     grads[slots[l]['w']] = dw
+                if 'b' in slots[l] and need[3 + slots[l]['b']]:
+                    grads[slots[l]['b']] = torch.zeros_like(dbeta)
             elif need_w:
                 grads[slots[l]['w']] = _wgrad(backend, dz, src, src_coef, ng=S)
             if l == 0:
@@ -743,9 +791,8 @@ class Stack1dFn(Function):
         return (dx, None, None) + tuple(grads)
 
 
-# A/B switch (NESIE_STACK1D, default 15): bit 0 vote module, 1 prediction head, 2 feature
-# propagation, 3 score heads -- which chains run through Stack1dFn
-import os as _os
+# A/B switch (NESIE_STACK1D, default 31): bit 0 vote module, 1 prediction head, 2 feature
+# propagation, 3 score heads, 4 the prediction head's output convs -- which chains run through Stack1dFn
 STACK1D_MASK = int(_os.environ.get('NESIE_STACK1D', '31'))
 VOTE, PRED, FPROP, HEADS, PRED_OUT = 1, 2, 4, 8, 16   # (PRED_OUT: the prediction head's three output convs)
 

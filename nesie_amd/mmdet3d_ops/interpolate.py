@@ -128,21 +128,8 @@ class BlendConv(Function):
         segs, seg_len, b, m, pitch, h = ctx.dims
         d_table = dy.new_zeros(b, m, pitch)
         d_wx = dy.new_zeros(segs, h, 3)
-        # A consumer that applies a training norm + ReLU to this output may leave the norm backward
-        # to this kernel's tile load (fused_mlp.MiniHeadFn: it attached `pending_norm` to this node in
-        # its forward and fills it in its backward): dy is then the gradient of the NORMALISED
-        # activation, z this function's own output.
-        pend = getattr(ctx, 'pending_norm', None)
-        if pend is not None and pend.get('bnb') is not None:
-            if dy.data_ptr() != pend['ptr'] or not dy.is_contiguous():
-                raise RuntimeError('BlendConv.backward: the gradient handed over by the norm consumer was '
-                                   'replaced on the way (hook or accumulation): cannot apply its norm backward')
-            z, bnb = pend.pop('z'), pend.pop('bnb')
-            backend_for(dy).blend_conv_backward(dy, h, idx, weight, rel, d_table, d_wx, segs, seg_len,
-                                                bn_z=z.view(dy.shape), bnb=bnb)
-        else:
-            backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
-                                                segs, seg_len)
+        backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
+                                            segs, seg_len)
         return d_table, d_wx, None, None, None, None, None, None
 
 

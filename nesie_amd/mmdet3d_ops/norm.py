@@ -78,9 +78,11 @@ class BNReLUTrain(Function):
         x, y, weight, bias, save_mean, save_invstd, fwd_coef = ctx.saved_tensors[:7]
         row_bias = ctx.saved_tensors[7] if ctx.has_row_bias else None
         # a per-channel row_bias is a conv bias folded into the norm: the mean subtraction removes
-        # it, its gradient is identically zero and is reported as None (a summation of dx, as the
-        # unfused graph does, returns rounding noise around that zero)
+        # it, its gradient is identically zero and is returned as a zero tensor (a summation of dx,
+        # as the unfused graph does, returns rounding noise around that zero; a None would make a
+        # per-parameter optimiser skip the bias -- no weight decay on it)
         d_row_bias = torch.empty_like(row_bias) if ctx.has_row_bias and row_bias.dim() != 1 else None
+        d_chan_bias = torch.zeros_like(row_bias) if ctx.has_row_bias and row_bias.dim() == 1 else None
         dy = dy.contiguous()
         c = x.shape[1]
         dx = torch.empty_like(x)
@@ -88,7 +90,8 @@ class BNReLUTrain(Function):
         backend_for(dy).bn_relu_backward(dy, x, y, weight, bias, save_mean, save_invstd, fwd_coef,
                                          ctx.relu, dx, dgamma, dbeta, row_bias=row_bias,
                                          d_row_bias=d_row_bias)
-        return dx, dgamma, dbeta, None, None, None, None, None, d_row_bias, None
+        return dx, dgamma, dbeta, None, None, None, None, None, \
+            (d_row_bias if d_chan_bias is None else d_chan_bias), None
 
 
 class BNReLUMaxPoolTrain(Function):

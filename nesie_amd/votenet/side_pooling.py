@@ -28,6 +28,42 @@ def rot_gpu(t):
                         torch.stack([z, z, o], -1)], -2)
 
 
+class DeferredBlendConv:
+    """The raw first-conv outputs of S MiniPointNets, (B, S, H, K, G), NOT evaluated yet: the
+    operands of ``mmdet3d_ops.BlendConv`` (side_pooling_module.py:226-243, 346-349 through the 3-NN
+    blend).  The fused MiniPointNet path evaluates them inside ``fused_mlp.BlendMiniHeadFn`` -- one
+    autograd node for the blend, the first norm and the second conv, so the conv output and the
+    half-finished gradient the blend backward completes never exist as autograd tensors; every
+    other consumer calls ``materialize()`` and gets the ordinary differentiable tensor."""
+
+    def __init__(self, table, wx, idx, weight, rel, segs, G, K):
+        self.table, self.wx, self.idx, self.weight, self.rel = table, wx, idx, weight, rel
+        self.segs, self.G, self.K = segs, G, K
+        B, H = table.shape[0], table.shape[2] // segs
+        self.shape = (B, segs, H, K, G)
+        self.dtype, self.device = table.dtype, table.device
+
+    @property
+    def has_stats(self):
+        from ..mmdet3d_ops import fused_mlp
+        return fused_mlp.blend_mini_head_supported(backend_for(self.table), self.table, self.idx, self.segs)
+
+    def materialize(self):
+        """-> (c0 (B, S, H, K, G), statistics partials or None)."""
+        out, stats = blend_conv(self.table, self.wx, self.idx, self.weight, self.rel, self.segs,
+                                self.G, True)
+        return out.view(self.shape), (stats if stats.numel() else None)
+
+
+def _resolve_c0(nets, c0, c0_stats):
+    """A deferred first-conv output stays deferred only for the fused MiniPointNet path."""
+    if isinstance(c0, DeferredBlendConv):
+        if fused_mini_ok(nets, c0, None):
+            return c0, None
+        return c0.materialize()
+    return c0, c0_stats
+
+
 class MiniPointNet(nn.Module):
     """(B,C,K,G) -> (B,feature_dim,K): conv-bn-relu-conv, max over G, concat
     [global, local], conv-bn-relu-conv, max over G  (:343-370)."""
@@ -56,6 +92,11 @@ class MiniPointNet(nn.Module):
         Differences from the concatenated form are summation-order rounding only."""
         conv0, bn0, _, conv3 = self.first_conv
         sconv0, sbn0, _, sconv3 = self.second_conv
+        if isinstance(conv0_out, DeferredBlendConv):      # (one net: S = 1)
+            conv0_out, c0_stats = _resolve_c0([self], conv0_out, c0_stats)
+            if isinstance(conv0_out, DeferredBlendConv):
+                return fused_mini_pointnets([self], conv0_out, c0_stats).squeeze(1)
+            conv0_out = conv0_out.squeeze(1)
         if a0 is None and conv0_out is not None and fused_mini_ok([self], conv0_out.unsqueeze(1), c0_stats):
             return fused_mini_pointnets([self], conv0_out.unsqueeze(1), c0_stats).squeeze(1)
         if a0 is None:   # c0_stats: (sum, sum^2) partials of conv0_out left by its producer
@@ -133,6 +174,8 @@ def grouped_mini_pointnets(nets, c0, normed=False, c0_stats=None):
     ``net(conv0_out=c0[:, i])`` for each net (see MiniPointNet.forward for the algebra); every
     1x1 conv is one broadcast batched GEMM over the stacked weights (48 instead of 8 matrices
     per launch at B = 8) and every norm layer one stacked BatchNorm."""
+    if not normed:
+        c0, c0_stats = _resolve_c0(nets, c0, c0_stats)
     B, S, H, K, G = c0.shape
     if not normed and fused_mini_ok(nets, c0, c0_stats):
         return fused_mini_pointnets(nets, c0, c0_stats)
@@ -164,17 +207,20 @@ def fused_mini_ok(nets, c0, c0_stats):
     """The S = len(nets) MiniPointNets can run on the fused layer kernels (fused_mlp.MiniHeadFn /
     MiniTailFn): training-mode native norms, statistics partials of c0 at hand, built shapes."""
     from ..mmdet3d_ops import fused_mlp
-    backend = backend_for(c0)
+    backend = backend_for(c0.table if isinstance(c0, DeferredBlendConv) else c0)
     bn0s, bn1s = [n.first_conv[1] for n in nets], [n.second_conv[1] for n in nets]
     training = all(l.training for l in bn0s + bn1s)
     evaluating = not any(l.training for l in bn0s + bn1s) and not torch.is_grad_enabled()
+    if isinstance(c0, DeferredBlendConv):    # its statistics partials come with its evaluation
+        c0_stats = c0.table if c0.has_stats else None
     if not (training or evaluating) or (training and c0_stats is None):
         return False
     if not (_stackable_bn(bn0s) and _stackable_bn(bn1s)):
         return False
     if any(n.first_conv[0].bias is not None or n.second_conv[0].bias is not None for n in nets):
         return False
-    return fused_mlp.mini_pointnets_fused_supported(backend, c0, c0_stats if training else c0,
+    ref = c0.table if isinstance(c0, DeferredBlendConv) else c0
+    return fused_mlp.mini_pointnets_fused_supported(backend, c0, c0_stats if training else ref,
                                                     c0.shape[-1])
 
 
@@ -210,10 +256,17 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     gamma0, beta0, w3, w, b3, gamma1, beta1, w4, *b4 = fused_mlp.stack_groups(groups)
     evaluating = not bn0s[0].training
     backend = backend_for(c0)
+    deferred = c0 if isinstance(c0, DeferredBlendConv) else None
     if evaluating:   # test path: the folded running statistics are the operand transforms
+        if deferred is not None:
+            c0 = deferred.materialize()[0]
         coef0 = _norm.stacked_eval_coef(bn0s)
         c, g, _ = fused_mlp.mini_head_kernels(backend, c0.reshape(B, S, H, K * G).contiguous(),
                                                coef0, w3, G)
+    elif deferred is not None:   # blend + first norm + second conv as ONE autograd node
+        d = deferred
+        c, g = fused_mlp.BlendMiniHeadFn.apply(d.table, d.wx, d.idx, d.weight, d.rel, d.segs, d.G,
+                                               stacked(bn0s), G, gamma0.reshape(-1), beta0.reshape(-1), w3)
     else:
         c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
                                           gamma0.reshape(-1), beta0.reshape(-1), w3)  # w3 (S, half, H)
@@ -237,7 +290,8 @@ def fused_mini_pointnets(nets, c0, c0_stats):
 
 
 def mini_pointnets_groupable(nets, c0):
-    if backend_for(c0).name != 'hip' or c0.dtype != torch.float32:
+    ref = c0.table if isinstance(c0, DeferredBlendConv) else c0
+    if backend_for(ref).name != 'hip' or c0.dtype != torch.float32:
         return False
     G = c0.shape[-1]
     if not (4 <= G <= 64 and G & (G - 1) == 0):   # row-bias norm and max-pool kernels
@@ -470,12 +524,13 @@ class SidePooling(nn.Module):
         return idx, weight, relative_grid.contiguous()
 
     def first_conv_through_blend(self, nets, origin_xyz, origin_features, whole_grid, center,
-                                 taps=None, with_norm=False):
+                                 taps=None, with_norm=False, defer=False):
         """Outputs of ``net.first_conv[0]`` for the S = len(nets) MiniPointNets that read the
         S consecutive point groups of every proposal: ((B,S,H,K,G), normed?, statistics partials
         of the output for the first norm layer or None), evaluated as
         W_xyz . rel + blend(W_f . F) (mmdet3d_ops.BlendConv) instead of
-        conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points."""
+        conv(cat[rel, blend(F)]) -- the conv runs over the N seeds, not the K*S*G grid points.
+        ``defer``: return the operands as a ``DeferredBlendConv`` instead of the tensor."""
         B, K = center.shape[:2]
         segs = len(nets)
         idx, weight, rel = taps if taps is not None \
@@ -500,6 +555,8 @@ class SidePooling(nn.Module):
                 for l in bns:
                     _norm.count_batch(l.num_batches_tracked)
             return out.view(B, segs, H, K, G), True, None
+        if defer:   # evaluated by its consumer (BlendMiniHeadFn, or materialize() for any other)
+            return DeferredBlendConv(table, w[:, :, :3], idx, weight, rel, segs, G, K), False, None
         # (B, S, H, K*G) and the (sum, sum^2) partials of it for the first norm layer
         out, stats = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G, True)
         return out.view(B, segs, H, K, G), False, (stats if stats.numel() else None)
@@ -543,12 +600,13 @@ class SidePooling(nn.Module):
             side_c0, side_normed, side_stats = self.first_conv_through_blend(
                 side_nets, origin_xyz, origin_features, None, center,
                 taps=self.fused_taps(origin_xyz, center, size, heading, 'side'),
-                with_norm=self.fuse_first_norm)
+                with_norm=self.fuse_first_norm, defer=True)
             bbox_c0, bbox_normed, bbox_stats = self.first_conv_through_blend(
                 self.mlps_before[6:7], origin_xyz, origin_features, None, center,
                 taps=self.fused_taps(origin_xyz, center, size, heading, 'box'),
-                with_norm=self.fuse_first_norm)
-            bbox_c0 = bbox_c0.squeeze(1)   # (a view: indexing [:, 0] costs a zero-filled gradient)
+                with_norm=self.fuse_first_norm, defer=True)
+            if not isinstance(bbox_c0, DeferredBlendConv):
+                bbox_c0 = bbox_c0.squeeze(1)   # (a view: indexing [:, 0] costs a zero-filled gradient)
         else:
             whole_grid = self.generate_grid(size)
             side_grid = self.grid_for_side(whole_grid, center, heading).view(B, -1, 3).contiguous()
@@ -561,6 +619,8 @@ class SidePooling(nn.Module):
             pooled = grouped_mini_pointnets(side_nets, side_c0, normed=side_normed,
                                             c0_stats=side_stats)               # (B,6,128,2K)
         elif fused:
+            if isinstance(side_c0, DeferredBlendConv):
+                side_c0, side_stats = side_c0.materialize()
             key = 'a0' if side_normed else 'conv0_out'
             pooled = torch.stack([side_nets[i](**{key: side_c0[:, i]}) for i in range(6)], 1)
         else:

@@ -236,3 +236,32 @@ def test_two_rank_semi_supervised_step(tmp_path):
         touched = (s["ulb_flag"] == 0).nonzero().flatten().tolist()
         assert touched == [10 * r + 5, 10 * r + 7], touched
     assert not torch.equal(a["ulb_list"], b["ulb_list"])
+
+
+def test_bench_launcher_returns_the_first_failing_ranks_code_promptly(tmp_path):
+    """`python bench.py --gpus N` without a launcher: a rank that dies while the others are still
+    inside a collective must end the job with ITS exit code within seconds (the launcher polls every
+    child; it used to wait for rank 0 first, i.e. for the collective time-out)."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location(
+        'bench_launcher', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, sys, time\n'
+        'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["WORLD_SIZE"] == "3"\n'
+        'r = int(os.environ["RANK"])\n'
+        'open(sys.argv[1] + f"/started{r}", "w").close()\n'
+        'if r == 2:\n'
+        '    time.sleep(0.5); sys.exit(7)\n'
+        'time.sleep(120)\n')
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(3, [str(tmp_path)], script=str(script))
+    assert rc == 7
+    assert time.monotonic() - t0 < 30
+    assert all((tmp_path / f'started{r}').exists() for r in range(3))
+    ok = tmp_path / 'ok.py'
+    ok.write_text('import sys; sys.exit(0)\n')
+    assert bench.spawn_ranks(2, [], script=str(ok)) == 0

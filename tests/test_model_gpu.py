@@ -432,9 +432,11 @@ def test_folded_norm_backward_matches_the_separate_apply_pass(hip_device):
     """NESIE_FOLD_NORM_BWD on vs off on the reduced model, one training step from the same state:
     the norm backward applied inside its consumer -- the weight gradient (SA stacks, 1-D chains,
     MiniPointNet norm 1 with the row-bias gradient) or the blend backward (MiniPointNet norm 0,
-    handed over on the BlendConv node) -- gives the gradients of the separate apply pass."""
+    inside the one autograd node fused_mlp.BlendMiniHeadFn) -- gives the gradients of the separate
+    apply pass."""
     import copy
-    from nesie_amd.mmdet3d_ops import fused_mlp, interpolate
+    from nesie_amd import kernels
+    from nesie_amd.mmdet3d_ops import fused_mlp
     model = _small.small_model().to(hip_device).train()
     pts, boxes, labels = _small.small_batch()
     pts = pts.to(hip_device)
@@ -442,21 +444,22 @@ def test_folded_norm_backward_matches_the_separate_apply_pass(hip_device):
     _small.force_vote_sampling(model, 'fold')
     _small.force_grid_taps(model, 'fold')
     seen = []
-    real = interpolate.BlendConv.backward
+    backend = type(kernels.backend_for(pts))
+    real = backend.blend_conv_backward
 
-    def spy(ctx, dy, *rest):
-        seen.append(getattr(ctx, 'pending_norm', None) is not None and ctx.pending_norm.get('bnb') is not None)
-        return real(ctx, dy, *rest)
+    def spy(self, *a, **kw):
+        seen.append(kw.get('bnb') is not None)
+        return real(self, *a, **kw)
     out = []
     for fold in (False, True):
         fused_mlp.FOLD_NORM_BWD = fold
-        interpolate.BlendConv.backward = staticmethod(spy)
+        backend.blend_conv_backward = spy
         try:
             m = copy.deepcopy(model)
             out.append(_small.train_step_losses(m, pts, boxes, labels))
         finally:
             fused_mlp.FOLD_NORM_BWD = True
-            interpolate.BlendConv.backward = staticmethod(real)
+            backend.blend_conv_backward = real
     n = len(seen) // 2
     assert n >= 2 and not any(seen[:n]) and all(seen[n:]), seen       # the hand-over really happened
     (l0, g0), (l1, g1) = out

@@ -513,6 +513,87 @@ def test_fused_mini_pointnets_match_the_module_by_module_path(S, G):
             torch.testing.assert_close(a, b, rtol=1e-3, atol=3e-4 * max(b.abs().max().item(), 1e-2 * scale))
 
 
+@pytest.mark.parametrize('S,G,second_consumer', [(6, 16, False), (1, 64, False), (6, 16, True)])
+def test_deferred_blend_into_fused_mini_pointnets(S, G, second_consumer):
+    """side_pooling.DeferredBlendConv -> fused_mlp.BlendMiniHeadFn (blend conv + first norm + second
+    conv as ONE autograd node, the norm backward on the blend backward's tile load) against the
+    materialised BlendConv tensor through the module-by-module MiniPointNets: outputs, running
+    statistics, gradients of the table, the coordinate weights and every parameter.
+    ``second_consumer``: the conv output ALSO feeds another loss term -- through ``materialize()``,
+    the only way to reach it; the fused node's internal tensors cannot be consumed, hooked or
+    accumulated into (the hand-over this replaces travelled on the gradient of an autograd tensor
+    and a second consumer silently corrupted it)."""
+    import copy
+    from nesie_amd.mmdet3d_ops import fused_mlp
+    from nesie_amd.votenet.side_pooling import DeferredBlendConv, MiniPointNet, grouped_mini_pointnets
+    torch.manual_seed(2)
+    dev = _dev()
+    nets = [MiniPointNet(259, 128).to(dev) for _ in range(S)]
+    with torch.no_grad():
+        for n in nets:
+            for m in n.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(-1.0, 1.5)
+                    m.bias.normal_(0, 0.3)
+    B, H, K, M = 2, 256, 64, 128
+    g = torch.Generator(device=dev).manual_seed(G + S)
+    table0 = torch.randn(B, M, S * H, device=dev, generator=g) * 0.5
+    wx0 = torch.randn(S, H, 3, device=dev, generator=g)
+    n = K * S * G
+    idx = torch.randint(0, M, (B, n, 3), device=dev, generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, device=dev, generator=g) + 0.05
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    rel = torch.randn(B, n, 3, device=dev, generator=g) * 0.3
+    pick = torch.linspace(-1, 1, B * S * 128 * K, device=dev)
+    seen = []
+
+    def run(fused):
+        local = copy.deepcopy(nets)
+        params = [p_ for net in local for p_ in net.parameters()]
+        table, wx = table0.clone().requires_grad_(True), wx0.clone().requires_grad_(True)
+        d = DeferredBlendConv(table, wx, idx, w, rel, S, G, K)
+        fused_mlp.ENABLED = fused
+        try:
+            if fused:
+                assert d.has_stats
+                out = grouped_mini_pointnets(local, d)
+            else:
+                c0, stats = d.materialize()
+                out = grouped_mini_pointnets(local, c0, c0_stats=stats)
+            loss = (out * pick.view_as(out)).sum()
+            if second_consumer:
+                loss = loss + d.materialize()[0].square().mean() * 3.0
+            loss.backward()
+        finally:
+            fused_mlp.ENABLED = True
+        stats_ = [b_.clone() for net in local for b_ in net.buffers()]
+        return out.detach(), table.grad, wx.grad, [None if p_.grad is None else p_.grad.clone() for p_ in params], stats_
+
+    real = fused_mlp.BlendMiniHeadFn.forward
+
+    def spy(*a, **k):
+        seen.append(True)
+        return real(*a, **k)
+    fused_mlp.BlendMiniHeadFn.forward = staticmethod(spy)
+    try:
+        want = run(False)
+        assert not seen
+        got = run(True)
+        assert seen, 'the deferred conv did not go through BlendMiniHeadFn'
+    finally:
+        fused_mlp.BlendMiniHeadFn.forward = staticmethod(real)
+    torch.testing.assert_close(got[0], want[0], rtol=1e-4, atol=1e-4)
+    for a, b in ((got[1], want[1]), (got[2], want[2])):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=3e-4 * b.abs().max().item())
+    scale = max(b.abs().max().item() for b in want[3] if b is not None)
+    for a, b in zip(got[3], want[3]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=3e-4 * max(b.abs().max().item(), 1e-2 * scale))
+    for a, b in zip(got[4], want[4]):
+        torch.testing.assert_close(a.float(), b.float(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize('c_in,mlp,ns', [(1, [64, 64, 128], 64), (256, [128, 128, 256], 16)])
 def test_eval_mode_sa_stack_matches_the_module_by_module_path(c_in, mlp, ns):
     from nesie_amd.mmdet3d_ops import fused_mlp

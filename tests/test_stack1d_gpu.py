@@ -53,8 +53,8 @@ def _compare(fused, plain, zero_bias=()):
     gmax = max(float(g.abs().max()) for g in plain[2].values() if g is not None)
     for n, gp in plain[2].items():
         gf = fused[2][n]
-        if n in zero_bias:      # a conv bias in front of a norm: exactly zero, reported as None
-            assert gf is None or float(gf.abs().max()) < 1e-6 * gmax, n
+        if n in zero_bias:      # a conv bias in front of a norm: exactly zero, a ZERO TENSOR (not None)
+            assert gf is not None and float(gf.abs().max()) == 0.0, n
             assert gp is None or float(gp.abs().max()) < 1e-4 * gmax, n   # (folded there too, or rounding noise)
             continue
         assert gf is not None, n
