@@ -116,46 +116,164 @@ class GemmTimer:
         return n, ms, fl, by
 
 
-def parity_gate(device):
-    """before any timing, the CPU-oracle leg and the HIP leg run ONE step of
-    the same B = 2, 40 000-point batch with identical weights; every loss term must agree
-    within 1e-4 (relative to max(1, |value|)).  -> dict for the JSON line."""
+GATE_LOSS_TOL = 1e-4      # north_star: fp32 features / losses within 1e-4 of the CPU path
+GATE_GRAD_TOL = 5e-3      # flat gradient, HIP leg vs CPU-oracle leg (both fp32), relative L2.  The
+#                           fp64-referenced bound (HIP no farther from float64 than the CPU path is)
+#                           lives in tests/test_parity_gpu.py; two fp32 legs sit 2e-3 .. 3.5e-3 from
+#                           float64 each at this size, on either side of it
+
+
+def _index_ops_equal(cpu_tree, hip_tree):
+    """-> (tensors compared, names that differ): FPS picks, sampled centres, ball-query rows,
+    composed input indices and the feature-propagation 3-NN taps of the whole backbone index
+    chain: integer tensors and gathered coordinates bit for bit, the
+    taps' inverse-distance weights to 1e-6."""
+    bad, n = [], 0
+    for lvl, (c, h) in enumerate(zip(cpu_tree, hip_tree)):
+        pairs = [('fps_idx', c['indices'], h['indices']), ('new_xyz', c['new_xyz'], h['new_xyz']),
+                 ('input_indices', c['input_indices'], h['input_indices'])]
+        pairs += [(f'ball_query_idx[{i}]', a, b) for i, (a, b) in enumerate(zip(c['group_idx'], h['group_idx']))]
+        for j, (ct, ht) in enumerate(zip(c.get('fp_taps', ()), h.get('fp_taps', ()))):
+            pairs.append((f'fp_taps[{j}].idx', ct[0], ht[0]))
+            n += 1
+            if not torch.allclose(ht[1].cpu(), ct[1], rtol=1e-6, atol=1e-7):
+                bad.append(f'level {lvl} fp_taps[{j}].weight')
+        for name, a, b in pairs:
+            n += 1
+            if not torch.equal(b.cpu(), a):
+                bad.append(f'level {lvl} {name}')
+    return n, bad
+
+
+def _gate_model(workload):
+    """The gate's own model (never the timed one): supervised detector, or the student/teacher
+    detector with a teacher biased so that its pseudo-label filters pass SOME proposals at random
+    init (the filters must decide identically on both legs; tests/test_parity_gpu.py::_semi_pair)."""
+    if workload == 'pretrain':
+        model = build_nesie_votenet()
+    else:
+        model = semi.build_saqe_votenet_semi() if workload == 'saqe' else semi.build_nesie_votenet_semi()
+        model.train_cfg.update(pos_distance_thr=1.0, neg_distance_thr=1.5)
+        obj_bias = 1.3 if workload == 'saqe' else 1.7
+        with torch.no_grad():
+            model.bbox_head.conv_pred.conv_cls.bias[1] += obj_bias
+            model.bbox_head.conv_pred.conv_cls.bias[2] += 0.75
+            if workload == 'saqe':   # VoteNetSAQE filters on the quality head's objectness (last 2 of 38)
+                model.bbox_head.grid_conv.mlps_head[6][6].bias[37] += obj_bias
+        model.teacher.resync()
+    return model.train()
+
+
+def parity_gate(device, workload='pretrain'):
+    """SURVEY section 8(d) / BASELINE.md section 2, before any timing: the CPU-oracle leg and the
+    HIP leg run ONE training step (forward + backward) of the same full-size batch -- 2 scenes x
+    40 000 points (supervised) or 3 scenes, 1 labeled : 2 unlabeled, student + teacher (semi /
+    saqe) -- with identical weights, inputs and jitter:
+      * index ops of the backbone chain (FPS, gathered centres, ball query, composed indices, FP
+        3-NN taps) and the per-point vote targets: bit-exact;
+      * semi / saqe: the teacher's pseudo-label decisions (validity, classes, class histogram): exact;
+      * every loss term within 1e-4 (relative to max(1, |value|));
+      * the flat parameter gradient within GATE_GRAD_TOL (relative L2, fp32 leg vs fp32 leg).
+    Two chains of discrete decisions over PREDICTED coordinates are replayed from the CPU leg
+    (oracle/forcing.py: the vote FPS picks and the quality head's 3-NN grid taps; both kernels
+    are compared bit for bit on identical inputs in tests/); how often the HIP leg's own decision
+    agreed is reported.  -> dict for the JSON line; ``passed`` False ends the run with status 3."""
+    import copy
+
     import oracle
+    from oracle.forcing import force_grid_taps, force_vote_sampling
     torch.manual_seed(0)
-    pts, boxes, labels = make_batch(4242, 2, NUM_POINTS)
-    cpu_model = build_nesie_votenet()
-    cpu_model.train()
-    state = {k: v.clone() for k, v in cpu_model.state_dict().items()}
+    semi_like = workload != 'pretrain'
+    nscene = 3 if semi_like else 2
+    pts, boxes, labels = make_batch(4242, nscene, NUM_POINTS)
+    cpu_model = _gate_model(workload)
     # the head jitters its proposals with host-side Gaussian noise (nesie_head.py:178-209): both
     # legs get the same draw
     g = torch.Generator().manual_seed(3)
     k = cpu_model.bbox_head.num_proposal
-    noise = (torch.randn(2, k, 3, generator=g), torch.randn(2, k, 3, generator=g))
+    noise = (torch.randn(nscene, k, 3, generator=g), torch.randn(nscene, k, 3, generator=g))
     cpu_model.bbox_head.jitter_noise = noise
-    # ... and the same vote-sampling picks: furthest-point sampling of the PREDICTED votes is a
-    # chain of arg-max decisions that a last-bit difference can flip (oracle/forcing.py); the
-    # sampling kernel itself is compared bit-for-bit on identical inputs in tests/
-    from oracle.forcing import force_vote_sampling
-    sampler = force_vote_sampling(cpu_model, 'bench-gate')
+    sampler = force_vote_sampling(cpu_model, 'bench-gate-' + workload)
+    tap_stats = force_grid_taps(cpu_model, 'bench-gate-' + workload)
+    gpu_model = copy.deepcopy(cpu_model).to(device)     # (shares the recorded picks / taps)
+    gpu_model.bbox_head.jitter_noise = tuple(t.to(device) for t in noise)
+    gpu_sampler = gpu_model.bbox_head.vote_aggregation.points_sampler
+
+    def leg(model, dev):
+        p = pts.to(dev)
+        picks = {}
+        if semi_like:
+            model.init_label_state(120, 1081, dev)
+            gen = torch.Generator().manual_seed(1)
+            meta_t = semi.AugMeta.random(nscene, dev, gen, strong=False)
+            meta_s = semi.AugMeta.random(nscene, dev, gen, strong=True)
+            gt = GTBatch.collate(boxes[:1], labels[:1], dev)
+            rows = torch.tensor([5, 17], device=dev)
+            inner = model.get_pseudo_labels
+
+            def recording(preds, name='ScanNet'):
+                out = inner(preds, name)
+                picks.update(labels=out[0].cpu(), valid=out[3].cpu())
+                return out
+            model.get_pseudo_labels = recording
+            tree = model.backbone.sample_and_group_indices(meta_s.apply_points(p))
+            losses = model.forward_train(meta_s.apply_points(p), meta_t.apply_points(p), gt,
+                                         [True, False, False], meta_s, meta_t, rows)
+            del model.get_pseudo_labels
+            picks.update(ulb_list=model.state.ulb_list.cpu(), ulb_flag=model.state.ulb_flag.cpu())
+            votes = ()
+        else:
+            gt = GTBatch.collate(boxes, labels, dev)
+            tree = model.backbone.sample_and_group_indices(p)
+            votes = tuple(t.cpu() for t in model.bbox_head.vote_targets_of(p, gt))
+            losses = model.forward_train(p, None, gt, None)
+        model.parse_losses(losses).backward()
+        grads = {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.grad is not None}
+        return {kk: float(v.detach().sum()) for kk, v in losses.items()}, grads, tree, votes, picks
+
     with kernels.use_backend(oracle.OracleKernels()):
-        want = cpu_model.forward_train(pts, None, GTBatch.collate(boxes, labels, torch.device('cpu')), None)
-        want = {k: float(v.detach().sum()) for k, v in want.items()}
-    gpu_model = build_nesie_votenet()
-    gpu_model.load_state_dict(state)
-    gpu_model.to(device).train()
-    gpu_model.bbox_head.jitter_noise = noise
-    gpu_sampler = force_vote_sampling(gpu_model, 'bench-gate-replay')
-    gpu_sampler.key = sampler.key   # replay the CPU leg's picks
-    got = gpu_model.forward_train(pts.to(device), None, GTBatch.collate(boxes, labels, device), None)
-    got = {k: float(v.detach().sum()) for k, v in got.items()}
-    diffs = {k: abs(got[k] - want[k]) / max(1.0, abs(want[k])) for k in want}
+        want, want_g, want_tree, want_votes, want_picks = leg(cpu_model, torch.device('cpu'))
+    got, got_g, got_tree, got_votes, got_picks = leg(gpu_model, device)
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    diffs = {kk: abs(got[kk] - want[kk]) / max(1.0, abs(want[kk])) for kk in want}
     worst = max(diffs, key=diffs.get)
+    n_idx, bad_idx = _index_ops_equal(want_tree, got_tree)
+    for i, (a, b) in enumerate(zip(want_votes, got_votes)):
+        n_idx += 1
+        same = torch.equal(a, b) if not a.dtype.is_floating_point else torch.allclose(a, b, rtol=0, atol=1e-6)
+        if not same:
+            bad_idx.append(f'vote_targets[{i}]')
+    pseudo_ok = all(torch.equal(got_picks[kk][want_picks['valid']] if kk == 'labels' else got_picks[kk],
+                                want_picks[kk][want_picks['valid']] if kk == 'labels' else want_picks[kk])
+                    for kk in want_picks)
+    names = sorted(n for n in want_g if n in got_g)
+    w = torch.cat([want_g[n].flatten() for n in names])
+    h = torch.cat([got_g[n].flatten() for n in names])
+    grad_rel = float((h - w).norm() / w.norm())
+    gmax = float(w.abs().max())
+    per_param = max(((float((got_g[n] - want_g[n]).abs().max()) / max(float(want_g[n].abs().max()), 1e-3 * gmax), n)
+                     for n in names))
+    passed = (diffs[worst] <= GATE_LOSS_TOL and not bad_idx and pseudo_ok and grad_rel <= GATE_GRAD_TOL
+              and set(want_g) == set(got_g))
     del gpu_model, cpu_model
-    torch.cuda.empty_cache()
-    return dict(passed=bool(diffs[worst] <= 1e-4), max_rel_diff=diffs[worst], worst_term=worst,
-                terms=len(diffs), tolerance=1e-4, own_vote_picks_agreed=bool(all(gpu_sampler.agreed)),
-                sample='one supervised step, 2 scenes x 40000 pts, same weights and inputs on the '
-                       'CPU-oracle leg and the HIP leg')
+    if device.type == 'cuda':
+        torch.cuda.empty_cache()
+    out = dict(passed=bool(passed), workload=workload, max_rel_diff=diffs[worst], worst_term=worst,
+               terms=len(diffs), tolerance=GATE_LOSS_TOL,
+               index_ops=dict(tensors_compared=n_idx, bit_exact=not bad_idx, differing=bad_idx[:8]),
+               gradient=dict(flat_rel_l2_hip_vs_cpu=grad_rel, tolerance=GATE_GRAD_TOL, parameters=len(names),
+                             worst_parameter=dict(name=per_param[1], max_err_over_max_grad=per_param[0])),
+               own_vote_picks_agreed=bool(all(gpu_sampler.agreed)),
+               grid_taps=dict(replayed_from_cpu_leg=True, grid_points_compared=tap_stats[1],
+                              own_taps_differed=tap_stats[0]),
+               sample=f'one {"student/teacher" if semi_like else "supervised"} step (forward + backward), '
+                      f'{nscene} scenes x {NUM_POINTS} pts, same weights and inputs on the CPU-oracle '
+                      'leg and the HIP leg')
+    if semi_like:
+        out['pseudo_labels'] = dict(exact=bool(pseudo_ok), boxes_kept=int(want_picks['valid'].sum()),
+                                    of=int(want_picks['valid'].numel()))
+    return out
 
 
 def transform_gt(boxes, meta, i):
@@ -268,7 +386,10 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         if workload in ('semi', 'saqe'):
             model.teacher.update(1000)  # past the warm-up: momentum 0.001 (simi_teacher_hook.py:57-58)
 
+    comm.steps = 0
+
     def eager_step(pre=None):
+        comm.steps += 1
         phase1(pre)
         comm.launch(e_bb, e_all)
         phase2()
@@ -277,7 +398,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         update()
         return loss_out
 
-    eager_step.inputs, eager_step.optimizer = inputs, opt
+    eager_step.inputs, eager_step.optimizer, eager_step.comm = inputs, opt, comm
     if not (graph and on_gpu):
         return model, eager_step, bucket
 
@@ -382,6 +503,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                     g_idx.replay()
                 ready.record(side)
         stage('input graph launched for the next step')
+        comm.steps += 1
         g1a.replay()                 # forward + head backward
         comm.launch(e_bb, e_all)     # the head's gradients travel ...
         g1b.replay()                 # ... while the backbone's backward computes
@@ -394,13 +516,16 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         stage('update graph replayed')
         return loss_out
     graph_step.eager = eager_step
-    graph_step.inputs, graph_step.optimizer = inputs, opt
+    graph_step.inputs, graph_step.optimizer, graph_step.comm = inputs, opt, comm
     return model, graph_step, bucket
 
 
-def cpu_baseline(sample_batch, steps):
+def cpu_baseline(sample_batch, steps, warmup=2):
     """The same training step on the host cores: index ops through oracle/ (the CPU
-    restatement, OpenMP), dense ops through PyTorch-CPU.  kind = "port"."""
+    restatement, OpenMP), dense ops through PyTorch-CPU.  kind = "port".  BASELINE.md section 2:
+    2 warm-up steps, then the MEDIAN of >= 5 timed steps."""
+    import statistics
+
     import oracle
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -408,15 +533,19 @@ def cpu_baseline(sample_batch, steps):
     with kernels.use_backend(oracle.OracleKernels()):
         model, step, _ = build_step(torch.device('cpu'), sample_batch, 1000,
                                     cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'])
-        step()  # warm-up (allocator, oneDNN primitives)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(warmup):  # allocator, oneDNN primitives, OpenMP teams
             step()
-        dt = (time.perf_counter() - t0) / steps
+        times = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     return dict(value=sample_batch / dt, unit='scenes/s', cores=cores, kind='port',
-                sample=f'{steps} timed training step(s) (after 1 warm-up) of {sample_batch} '
-                       f'scene(s) x {NUM_POINTS} pts, fwd+bwd+AdamW, oracle index ops + '
-                       f'PyTorch-CPU dense ops, {dt:.2f} s/step')
+                step_seconds=dict(median=dt, min=min(times), max=max(times), mean=sum(times) / len(times)),
+                sample=f'median of {steps} timed training step(s) (after {warmup} warm-ups) of '
+                       f'{sample_batch} scene(s) x {NUM_POINTS} pts, fwd+bwd+AdamW, oracle index ops + '
+                       f'PyTorch-CPU dense ops on {cores} host threads, {dt:.2f} s/step')
 
 
 def spawn_ranks(n, argv, script=None):
@@ -491,9 +620,13 @@ def main():
                          'augmented batch per step on the side stream (input_pipeline.py)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 to skip the CPU leg')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--cpu-steps', type=int, default=9)
+    ap.add_argument('--loss-trace', type=int, default=0,
+                    help='1: keep the total loss of every timed step (a device-side copy per step, no '
+                         'synchronisation) and print it as `loss_trace` (tests)')
     ap.add_argument('--parity-gate', type=int, default=1,
-                    help='0 to skip the CPU-vs-HIP loss check that precedes the timing (N = 1 only)')
+                    help='0 to skip the CPU-vs-HIP check (index ops, loss dict, gradients) that '
+                         'precedes the timing (N = 1 only)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -515,12 +648,13 @@ def main():
         assert dist.is_initialized() and dist.get_world_size() == args.gpus, \
             f'process group has {dist.get_world_size()} ranks, --gpus {args.gpus}'
     gate = None
-    if args.parity_gate and world == 1 and args.workload == 'pretrain':
-        gate = parity_gate(device)
+    if args.parity_gate and world == 1:
+        gate = parity_gate(device, args.workload)
         if not gate['passed']:
             print(json.dumps({'parity_gate': gate}), flush=True)
-            print(f"parity gate FAILED: {gate['worst_term']} differs by {gate['max_rel_diff']:.3e}",
-                  file=sys.stderr)
+            print(f"parity gate FAILED: worst loss term {gate['worst_term']} differs by "
+                  f"{gate['max_rel_diff']:.3e}; index ops exact: {gate['index_ops']['bit_exact']}; "
+                  f"gradient rel. L2 {gate['gradient']['flat_rel_l2_hip_vs_cpu']:.3e}", file=sys.stderr)
             sys.exit(3)
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,
@@ -574,12 +708,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = []
     for _ in range(args.warmup):
-        step()
+        loss = step()
+        if args.loss_trace:
+            trace.append(loss.detach().clone())
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        loss = step()
+        if args.loss_trace:
+            trace.append(loss.detach().clone())
     sync()
     elapsed = time.perf_counter() - t0
     # Kernel-level timing for the roofline entry: HIP events cannot bracket a kernel inside
@@ -625,6 +764,9 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'world_size': dist.get_world_size() if dist.is_initialized() else 1,
                        'collective_backend': dist.get_backend() if dist.is_initialized() else None,
+                       # all-reduce launches per step (2 = head segment during the backbone's backward
+                       # graph + backbone segment after it; 0 without a process group)
+                       'collectives_per_step': step.comm.collectives / max(1, step.comm.steps),
                        'hip_graph': bool(args.graph),
                        'index_chain_pipelined': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes(),
@@ -656,46 +798,70 @@ def main():
         # on the operand load from (dA, Z) and written once): 4 tensor passes per launch instead of 2,
         # HBM co-bound -- priced on their own below, and shown inside the family as well
         n_wf, ms_wf, fl_wf, by_wf = gemm_timers[3].totals()
+        # ... and the same kernels on the 1-D per-seed / per-proposal chains (vote module, prediction
+        # trunk, feature propagation, score heads): 8 x 256 .. 1024 positions, launch-bound
+        sn, sms, sfl, sby = (sum(v) for v in zip(*(t.totals(big=False) for t in gemm_timers)))
         if n_l + n_w:
-            tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             per_step = lambda v: v / eager_steps  # noqa: E731
+            # THE entry: every launch of the family -- large plain launches, the weight-gradient launches
+            # that carry the norm backward's streaming half, and the small launch-bound 1-D-chain launches
+            fl_all, ms_all = fl_l + fl_w + fl_wf + sfl, ms_l + ms_w + ms_wf + sms
+            n_all = n_l + n_w + n_wf + sn
+            tf_all = fl_all / (ms_all * 1e-3) / 1e12
+            tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             # HBM bytes of the family as rocprofv3 counted them (separate --pmc FETCH_SIZE / WRITE_SIZE
-            # passes of this command, gfx950 fetch correction applied): produced by
-            # tools/make_r03_profiles.py, LOADED here, never measured inside this run
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
-            if os.path.exists(tpath) and args.workload == 'pretrain' and args.batch == 8:
-                t = json.load(open(tpath))
-                traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
-                           'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf),   # (PMC rows include the fused weight-gradient launches)
-                           # the family's largest launch by bytes, counted / algorithmic (both lists' maxima:
-                           # the MiniPointNet 128 -> 256 input gradient + reduction)
-                           'largest_launch_over_algorithmic': (
-                               (t['largest_launch']['fetch_corrected_bytes'] + t['largest_launch']['write_bytes'])
-                               / max(b_ for tm in (gemm_timers[0], gemm_timers[2]) for (_, b_, _) in tm.work)),
-                           'source': 'profiles/r03_pmc_hbm_traffic.json', 'measured_in_run': False}
+            # passes of this command, gfx950 fetch correction applied): produced by tools/make_profiles.py
+            # together with the sha256 of the library that ran; LOADED here, never measured inside this
+            # run, and dropped (null) when the library loaded now is not the one that was profiled
+            traffic, traffic_note = None, None
+            lib_sha = _lib.library_sha256()
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles'))
+                           if f.endswith('_pmc_hbm_traffic.json'))
+            if not (args.workload == 'pretrain' and args.batch == 8):
+                traffic_note = 'PMC traffic was collected for the pretrain workload at B = 8 only'
+            elif not cands:
+                traffic_note = 'no profiles/*_pmc_hbm_traffic.json'
+            else:
+                t = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+                if t.get('lib_sha256') != lib_sha:
+                    traffic_note = (f'profiles/{cands[-1]} was collected with another build of libnesie_hip.so '
+                                    f'(sha256 {str(t.get("lib_sha256"))[:12]}.. vs loaded {lib_sha[:12]}..): not quoted')
+                else:
+                    traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
+                               'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf),   # (PMC rows include the fused weight-gradient launches)
+                               # the family's largest launch by bytes, counted / algorithmic
+                               'largest_launch_over_algorithmic': (
+                                   (t['largest_launch']['fetch_corrected_bytes'] + t['largest_launch']['write_bytes'])
+                                   / max(b_ for tm in (gemm_timers[0], gemm_timers[2]) for (_, b_, _) in tm.work)),
+                               'worst_launch': t.get('worst_launch'),
+                               'source': 'profiles/' + cands[-1], 'lib_sha256': lib_sha, 'measured_in_run': False}
             out['roofline'] = {
                 'kernel': 'nesie::pw_fwd_kernel (forward products + input gradients, with the operand '
                           'normalisation / statistics / pooling / norm-backward reduction epilogues) + '
-                          'nesie::pw_wgrad_kernel on the grouped per-seed MLPs: the 1x1-conv layers of the '
-                          'SA stacks and the MiniPointNets (>= 32768 positions per launch), fp32 MFMA '
-                          '(v_mfma_f32_16x16x4_f32)',
-                'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': tf / MFMA_F32_PEAK_TFLOPS,
-                'traffic': traffic,
-                'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf),   # incl. the fused weight-gradient launches below
+                          'nesie::pw_wgrad_kernel (plain and with the norm backward on its operand load): EVERY '
+                          'launch of the step -- the grouped per-seed MLPs of the SA stacks and the MiniPointNets '
+                          'and the 1-D per-seed / per-proposal chains -- fp32 MFMA (v_mfma_f32_16x16x4_f32)',
+                'bound': 'mfma', 'achieved': tf_all, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf_all / MFMA_F32_PEAK_TFLOPS,
+                'traffic': traffic, 'traffic_note': traffic_note,
+                'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf),   # launches over >= 32768 positions
                 'algorithmic_hbm_gbs': (by_l + by_w + by_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e9,
-                'launches_per_step': per_step(n_l + n_w),
-                'family_ms_per_step': per_step(ms_l + ms_w),
-                'avg_launch_ms': (ms_l + ms_w) / (n_l + n_w),
-                'algorithmic_flops_per_launch': (fl_l + fl_w) / (n_l + n_w),
-                'layer_kernel': {'launches_per_step': per_step(n_l), 'ms_per_step': per_step(ms_l),
-                                 'tflops': fl_l / (ms_l * 1e-3) / 1e12 if ms_l else None},
-                'wgrad_kernel': {'launches_per_step': per_step(n_w), 'ms_per_step': per_step(ms_w),
-                                 'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None},
-                # the same family WITH the fused weight-gradient + norm-backward launches counted as
-                # GEMMs (their streaming half adds time but no FLOPs)
-                'with_fused_norm_backward_launches': {
+                'launches_per_step': per_step(n_all),
+                'family_ms_per_step': per_step(ms_all),
+                'avg_launch_ms': ms_all / n_all,
+                'algorithmic_flops_per_launch': fl_all / n_all,
+                # sub-entry: the launches over >= 32768 positions WITHOUT the fused norm-backward ones
+                # (what rounds 1-3 quoted as `frac`)
+                'large_plain_launch_subset': {
+                    'launches_per_step': per_step(n_l + n_w), 'ms_per_step': per_step(ms_l + ms_w),
+                    'tflops': tf, 'frac': tf / MFMA_F32_PEAK_TFLOPS,
+                    'layer_kernel': {'launches_per_step': per_step(n_l), 'ms_per_step': per_step(ms_l),
+                                     'tflops': fl_l / (ms_l * 1e-3) / 1e12 if ms_l else None},
+                    'wgrad_kernel': {'launches_per_step': per_step(n_w), 'ms_per_step': per_step(ms_w),
+                                     'tflops': fl_w / (ms_w * 1e-3) / 1e12 if ms_w else None}},
+                # ... and with the fused weight-gradient + norm-backward launches counted as GEMMs
+                # (their streaming half adds time but no FLOPs)
+                'large_launches_with_fused_norm_backward': {
                     'launches_per_step': per_step(n_l + n_w + n_wf),
                     'ms_per_step': per_step(ms_l + ms_w + ms_wf),
                     'tflops': (fl_l + fl_w + fl_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e12,
@@ -711,9 +877,6 @@ def main():
                     'launches_per_step': per_step(n_wf), 'ms_per_step': per_step(ms_wf),
                     'avg_launch_ms': ms_wf / n_wf, 'algorithmic_bytes_per_launch': by_wf / n_wf,
                     'tflops': fl_wf / (ms_wf * 1e-3) / 1e12}
-            # the same kernels on the 1-D per-seed / per-proposal chains (vote module, prediction
-            # trunk, feature propagation, score heads): 8 x 256 .. 1024 positions, launch-bound
-            sn, sms, sfl, _ = (sum(v) for v in zip(*(t.totals(big=False) for t in gemm_timers)))
             if sn:
                 out['roofline_small_layers'] = {
                     'kernel': 'the same kernels on the 1-D chains (fused_mlp.Stack1dFn): P = 256 .. 1024 '
@@ -748,10 +911,12 @@ def main():
             'compulsory_hbm_bytes_per_launch': alg_bytes, 'peak': None, 'frac': None, 'traffic': None}
         if gate is not None:
             out['parity_gate'] = gate
+        if args.loss_trace:
+            out['loss_trace'] = [float(t) for t in trace]
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -170,3 +170,14 @@ def call(name, *args):
     if status != 0:
         msg = lib.nesie_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{name} failed (status {status}): {msg}")
+
+
+def library_sha256():
+    """sha256 of the library file ``load()`` maps (bench.py ties the PMC traffic figures under
+    profiles/ to the build that produced them with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    return h.hexdigest()

@@ -13,6 +13,10 @@ import torch
 import torch.distributed as dist
 
 
+def force_process_group():
+    return os.environ.get('NESIE_FORCE_PG', '0') not in ('', '0')
+
+
 def init_distributed(backend=None):
     """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract).
     Returns (rank, world_size, local_rank).  backend: 'nccl' (= RCCL on ROCm) on GPUs,
@@ -20,7 +24,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # NESIE_FORCE_PG=1: build the process group even for ONE rank, so that the single-GPU run
+    # launches the real collectives (RCCL all-reduce of both gradient segments on the communication
+    # stream between the graph replays) -- the only way to execute that path without a second GPU
+    if (world > 1 or force_process_group()) and not dist.is_initialized():
         if backend is None:
             # NESIE_DIST_BACKEND=gloo: rehearse the N > 1 step with several ranks on ONE GPU
             # (RCCL refuses two ranks on a device; gloo stages the all-reduce through the host)
@@ -245,14 +252,20 @@ class SegmentedAllReduce:
 
     def __init__(self, flat, group=None):
         self.flat, self.group = flat, group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.stream = torch.cuda.Stream(flat.device) if flat.is_cuda and self.world > 1 else None
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        # a one-rank group exchanges nothing, but with NESIE_FORCE_PG the collectives are launched
+        # all the same (sum over one rank, division by 1: the gradient is unchanged bit for bit)
+        self.active = self.world > 1 or (ready and force_process_group())
+        self.stream = torch.cuda.Stream(flat.device) if flat.is_cuda and self.active else None
         self.launched = []
+        self.collectives = 0       # all-reduces actually issued
 
     def launch(self, lo, hi):
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if not self.active:
             return
+        self.collectives += 1
         seg = self.flat[lo:hi]
         if self.stream is None:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)

@@ -401,6 +401,47 @@ def test_bare_bench_command_starts_its_own_ranks(workload, batch):
     assert res['config']['global_batch'] == 2 * batch and res['value'] > 0
 
 
+def test_rccl_all_reduce_runs_between_the_graph_replays_on_one_gpu():
+    """RCCL itself under the captured step: ``bench.py --gpus 1`` with NESIE_FORCE_PG=1 builds a
+    world_size = 1 ``nccl`` (= RCCL) process group, so dp.SegmentedAllReduce really launches both
+    gradient all-reduces on the communication stream -- the head's segment between the g1a and g1b
+    replays, the backbone's before g2 -- for 50 steps.  A one-rank sum divided by 1 is the identity,
+    so the loss trajectory must follow the run without a group (the reference's collective is NCCL
+    through torch.distributed: train.py:132-139, nesie-votenet-scannet-train-010.py:143).  Children are
+    fresh processes; nothing that touched the GPU is re-executed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items()
+            if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'NESIE_DIST_BACKEND', 'NESIE_FORCE_PG')}
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    runs = {}
+    for name, extra in (('plain', {}), ('rccl', dict(NESIE_FORCE_PG='1', MASTER_ADDR='127.0.0.1',
+                                                     MASTER_PORT='29541'))):
+        out = subprocess.run(
+            [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '47', '--warmup', '3',
+             '--batch', '2', '--cpu-baseline', '0', '--parity-gate', '0', '--loss-trace', '1'],
+            env=dict(base, **extra), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1, out.stdout[-2000:]
+        runs[name] = json.loads(lines[0])
+    plain, rccl = runs['plain'], runs['rccl']
+    assert plain['config']['collective_backend'] is None and plain['config']['collectives_per_step'] == 0
+    assert rccl['config']['collective_backend'] == 'nccl' and rccl['config']['world_size'] == 1
+    assert rccl['config']['collectives_per_step'] == 2 and rccl['config']['hip_graph']
+    a, b = plain['loss_trace'], rccl['loss_trace']
+    assert len(a) == len(b) == 50 and all(v == v and v > 0 for v in b)
+    # identical inputs, weights and jitter seeds; what differs between two runs is the order of the
+    # backward's float atomics, which Adam's early sign-like steps amplify slowly
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert abs(x - y) <= (1e-4 if i < 3 else 3e-2) * max(1.0, abs(x)), (i, x, y)
+    print('loss trajectory with / without the RCCL group: first', a[:3], b[:3], 'last', a[-1], b[-1],
+          'largest gap', max(abs(x - y) / max(1.0, abs(x)) for x, y in zip(a, b)))
+
+
 def test_stream_first_layer_equals_the_gemm_path(hip_device):
     """ConvModule's skinny-first-layer path (streaming MFMA kernel + statistics epilogue feeding
     the norm) against the plain conv -> norm path: outputs, running statistics, gradients."""
