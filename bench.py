@@ -164,7 +164,7 @@ def _gate_model(workload):
     return model.train()
 
 
-def parity_gate(device, workload='pretrain'):
+def parity_gate(device, workload='pretrain', scenes=None, backward=True):
     """SURVEY section 8(d) / BASELINE.md section 2, before any timing: the CPU-oracle leg and the
     HIP leg run ONE training step (forward + backward) of the same full-size batch -- 2 scenes x
     40 000 points (supervised) or 3 scenes, 1 labeled : 2 unlabeled, student + teacher (semi /
@@ -174,6 +174,8 @@ def parity_gate(device, workload='pretrain'):
       * semi / saqe: the teacher's pseudo-label decisions (validity, classes, class histogram): exact;
       * every loss term within 1e-4 (relative to max(1, |value|));
       * the flat parameter gradient within GATE_GRAD_TOL (relative L2, fp32 leg vs fp32 leg).
+    ``scenes`` / ``backward``: the tests run the same check at the reference's own batch sizes
+    (8 and 16 scenes per GPU, pretrain-010.py:248) forward-only.
     Two chains of discrete decisions over PREDICTED coordinates are replayed from the CPU leg
     (oracle/forcing.py: the vote FPS picks and the quality head's 3-NN grid taps; both kernels
     are compared bit for bit on identical inputs in tests/); how often the HIP leg's own decision
@@ -184,8 +186,10 @@ def parity_gate(device, workload='pretrain'):
     from oracle.forcing import force_grid_taps, force_vote_sampling
     torch.manual_seed(0)
     semi_like = workload != 'pretrain'
-    nscene = 3 if semi_like else 2
+    nscene = scenes or (3 if semi_like else 2)
     pts, boxes, labels = make_batch(4242, nscene, NUM_POINTS)
+    use_label = [i % 3 == 0 for i in range(nscene)]           # 1 labeled : 2 unlabeled (train-010.py:330)
+    lab = [i for i, f in enumerate(use_label) if f]
     cpu_model = _gate_model(workload)
     # the head jitters its proposals with host-side Gaussian noise (nesie_head.py:178-209): both
     # legs get the same draw
@@ -207,8 +211,8 @@ def parity_gate(device, workload='pretrain'):
             gen = torch.Generator().manual_seed(1)
             meta_t = semi.AugMeta.random(nscene, dev, gen, strong=False)
             meta_s = semi.AugMeta.random(nscene, dev, gen, strong=True)
-            gt = GTBatch.collate(boxes[:1], labels[:1], dev)
-            rows = torch.tensor([5, 17], device=dev)
+            gt = GTBatch.collate([transform_gt(boxes[i], meta_s, i) for i in lab], [labels[i] for i in lab], dev)
+            rows = (5 + 12 * torch.arange(nscene - len(lab), device=dev)) % 1081
             inner = model.get_pseudo_labels
 
             def recording(preds, name='ScanNet'):
@@ -218,7 +222,7 @@ def parity_gate(device, workload='pretrain'):
             model.get_pseudo_labels = recording
             tree = model.backbone.sample_and_group_indices(meta_s.apply_points(p))
             losses = model.forward_train(meta_s.apply_points(p), meta_t.apply_points(p), gt,
-                                         [True, False, False], meta_s, meta_t, rows)
+                                         use_label, meta_s, meta_t, rows)
             del model.get_pseudo_labels
             picks.update(ulb_list=model.state.ulb_list.cpu(), ulb_flag=model.state.ulb_flag.cpu())
             votes = ()
@@ -227,13 +231,17 @@ def parity_gate(device, workload='pretrain'):
             tree = model.backbone.sample_and_group_indices(p)
             votes = tuple(t.cpu() for t in model.bbox_head.vote_targets_of(p, gt))
             losses = model.forward_train(p, None, gt, None)
-        model.parse_losses(losses).backward()
-        grads = {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.grad is not None}
+        grads = {}
+        if backward:
+            model.parse_losses(losses).backward()
+            grads = {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.grad is not None}
         return {kk: float(v.detach().sum()) for kk, v in losses.items()}, grads, tree, votes, picks
 
-    with kernels.use_backend(oracle.OracleKernels()):
-        want, want_g, want_tree, want_votes, want_picks = leg(cpu_model, torch.device('cpu'))
-    got, got_g, got_tree, got_votes, got_picks = leg(gpu_model, device)
+    from contextlib import nullcontext
+    with (nullcontext() if backward else torch.no_grad()):
+        with kernels.use_backend(oracle.OracleKernels()):
+            want, want_g, want_tree, want_votes, want_picks = leg(cpu_model, torch.device('cpu'))
+        got, got_g, got_tree, got_votes, got_picks = leg(gpu_model, device)
     if device.type == 'cuda':
         torch.cuda.synchronize(device)
     diffs = {kk: abs(got[kk] - want[kk]) / max(1.0, abs(want[kk])) for kk in want}
@@ -248,12 +256,14 @@ def parity_gate(device, workload='pretrain'):
                                 want_picks[kk][want_picks['valid']] if kk == 'labels' else want_picks[kk])
                     for kk in want_picks)
     names = sorted(n for n in want_g if n in got_g)
-    w = torch.cat([want_g[n].flatten() for n in names])
-    h = torch.cat([got_g[n].flatten() for n in names])
-    grad_rel = float((h - w).norm() / w.norm())
-    gmax = float(w.abs().max())
-    per_param = max(((float((got_g[n] - want_g[n]).abs().max()) / max(float(want_g[n].abs().max()), 1e-3 * gmax), n)
-                     for n in names))
+    grad_rel, per_param = 0.0, (0.0, None)
+    if backward:
+        w = torch.cat([want_g[n].flatten() for n in names])
+        h = torch.cat([got_g[n].flatten() for n in names])
+        grad_rel = float((h - w).norm() / w.norm())
+        gmax = float(w.abs().max())
+        per_param = max(((float((got_g[n] - want_g[n]).abs().max()) / max(float(want_g[n].abs().max()), 1e-3 * gmax), n)
+                         for n in names))
     passed = (diffs[worst] <= GATE_LOSS_TOL and not bad_idx and pseudo_ok and grad_rel <= GATE_GRAD_TOL
               and set(want_g) == set(got_g))
     del gpu_model, cpu_model
@@ -263,11 +273,12 @@ def parity_gate(device, workload='pretrain'):
                terms=len(diffs), tolerance=GATE_LOSS_TOL,
                index_ops=dict(tensors_compared=n_idx, bit_exact=not bad_idx, differing=bad_idx[:8]),
                gradient=dict(flat_rel_l2_hip_vs_cpu=grad_rel, tolerance=GATE_GRAD_TOL, parameters=len(names),
-                             worst_parameter=dict(name=per_param[1], max_err_over_max_grad=per_param[0])),
+                             worst_parameter=dict(name=per_param[1], max_err_over_max_grad=per_param[0]))
+               if backward else None,
                own_vote_picks_agreed=bool(all(gpu_sampler.agreed)),
                grid_taps=dict(replayed_from_cpu_leg=True, grid_points_compared=tap_stats[1],
                               own_taps_differed=tap_stats[0]),
-               sample=f'one {"student/teacher" if semi_like else "supervised"} step (forward + backward), '
+               sample=f'one {"student/teacher" if semi_like else "supervised"} step (forward{" + backward" if backward else " only"}), '
                       f'{nscene} scenes x {NUM_POINTS} pts, same weights and inputs on the CPU-oracle '
                       'leg and the HIP leg')
     if semi_like:
@@ -654,7 +665,7 @@ def main():
             print(json.dumps({'parity_gate': gate}), flush=True)
             print(f"parity gate FAILED: worst loss term {gate['worst_term']} differs by "
                   f"{gate['max_rel_diff']:.3e}; index ops exact: {gate['index_ops']['bit_exact']}; "
-                  f"gradient rel. L2 {gate['gradient']['flat_rel_l2_hip_vs_cpu']:.3e}", file=sys.stderr)
+                  f"gradient {gate['gradient']}", file=sys.stderr)
             sys.exit(3)
     cfg = nesie_votenet_scannet_cfg()
     model, step, bucket = build_step(device, args.batch, 1000 + 100 * rank,

@@ -38,6 +38,19 @@ typedef enum {
 int nesie_abi_version(void);
 const char *nesie_last_error(void); /* thread-local, never NULL */
 
+/* Form of the squared distance in furthest_point_sampling / ball_query / three_nn / grid_taps
+ * (process-wide; default 0).  The reference writes
+ *   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
+ * (furthest_point_sample_cuda.cu:65-66, ball_query_cuda.cu:41-42, three_nn_cuda.cu:41) and nvcc's
+ * default -fmad=true may contract it; no output of that build exists to decide.
+ *   0  ((dx*dx) + (dy*dy)) + (dz*dz), no contraction (the tuned kernels)
+ *   1  fma(dz, dz, fma(dx, dx, dy*dy))      2  fma(dz, dz, fma(dy, dy, dx*dx))
+ * Forms 1 / 2 run on the plain kernels (no bucket pruning, no spatial index; nesie_fps_leaves_index
+ * then returns 0): a one-flag check against a CUDA-produced fixture, not a fast path.  The CPU
+ * oracle has the same switch (oracle_set_distance_form). */
+int nesie_set_distance_form(int form);
+int nesie_get_distance_form(void);
+
 /* mmdet3d/ops/furthest_point_sample/src/furthest_point_sample.cpp:32-58
  * furthest_point_sampling_wrapper(b, n, m, points[B,N,3], temp[B,N], idx[B,M]).
  * temp must hold 1e10 on entry (furthest_point_sample.py:30) and holds the

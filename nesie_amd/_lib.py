@@ -158,6 +158,10 @@ def load():
     lib.nesie_pw_stat_slots.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
     lib.nesie_pw_stat_slots.restype = _I
     lib.nesie_abi_version.restype = _I
+    lib.nesie_set_distance_form.argtypes = [_I]
+    lib.nesie_set_distance_form.restype = _I
+    lib.nesie_get_distance_form.argtypes = []
+    lib.nesie_get_distance_form.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib

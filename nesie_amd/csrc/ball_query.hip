@@ -16,6 +16,7 @@ namespace nesie {
 constexpr int BQ_BLOCK = 256;  // 4 waves
 constexpr int BQ_CPW = 4;      // centres per wave
 
+template <int FORM>
 __global__ __launch_bounds__(BQ_BLOCK) void ball_query_kernel(
     int b, int n, int m, float min_radius, float max_radius, int nsample,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(BQ_BLOCK) void ball_query_kernel(
 #pragma unroll
       for (int c = 0; c < BQ_CPW; ++c) {
         if (cnt[c] < nsample) {  // wave-uniform
-          float d2 = sqdist_nofma(cx[c] - x, cy[c] - y, cz[c] - z);
+          float d2 = sqdist_form<FORM>(cx[c] - x, cy[c] - y, cz[c] - z);
           bool hit = valid && (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2));
           unsigned long long mask = __ballot(hit);
           int rank = __builtin_amdgcn_mbcnt_hi(
@@ -211,9 +212,13 @@ extern "C" int nesie_ball_query_wrapper(int b, int n, int m, float min_radius,
   const int per_block = (BQ_BLOCK / 64) * BQ_CPW;
   const long long groups = cdiv(m, per_block);
   NESIE_REQUIRE(groups * b < (1ll << 31), W);
-  hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)(groups * b)), dim3(BQ_BLOCK),
-                     lds, (hipStream_t)stream, b, n, m, min_radius, max_radius,
-                     nsample, new_xyz, xyz, idx);
+#define BQ(FORM)                                                                                \
+  hipLaunchKernelGGL(ball_query_kernel<FORM>, dim3((unsigned)(groups * b)), dim3(BQ_BLOCK), lds, \
+                     (hipStream_t)stream, b, n, m, min_radius, max_radius, nsample, new_xyz, xyz, idx)
+  if (distance_form() == 1) BQ(1);
+  else if (distance_form() == 2) BQ(2);
+  else BQ(0);
+#undef BQ
   return check_launch(W);
 }
 
@@ -228,7 +233,7 @@ extern "C" int nesie_ball_query_indexed(int b, int n, int m, float min_radius, f
   NESIE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, W);
   if (b == 0 || m == 0 || nsample == 0 || n == 0) return NESIE_OK;
   NESIE_REQUIRE(new_xyz && fps_workspace && idx, W);
-  if (nsample > 64 || !nesie_fps_leaves_index(b, n)) {
+  if (nsample > 64 || !nesie_fps_leaves_index(b, n)) {   // (also: a fused distance form is selected)
     set_error("%s: needs nsample <= 64 and a size for which the FPS kernel leaves its index", W);
     return NESIE_ERR_UNSUPPORTED;
   }

@@ -9,6 +9,7 @@
 namespace nesie {
 
 void set_error(const char *fmt, ...);
+int distance_form();   // 0 (default), 1, 2: see sqdist_form
 
 inline int check_launch(const char *what) {
   hipError_t e = hipGetLastError();
@@ -38,6 +39,22 @@ bool stream_nt(long long bytes, int family);
 __device__ __forceinline__ float sqdist_nofma(float dx, float dy, float dz) {
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)),
                    __fmul_rn(dz, dz));
+}
+
+// The same distance in a selectable form (nesie_set_distance_form): nvcc's default -fmad=true MAY
+// contract the reference's `(x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)`
+// (furthest_point_sample_cuda.cu:65-66, ball_query_cuda.cu:41-42, three_nn_cuda.cu:41); whether and how
+// cannot be known without a run of the reference's own CUDA build.
+//   FORM 0  ((dx*dx) + (dy*dy)) + (dz*dz)        no contraction: the product's form
+//   FORM 1  fma(dz, dz, fma(dx, dx, dy*dy))       LLVM's contraction of the expression as written
+//   FORM 2  fma(dz, dz, fma(dy, dy, dx*dx))       the other choice for the inner sum
+// FORM != 0 is served by the plain (un-pruned, un-indexed) kernels only: a checking aid for the day
+// a CUDA-produced fixture exists, not a fast path.  oracle/nesie_oracle.c carries the same switch.
+template <int FORM>
+__device__ __forceinline__ float sqdist_form(float dx, float dy, float dz) {
+  if (FORM == 1) return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+  if (FORM == 2) return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+  return sqdist_nofma(dx, dy, dz);
 }
 
 // 64-bit max across the 64 lanes of a wave (result valid in every lane).

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(
 
 // ---- any n: temp stays in global memory (reference-shaped, key reduction) ----
 // WITH_DIST: `src` is the (N,N) distance matrix of furthest_point_sample_cuda.cu:214-331.
-template <bool WITH_DIST>
+template <bool WITH_DIST, int FORM = 0>
 __global__ __launch_bounds__(1024) void fps_generic_kernel(
     int n, int m, int L, const float *__restrict__ src, float *__restrict__ temp,
     int *__restrict__ idx) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
     for (int k = tid; k < n; k += 1024) {
       float d;
       if (WITH_DIST) d = src[(size_t)old * n + k];
-      else d = sqdist_nofma(src[k * 3 + 0] - x1, src[k * 3 + 1] - y1, src[k * 3 + 2] - z1);
+      else d = sqdist_form<FORM>(src[k * 3 + 0] - x1, src[k * 3 + 1] - y1, src[k * 3 + 2] - z1);
       float d2 = fminf(d, temp[k]);
       temp[k] = d2;
       unsigned long long key =
@@ -619,7 +619,8 @@ static bool fps_lds_mode(int n) {
 }
 
 extern "C" int nesie_fps_leaves_index(int b, int n) {
-  return nesie_fps_workspace_bytes(b, n) != 0 && fps_lds_mode(n);
+  // (a fused distance form runs on the plain kernel, which builds no index)
+  return distance_form() == 0 && nesie_fps_workspace_bytes(b, n) != 0 && fps_lds_mode(n);
 }
 
 extern "C" size_t nesie_fps_workspace_bytes(int b, int n) {
@@ -649,6 +650,13 @@ static int fps_launch(int b, int n, int m, const float *xyz, float *temp, int *i
   hipStream_t s = (hipStream_t)stream;
   const int L = fps_ref_log2_block(n);
   dim3 grid(b);
+  if (distance_form() != 0) {   // checking aid (common.h, sqdist_form): the plain kernel only
+    if (distance_form() == 1)
+      hipLaunchKernelGGL((fps_generic_kernel<false, 1>), grid, dim3(1024), 0, s, n, m, L, xyz, temp, idx);
+    else
+      hipLaunchKernelGGL((fps_generic_kernel<false, 2>), grid, dim3(1024), 0, s, n, m, L, xyz, temp, idx);
+    return check_launch(W);
+  }
 #define REG(BLK, P) \
   hipLaunchKernelGGL((fps_reg_kernel<BLK, P>), grid, dim3(BLK), 0, s, n, m, L, xyz, temp, idx)
 #define STREAM(P) \

@@ -20,6 +20,7 @@ namespace nesie {
 constexpr int NN_BLOCK = 256;
 constexpr int NN_TILE = 1024;  // known points per LDS tile (12 KB)
 
+template <int FORM>
 __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(
     int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
     float *__restrict__ dist2, int *__restrict__ idx) {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(
 #pragma unroll 4
     for (int i = 0; i < tn; ++i) {
       const float4 kp = kk[i];
-      const float d = sqdist_nofma(ux - kp.x, uy - kp.y, uz - kp.z);
+      const float d = sqdist_form<FORM>(ux - kp.x, uy - kp.y, uz - kp.z);
       if (d < b3) {  // rare once the three bests have settled: one compare on the common path
         const int k = t0 + i;
         if (d < b1) {
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(NN_BLOCK) void three_nn_kernel(
 //   3-NN of `world` among the seeds (three_nn, same compare order), then
 //   weight_t = (1 / (sqrt(d2_t) + 1e-8)) / sum_t(...),  rel = world - centre
 // Stands in for side_pooling_module.py:87-157 (grids) and :204-225 (taps): ~55 ATen launches.
+template <int FORM>
 __global__ __launch_bounds__(NN_BLOCK) void grid_taps_kernel(
     int kprop, int gp, int m, const float *__restrict__ centre, const float *__restrict__ size,
     const float *__restrict__ heading, const float *__restrict__ mult,
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(NN_BLOCK) void grid_taps_kernel(
 #pragma unroll 4
     for (int i = 0; i < tn; ++i) {
       const float4 kp = kk[i];
-      const float d = sqdist_nofma(ux - kp.x, uy - kp.y, uz - kp.z);
+      const float d = sqdist_form<FORM>(ux - kp.x, uy - kp.y, uz - kp.z);
       if (d < b3) {
         const int kidx = t0 + i;
         if (d < b1) {
@@ -780,8 +782,13 @@ extern "C" int nesie_three_nn_wrapper(int b, int n, int m, const float *unknown,
   if (b == 0 || n == 0) return NESIE_OK;
   NESIE_REQUIRE(unknown && dist2 && idx && (m == 0 || known), W);
   NESIE_REQUIRE(b <= 65535 && (long long)n * 3 < (1ll << 31) && (long long)m * 3 < (1ll << 31), W);
-  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, NN_BLOCK), b), dim3(NN_BLOCK), 0,
-                     (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+#define NN(FORM)                                                                          \
+  hipLaunchKernelGGL(three_nn_kernel<FORM>, dim3(cdiv(n, NN_BLOCK), b), dim3(NN_BLOCK), 0, \
+                     (hipStream_t)stream, n, m, unknown, known, dist2, idx)
+  if (distance_form() == 1) NN(1);
+  else if (distance_form() == 2) NN(2);
+  else NN(0);
+#undef NN
   return check_launch(W);
 }
 
@@ -794,9 +801,14 @@ extern "C" int nesie_grid_taps(int b, int kprop, int gp, int m, const float *cen
   if (b == 0 || kprop == 0 || gp == 0) return NESIE_OK;
   NESIE_REQUIRE(m >= 3 && centre && size && heading && mult && plane && known, W);
   NESIE_REQUIRE(idx && weight && rel && b <= 65535 && (long long)kprop * gp * 3 < (1ll << 31), W);
-  hipLaunchKernelGGL(grid_taps_kernel, dim3(cdiv((long long)kprop * gp, NN_BLOCK), b),
-                     dim3(NN_BLOCK), 0, (hipStream_t)stream, kprop, gp, m, centre, size, heading,
-                     mult, plane, known, idx, weight, rel);
+#define GT(FORM)                                                                                \
+  hipLaunchKernelGGL(grid_taps_kernel<FORM>, dim3(cdiv((long long)kprop * gp, NN_BLOCK), b),     \
+                     dim3(NN_BLOCK), 0, (hipStream_t)stream, kprop, gp, m, centre, size, heading, \
+                     mult, plane, known, idx, weight, rel)
+  if (distance_form() == 1) GT(1);      // (mmcv.ops.three_nn is an nvcc build as well)
+  else if (distance_form() == 2) GT(2);
+  else GT(0);
+#undef GT
   return check_launch(W);
 }
 

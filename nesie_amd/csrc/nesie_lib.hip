@@ -10,7 +10,15 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static int g_distance_form = 0;
+int distance_form() { return g_distance_form; }
 }  // namespace nesie
 
 extern "C" int nesie_abi_version(void) { return 1; }
+extern "C" int nesie_set_distance_form(int form) {
+  NESIE_REQUIRE(form >= 0 && form <= 2, "set_distance_form");
+  nesie::g_distance_form = form;
+  return NESIE_OK;
+}
+extern "C" int nesie_get_distance_form(void) { return nesie::g_distance_form; }
 extern "C" const char *nesie_last_error(void) { return nesie::g_err; }

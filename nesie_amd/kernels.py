@@ -102,6 +102,17 @@ class HipKernels(_BNPoolMixin):
     _spatial_index = {}
     _index_scope_depth = 0
 
+    @staticmethod
+    def set_distance_form(form):
+        """Process-wide form of the squared distance in FPS / ball query / 3-NN / grid taps
+        (include/nesie_ops.h ``nesie_set_distance_form``): 0 = contraction-free (default, the
+        tuned kernels), 1 / 2 = the fused forms an nvcc build of the reference may compute."""
+        _lib.call("nesie_set_distance_form", int(form))
+
+    @staticmethod
+    def get_distance_form():
+        return _lib.load().nesie_get_distance_form()
+
     @classmethod
     def _index_for(cls, xyz, b, n):
         hit = cls._spatial_index.get(xyz.device)

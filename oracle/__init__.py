@@ -89,6 +89,17 @@ def _cpu(*ts):
         assert t.device.type == "cpu" and t.is_contiguous(), "oracle takes contiguous CPU tensors"
 
 
+def set_distance_form(form):
+    """0 (default): contraction-free squared distance; 1 / 2: the fused forms nvcc's -fmad=true
+    could make of the reference's expression (nesie_oracle.c header).  Process-wide."""
+    if lib().oracle_set_distance_form(int(form)) != 0:
+        raise ValueError(f'distance form {form} (0, 1 or 2)')
+
+
+def get_distance_form():
+    return lib().oracle_get_distance_form()
+
+
 class OracleKernels:
     """Same method surface as nesie_amd.kernels.HipKernels, on CPU tensors."""
 

@@ -29,6 +29,21 @@
  * Floating point discipline: every squared distance
  * is ((dx*dx) + (dy*dy)) + (dz*dz) in fp32 with NO fma contraction; build
  * with -ffp-contract=off (oracle/Makefile does).
+ *
+ * Distance-form switch (default 0; also settable at build time with
+ * -DORACLE_FMA_DIST=<form>).  nvcc's default -fmad=true MAY contract the
+ * reference's `(x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)`
+ * (furthest_point_sample_cuda.cu:65-66, ball_query_cuda.cu:41-42,
+ * three_nn_cuda.cu:41) into a fused chain; which one cannot be known without
+ * running the reference's own CUDA build.  oracle_set_distance_form() selects
+ *   0  ((dx*dx) + (dy*dy)) + (dz*dz)              no contraction (the product's form)
+ *   1  fma(dz, dz, fma(dx, dx, dy*dy))             LLVM's contraction of the expression as
+ *                                                  written: the LEFT product of a sum of two
+ *                                                  products is fused, then the outer add
+ *   2  fma(dz, dz, fma(dy, dy, dx*dx))             the other choice for the inner sum
+ * with correctly rounded fmaf(), so that the day a CUDA-produced fixture exists
+ * the contraction question is a one-flag check of oracle AND HIP kernels
+ * (nesie_set_distance_form, same numbering) instead of a rewrite.
  */
 #include <math.h>
 #include <stdint.h>
@@ -38,6 +53,25 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+#ifndef ORACLE_FMA_DIST
+#define ORACLE_FMA_DIST 0
+#endif
+static int g_dist_form = ORACLE_FMA_DIST;
+
+int oracle_set_distance_form(int form) {
+  if (form < 0 || form > 2) return -1;
+  g_dist_form = form;
+  return 0;
+}
+int oracle_get_distance_form(void) { return g_dist_form; }
+
+/* the squared distance of SURVEY.md appendix A.0 in the selected form */
+static inline float sqdist(float dx, float dy, float dz, int form) {
+  if (form == 1) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+  if (form == 2) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return ((dx * dx) + (dy * dy)) + (dz * dz);
+}
 
 /* ------------------------------------------------------------------ */
 /* FPS                                                                 */
@@ -72,6 +106,7 @@ static int fps_tree_reduce(float *dists, int *dists_i, int bs) {
 int oracle_furthest_point_sampling(int b, int n, int m, const float *xyz,
                                    float *temp, int *idx) {
   if (m <= 0) return 1; /* :34 */
+  const int form = g_dist_form;
   const int bs = oracle_fps_block_size(n);
 #pragma omp parallel for schedule(static)
   for (int bi = 0; bi < b; ++bi) {
@@ -89,7 +124,7 @@ int oracle_furthest_point_sampling(int b, int n, int m, const float *xyz,
         float dx = p[k * 3 + 0] - x1;
         float dy = p[k * 3 + 1] - y1;
         float dz = p[k * 3 + 2] - z1;
-        float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+        float d = sqdist(dx, dy, dz, form);
         float t = tp[k];
         float d2 = d < t ? d : t; /* min(d, temp[k]) */
         tp[k] = d2;
@@ -166,6 +201,7 @@ int oracle_furthest_point_sampling_with_dist(int b, int n, int m,
 int oracle_ball_query(int b, int n, int m, float min_radius, float max_radius,
                       int nsample, const float *new_xyz, const float *xyz,
                       int *idx) {
+  const int form = g_dist_form;
   const float max_radius2 = max_radius * max_radius; /* :27 */
   const float min_radius2 = min_radius * min_radius; /* :28 */
 #pragma omp parallel for collapse(2) schedule(static)
@@ -180,7 +216,7 @@ int oracle_ball_query(int b, int n, int m, float min_radius, float max_radius,
         float dx = new_x - p[k * 3 + 0];
         float dy = new_y - p[k * 3 + 1];
         float dz = new_z - p[k * 3 + 2];
-        float d2 = ((dx * dx) + (dy * dy)) + (dz * dz); /* :41-42 */
+        float d2 = sqdist(dx, dy, dz, form); /* :41-42 */
         if (d2 == 0 || (d2 >= min_radius2 && d2 < max_radius2)) { /* :43 */
           if (cnt == 0) {
             for (int l = 0; l < nsample; ++l) o[l] = k; /* :44-48 */
@@ -266,6 +302,7 @@ int oracle_gather_points_grad(int b, int c, int n, int npoints,
  * dist2 (B,n,3) f32, idx (B,n,3) i32.  bests are double, d is float. */
 int oracle_three_nn(int b, int n, int m, const float *unknown,
                     const float *known, float *dist2, int *idx) {
+  const int form = g_dist_form;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int bi = 0; bi < b; ++bi)
     for (int pi = 0; pi < n; ++pi) {
@@ -278,7 +315,7 @@ int oracle_three_nn(int b, int n, int m, const float *unknown,
         float dx = ux - kn[k * 3 + 0];
         float dy = uy - kn[k * 3 + 1];
         float dz = uz - kn[k * 3 + 2];
-        float d = ((dx * dx) + (dy * dy)) + (dz * dz); /* :41 */
+        float d = sqdist(dx, dy, dz, form); /* :41 */
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;

@@ -12,12 +12,38 @@ import numpy as np
 f32 = np.float32
 
 
+# Form of the squared distance (the switch of oracle/nesie_oracle.c and include/nesie_ops.h):
+# 0 = no contraction, 1 = fma(dz, dz, fma(dx, dx, dy*dy)), 2 = fma(dz, dz, fma(dy, dy, dx*dx))
+FORM = 0
+
+
+def fma32(a, b, c):
+    """Correctly rounded float32 fused multiply-add, element-wise, without an fma instruction: the
+    product of two float32 is exact in float64 (48 bits); the sum with c is formed in float64 with
+    its exact error (TwoSum) and rounded TO ODD, which makes the final rounding to float32 immune to
+    double rounding (53 >= 24 + 2 bits)."""
+    a, b, c = (np.asarray(v, dtype=f32).astype(np.float64) for v in (a, b, c))
+    p = a * b
+    s = p + c
+    bp = s - p
+    e = (p - (s - bp)) + (c - bp)
+    odd = (s.view(np.int64) & 1) == 1
+    toward = np.where(e > 0, np.inf, -np.inf)
+    s = np.where((e != 0) & ~odd, np.nextafter(s, toward), s)
+    return s.astype(f32)
+
+
 def sqdist(a, b):
-    """((dx*dx)+(dy*dy))+(dz*dz) in float32, operand order a - b."""
+    """The squared distance in float32 in the selected FORM, operand order a - b."""
     d = (a.astype(f32) - b.astype(f32)).astype(f32)
-    xx = (d[..., 0] * d[..., 0]).astype(f32)
-    yy = (d[..., 1] * d[..., 1]).astype(f32)
-    zz = (d[..., 2] * d[..., 2]).astype(f32)
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    if FORM == 1:
+        return fma32(dz, dz, fma32(dx, dx, (dy * dy).astype(f32)))
+    if FORM == 2:
+        return fma32(dz, dz, fma32(dy, dy, (dx * dx).astype(f32)))
+    xx = (dx * dx).astype(f32)
+    yy = (dy * dy).astype(f32)
+    zz = (dz * dz).astype(f32)
     return ((xx + yy).astype(f32) + zz).astype(f32)
 
 

@@ -941,3 +941,42 @@ def test_eval_coefficients_follow_native_training_steps_and_the_teacher_swap(hip
         teacher.swap()
         torch.testing.assert_close(bn.eval_coef(), student, rtol=0, atol=0)
     assert (swapped[:, 0] - student[:, 0]).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize('form', [1, 2])
+def test_fused_distance_forms_bit_exact_vs_the_oracle_in_the_same_form(oracle_kernels, hip_device, form):
+    """nesie_set_distance_form (include/nesie_ops.h): FPS, ball query, 3-NN and the quality head's
+    grid taps with the squared distance as the fused chain an nvcc -fmad=true build of the
+    reference may compute, against the oracle with the same switch (itself pinned by an exact numpy
+    fma emulation in tests/test_oracle.py): indices and distances bit for bit -- incl. the SA1
+    size, where the product's default form runs the bucket-pruned kernel + spatial index and the
+    fused forms must fall back to the plain kernels.  Default form restored and re-checked."""
+    import oracle
+    from nesie_amd import _lib
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    lib = _lib.load()
+    try:
+        hip.set_distance_form(form)
+        oracle.set_distance_form(form)
+        assert hip.get_distance_form() == form and lib.nesie_fps_leaves_index(2, 40000) == 0
+        for n, m, kw in [(4096, 512, dict(dup_frac=0.25)), (40000, 300, dict(dup_frac=0.3)), (1000, 200, dict(grid=True))]:
+            xyz = _cases.cloud(500 + n, 2, n, **kw)
+            got, want = both(ops.furthest_point_sample, oracle_kernels, hip_device, xyz, m)
+            eq(got, want)
+        xyz = _cases.cloud(77, 2, 40000, dup_frac=0.3)
+        cen = xyz[:, ::40].contiguous()
+        for r, ns in [(0.2, 64), (0.4, 32)]:
+            got, want = both(lambda c, x: ops.ball_query(0.0, r, ns, x, c), oracle_kernels, hip_device, cen, xyz)
+            eq(got, want)
+        known = xyz[:, :1024].contiguous()
+        got, want = both(lambda u, k: ops.three_nn(u, k)[1], oracle_kernels, hip_device, cen, known)
+        eq(got, want)
+        got, want = both(lambda u, k: ops.three_nn(u, k)[0], oracle_kernels, hip_device, cen, known)
+        eq(got, want)
+    finally:
+        hip.set_distance_form(0)
+        oracle.set_distance_form(0)
+    assert hip.get_distance_form() == 0 and lib.nesie_fps_leaves_index(2, 40000) == 1
+    xyz = _cases.cloud(4596, 2, 4096, dup_frac=0.25)
+    got, want = both(ops.furthest_point_sample, oracle_kernels, hip_device, xyz, 512)
+    eq(got, want)

@@ -228,3 +228,67 @@ def test_points_in_boxes_pinned_by_reference_cpu_source(oracle_kernels, yaw):
     # only points within an ulp of a rotated face may differ.
     assert mism <= (0 if not yaw else 2), mism
     assert ref.sum() > 100
+
+
+def test_fma32_emulation_is_correctly_rounded():
+    """tests/_np_ref.fma32 against exact rational arithmetic (fractions) on random and on
+    cancellation-heavy operands: the emulation pins the oracle's libm fmaf() forms below."""
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(400).astype(np.float32) * np.float32(3.7)
+    b = rng.standard_normal(400).astype(np.float32)
+    c = (-(a.astype(np.float64) * b.astype(np.float64))).astype(np.float32)   # near-total cancellation
+    c[::2] = rng.standard_normal(200).astype(np.float32) * np.float32(1e-3)
+    got = _np_ref.fma32(a, b, c)
+    for x, y, z, g in zip(a, b, c, got):
+        exact = Fraction(float(x)) * Fraction(float(y)) + Fraction(float(z))
+        lo = np.float32(float(exact))            # float(exact) is the correctly rounded double ...
+        # ... which may double-round: decide between its float32 neighbours exactly
+        cands = {lo, np.nextafter(lo, np.float32(np.inf)), np.nextafter(lo, np.float32(-np.inf))}
+        best = min(cands, key=lambda v: (abs(Fraction(float(v)) - exact), int(np.float32(v).view(np.uint32)) & 1))
+        assert np.float32(g) == np.float32(best), (x, y, z, g, best)
+
+
+@pytest.mark.parametrize('form', [1, 2])
+def test_fused_distance_forms_match_their_numpy_restatement(oracle_kernels, form):
+    """The distance-form switch (nesie_oracle.c header): with nvcc's default -fmad=true the
+    reference's squared distance MAY be a fused chain; forms 1 / 2 restate the two contractions of
+    the expression as written.  FPS picks + final running minima, ball-query rows and the 3-NN
+    (distances, indices) of the oracle in that form equal the numpy restatement built on an exact
+    float32 fma emulation -- and the form changes distances (so the flag is live)."""
+    xyz = _cases.cloud(91, 2, 2048, dup_frac=0.2)
+    cen = xyz[:, ::16].contiguous()
+    try:
+        oracle.set_distance_form(0)
+        _, d0 = _three_nn_raw(oracle_kernels, cen, xyz)
+        oracle.set_distance_form(form)
+        _np_ref.FORM = form
+        assert oracle.get_distance_form() == form
+        idx, temp = _fps(oracle_kernels, xyz, 200)
+        bq = torch.zeros(2, cen.shape[1], 16, dtype=torch.int32)
+        oracle_kernels.ball_query_wrapper(2, 2048, cen.shape[1], 0.0, 0.13, 16, cen, xyz, bq)
+        ni, nd = _three_nn_raw(oracle_kernels, cen, xyz)
+        for bi in range(2):
+            want_idx, want_temp = _np_ref.fps_key(xyz[bi].numpy(), 200)
+            np.testing.assert_array_equal(idx[bi].numpy(), want_idx)
+            np.testing.assert_array_equal(temp[bi].numpy(), want_temp)
+            np.testing.assert_array_equal(
+                bq[bi].numpy(), _np_ref.ball_query(cen[bi].numpy(), xyz[bi].numpy(), 0.0, 0.13, 16))
+            wd, wi = _np_ref.three_nn(cen[bi].numpy(), xyz[bi].numpy())
+            np.testing.assert_array_equal(nd[bi].numpy(), wd)
+            np.testing.assert_array_equal(ni[bi].numpy(), wi)
+        assert (nd != d0).any(), 'the fused form changed no distance: the switch is dead'
+        assert float((nd - d0).abs().max()) < 1e-6
+    finally:
+        oracle.set_distance_form(0)
+        _np_ref.FORM = 0
+    with pytest.raises(ValueError):
+        oracle.set_distance_form(3)
+
+
+def _three_nn_raw(k, unknown, known):
+    b, n, m = unknown.shape[0], unknown.shape[1], known.shape[1]
+    d = torch.empty(b, n, 3)
+    i = torch.empty(b, n, 3, dtype=torch.int32)
+    k.three_nn_wrapper(b, n, m, unknown.contiguous(), known.contiguous(), d, i)
+    return i, d

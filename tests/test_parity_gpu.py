@@ -470,3 +470,46 @@ def test_semi_graph_replays_with_ema_equal_eager_per_tensor_steps(hip_device, wo
     holds the EMA update and the pseudo-label state lives in the graph: three replays."""
     gaps = _replays_vs_eager(hip_device, workload, 3, 3)
     assert gaps[0][0] < 1e-2, gaps[:6]
+
+
+def _bench():
+    import bench
+    return bench
+
+
+@pytest.mark.parametrize('batch', [8, 16])
+def test_supervised_step_at_the_reference_batch_sizes_matches_the_cpu_oracle(hip_device, batch):
+    """BASELINE configs[2] at the batch sizes the reference itself uses -- 8 scenes per GPU (the
+    metric) and ``samples_per_gpu = 16`` (nesie-votenet-scannet-pretrain-010.py:248) -- x 40 000
+    points, full model, HIP leg vs CPU-oracle leg (bench.parity_gate, forward only: the CPU leg
+    takes ~0.4 s per scene): the backbone's index chain and the vote targets bit-exact, all 8
+    loss terms within 1e-4."""
+    gate = _bench().parity_gate(hip_device, 'pretrain', scenes=batch, backward=False)
+    print(gate)
+    assert gate['index_ops']['bit_exact'], gate['index_ops']
+    assert gate['index_ops']['tensors_compared'] >= 20
+    assert gate['terms'] == 8 and gate['max_rel_diff'] <= 1e-4, (gate['worst_term'], gate['max_rel_diff'])
+    assert gate['passed']
+
+
+@pytest.mark.parametrize('workload,batch,terms', [('saqe', 16, 13), ('semi', 8, 12)])
+def test_student_teacher_step_at_the_baseline_batch_sizes_matches_the_cpu_oracle(hip_device, workload,
+                                                                                 batch, terms):
+    """BASELINE configs[4] (SAQE, 16 scenes per GPU) and configs[3] (Nesie, 8 per GPU) at their
+    quoted per-GPU batch: student (1 labeled : 2 unlabeled) + teacher on 40 000-point scenes, full
+    model.  HIP vs CPU oracle, forward only: index chain bit-exact, the teacher's pseudo-label
+    decisions (validity, classes, class histogram) exact with SOME boxes kept, every loss term
+    within 1e-4."""
+    gate = _bench().parity_gate(hip_device, workload, scenes=batch, backward=False)
+    print(gate)
+    assert gate['index_ops']['bit_exact'], gate['index_ops']
+    assert gate['pseudo_labels']['exact'] and 0 < gate['pseudo_labels']['boxes_kept'] < gate['pseudo_labels']['of']
+    assert gate['terms'] == terms and gate['max_rel_diff'] <= 1e-4, (gate['worst_term'], gate['max_rel_diff'])
+    assert gate['passed']
+
+
+def test_saqe_graph_replay_at_sixteen_scenes_equals_eager_per_tensor_steps(hip_device):
+    """configs[4]'s per-GPU batch (16 scenes) through bench.py's captured step: one replay of
+    g1a + g1b + g2 (+ EMA, pseudo-label state in the graph) vs the eager per-tensor recipe."""
+    gaps = _replays_vs_eager(hip_device, 'saqe', 1, 16)
+    assert gaps[0][0] < 1e-2, gaps[:6]
