@@ -203,6 +203,15 @@ def parity_gate(device, workload='pretrain', scenes=None, backward=True):
     gpu_model.bbox_head.jitter_noise = tuple(t.to(device) for t in noise)
     gpu_sampler = gpu_model.bbox_head.vote_aggregation.points_sampler
 
+    if semi_like:
+        # the two augmented views are INPUTS of the step: built once (on the host) and handed to both
+        # legs -- a bmm on either device would already differ in the last bit of a coordinate
+        gen = torch.Generator().manual_seed(1)
+        cpu_dev = torch.device('cpu')
+        host_t = semi.AugMeta.random(nscene, cpu_dev, gen, strong=False)
+        host_s = semi.AugMeta.random(nscene, cpu_dev, gen, strong=True)
+        views = (host_s.apply_points(pts), host_t.apply_points(pts))
+
     def leg(model, dev):
         p = pts.to(dev)
         picks = {}
@@ -211,6 +220,7 @@ def parity_gate(device, workload='pretrain', scenes=None, backward=True):
             gen = torch.Generator().manual_seed(1)
             meta_t = semi.AugMeta.random(nscene, dev, gen, strong=False)
             meta_s = semi.AugMeta.random(nscene, dev, gen, strong=True)
+            pts_s, pts_t = views[0].to(dev), views[1].to(dev)
             gt = GTBatch.collate([transform_gt(boxes[i], meta_s, i) for i in lab], [labels[i] for i in lab], dev)
             rows = (5 + 12 * torch.arange(nscene - len(lab), device=dev)) % 1081
             inner = model.get_pseudo_labels
@@ -220,9 +230,8 @@ def parity_gate(device, workload='pretrain', scenes=None, backward=True):
                 picks.update(labels=out[0].cpu(), valid=out[3].cpu())
                 return out
             model.get_pseudo_labels = recording
-            tree = model.backbone.sample_and_group_indices(meta_s.apply_points(p))
-            losses = model.forward_train(meta_s.apply_points(p), meta_t.apply_points(p), gt,
-                                         use_label, meta_s, meta_t, rows)
+            tree = model.backbone.sample_and_group_indices(pts_s)
+            losses = model.forward_train(pts_s, pts_t, gt, use_label, meta_s, meta_t, rows)
             del model.get_pseudo_labels
             picks.update(ulb_list=model.state.ulb_list.cpu(), ulb_flag=model.state.ulb_flag.cpu())
             votes = ()
@@ -354,7 +363,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         inputs = dict(points=pts, gt=gt)
     # parameters and gradients as two flat vectors (dp.FlatTrainState): the gradient
     # all-reduce, the clip and AdamW each see ONE tensor
-    bucket = dp.FlatTrainState(model.parameters())
+    groups = model.stacked_parameter_groups() if hasattr(model, 'stacked_parameter_groups') else None
+    bucket = dp.FlatTrainState(model.parameters(), stack_groups=groups)
     if on_gpu:
         # clip (max_norm 10) + AdamW as two launches over the flat vectors (dp.FlatAdamW)
         opt = dp.FlatAdamW(bucket.flat_param, lr=lr, weight_decay=wd, max_norm=10)

@@ -122,16 +122,33 @@ int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample
                                    void *stream);
 /* Same result through an inverted index of idx: order[B, M*ns] = the grouped columns sorted
  * by their source point, sources[B, M*ns] = that point for each (nesie_inverted_index builds
- * both, n <= 8192).  Lanes own sorted entries, a segmented scan inside each wave sums the runs
- * and only the last lane of a run adds its total into grad_features (zeroed by the caller):
- * a few float atomics per point instead of one per entry, balanced whatever the run lengths.
- * Inside a run the columns are in ascending order (scratch[B, M*ns] holds the arrival-order
- * placement that the second pass ranks), so the sums are reproducible from run to run. */
+ * both, n <= 8192).  Lanes own sorted entries, a segmented scan inside each wave sums the runs;
+ * every run is summed by exactly ONE wave (the one that holds its first entry follows it through
+ * the next chunks) and added into grad_features (zeroed by the caller) by one lane: no float
+ * atomics.  Inside a run the columns are in ascending order (scratch[B, M*ns] holds the
+ * arrival-order placement that the second pass ranks), so the sums are bitwise reproducible. */
 int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
                          int *sources, int *scratch, void *stream);
 int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsample,
                                        const float *grad_out, const int *order,
                                        const int *sources, float *grad_features, void *stream);
+
+/* QueryAndGroup over NETWORK-COMPUTED coordinates (vote aggregation groups the predicted votes
+ * around centres sampled from them, nesie_head.py:243 -> point_sa_module.py:122-131,
+ * group_points.py:98-110): the sampled centres straight from the (B, N, 3) array, and the
+ * coordinate gradient -- what autograd assembles from the backward of transpose / gather_points /
+ * group_points (two atomicAdd scatters) / sub / div / cat:
+ *   d_xyz[p] = (1/r) sum_{idx[e] = p} g[0:3, e] - (1/r) sum_{sample[m] = p} sum_s g[0:3, m, s]
+ *              + sum_{sample[m] = p} d_centres[m]          (r = radius, 0: no division)
+ * with grad_out (B, 3+c, npoints, nsample), (order, sources) = nesie_inverted_index(idx),
+ * sample (B, npoints) the centres' indices, d_centres (B, npoints, 3) or NULL; d_xyz (B, N, 3) is
+ * written (not accumulated), every point by one thread in a fixed order. */
+int nesie_gather_rows3(int b, int n, int m, const float *xyz, const int *sample, float *centres,
+                       void *stream);
+int nesie_query_and_group_backward_xyz(int b, int c, int n, int npoints, int nsample, float radius,
+                                       const float *grad_out, const int *order,
+                                       const int *sources, const int *sample,
+                                       const float *d_centres, float *d_xyz, void *stream);
 
 /* three_interpolate_grad_wrapper through an inverted index of idx[B, n, 3] over the m known
  * points (nesie_inverted_index with e_total = 3n): grad_points[B, C, m] (zeroed) +=
@@ -516,8 +533,12 @@ int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, i
  * dw (ng, co, ci); partials are added in a fixed order (bitwise reproducible).
  * Supported: co <= 256, 9 <= ci <= 1024, p % 32 == 0; a layer wider than one workgroup's
  * accumulators (co <= 128: ci > 320; co > 128: ci > 128) runs as column blocks of dw, one
- * launch each.  workspace = nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p). */
+ * launch each -- or, when the position count is small (nesie_pw_wgrad_tiled: the 1-D chains,
+ * 256 x 512 over 8 x 1024 positions), as ONE launch over 64 x 64 blocks of the product, every
+ * block with its own runs of positions (split-K with a fixed-order reduction).
+ * workspace = nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p). */
 int nesie_pw_wgrad_supported(int co, int ci, long long p);
+int nesie_pw_wgrad_tiled(int nb, int ng, int co, int ci, long long p);
 size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p);
 int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
                    long long dy_bstride, const float *x, long long x_bstride,

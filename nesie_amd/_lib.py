@@ -58,6 +58,8 @@ SIGNATURES = {
     "nesie_three_interpolate_grad_csr": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_gather_rows3": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_query_and_group_backward_xyz": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P],
     "nesie_group_max_pool_backward_add": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],
     "nesie_lhs_nms_samecls": [_I, _I, _P, _F, _P, _P],
@@ -147,6 +149,8 @@ def load():
     lib.nesie_mlp_stream_partials.restype = ctypes.c_longlong
     lib.nesie_pw_wgrad_supported.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_supported.restype = _I
+    lib.nesie_pw_wgrad_tiled.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
+    lib.nesie_pw_wgrad_tiled.restype = _I
     lib.nesie_pw_wgrad_bn_supported.argtypes = [_I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_bn_supported.restype = _I
     lib.nesie_pw_wgrad_workspace_bytes.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]

@@ -68,8 +68,8 @@ def per_parameter_optimizer_state(optimizer, flat_state):
     if len(sd['param_groups']) != 1 or len(sd['param_groups'][0]['params']) != 1:
         raise ValueError('expected an optimiser over the single flat parameter')
     flat = sd['state'].get(sd['param_groups'][0]['params'][0], {})
-    state, off = {}, 0
-    for i, p in enumerate(flat_state.params):
+    state = {}
+    for i, (p, off) in enumerate(zip(flat_state.params, flat_state.offsets)):
         n = p.numel()
         entry = {}
         for k, v in flat.items():
@@ -79,7 +79,6 @@ def per_parameter_optimizer_state(optimizer, flat_state):
                 entry[k] = v.detach().cpu().clone() if torch.is_tensor(v) else v
         if entry:
             state[i] = entry
-        off += n
     group = dict(sd['param_groups'][0], params=list(range(len(flat_state.params))))
     return {'state': state, 'param_groups': [group]}
 
@@ -98,8 +97,8 @@ def load_per_parameter_optimizer_state(optimizer, flat_state, reference_state):
     if ref:
         total = flat_state.flat.numel()
         like = flat_state.flat_param
-        merged, off, step = {}, 0, None
-        for i, p in zip(order, flat_state.params):
+        merged, step = {}, None
+        for i, p, off in zip(order, flat_state.params, flat_state.offsets):
             n = p.numel()
             for k, v in ref.get(i, {}).items():
                 if torch.is_tensor(v) and v.numel() == n and k != 'step':
@@ -110,7 +109,6 @@ def load_per_parameter_optimizer_state(optimizer, flat_state, reference_state):
                     merged[k][off:off + n] = v.reshape(-1).to(like.device, like.dtype)
                 elif k == 'step':
                     step = v
-            off += n
         if step is not None:
             old = sd['state'].get(key, {}).get('step')
             merged['step'] = (torch.as_tensor(float(step)).to(old.device, old.dtype)

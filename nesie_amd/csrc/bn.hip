@@ -218,7 +218,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ row_bias, int group, float *__restrict__ partial,
-    const float *__restrict__ raw_coef) {
+    const float *__restrict__ raw_coef, const float *__restrict__ fwd_coef) {
+  // save_mean / save_invstd NULL: columns 2 / 3 of fwd_coef (scale, bias, mean, invstd).
   // raw_coef != NULL: the normalised tensor y was never stored (the next layer applied the
   // norm + ReLU on its operand load, pwconv.hip): the ReLU mask is fma(x, scale, bias) > 0,
   // the fused form that kernel used
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(
   const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c_total + c) * p;
   const float *rb = row_bias ? row_bias + rb_offset(b, c, c_total, p, group) : nullptr;
-  float mean = save_mean[c], invstd = save_invstd[c];
+  float mean = save_mean ? save_mean[c] : fwd_coef[c * 4 + 2];
+  float invstd = save_invstd ? save_invstd[c] : fwd_coef[c * 4 + 3];
   const float rsc = raw_coef ? raw_coef[c * 4 + 0] : 0.f, rbi = raw_coef ? raw_coef[c * 4 + 1] : 0.f;
   // With the ReLU fused, xhat is only needed where y > 0, and there y = gamma*xhat + beta:
   // xhat = (y - beta) / gamma needs no read of x (one tensor pass less).  Channels whose
@@ -546,7 +548,8 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   const char *W = "bn_relu_backward";
   int st = bn_check(W, b, c, p, workspace, workspace_bytes);
   if (st || b == 0 || c == 0 || p == 0) return st;
-  NESIE_REQUIRE(dy && x && dx && save_mean && save_invstd && fwd_coef, W);
+  NESIE_REQUIRE(dy && x && dx && fwd_coef && (save_mean == nullptr) == (save_invstd == nullptr), W);
+  // save_mean / save_invstd NULL: columns 2 / 3 of fwd_coef.
   // y == NULL with relu: the normalised tensor was never stored (fused forward): the mask is
   // re-derived from x with the forward's fused scale / bias.  d_row_bias without row_bias: only
   // the per-group sums of dx are wanted (the producer had added the row term itself).
@@ -565,7 +568,7 @@ extern "C" int nesie_bn_relu_backward(int b, int c, long long p, const float *dy
   const bool nt = bn_use_nt((long long)b * c * p);
 #define LR(R, N) hipLaunchKernelGGL((bn_bwd_reduce_kernel<R, N>), grid, dim3(BN_BLOCK), 0, s, c, p, sp, dy, \
                                     x, y, save_mean, save_invstd, gamma, beta, row_bias, group, partial, \
-                                    raw ? fwd_coef : (const float *)nullptr)
+                                    raw ? fwd_coef : (const float *)nullptr, fwd_coef)
   if (relu) { if (nt) LR(true, true); else LR(true, false); }
   else { if (nt) LR(false, true); else LR(false, false); }
 #undef LR

@@ -98,12 +98,18 @@ static int launch_group(bool fwd, const char *W, int b, int c, int n, long long 
 }
 
 // Scatter-add through an inverted index: order[b][.] lists the grouped columns sorted by their
-// source point and src[b][.] the source point of each.  A LANE owns one sorted entry, a wave 64
-// consecutive ones; within the wave a segmented scan (keys are contiguous) sums the entries of
-// each point and only the last lane of a run adds its total -- one float atomic per (point,
-// wave) instead of one LDS atomic per entry (which run at 0.32 lanes/clk/CU here), and the
-// work per wave is the same whatever the run lengths.  The index depends on the coordinates
-// only, so a training loop builds it ahead of the step together with the ball-query indices.
+// source point (each point's run in ascending column order) and src[b][.] the source point of
+// each.  A LANE owns one sorted entry, a wave 64 consecutive ones; within the wave a segmented
+// scan (keys are contiguous) sums the entries of each point.  EVERY RUN IS SUMMED BY EXACTLY ONE
+// WAVE -- the one whose 64 entries hold the run's first entry: it follows a run that leaves its
+// chunk through the next chunks (wave-uniform loop, fixed butterfly order), and the waves of those
+// chunks skip the entries that continue a run from before.  So the result of a point is one plain
+// read-modify-write by one lane: no float atomics, and the sum order depends on the index alone --
+// two launches on the same inputs give the same bits (round 3 added a wave's share of a run with a
+// float atomic: runs longer than 64 entries -- low-index points sit in a hundred balls, ball query
+// keeps the FIRST nsample hits -- met three or more adds in arrival order).  Work per wave is the
+// same whatever the run lengths, except for the owner of a long run.  The index depends on the
+// coordinates only, so a training loop builds it ahead of the step together with the ball query.
 __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
     int c, int n, int e_total, long long gstride, int ediv, const float *__restrict__ grad_out,
     const float *__restrict__ weight, const int *__restrict__ order,
@@ -114,10 +120,16 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
   const int c0 = blockIdx.y * GG_CH;
   const int bi = blockIdx.z;
   const int lane = threadIdx.x & 63;
+  const int base = e - lane;                               // first entry of this wave's chunk
+  if (base >= e_total) return;                             // (wave-uniform)
+  const int *sb = src + (size_t)bi * e_total;
+  const int *ob = order + (size_t)bi * e_total;
   const bool live = e < e_total;
   const int ee = live ? e : e_total - 1;
-  const int col = order[(size_t)bi * e_total + ee];
-  const int key = live ? src[(size_t)bi * e_total + ee] : -1;
+  const int col = ob[ee];
+  const int key = live ? sb[ee] : -1;
+  const int prev = base > 0 ? sb[base - 1] : -2;           // (uniform) the entry in front of the chunk
+  const bool cont = live && key == prev;                   // continues a run an earlier wave owns
   // same[d]: the entry d lanes below belongs to the same point (then so do all in between)
   bool same[6];
 #pragma unroll
@@ -126,10 +138,12 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
     same[d] = lane >= (1 << d) && kd == key;
   }
   const int knext = __shfl_down(key, 1, 64);
-  const bool tail = live && (lane == 63 || knext != key);
+  const bool tail = live && !cont && (lane == 63 || knext != key);
   const int ncols = e_total / ediv;
-  const float wgt = weight ? weight[(size_t)bi * e_total + col] : 1.f;
-  const float *g = grad_out + (size_t)bi * gstride + (size_t)c0 * ncols + col / ediv;
+  const float *gbase = grad_out + (size_t)bi * gstride + (size_t)c0 * ncols;
+  const float *wb = weight ? weight + (size_t)bi * e_total : nullptr;
+  const float wgt = wb ? wb[col] : 1.f;
+  const float *g = gbase + col / ediv;
   float *dst = grad_points + ((size_t)bi * c + c0) * n + (key < 0 ? 0 : key);
   const int cend = c - c0 < GG_CH ? c - c0 : GG_CH;
   float v[GG_CH];
@@ -143,8 +157,37 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
       const float t = __shfl_up(v[i], 1 << d, 64);
       if (same[d]) v[i] += t;
     }
-    if (tail && i < cend) atomicAdd(dst + (size_t)i * n, v[i]);
   }
+  // the chunk's LAST run may go on in the following chunks: its owner (this wave, unless the run
+  // itself came from before) collects the rest, 64 entries per trip
+  const int klast = __builtin_amdgcn_readlane(key, 63);
+  const int clast = __builtin_amdgcn_readlane((int)cont, 63);
+  if (klast >= 0 && !clast && base + 64 < e_total && sb[base + 64] == klast) {   // (uniform)
+    float extra[GG_CH];
+#pragma unroll
+    for (int i = 0; i < GG_CH; ++i) extra[i] = 0.f;
+    for (int pos = base + 64; pos < e_total; pos += 64) {
+      const int e2 = pos + lane;
+      const bool in = e2 < e_total && sb[e2 < e_total ? e2 : e_total - 1] == klast;
+      const unsigned long long m = __ballot(in);
+      if (m == 0ull) break;
+      const int col2 = ob[in ? e2 : pos];
+      const float w2 = wb ? wb[col2] : 1.f;
+#pragma unroll
+      for (int i = 0; i < GG_CH; ++i) {
+        float t = (in && i < cend) ? __fmul_rn(gbase[(size_t)i * ncols + col2 / ediv], w2) : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        extra[i] += t;
+      }
+      if (m != ~0ull) break;                               // the run ended inside this trip
+    }
+#pragma unroll
+    for (int i = 0; i < GG_CH; ++i) v[i] += lane == 63 ? extra[i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < GG_CH; ++i)
+    if (tail && i < cend) dst[(size_t)i * n] += v[i];      // one lane per point in the whole launch
 }
 
 // Inverted index of idx[b][0..e_total) over n source points, one workgroup per scene: LDS
@@ -152,8 +195,7 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
 // point's run (returning ds_add).  Built on the side stream with the ball query: 8 workgroups,
 // tens of microseconds.  The slots are claimed in arrival order into `scratch`; a second pass
 // ranks every entry inside its run (runs are short: M ns / N on average), so `order` lists each
-// run in ascending column order and the segmented sums of the backward are reproducible (only a
-// run longer than a wave's 64 entries can still meet more than two float atomics).
+// run in ascending column order and the segmented sums of the backward are reproducible.
 constexpr int II_BLOCK = 1024;
 
 __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
@@ -236,9 +278,100 @@ __global__ __launch_bounds__(GG_BLOCK) void group_xyz_kernel(
   }
 }
 
+// centres[b][m][:] = xyz[b][sample[b][m]][:]: the sampled centres straight from the (B, N, 3) array
+// (the reference transposes to channel-major, gathers, transposes back: point_sa_module.py:122-131)
+__global__ __launch_bounds__(GG_BLOCK) void gather_rows3_kernel(
+    int n, int m, const float *__restrict__ xyz, const int *__restrict__ sample,
+    float *__restrict__ centres) {
+  const int i = blockIdx.x * GG_BLOCK + threadIdx.x, bi = blockIdx.y;
+  if (i >= m) return;
+  int s = sample[(size_t)bi * m + i];
+  s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+  const float *p = xyz + ((size_t)bi * n + s) * 3;
+  float *o = centres + ((size_t)bi * m + i) * 3;
+  o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
+// Coordinate gradient of QueryAndGroup when the grouped coordinates are NETWORK OUTPUTS (vote
+// aggregation groups the predicted votes around centres sampled from them): channels 0..2 of the
+// grouped tensor are (xyz[idx] - centre) / r with centre = xyz[sample], so
+//   d_xyz[p] = (1/r) sum_{entries e with idx[e] = p} g[:, e]
+//              - (1/r) sum_{m: sample[m] = p} sum_s g[:, m, s]  +  sum_{m: sample[m] = p} d_centre[m]
+// One thread per point: its run of the inverted index (found by bisection in the sorted source
+// list, walked in ascending column order), then the centres that are this point.  Every point is
+// written once, sums in a fixed order: reproducible (the reference reaches the same sums through
+// autograd's cat / sub / div / transpose backward and two atomicAdd scatters).
+__global__ __launch_bounds__(GG_BLOCK) void qg_xyz_bwd_kernel(
+    int n, int m, int ns, long long gstride, float radius, const float *__restrict__ grad_out,
+    const int *__restrict__ order, const int *__restrict__ src, const int *__restrict__ sample,
+    const float *__restrict__ d_centre, float *__restrict__ d_xyz) {
+  const int p = blockIdx.x * GG_BLOCK + threadIdx.x, bi = blockIdx.y;
+  if (p >= n) return;
+  const int e_total = m * ns;
+  const int *sb = src + (size_t)bi * e_total, *ob = order + (size_t)bi * e_total;
+  const float *g = grad_out + (size_t)bi * gstride;       // channels 0..2: rows of e_total
+  int lo = 0, hi = e_total;                               // first sorted entry with source >= p
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sb[mid] < p) lo = mid + 1; else hi = mid;
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int j = lo; j < e_total && sb[j] == p; ++j) {
+    const int e = ob[j];
+    a0 += g[e]; a1 += g[(size_t)e_total + e]; a2 += g[2 * (size_t)e_total + e];
+  }
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  const int *sm = sample + (size_t)bi * m;
+  for (int i = 0; i < m; ++i) {
+    int s = sm[i];
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    if (s != p) continue;
+    for (int k = 0; k < ns; ++k) {
+      const size_t e = (size_t)i * ns + k;
+      c0 += g[e]; c1 += g[(size_t)e_total + e]; c2 += g[2 * (size_t)e_total + e];
+    }
+    if (d_centre) {
+      const float *dc = d_centre + ((size_t)bi * m + i) * 3;
+      t0 += dc[0]; t1 += dc[1]; t2 += dc[2];
+    }
+  }
+  a0 -= c0; a1 -= c1; a2 -= c2;
+  if (radius > 0.f) { a0 = a0 / radius; a1 = a1 / radius; a2 = a2 / radius; }
+  float *o = d_xyz + ((size_t)bi * n + p) * 3;
+  o[0] = a0 + t0; o[1] = a1 + t1; o[2] = a2 + t2;
+}
+
 }  // namespace nesie
 
 using namespace nesie;
+
+extern "C" int nesie_gather_rows3(int b, int n, int m, const float *xyz, const int *sample,
+                                  float *centres, void *stream) {
+  const char *W = "gather_rows3";
+  NESIE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && b <= 65535, W);
+  if (b == 0 || m == 0) return NESIE_OK;
+  NESIE_REQUIRE(n >= 1 && xyz && sample && centres, W);
+  hipLaunchKernelGGL(gather_rows3_kernel, dim3(cdiv(m, GG_BLOCK), b), dim3(GG_BLOCK), 0,
+                     (hipStream_t)stream, n, m, xyz, sample, centres);
+  return check_launch(W);
+}
+
+extern "C" int nesie_query_and_group_backward_xyz(int b, int c, int n, int npoints, int nsample,
+                                                  float radius, const float *grad_out,
+                                                  const int *order, const int *sources,
+                                                  const int *sample, const float *d_centres,
+                                                  float *d_xyz, void *stream) {
+  const char *W = "query_and_group_backward_xyz";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0 && b <= 65535, W);
+  if (b == 0 || n == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && order && sources && sample && d_xyz, W);
+  NESIE_REQUIRE((long long)npoints * nsample < (1ll << 31), W);
+  hipLaunchKernelGGL(qg_xyz_bwd_kernel, dim3(cdiv(n, GG_BLOCK), b), dim3(GG_BLOCK), 0,
+                     (hipStream_t)stream, n, npoints, nsample,
+                     (long long)(3 + c) * npoints * nsample, radius, grad_out, order, sources,
+                     sample, d_centres, d_xyz);
+  return check_launch(W);
+}
 
 extern "C" int nesie_query_and_group_forward(int b, int c, int n, int npoints, int nsample,
                                              const float *xyz, const float *centres,

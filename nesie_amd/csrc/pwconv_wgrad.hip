@@ -34,12 +34,24 @@ namespace nesie {
 // lanes that hold a row's 32 positions add their words with shuffles; a 64-group spans two tiles
 // (of different workgroups): two float atomics into a zero-filled buffer (two addends: the order
 // cannot matter).
+// TILED launches (gridDim.y x gridDim.z > 1; plain weight gradients only): the product is cut
+// into (CO16 * 16) x (CI16 * 16) blocks, blockIdx.y = row block, blockIdx.z = column block, every
+// block with its own runs of positions and its own partials -- for layers whose co x ci is large
+// and whose position count is small (the 1-D chains: 256 x 512 over 8 x 1024 positions), where one
+// whole-product workgroup per 32 positions wrote 128 KB of partial per 32 positions.
 template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(
-    int nb, int ng, int co, int ci, long long p, const float *__restrict__ dy, long long dy_bs,
+    int nb, int ng, int co_all, int ci_all, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
     float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
     const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group) {
+  const int row0 = blockIdx.y * CO16 * 16, col0 = blockIdx.z * CI16 * 16;   // (0, 0) unless tiled
+  const int co = co_all - row0 < CO16 * 16 ? co_all - row0 : CO16 * 16;     // this block's extent
+  const int ci = ci_all - col0 < CI16 * 16 ? ci_all - col0 : CI16 * 16;
+  dy += (size_t)row0 * p;
+  x += (size_t)col0 * p;
+  if (AFF) x_coef += (size_t)col0 * 4;
+  partial += (size_t)(blockIdx.y * gridDim.z + blockIdx.z) * ng * nwg_g * (CO16 * 16) * (CI16 * 16);
   constexpr int MB = CO16 / WM, NB = CI16 / WN, PT = 32, PITCH = PT + 4, CPR = PT / 4;
   constexpr int ROWS = (CO16 + CI16) * 16, NT = 512;
   constexpr int NX = (ROWS * CPR + NT - 1) / NT;
@@ -211,7 +223,9 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     float *const tb = b0; b0 = b1; b1 = tb;
   }
   // partial[(g * nwg + rank)][co][ci]: lane (quad, l16) holds rows 4 quad + r, column l16
-  float *dst = partial + ((size_t)g * nwg_g + rank) * co * ci;
+  // (tiled: [block][g * nwg + rank][co][ci] with each block's own co x ci, stride the full block)
+  const bool tiled = gridDim.y * gridDim.z > 1;
+  float *dst = partial + ((size_t)g * nwg_g + rank) * (tiled ? (size_t)(CO16 * 16) * (CI16 * 16) : (size_t)co * ci);
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -254,6 +268,28 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
   }
 }
 
+// tiled launches: dw[g][rb * BR + m][cb * BC + k] = sum over the nparts partials of (block, g), fixed order;
+// partial[block][g * nparts + r][co_b][ci_b] with co_b x ci_b that block's own extent
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_tiled_kernel(int co, int ci, int br, int bc, int nparts,
+                                                                    const float *__restrict__ partial,
+                                                                    float *__restrict__ dw) {
+  const int ncb = (ci + bc - 1) / bc;
+  const int blk = blockIdx.y, g = blockIdx.z, rb = blk / ncb, cb = blk % ncb;
+  const int co_b = co - rb * br < br ? co - rb * br : br, ci_b = ci - cb * bc < bc ? ci - cb * bc : bc;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= co_b * ci_b) return;
+  const float *src = partial + ((size_t)blk * gridDim.z + g) * nparts * br * bc + i;
+  float s = 0.f;
+  int r = 0;
+  for (; r + 3 < nparts; r += 4) {
+    const float v0 = src[(size_t)r * br * bc], v1 = src[(size_t)(r + 1) * br * bc],
+                v2 = src[(size_t)(r + 2) * br * bc], v3 = src[(size_t)(r + 3) * br * bc];
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; r < nparts; ++r) s += src[(size_t)r * br * bc];
+  dw[((size_t)g * co + rb * br + i / ci_b) * ci + cb * bc + i % ci_b] = s;
+}
+
 // workgroups per weight group: one per CU; TWO per CU where a block's tiles (<= 74 KB of LDS) and
 // registers (<= 128) allow it (NESIE_WGRAD_PER_CU=1: A/B switch)
 static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw, bool bnb = false) {
@@ -279,9 +315,36 @@ extern "C" int nesie_pw_wgrad_supported(int co, int ci, long long p) {
   return p % 32 == 0 && ci >= 9 && co <= 256 && ci <= 1024 ? 1 : 0;
 }
 
+// Tiled mode (pw_wgrad_kernel): 64 x 64 blocks of the product, each with its own position runs.
+// Chosen for wide products over few positions: at most TILED_MAX_TILES 32-position tiles per
+// weight group and more than one whole-product column block's worth of output.
+constexpr int TILED_B = 64, TILED_MAX_TILES = 1024;
+static bool pw_wgrad_tiled(int nb, int ng, int co, int ci, long long p) {
+  static const int on = getenv("NESIE_WGRAD_TILED") ? atoi(getenv("NESIE_WGRAD_TILED")) : 1;   // A/B switch
+  if (!on || nb <= 0 || ng <= 0 || nb % ng || p <= 0 || p % 32 || ci < 9 || ci > 1024 || co < 1 || co > 1024) return false;
+  const long long tiles = (long long)(nb / ng) * (p / 32);
+  return tiles <= TILED_MAX_TILES && (long long)co * ci >= 128 * 192;
+}
+// position runs per block and weight group: fill the chip about twice over all blocks
+static int pw_wgrad_tiled_nwg(int nb, int ng, int co, int ci, long long p) {
+  const long long tiles = (long long)(nb / ng) * (p / 32);
+  const int blocks = cdiv(co, TILED_B) * cdiv(ci, TILED_B);
+  long long nwg = 512 / ((long long)blocks * ng);
+  if (nwg < 1) nwg = 1;
+  if (nwg > tiles) nwg = tiles;
+  return (int)nwg;
+}
+
+extern "C" int nesie_pw_wgrad_tiled(int nb, int ng, int co, int ci, long long p) {
+  return pw_wgrad_tiled(nb, ng, co, ci, p) ? 1 : 0;     // (also serves co up to 1024, beyond nesie_pw_wgrad_supported)
+}
+
 extern "C" size_t nesie_pw_wgrad_workspace_bytes(int nb, int ng, int co, int ci, long long p) {
   if (nb <= 0 || ng <= 0 || p <= 0) return 0;
-  return (size_t)ng * pw_wgrad_nwg(nb, ng, p, co, pw_wgrad_block(co, ci)) * co * pw_wgrad_block(co, ci) * sizeof(float);
+  const size_t whole = (size_t)ng * pw_wgrad_nwg(nb, ng, p, co, pw_wgrad_block(co, ci)) * co * pw_wgrad_block(co, ci) * sizeof(float);
+  const size_t tiled = (size_t)cdiv(co, TILED_B) * cdiv(ci, TILED_B) * ng * pw_wgrad_tiled_nwg(nb, ng, co, ci, p) *
+                       TILED_B * TILED_B * sizeof(float);
+  return whole > tiled ? whole : tiled;     // (either mode may serve the shape)
 }
 
 namespace nesie {
@@ -328,7 +391,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     (void)hipMemsetAsync(dw, 0, (size_t)ng * co * ci * sizeof(float), s);
     return NESIE_OK;
   }
-  if (!nesie_pw_wgrad_supported(co, ci, p)) {
+  const bool tiled_mode = !bnb && !d_rb && pw_wgrad_tiled(nb, ng, co, ci, p);
+  if (!tiled_mode && !nesie_pw_wgrad_supported(co, ci, p)) {
     set_error("%s: %d x %d over %lld positions is outside the built tiles", W, co, ci, p);
     return NESIE_ERR_UNSUPPORTED;
   }
@@ -337,6 +401,30 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
   NESIE_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && (dy_bstride & 3) == 0 && (x_bstride & 3) == 0, W);
   NESIE_REQUIRE((long long)(co > ci ? co : ci) * p < (1ll << 30), W);
   NESIE_REQUIRE((long long)(nb / ng) * (p / 32) < (1ll << 30), W);     // (32-bit tile cursor)
+  const float lo0 = x_relu ? 0.f : -__builtin_inff();
+  if (tiled_mode) {
+    const int nwg = pw_wgrad_tiled_nwg(nb, ng, co, ci, p);
+    const int nrb = cdiv(co, TILED_B), ncb = cdiv(ci, TILED_B);
+    float *partial = (float *)workspace;
+    const size_t lds = (size_t)2 * (4 + 4) * 16 * 36 * sizeof(float);
+#define LT(AFF)                                                                                        \
+    do {                                                                                               \
+      auto kern = pw_wgrad_kernel<4, 4, 2, 4, AFF, false>;                                             \
+      static bool attr = false;                                                                        \
+      if (!attr) {                                                                                     \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        attr = true;                                                                                   \
+      }                                                                                                \
+      hipLaunchKernelGGL(kern, dim3(nwg * ng, nrb, ncb), dim3(512), lds, s, nb, ng, co, ci, p, dy, dy_bstride, x, \
+                         x_bstride, x_coef, ci, lo0, partial, nwg, (const float *)nullptr, (const float *)nullptr, \
+                         (float *)nullptr, (float *)nullptr, 0);                                        \
+    } while (0)
+    if (x_coef) LT(true); else LT(false);
+#undef LT
+    hipLaunchKernelGGL(pw_wgrad_reduce_tiled_kernel, dim3(cdiv(TILED_B * TILED_B, 256), nrb * ncb, ng), dim3(256), 0, s,
+                       co, ci, TILED_B, TILED_B, nwg, partial, dw);
+    return check_launch(W);
+  }
   const int block = pw_wgrad_block(co, ci);
   // (the fused norm backward writes dZ while it forms it: one launch must own every column)
   NESIE_REQUIRE(!bnb || (bnz && dz && block == ci && (((uintptr_t)bnz | (uintptr_t)dz) & 15) == 0), W);

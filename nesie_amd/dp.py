@@ -43,18 +43,43 @@ def init_distributed(backend=None):
 
 class FlatGradBucket:
     """All parameters' gradients as views into one contiguous buffer, so the per-step
-    exchange is a single all-reduce and the optimiser sees ordinary ``p.grad``s."""
+    exchange is a single all-reduce and the optimiser sees ordinary ``p.grad``s.
 
-    def __init__(self, params):
+    ``params`` keeps the model's ``parameters()`` order; ``offsets[i]`` is where parameter i
+    starts in the flat vector.  Without ``stack_groups`` that is the running sum of the sizes.
+    ``stack_groups`` = lists of S same-shaped parameters that the step uses STACKED (the six side
+    MiniPointNets / score heads of the quality head): each group is laid out contiguously behind
+    the ungrouped parameters, so its (S, ...) stack is a view (``grad_slots``)."""
+
+    def __init__(self, params, stack_groups=None):
         self.params = [p for p in params if p.requires_grad]
+        ids = {id(p) for p in self.params}
+        groups = []
+        seen = set()
+        for g in stack_groups or ():
+            g = list(g)
+            if (len(g) > 1 and all(id(p) in ids and id(p) not in seen for p in g)
+                    and all(p.shape == g[0].shape for p in g)):
+                groups.append(g)
+                seen.update(id(p) for p in g)
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        where, off = {}, 0
+        for p in self.params:                       # ungrouped, in model order
+            if id(p) not in seen:
+                where[id(p)] = off
+                off += p.numel()
+        self.group_spans = []                       # (offset, S, numel of one member, shape)
+        for g in groups:
+            self.group_spans.append((off, len(g), g[0].numel(), tuple(g[0].shape), g))
+            for p in g:
+                where[id(p)] = off
+                off += p.numel()
+        assert off == total
+        self.offsets = [where[id(p)] for p in self.params]
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def zero_(self):
         self.flat.zero_()
@@ -86,46 +111,62 @@ class FlatTrainState(FlatGradBucket):
       of adding it into a zeroed view (one launch per parameter); ``collect()`` gathers them
       into the flat vector with one multi-tensor copy, zero-fills parameters the loss did not
       reach (their ``.grad`` would have stayed zero), and re-attaches the views.
+    * Between ``begin()`` and ``collect()`` the hand-written backward kernels may write a
+      gradient straight into its slot of the flat vector (``grad_slots.take``): what autograd
+      then hands over IS the slot and ``collect()`` copies nothing for it.
     Both calls are capture-safe: under a hipGraph the python bookkeeping runs once at capture
     time and the gradient tensors live in the graph's pool at fixed addresses."""
 
-    def __init__(self, params):
-        super().__init__(params)
+    def __init__(self, params, stack_groups=None):
+        super().__init__(params, stack_groups)
+        from . import grad_slots
         ref = self.params[0]
         flat_p = torch.empty(self.flat.numel(), dtype=ref.dtype, device=ref.device)
-        self.views, self.grad_views, off = [], [], 0
+        self.views, self.grad_views = [], []
         with torch.no_grad():
-            for p in self.params:
+            for p, o in zip(self.params, self.offsets):
                 n = p.numel()
-                v = flat_p[off:off + n].view_as(p)
+                v = flat_p[o:o + n].view_as(p)
                 v.copy_(p.data)
                 p.data = v
                 self.views.append(v)
                 self.grad_views.append(p.grad)
-                off += n
         self.flat_param = torch.nn.Parameter(flat_p)
         self.flat_param.grad = self.flat
         self._held = []
+        stacked = [(g, flat_p[o:o + s * n].view(s, *shape), self.flat[o:o + s * n].view(s, *shape))
+                   for o, s, n, shape, g in self.group_spans]
+        grad_slots.register(self, self.params, self.grad_views, stacked)
 
     def begin(self):
+        from . import grad_slots
         self._held = []
         for p in self.params:
             p.grad = None
+        grad_slots.begin(self)
 
     def split_after(self, first_params):
         """-> (number of parameters, number of elements) of the leading block ``first_params``
-        (which must be a prefix of the bucket's parameter order, e.g. ``model.backbone``)."""
+        (which must be a prefix of the bucket's parameter order AND of its layout, e.g.
+        ``model.backbone``: no member of a stack group)."""
         first = [p for p in first_params if p.requires_grad]
         assert [id(p) for p in first] == [id(p) for p in self.params[:len(first)]], \
             'not a prefix of the bucket'
-        return len(first), sum(p.numel() for p in first)
+        elems = sum(p.numel() for p in first)
+        assert sorted(self.offsets[:len(first)]) == self.offsets[:len(first)] and \
+            (not first or self.offsets[len(first) - 1] + first[-1].numel() == elems), \
+            'the leading block is not contiguous in the flat layout'
+        return len(first), elems
 
     def collect(self, lo=0, hi=None):
         """Gather the gradients of parameters [lo, hi) (default: all) into the flat vector."""
+        from . import grad_slots
         src, dst, missing = [], [], []
         for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:
                 missing.append(v)
+            elif p.grad.data_ptr() == v.data_ptr() and p.grad.is_contiguous() and p.grad.numel() == v.numel():
+                self._held.append(p.grad)        # written in place by the backward kernel (grad_slots)
             else:
                 src.append(p.grad)
                 dst.append(v)
@@ -136,6 +177,9 @@ class FlatTrainState(FlatGradBucket):
             torch._foreach_zero_(missing)
         for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             p.grad = v
+        # their .grad views are attached again: a later backward ACCUMULATES into them, so their
+        # slots must not be handed to a kernel any more (until the next begin())
+        grad_slots.close(self, self.params[lo:hi])
 
     def zero_(self):
         self.flat.zero_()

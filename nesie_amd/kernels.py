@@ -254,6 +254,33 @@ class HipKernels(_BNPoolMixin):
                       _ptr(scratch), _stream(idx))
         return order, sources
 
+    def gather_rows3(self, xyz, sample):
+        """xyz (B, N, 3), sample (B, M) int32 -> xyz[b, sample[b, m]] (B, M, 3)."""
+        _check(xyz, sample); _f32(xyz); _i32(sample)
+        b, n = xyz.shape[:2]
+        m = sample.shape[1]
+        out = torch.empty(b, m, 3, dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.call("nesie_gather_rows3", b, n, m, _ptr(xyz), _ptr(sample), _ptr(out), _stream(xyz))
+        return out
+
+    def query_and_group_backward_xyz(self, grad_out, radius, order, sources, sample, d_centres, n):
+        """Coordinate gradient (B, N, 3) of QueryAndGroup over network-computed coordinates whose
+        centres are xyz[sample] (nesie_query_and_group_backward_xyz); grad_out (B, 3+C, M, ns),
+        d_centres (B, M, 3) or None."""
+        _check(grad_out, order, sources, sample); _f32(grad_out); _i32(order, sources, sample)
+        b, c3, m, ns = grad_out.shape
+        assert tuple(order.shape) == (b, m * ns) == tuple(sources.shape) and tuple(sample.shape) == (b, m)
+        if d_centres is not None:
+            _check(d_centres); _f32(d_centres)
+            assert tuple(d_centres.shape) == (b, m, 3)
+        d_xyz = torch.empty(b, n, 3, dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_query_and_group_backward_xyz", b, c3 - 3, n, m, ns, float(radius),
+                      _ptr(grad_out), _ptr(order), _ptr(sources), _ptr(sample),
+                      0 if d_centres is None else _ptr(d_centres), _ptr(d_xyz), _stream(grad_out))
+        return d_xyz
+
     def query_and_group_backward_csr(self, grad_out, idx_shape, order, offsets, grad_features):
         """grad_features (B,C,N, zeroed) += channels 3.. of grad_out through (order, sources)."""
         _check(grad_out, order, offsets, grad_features); _f32(grad_out, grad_features)
@@ -639,6 +666,11 @@ class HipKernels(_BNPoolMixin):
 
     def pw_wgrad_supported(self, co, ci, p):
         return bool(_lib.load().nesie_pw_wgrad_supported(int(co), int(ci), int(p)))
+
+    def pw_wgrad_tiled(self, nb, ng, co, ci, p):
+        """True when ``pw_wgrad`` serves this shape as ONE launch over 64 x 64 blocks of the product
+        (wide layers over few positions: the 1-D chains)."""
+        return bool(_lib.load().nesie_pw_wgrad_tiled(int(nb), int(ng), int(co), int(ci), int(p)))
 
     def pw_wgrad(self, dy, x, dw, ng=1, x_coef=None, x_relu=True):
         """dw (ng, co, ci) = sum over n % ng == g and positions of dy[n] (co, P) act(x[n])^T
@@ -1098,8 +1130,12 @@ class HipKernels(_BNPoolMixin):
     def bn_relu_backward(self, dy, x, y, gamma, beta, save_mean, save_invstd, fwd_coef, relu,
                          dx, dgamma, dbeta, row_bias=None, d_row_bias=None, group=None):
         """y None with relu: x is the raw conv output of a fused forward (mask re-derived from
-        fwd_coef).  d_row_bias without row_bias (+ ``group``): per-group sums of dx."""
-        _check(dy, x, dx, save_mean, save_invstd); _f32(dy, x, dx)
+        fwd_coef).  d_row_bias without row_bias (+ ``group``): per-group sums of dx.
+        save_mean / save_invstd None: columns 2 / 3 of fwd_coef."""
+        _check(dy, x, dx, fwd_coef); _f32(dy, x, dx)
+        assert (save_mean is None) == (save_invstd is None)
+        if save_mean is not None:
+            _check(save_mean, save_invstd)
         b, c = x.shape[:2]
         p = x.numel() // (b * c) if b * c else 0
         if row_bias is None and d_row_bias is not None:
@@ -1117,7 +1153,7 @@ class HipKernels(_BNPoolMixin):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
             opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
             _lib.call("nesie_bn_relu_backward", b, c, p, _ptr(dy), _ptr(x), opt(y), opt(gamma),
-                      opt(beta), _ptr(save_mean), _ptr(save_invstd), _ptr(fwd_coef),
+                      opt(beta), opt(save_mean), opt(save_invstd), _ptr(fwd_coef),
                       int(bool(relu)), _ptr(dx), opt(dgamma), opt(dbeta), opt(row_bias), group,
                       opt(d_row_bias), _ptr(ws), need, _stream(x))
 

@@ -23,6 +23,7 @@ import os as _os
 import torch
 from torch.autograd import Function
 
+from .. import grad_slots
 from ..kernels import backend_for
 
 
@@ -37,22 +38,50 @@ _OWNED_MARK = '_nesie_fresh_grad'
 
 
 # Layers wider than one workgroup's accumulators (the 1-D chains' 256 x 256 / 256 x 512 at 8 x 1024
-# positions) run in nesie_pw_wgrad as column blocks, one launch + one partial reduction each; at
+# positions) ran in nesie_pw_wgrad as column blocks, one launch + one partial reduction each; at
 # these sizes (one 32-position tile per workgroup, 32 MB of partials per block) a transposed copy +
-# one rocBLAS GEMM is faster: 553 / 557 vs 548 / 548 scenes/s, same-box A/B.  NESIE_WGRAD_WIDE=1
-# selects the native column blocks.
+# one rocBLAS GEMM was faster (553 / 557 vs 548 / 548 scenes/s, same-box A/B), so round 3 kept
+# rocBLAS there.  Round 4: such shapes run TILED (``pw_wgrad_tiled``: one launch over 64 x 64 blocks
+# of the product, split-K with a fixed-order reduction, 8 MB of partials) -- no transposed copies,
+# no rocBLAS.  NESIE_WGRAD_WIDE=1 forces the native kernel for every shape it supports,
+# NESIE_WGRAD_TILED=0 switches the tiled mode off (A/B).
 WIDE_WGRAD = _os.environ.get('NESIE_WGRAD_WIDE', '0') != '0'
 
 
-def _wgrad(backend, dy, x, x_coef, ng=1):
+def _dst(slot, like, *shape):
+    """Where a backward kernel writes a parameter gradient: the parameter's slot of the flat
+    gradient vector (``grad_slots.take`` in the forward) or a fresh tensor."""
+    return slot.view(*shape) if slot is not None else like.new_empty(*shape)
+
+
+def _into(slot, g):
+    """A gradient that some other op produced, moved into the slot that was taken for it."""
+    if slot is None or g is None:
+        return g
+    slot.view(g.shape).copy_(g)
+    return slot.view(g.shape)
+
+
+def _wgrad(backend, dy, x, x_coef, ng=1, slot=None):
     """dW (ng, Cout, Cin) = sum over n % ng == g of dy[n] @ act(x[n])^T; act = relu(scale * x +
-    bias) when x_coef (ng * Cin, 4)."""
+    bias) when x_coef (ng * Cin, 4).  ``slot``: the weight's gradient slot (written in place)."""
     nb, co, p = dy.shape
     ci = x.shape[1]
-    if backend.pw_wgrad_supported(co, ci, p) and (WIDE_WGRAD or (ci <= 320 if co <= 128 else ci <= 128)):
-        dw = dy.new_empty(ng, co, ci)
+    if backend.pw_wgrad_tiled(nb, ng, co, ci, p) or (
+            backend.pw_wgrad_supported(co, ci, p) and (WIDE_WGRAD or (ci <= 320 if co <= 128 else ci <= 128))):
+        dw = _dst(slot, dy, ng, co, ci)
         backend.pw_wgrad(dy, x, dw, ng=ng, x_coef=x_coef, x_relu=True)
         return dw
+    if ng == 1 and ci <= 8 and backend.conv_wgrad_supported(co, ci):
+        dw = _dst(slot, dy, co, ci)
+        backend.conv_wgrad(dy, x, dw, x_coef=x_coef, x_relu=x_coef is not None)
+        return dw.view(1, co, ci)
+    return _into(slot, _wgrad_aten(backend, dy, x, x_coef, ng))
+
+
+def _wgrad_aten(backend, dy, x, x_coef, ng):
+    nb, co, p = dy.shape
+    ci = x.shape[1]
     out = []
     for g in range(ng):      # shapes outside the native kernels (short rows, wide layers)
         dyg, xg = dy[g::ng], x[g::ng]
@@ -80,32 +109,35 @@ def _wgrad(backend, dy, x, x_coef, ng=1):
 FOLD_NORM_BWD = _os.environ.get('NESIE_FOLD_NORM_BWD', '1') != '0'
 
 
-def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1, need_dz=True):
+def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1, need_dz=True,
+                         slots=(None, None, None)):
     """The backward of relu(bn(z)) given da (its gradient) and the reduction partials the
     input-gradient launch left, and the weight gradient dz . act(src)^T of the conv that produced z:
     -> (dz, dw | None, dgamma, dbeta).  One launch where the layer kernel's weight gradient serves
     the shape (``nesie_pw_wgrad_bn_backward``: dz is formed on the operand load and written over
     da), the apply pass + ``_wgrad`` otherwise.  ``need_dz`` False (the layer's input needs no
     gradient) and a skinny input (Cin <= 8, the first layer of SA1): ``nesie_conv_wgrad_bn`` forms
-    dz on its load and never writes it -> dz None."""
+    dz on its load and never writes it -> dz None.  ``slots`` = gradient slots of (weight, gamma,
+    beta): the kernels write there."""
     nb, co, p = da.shape
     ci = src.shape[1]
-    dgamma, dbeta = da.new_empty(ng * co), da.new_empty(ng * co)
+    s_w, s_g, s_b = slots
+    dgamma, dbeta = _dst(s_g, da, ng * co), _dst(s_b, da, ng * co)
     if FOLD_NORM_BWD and need_w and backend.pw_wgrad_bn_supported(co, ci, p):
-        dw = da.new_empty(ng, co, ci)
+        dw = _dst(s_w, da, ng, co, ci)
         backend.pw_wgrad_bn_backward(da, z, coef, gamma, part, src, da, dw, dgamma, dbeta, ng=ng,
                                      x_coef=src_coef)
         return da, dw, dgamma, dbeta
     if FOLD_NORM_BWD and need_w and not need_dz and ng == 1 and ci <= 8 and backend.conv_wgrad_supported(co, ci):
         bnb = backend.pw_bnb_coef(part, coef, gamma, float(nb) * float(p), dgamma, dbeta)
-        dw = da.new_empty(co, ci)
+        dw = _dst(s_w, da, co, ci)
         backend.conv_wgrad(da, src, dw, x_coef=src_coef, x_relu=src_coef is not None, bn_z=z, bnb=bnb)
-        return None, dw.unsqueeze(0), dgamma, dbeta
+        return None, dw.view(1, co, ci), dgamma, dbeta
     dz = torch.empty_like(da)
     b = nb // ng
     backend.bn_relu_backward_apply(da.view(b, ng * co, p), z.view(b, ng * co, p), gamma, None, coef, part,
                                    dz.view(b, ng * co, p), dgamma, dbeta)
-    dw = _wgrad(backend, dz, src, src_coef, ng=ng) if need_w else None
+    dw = _wgrad(backend, dz, src, src_coef, ng=ng, slot=s_w) if need_w else None
     return dz, dw, dgamma, dbeta
 
 
@@ -159,6 +191,8 @@ class SAStackFn(Function):
         argmax = torch.empty(B, cl, M, dtype=torch.uint8, device=x.device)
         backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
         ctx.L, ctx.ns, ctx.fixed_lead = L, ns, int(fixed_lead)
+        # gradient slots of (weight, gamma, beta) per layer -- only when a backward will follow
+        ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[3 + j] else None for j, t in enumerate(params)]
         ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *params)
         ctx.mark_non_differentiable(argmax)
         return pooled
@@ -178,7 +212,8 @@ class SAStackFn(Function):
         yl = ys[-1]
         cl = yl.shape[1]
         dy = torch.empty_like(yl)
-        dgamma, dbeta = g.new_empty(cl), g.new_empty(cl)
+        slots = ctx.slots
+        dgamma, dbeta = _dst(slots[3 * (L - 1) + 1], g, cl), _dst(slots[3 * (L - 1) + 2], g, cl)
         backend.bn_relu_maxpool_backward(g.contiguous(), argmax, yl.view(B, cl, M, ns), pooled,
                                          params[3 * (L - 1) + 1], None, coefs[-1],
                                          dy.view(B, cl, M, ns), dgamma, dbeta)
@@ -195,12 +230,12 @@ class SAStackFn(Function):
             if pending is not None:     # norm backward of this layer, with its weight gradient
                 dy, dw, dgamma, dbeta = _norm_backward_wgrad(
                     backend, pending[0], ys[l], params[3 * l + 1], coefs[l], pending[1], src, src_coef,
-                    need_w, need_dz=l > 0 or bool(ctx.needs_input_grad[0]))
+                    need_w, need_dz=l > 0 or bool(ctx.needs_input_grad[0]), slots=slots[3 * l:3 * l + 3])
                 grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
                 if dw is not None:
                     grads[3 * l] = dw.view_as(w)
             elif need_w:
-                grads[3 * l] = _wgrad(backend, dy, src, src_coef).view_as(w)
+                grads[3 * l] = _wgrad(backend, dy, src, src_coef, slot=slots[3 * l]).view_as(w)
             if l == 0:
                 if ctx.needs_input_grad[0]:
                     # the layer kernel serves up to 256 output rows: the (at most 3) coordinate
@@ -366,11 +401,19 @@ class CatRows(Function):
 
 
 def stack_groups(groups):
-    """[[t_0 .. t_{S-1}], ...] -> [stacked (S, ...) per group]; S = 1 needs no copy at all."""
+    """[[t_0 .. t_{S-1}], ...] -> [stacked (S, ...) per group]; S = 1 needs no copy at all, and
+    neither does a group whose members sit side by side in the flat parameter vector
+    (``grad_slots.stacked``: a view, with the group's gradient slot attached); the rest share one
+    multi-tensor copy."""
     if len(groups[0]) == 1:
         return [g[0].unsqueeze(0) for g in groups]
-    flat = [t for g in groups for t in g]
-    return list(StackGroups.apply(tuple(len(g) for g in groups), *flat))
+    out = [grad_slots.stacked(g) for g in groups]
+    rest = [i for i, o in enumerate(out) if o is None]
+    if rest:
+        flat = [t for i in rest for t in groups[i]]
+        for i, o in zip(rest, StackGroups.apply(tuple(len(groups[i]) for i in rest), *flat)):
+            out[i] = o
+    return out
 
 
 # ---- MiniPointNet (side_pooling_module.py:343-370) -------------------------------------------
@@ -444,7 +487,7 @@ def _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3):
     return c, g, arg, coef0
 
 
-def _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, G, need_w3):
+def _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, G, need_w3, slot_w3=None):
     """-> (da0 (B*S, H0, P) = gradient of relu(bn0(c0)), reduction partials, dw3)."""
     B, S, H0, P = c0.shape
     half = w3.shape[1]
@@ -468,7 +511,7 @@ def _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, G, need_w3)
     dw3 = None
     if need_w3:
         # per-net weight gradient: the S nets are the S strided batch subsets
-        dw3 = _wgrad(backend, dcf, x0, coef0, ng=S)
+        dw3 = _wgrad(backend, dcf, x0, coef0, ng=S, slot=slot_w3)
     da0 = c0.new_empty(B * S, H0, P)
     part = backend.pw_dgrad_bn_reduce(dcf, w3.transpose(1, 2), x0, coef0, da0, ng=S)
     return da0, part, dw3
@@ -484,6 +527,8 @@ class MiniHeadFn(Function):
         c0 = c0.contiguous()
         c, g, arg, coef0 = _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3)
         ctx.G = G
+        ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[4 + j] else None
+                     for j, t in enumerate((gamma0, beta0, w3))]
         ctx.save_for_backward(c0, coef0, arg, gamma0, beta0, w3)
         ctx.mark_non_differentiable(arg)
         return c, g
@@ -494,8 +539,8 @@ class MiniHeadFn(Function):
         backend = backend_for(c0)
         B, S, H0, P = c0.shape
         da0, part, dw3 = _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, ctx.G,
-                                             ctx.needs_input_grad[6])
-        dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
+                                             ctx.needs_input_grad[6], ctx.slots[2])
+        dgamma, dbeta = _dst(ctx.slots[0], c0, S * H0), _dst(ctx.slots[1], c0, S * H0)
         dc0 = torch.empty_like(c0)
         backend.bn_relu_backward_apply(da0.view(B, S * H0, P), c0.view(B, S * H0, P), gamma0,
                                        None, coef0, part, dc0.view(B, S * H0, P), dgamma, dbeta)
@@ -527,6 +572,8 @@ class BlendMiniHeadFn(Function):
                                    stat_partial=c0_part)
         c, g, arg, coef0 = _mini_head_forward(backend, c0, c0_part, bufs, G, gamma0, beta0, w3)
         ctx.G, ctx.dims = G, (segs, seg_len, b, m, pitch, h)
+        ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[9 + j] else None
+                     for j, t in enumerate((gamma0, beta0, w3))]
         ctx.save_for_backward(c0, coef0, arg, gamma0, w3, idx, weight, rel)
         ctx.mark_non_differentiable(arg)
         return c, g
@@ -538,8 +585,8 @@ class BlendMiniHeadFn(Function):
         backend = backend_for(c0)
         B, S, H0, P = c0.shape
         da0, part, dw3 = _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, ctx.G,
-                                             ctx.needs_input_grad[11])
-        dgamma, dbeta = c0.new_empty(S * H0), c0.new_empty(S * H0)
+                                             ctx.needs_input_grad[11], ctx.slots[2])
+        dgamma, dbeta = _dst(ctx.slots[0], c0, S * H0), _dst(ctx.slots[1], c0, S * H0)
         d_table = c0.new_zeros(b, m, pitch)
         d_wx = c0.new_zeros(segs, h, 3)
         if FOLD_NORM_BWD:
@@ -577,6 +624,8 @@ class MiniTailFn(Function):
         backend.pw_stats_finalize(part, gamma1, beta1, rm, rv, momentum, eps, coef1)
         out, arg = mini_tail_second(backend, y, coef1, w4, G)
         ctx.G = G
+        ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[5 + j] else None
+                     for j, t in enumerate((gamma1, beta1, w4))]
         ctx.save_for_backward(c, y, coef1, arg, wl, gamma1, beta1, w4)
         ctx.mark_non_differentiable(arg)
         return out
@@ -595,10 +644,10 @@ class MiniTailFn(Function):
         yf = y.view(B * S, H2, P)
         dw4 = None
         if ctx.needs_input_grad[7]:
-            dw4 = _wgrad(backend, dzf, yf, coef1, ng=S)
+            dw4 = _wgrad(backend, dzf, yf, coef1, ng=S, slot=ctx.slots[2])
         da = c.new_empty(B * S, H2, P)
         part = backend.pw_dgrad_bn_reduce(dzf, w4.transpose(1, 2), yf, coef1, da, ng=S)
-        dgamma, dbeta = c.new_empty(S * H2), c.new_empty(S * H2)
+        dgamma, dbeta = _dst(ctx.slots[0], c, S * H2), _dst(ctx.slots[1], c, S * H2)
         cf = c.view(B * S, half, P)
         dwl = None
         if (FOLD_NORM_BWD and ctx.needs_input_grad[4] and G in (16, 64)
@@ -706,6 +755,20 @@ class Stack1dFn(Function):
                                         act.view(NB // S, S * cl, P))
             out = act
         ctx.layers, ctx.S, ctx.n_tensors = layers, S, len(tensors)
+        # gradient slots of the tensors whose gradient a kernel (or a fill) writes: weights, norm
+        # scales / shifts, and the identically-zero bias in front of a norm (a plain conv's bias
+        # gradient is an ATen reduction: nothing to gain there)
+        ctx.slots, pos = [None] * len(tensors), 0
+        take = lambda i: grad_slots.take(ts[i]) if ctx.needs_input_grad[3 + i] else None  # noqa: E731
+        for lay in layers:
+            ctx.slots[pos] = take(pos); pos += 1
+            if lay.bias:
+                if lay.bn is not None:
+                    ctx.slots[pos] = take(pos)
+                pos += 1
+            if lay.bn is not None:
+                ctx.slots[pos], ctx.slots[pos + 1] = take(pos), take(pos + 1)
+                pos += 2
         ctx.save_for_backward(x, *ys, *[c for c in coefs if c is not None], *tensors)
         return out
 
@@ -740,24 +803,32 @@ class Stack1dFn(Function):
         B = NB // S
         grads = [None] * ctx.n_tensors
         need = ctx.needs_input_grad
-        dout = dout.contiguous()
+        tslots = ctx.slots
+
+        def zero_bias(l):      # the bias in front of layer l's norm: gradient identically zero
+            sl = tslots[slots[l]['b']]
+            return sl.zero_() if sl is not None else torch.zeros_like(per_layer[l][1])
+        # a channel slice of a wider gradient (the outputs of several chains concatenated by their
+        # consumer) is batch-strided: the layer kernels take a batch stride, no copy needed
+        if not (S == 1 and layers[-1].bn is None and dout.stride(2) == 1 and dout.stride(1) == P):
+            dout = dout.contiguous()
         # gradient of the last layer's RAW output
         w, b, gamma, beta = per_layer[-1]
         cl = ys[-1].shape[1]
         if layers[-1].bn is not None:
             coef = coefs[-1]
             dz = torch.empty_like(ys[-1])
-            dgamma, dbeta = dout.new_empty(S * cl), dout.new_empty(S * cl)
+            dgamma = _dst(tslots[slots[-1]['g']], dout, S * cl)
+            dbeta = _dst(tslots[slots[-1]['g'] + 1], dout, S * cl)
             backend.bn_relu_backward(dout.view(B, S * cl, P), ys[-1].view(B, S * cl, P), None, gamma, beta,
-                                     coef[:, 2].contiguous(), coef[:, 3].contiguous(), coef, True,
-                                     dz.view(B, S * cl, P), dgamma, dbeta)
+                                     None, None, coef, True, dz.view(B, S * cl, P), dgamma, dbeta)
             grads[slots[-1]['g']], grads[slots[-1]['g'] + 1] = dgamma, dbeta
             if 'b' in slots[-1] and need[3 + slots[-1]['b']]:
-                grads[slots[-1]['b']] = torch.zeros_like(dbeta)
+                grads[slots[-1]['b']] = zero_bias(L - 1)
         else:
             dz = dout
             if b is not None and need[3 + slots[-1]['b']]:
-                grads[slots[-1]['b']] = dz.view(B, S * cl, P).sum((0, 2)) 
+                grads[slots[-1]['b']] = dz.sum((0, 2)) if S == 1 else dz.view(B, S * cl, P).sum((0, 2))
         dx = None
         pending = None          # (da, part) of the layer whose norm backward has not been applied yet
         for l in range(L - 1, -1, -1):
@@ -767,15 +838,17 @@ class Stack1dFn(Function):
             src_coef = None if l == 0 else coefs[l - 1]
             need_w = need[3 + slots[l]['w']]
             if pending is not None:     # norm backward of this layer, with its weight gradient
-                dz, dw, dgamma, dbeta = _norm_backward_wgrad(backend, pending[0], ys[l], per_layer[l][2], coefs[l],
-                                                             pending[1], src, src_coef, need_w, ng=S)
+                dz, dw, dgamma, dbeta = _norm_backward_wgrad(
+                    backend, pending[0], ys[l], per_layer[l][2], coefs[l], pending[1], src, src_coef, need_w, ng=S,
+                    slots=(tslots[slots[l]['w']], tslots[slots[l]['g']], tslots[slots[l]['g'] + 1]))
                 grads[slots[l]['g']], grads[slots[l]['g'] + 1] = dgamma, dbeta
                 if dw is not None:
-                    grads[slots[l]['w']] = dw
+                    grads[slots[l]['w']] = dw.view(per_layer[l][0].shape)
                 if 'b' in slots[l] and need[3 + slots[l]['b']]:
-                    grads[slots[l]['b']] = torch.zeros_like(dbeta)
+                    grads[slots[l]['b']] = zero_bias(l)
             elif need_w:
-                grads[slots[l]['w']] = _wgrad(backend, dz, src, src_coef, ng=S)
+                grads[slots[l]['w']] = _wgrad(backend, dz, src, src_coef, ng=S,
+                                              slot=tslots[slots[l]['w']]).view(per_layer[l][0].shape)
             if l == 0:
                 if need[0]:
                     if backend.pw_supported(cout, cin, P):

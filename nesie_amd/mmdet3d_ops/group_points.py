@@ -87,6 +87,70 @@ class QueryGroupCat(Function):
         return None, None, grad_features, None, None, None
 
 
+class SampleQueryGroupCat(Function):
+    """Sample + group over NETWORK-COMPUTED coordinates as one autograd node: centres =
+    xyz[sample] and cat[(xyz[idx] - centre) (/ radius), features[idx]] for a ball query around
+    those centres -- the grouping of the vote aggregation module, whose points are the predicted
+    votes (nesie_head.py:243 -> point_sa_module.py:122-131, 160-211; group_points.py:98-128).
+    The reference reaches it through transpose / gather_points / transpose / ball_query /
+    group_points x 2 / sub / div / cat, and its backward through two atomicAdd scatters; here the
+    forward is four launches (centre gather, ball query, inverted index, one-pass grouping) and the
+    backward two: the feature scatter through the inverted index and ONE kernel for the coordinate
+    gradient (direct term, centre term, gradient of the returned centres), both in a fixed order.
+    -> (centres (B, M, 3), grouped (B, 3+C, M, ns), ball indices)."""
+
+    @staticmethod
+    def forward(ctx, points_xyz, features, sample, min_radius, max_radius, nsample, normalize):
+        backend = backend_for(points_xyz)
+        xyz = points_xyz.contiguous()
+        features = features.contiguous()
+        b, n = xyz.shape[:2]
+        centres = backend.gather_rows3(xyz, sample)
+        idx = xyz.new_zeros((b, sample.shape[1], nsample), dtype=torch.int32)
+        backend.ball_query_wrapper(b, n, sample.shape[1], min_radius, max_radius, nsample, centres, xyz, idx)
+        order, sources = backend.inverted_index(idx, n)
+        radius = float(max_radius) if normalize else 0.0
+        out = xyz.new_empty(b, 3 + features.shape[1], sample.shape[1], nsample)
+        backend.query_and_group_forward(xyz, centres, features, idx, radius, out)
+        ctx.save_for_backward(idx, order, sources, sample)
+        ctx.dims = (features.shape[1], n, radius)
+        ctx.mark_non_differentiable(idx)
+        return centres, out, idx
+
+    @staticmethod
+    def backward(ctx, d_centres, grad_out, _):
+        idx, order, sources, sample = ctx.saved_tensors
+        c, n, radius = ctx.dims
+        backend = backend_for(idx)
+        if grad_out is None:
+            grad_out = idx.new_zeros((idx.shape[0], 3 + c, idx.shape[1], idx.shape[2]), dtype=torch.float32)
+        grad_out = grad_out.contiguous()
+        d_feat = d_xyz = None
+        if ctx.needs_input_grad[1]:
+            d_feat = grad_out.new_zeros(grad_out.shape[0], c, n)
+            backend.query_and_group_backward_csr(grad_out, idx.shape, order, sources, d_feat)
+        if ctx.needs_input_grad[0]:
+            d_xyz = backend.query_and_group_backward_xyz(
+                grad_out, radius, order, sources, sample,
+                None if d_centres is None else d_centres.contiguous(), n)
+        return d_xyz, d_feat, None, None, None, None, None
+
+
+# Tests flip this to obtain the literal op-by-op grouping over differentiable coordinates.
+SAMPLE_GROUP_FUSED = True
+
+
+def sample_query_group_supported(points_xyz, features, grouper):
+    """True when ``SampleQueryGroupCat`` serves a grouper over differentiable coordinates."""
+    backend = backend_for(points_xyz)
+    return (SAMPLE_GROUP_FUSED and getattr(backend, 'name', '') == 'hip' and features is not None
+            and grouper.use_xyz
+            and not grouper.return_grouped_xyz and not grouper.return_grouped_idx
+            and points_xyz.dtype == torch.float32 and features.dtype == torch.float32
+            and points_xyz.shape[1] <= 8192 and torch.is_grad_enabled()
+            and (points_xyz.requires_grad or features.requires_grad))
+
+
 class QueryAndGroup(nn.Module):
     """ball query -> group xyz -> minus centre (-> / radius) -> group features ->
     concat [xyz(3), features(C)]  (reference :64-128).  kNN grouping

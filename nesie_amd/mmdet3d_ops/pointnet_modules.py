@@ -17,7 +17,8 @@ from ..kernels import backend_for, spatial_index_scope
 from . import fused_mlp
 from .furthest_point_sample import Points_Sampler
 from .gather_points import gather_points
-from .group_points import QueryAndGroup, inverted_index
+from .group_points import (QueryAndGroup, SampleQueryGroupCat, inverted_index,
+                           sample_query_group_supported)
 from .interpolate import three_interpolate, three_nn
 from .norm import FusedBNReLU1d, FusedBNReLU2d
 from .pool import group_max_pool
@@ -303,6 +304,17 @@ class BasePointSAModule(nn.Module):
 
     def _forward(self, points_xyz, features, indices, target_xyz, precomputed):
         new_features_list = []
+        if (precomputed is None and indices is None and target_xyz is None and len(self.groupers) == 1
+                and points_xyz.requires_grad and isinstance(self.groupers[0], QueryAndGroup)
+                and sample_query_group_supported(points_xyz, features, self.groupers[0])):
+            # coordinates computed by the network (vote aggregation): sample + group as ONE autograd
+            # node with a native coordinate gradient (group_points.SampleQueryGroupCat)
+            g = self.groupers[0]
+            indices = self.points_sampler(points_xyz, features)
+            new_xyz, grouped, _ = SampleQueryGroupCat.apply(
+                points_xyz, features, indices, float(g.min_radius), float(g.max_radius),
+                int(g.sample_num), bool(g.normalize_xyz))
+            return new_xyz, self._mlp_and_pool(self.mlps[0], grouped, 0), indices
         if precomputed is not None:
             new_xyz, indices = precomputed['new_xyz'], precomputed['indices']
         else:

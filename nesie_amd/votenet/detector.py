@@ -143,6 +143,12 @@ class VoteNet(nn.Module):
         copy to the host stay eager."""
         return GraphedSimpleTest(self, batch, num_points, feat_dim, device)
 
+    def stacked_parameter_groups(self):
+        """Parameter lists the step uses stacked (``SidePooling.stacked_parameter_groups``), for
+        ``dp.FlatTrainState(model.parameters(), stack_groups=...)``."""
+        pool = getattr(self.bbox_head, 'grid_conv', None)
+        return pool.stacked_parameter_groups() if hasattr(pool, 'stacked_parameter_groups') else []
+
     @staticmethod
     def parse_losses(losses):
         """Total = sum of every entry whose key contains 'loss' (mmdet BaseDetector._parse_losses);

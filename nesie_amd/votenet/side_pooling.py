@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import grad_slots
 from ..kernels import backend_for
 from ..mmdet3d_ops import blend_conv, blend_conv_bn, three_interpolate_segmented, three_nn
 from ..mmdet3d_ops.pool import group_max_pool, group_max_pool_shared
@@ -149,7 +150,7 @@ def _stacked_bn(layers, x, row_bias=None, pre_partial=None):
     pack = stacked_running_stats(layers)
     rm, rv = pack[0], pack[1]
     gamma, beta = fused_mlp.stack_groups([[l.weight for l in layers], [l.bias for l in layers]])
-    gamma, beta = gamma.reshape(-1), beta.reshape(-1)
+    gamma, beta = grad_slots.reshaped(gamma, -1), grad_slots.reshaped(beta, -1)
     y = _norm.BNReLUTrain.apply(x, gamma, beta, rm, rv, first.momentum, first.eps, first.fuse_relu,
                                 row_bias, pre_partial)
     for l in layers:    # (the running statistics were updated in place through their views)
@@ -245,7 +246,7 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     conv3, conv_g, conv4 = [x[3] for x in f], [x[0] for x in sc], [x[3] for x in sc]
     zero = None
     if conv3[0].bias is None:
-        zero = c0.new_zeros(half)
+        zero = conv3[0].weight.new_zeros(half)
     groups = [[l.weight for l in bn0s], [l.bias for l in bn0s],
               [m.weight.flatten(1) for m in conv3], [m.weight.flatten(1) for m in conv_g],
               [m.bias if m.bias is not None else zero for m in conv3],
@@ -255,8 +256,8 @@ def fused_mini_pointnets(nets, c0, c0_stats):
         groups.append([m.bias for m in conv4])
     gamma0, beta0, w3, w, b3, gamma1, beta1, w4, *b4 = fused_mlp.stack_groups(groups)
     evaluating = not bn0s[0].training
-    backend = backend_for(c0)
     deferred = c0 if isinstance(c0, DeferredBlendConv) else None
+    backend = backend_for(deferred.table if deferred is not None else c0)
     if evaluating:   # test path: the folded running statistics are the operand transforms
         if deferred is not None:
             c0 = deferred.materialize()[0]
@@ -266,10 +267,12 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     elif deferred is not None:   # blend + first norm + second conv as ONE autograd node
         d = deferred
         c, g = fused_mlp.BlendMiniHeadFn.apply(d.table, d.wx, d.idx, d.weight, d.rel, d.segs, d.G,
-                                               stacked(bn0s), G, gamma0.reshape(-1), beta0.reshape(-1), w3)
+                                               stacked(bn0s), G, grad_slots.reshaped(gamma0, -1),
+                                               grad_slots.reshaped(beta0, -1), w3)
     else:
         c, g = fused_mlp.MiniHeadFn.apply(c0.reshape(B, S, H, K * G), c0_stats, stacked(bn0s), G,
-                                          gamma0.reshape(-1), beta0.reshape(-1), w3)  # w3 (S, half, H)
+                                          grad_slots.reshaped(gamma0, -1), grad_slots.reshaped(beta0, -1),
+                                          w3)  # w3 (S, half, H)
     H2 = w.shape[1]                                                                  # w (S, H2, 2*half)
     # global half + everything the bias b3 contributes:  W_g (g + b3) + W_l b3.  The two halves
     # of w come from ONE split (its backward is one concatenation; three overlapping uses of w
@@ -283,7 +286,8 @@ def fused_mini_pointnets(nets, c0, c0_stats):
         out, _ = fused_mlp.mini_tail_second(backend, y, coef1, w4, G)
     else:
         out = fused_mlp.MiniTailFn.apply(c, small, stacked(bn1s), G, w_l,
-                                         gamma1.reshape(-1), beta1.reshape(-1), w4)  # w4 (S, F, H2)
+                                         grad_slots.reshaped(gamma1, -1), grad_slots.reshaped(beta1, -1),
+                                         w4)  # w4 (S, F, H2)
     if b4:
         out = out + b4[0].view(1, S, -1, 1)
     return out
@@ -367,11 +371,12 @@ def _heads_as_stack(heads, x, steps, weights, biases):
         if n is None:
             gammas.append(None); betas.append(None); stats.append(None)
         else:
-            gammas.append(next(stacked).reshape(-1)); betas.append(next(stacked).reshape(-1))
+            gammas.append(grad_slots.reshaped(next(stacked), -1))
+            betas.append(grad_slots.reshaped(next(stacked), -1))
             pack = stacked_running_stats(list(n))
             stats.append((pack[0], pack[1]))
     w = [weights[id(c[0])] for c in convs]
-    b = [biases[id(c[0])].reshape(-1) if c[0].bias is not None else None for c in convs]
+    b = [grad_slots.reshaped(biases[id(c[0])], -1) if c[0].bias is not None else None for c in convs]
     y = fused_mlp.stack1d(x.reshape(B * S, cin, P), [list(c) for c in convs],
                           [None if n is None else list(n) for n in norms], S=S, weights=w, biases=b,
                           gammas=gammas, betas=betas, stats=stats)
@@ -438,6 +443,19 @@ class SidePooling(nn.Module):
         head.append(_score_head(128, self.iou_size))
         self.mlps_before = nn.ModuleList(before)
         self.mlps_head = nn.ModuleList(head)
+
+    def stacked_parameter_groups(self):
+        """Lists of parameters the step uses STACKED: tensor kind by tensor kind, the six side
+        MiniPointNets and the six side score heads (``grouped_mini_pointnets`` / ``batched_heads``).
+        A flat training state that lays every list out contiguously (``dp.FlatTrainState(...,
+        stack_groups=)``) turns each stack into a view and each stacked gradient into one slot."""
+        groups = []
+        for modules in (list(self.mlps_before[:6]), list(self.mlps_head[:6])):
+            per = [list(m.parameters()) for m in modules]
+            if len(per) == 6 and all(len(p) == len(per[0]) for p in per):
+                groups += [list(kind) for kind in zip(*per)
+                           if all(t.shape == kind[0].shape for t in kind)]
+        return groups
 
     # BlendConvBN (first conv AND its norm + ReLU by recomputation, the conv output never
     # stored) is exact and saves 1.3 GB of activations, but measured break-even on MI355X: the
@@ -536,7 +554,8 @@ class SidePooling(nn.Module):
         idx, weight, rel = taps if taps is not None \
             else self._blend_taps(origin_xyz, whole_grid, center)
         G = idx.shape[1] // (K * segs)
-        w = torch.stack([net.first_conv[0].weight.flatten(1) for net in nets])   # (S, H, 3+C)
+        from ..mmdet3d_ops import fused_mlp
+        w = fused_mlp.stack_groups([[net.first_conv[0].weight.flatten(1) for net in nets]])[0]   # (S, H, 3+C)
         H = w.shape[1]
         table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
         bns = [net.first_conv[1] for net in nets]

@@ -1,0 +1,139 @@
+"""dp.FlatTrainState's layout with stack groups and nesie_amd.grad_slots (gradients written straight
+into the flat vector, stacked parameters as views) on a toy model, no GPU: a stand-in autograd
+function plays the part of the hand-written backward kernels."""
+import copy
+
+import torch
+from torch.autograd import Function
+
+from nesie_amd import checkpoint, dp, grad_slots
+
+
+class _Lin(Function):
+    """y[s] = x @ W[s]^T + b[s]; the backward WRITES dW / db into their slots when it got them."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[1 + j] else None for j, t in enumerate((W, b))]
+        ctx.save_for_backward(x, W)
+        return torch.einsum('bi,soi->sbo', x, W) + b[:, None, :]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        outs = []
+        for sl, v in zip(ctx.slots, (torch.einsum('sbo,bi->soi', g, x), g.sum(1))):
+            outs.append(v if sl is None else sl.copy_(v))
+        return torch.einsum('sbo,soi->bi', g, W), outs[0], outs[1]
+
+
+def _toy():
+    torch.manual_seed(0)
+    pre = torch.nn.Linear(5, 4)
+    nets = [torch.nn.Linear(4, 3) for _ in range(3)]
+    params = list(pre.parameters()) + [p for n in nets for p in n.parameters()]
+    return pre, nets, params
+
+
+def test_stack_groups_are_contiguous_views_and_gradients_land_in_their_slots():
+    pre, nets, params = _toy()
+    ref = copy.deepcopy([pre] + nets)
+    state = dp.FlatTrainState(params, stack_groups=[[n.weight for n in nets], [n.bias for n in nets]])
+    assert [id(p) for p in state.params] == [id(p) for p in params]            # model order kept
+    assert sorted(state.offsets) != state.offsets                               # ... the layout differs
+    assert state.split_after(pre.parameters()) == (2, 24)                       # ungrouped block first
+    W = grad_slots.stacked([n.weight for n in nets])
+    assert W.data_ptr() == nets[0].weight.data_ptr() and tuple(W.shape) == (3, 3, 4)
+    for i, n in enumerate(nets):
+        assert torch.equal(W[i], n.weight) and n.weight.data_ptr() == W[i].data_ptr()
+    assert grad_slots.stacked([nets[1].weight, nets[0].weight, nets[2].weight]) is None   # another order
+    assert grad_slots.take(W) is None                                           # nothing open yet
+    x = torch.randn(7, 5)
+
+    def loss():
+        W = grad_slots.stacked([n.weight for n in nets])
+        b = grad_slots.stacked([n.bias for n in nets])
+        return _Lin.apply(pre(x), W, b).square().sum()
+    state.begin()
+    grads = torch.autograd.grad(loss(), state.params)
+    for p, g in zip(state.params, grads):
+        p.grad = g
+    in_place = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(state.params, state.grad_views)]
+    assert in_place == [False, False] + [True] * 6          # the kernel-written ones never get copied
+    state.collect()
+    torch.stack([m(ref[0](x)) for m in ref[1:]]).square().sum().backward()
+    want = [p.grad for m in ref for p in m.parameters()]
+    for p, off, w in zip(state.params, state.offsets, want):
+        torch.testing.assert_close(state.flat[off:off + p.numel()].view_as(p), w, rtol=1e-5, atol=1e-6)
+    # outside begin() / collect() the attached .grad views ACCUMULATE: slots must stay closed
+    loss().backward()
+    for p, off, w in zip(state.params, state.offsets, want):
+        torch.testing.assert_close(state.flat[off:off + p.numel()].view_as(p), 2 * w, rtol=1e-5, atol=1e-6)
+    # a slot is handed out once per begin(): the second taker allocates, autograd adds, collect() copies
+    state.begin()
+    W = grad_slots.stacked([n.weight for n in nets])
+    b = grad_slots.stacked([n.bias for n in nets])
+    h = pre(x)
+    total = _Lin.apply(h, W, b).square().sum() + _Lin.apply(h, W, b).square().sum()
+    for p, g in zip(state.params, torch.autograd.grad(total, state.params)):
+        p.grad = g
+    state.collect()
+    for p, off, w in zip(state.params, state.offsets, want):
+        torch.testing.assert_close(state.flat[off:off + p.numel()].view_as(p), 2 * w, rtol=1e-5, atol=1e-6)
+    # no-grad passes (the EMA teacher's forward) take nothing
+    state.begin()
+    with torch.no_grad():
+        _Lin.apply(pre(x), grad_slots.stacked([n.weight for n in nets]), grad_slots.stacked([n.bias for n in nets]))
+    assert grad_slots.take(grad_slots.stacked([n.weight for n in nets])) is not None
+
+
+def test_registry_forgets_a_dead_state_and_reshapes_keep_the_tag():
+    pre, nets, params = _toy()
+    state = dp.FlatTrainState(params, stack_groups=[[n.bias for n in nets]])
+    state.begin()
+    b = grad_slots.stacked([n.bias for n in nets])
+    flat = grad_slots.reshaped(b, -1)
+    slot = grad_slots.take(flat)
+    assert slot is not None and tuple(slot.shape) == (9,) and slot.data_ptr() == state.grad_views[3].data_ptr()
+    assert grad_slots.take(b) is None                       # the same slot, already out
+    w = nets[0].weight.flatten(0)                           # a full-size contiguous view of a parameter
+    assert grad_slots.take(w).data_ptr() == state.grad_views[2].data_ptr()
+    assert grad_slots.take(nets[1].weight[:2]) is None      # a partial view has no slot
+    key = id(state)
+    del state, slot
+    import gc
+    gc.collect()
+    assert not any(v[2] == key for v in grad_slots._PARAM.values())
+    assert grad_slots.stacked([n.bias for n in nets]) is None
+
+
+def test_per_parameter_optimizer_state_follows_the_layout(tmp_path):
+    """checkpoint.per_parameter_optimizer_state / load_per_parameter_optimizer_state with a state whose
+    flat layout is NOT the running sum of the parameter sizes."""
+    pre, nets, params = _toy()
+    twin = copy.deepcopy([pre] + nets)
+    tparams = [p for m in twin for p in m.parameters()]
+    state = dp.FlatTrainState(params, stack_groups=[[n.weight for n in nets], [n.bias for n in nets]])
+    opt = torch.optim.AdamW([state.flat_param], lr=1e-2, weight_decay=0.05)
+    ref = torch.optim.AdamW(tparams, lr=1e-2, weight_decay=0.05)
+    x = torch.randn(6, 5)
+    for _ in range(2):
+        state.begin()
+        torch.stack([n(pre(x)) for n in nets]).square().sum().backward()
+        state.collect()
+        opt.step()
+        ref.zero_grad()
+        torch.stack([m(twin[0](x)) for m in twin[1:]]).square().sum().backward()
+        ref.step()
+    for p, t in zip(params, tparams):
+        torch.testing.assert_close(p, t, rtol=1e-5, atol=1e-7)
+    saved = checkpoint.per_parameter_optimizer_state(opt, state)
+    want = ref.state_dict()
+    for i in range(len(params)):
+        for k in ('exp_avg', 'exp_avg_sq'):
+            torch.testing.assert_close(saved['state'][i][k], want['state'][i][k], rtol=1e-6, atol=1e-8)
+    fresh = torch.optim.AdamW([state.flat_param], lr=1.0)
+    checkpoint.load_per_parameter_optimizer_state(fresh, state, want)
+    got, old = fresh.state[state.flat_param], opt.state[state.flat_param]
+    torch.testing.assert_close(got['exp_avg'], old['exp_avg'], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(got['exp_avg_sq'], old['exp_avg_sq'], rtol=1e-6, atol=1e-8)

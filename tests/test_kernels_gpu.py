@@ -669,8 +669,55 @@ def test_query_group_cat_matches_the_literal_chain(oracle_kernels, hip_device, n
         qg(xyz.to(hip_device), centres.to(hip_device), f2, idx=idx_d, csr=csr).backward(
             go.to(hip_device))
         grads.append(f2.grad.clone())
-    torch.testing.assert_close(grads[0], grads[1], rtol=1e-5, atol=1e-6)
+    assert torch.equal(grads[0], grads[1])          # one owner wave per run, no atomics: same bits
     torch.testing.assert_close(grads[0].cpu(), f0.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m,ns,c", [(512, 256, 16, 259), (1024, 512, 16, 40), (2048, 1024, 32, 9)])
+def test_csr_scatter_is_bitwise_reproducible_with_long_runs(hip_device, n, m, ns, c):
+    """The grouped scatter-add through the inverted index when a few points sit in hundreds of
+    groups (ball query keeps the FIRST nsample hits, so low-index points do): runs of 100 .. 3000
+    entries cross many 64-entry chunks.  Every run is summed by one wave in an order fixed by the
+    index: three launches give the same bits, equal to a float64 scatter within rounding -- also
+    for the weighted three-tap form (three_interpolate's backward)."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    g = torch.Generator().manual_seed(n + c)
+    # 60 % of the entries on 6 points, some points with no entry at all
+    hot = torch.randint(0, 6, (2, m * ns), generator=g)
+    cold = torch.randint(n // 2, n, (2, m * ns), generator=g)
+    idx = torch.where(torch.rand(2, m * ns, generator=g) < 0.6, hot, cold).int().view(2, m, ns).contiguous()
+    go = torch.randn(2, 3 + c, m, ns, generator=g)
+    idx_d, go_d = idx.to(hip_device), go.to(hip_device)
+    order, sources = hip.inverted_index(idx_d, n)
+    runs = torch.bincount(idx[0].flatten().long(), minlength=n)
+    assert int(runs.max()) > 3 * 64 and int((runs == 0).sum()) > 0
+    outs = []
+    for _ in range(3):
+        gf = torch.zeros(2, c, n, device=hip_device)
+        hip.query_and_group_backward_csr(go_d, (2, m, ns), order, sources, gf)
+        outs.append(gf.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = torch.zeros(2, c, n, dtype=torch.float64)
+    want.scatter_add_(2, idx.view(2, 1, -1).expand(-1, c, -1).long(), go[:, 3:].reshape(2, c, -1).double())
+    err = (outs[0].cpu().double() - want).abs().max().item()
+    assert err <= 2e-6 * want.abs().max().item(), err
+    # three weighted taps per column
+    nq = m * ns // 3
+    idx3 = idx.view(2, -1)[:, :nq * 3].reshape(2, nq, 3).contiguous()
+    w3 = torch.rand(2, nq, 3, generator=g)
+    go3 = torch.randn(2, c, nq, generator=g)
+    o3, s3 = hip.inverted_index(idx3.to(hip_device), n)
+    outs = []
+    for _ in range(3):
+        gp = torch.zeros(2, c, n, device=hip_device)
+        hip.three_interpolate_grad_csr(go3.to(hip_device), w3.to(hip_device), o3, s3, gp)
+        outs.append(gp.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = torch.zeros(2, c, n, dtype=torch.float64)
+    contrib = (go3.double().unsqueeze(-1) * w3.double().unsqueeze(1)).reshape(2, c, -1)
+    want.scatter_add_(2, idx3.view(2, 1, -1).expand(-1, c, -1).long(), contrib)
+    err = (outs[0].cpu().double() - want).abs().max().item()
+    assert err <= 2e-6 * want.abs().max().item(), err
 
 
 @pytest.mark.parametrize("n,m,c", [(1024, 512, 256), (512, 256, 256), (100, 7, 5)])
@@ -971,8 +1018,13 @@ def test_fused_distance_forms_bit_exact_vs_the_oracle_in_the_same_form(oracle_ke
         known = xyz[:, :1024].contiguous()
         got, want = both(lambda u, k: ops.three_nn(u, k)[1], oracle_kernels, hip_device, cen, known)
         eq(got, want)
-        got, want = both(lambda u, k: ops.three_nn(u, k)[0], oracle_kernels, hip_device, cen, known)
-        eq(got, want)
+        # the SQUARED distances as the kernels leave them (the python wrapper's sqrt is ATen's)
+        n_, m_ = cen.shape[1], known.shape[1]
+        d_g = torch.empty(2, n_, 3, device=hip_device); i_g = torch.empty(2, n_, 3, dtype=torch.int32, device=hip_device)
+        hip.three_nn_wrapper(2, n_, m_, cen.to(hip_device), known.to(hip_device), d_g, i_g)
+        d_c = torch.empty(2, n_, 3); i_c = torch.empty(2, n_, 3, dtype=torch.int32)
+        oracle_kernels.three_nn_wrapper(2, n_, m_, cen, known, d_c, i_c)
+        eq(d_g, d_c)
     finally:
         hip.set_distance_form(0)
         oracle.set_distance_form(0)
@@ -980,3 +1032,60 @@ def test_fused_distance_forms_bit_exact_vs_the_oracle_in_the_same_form(oracle_ke
     xyz = _cases.cloud(4596, 2, 4096, dup_frac=0.25)
     got, want = both(ops.furthest_point_sample, oracle_kernels, hip_device, xyz, 512)
     eq(got, want)
+
+
+@pytest.mark.parametrize("n,m,ns,c,norm,dup", [(1024, 256, 16, 256, True, False), (1024, 256, 16, 7, False, True),
+                                              (300, 64, 8, 5, True, True)])
+def test_sample_and_group_over_predicted_coordinates_matches_the_literal_chain(hip_device, n, m, ns, c, norm, dup):
+    """SampleQueryGroupCat (vote aggregation's sample + group as one autograd node with a native
+    coordinate gradient) vs the literal chain of the reference on the same device -- transpose,
+    gather_points, transpose, ball_query, group_points x 2, sub, div, cat and autograd's backward
+    through them (point_sa_module.py:122-131, group_points.py:98-128): centres, grouped tensor and
+    ball indices exact, gradients of coordinates and features to summation order -- with gradients
+    arriving at BOTH outputs, duplicated points (a point that is several centres) and twice for
+    bitwise reproducibility."""
+    import importlib
+    gp = importlib.import_module('nesie_amd.mmdet3d_ops.group_points')   # (the package re-exports a FUNCTION of that name)
+    from nesie_amd.mmdet3d_ops.pointnet_modules import PointSAModule
+    g = torch.Generator().manual_seed(n + ns)
+    xyz = torch.rand(2, n, 3, generator=g) * 2
+    if dup:
+        xyz[:, n // 2:] = xyz[:, :n - n // 2]          # every second half point duplicates a first half one
+    feats = torch.randn(2, c, n, generator=g)
+    sa = PointSAModule(mlp_channels=[c, 16, 16], num_point=m, radius=0.3, num_sample=ns,
+                       normalize_xyz=norm).to(hip_device)
+    picks = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(2)]).int()
+    if dup:
+        picks[:, 1] = picks[:, 0]                       # the same point sampled twice
+
+    class Fixed(torch.nn.Module):
+        def forward(self, *_):
+            return picks.to(hip_device)
+    sa.points_sampler = Fixed()
+    go_c = torch.randn(2, m, 3, generator=g).to(hip_device)
+    seen = {}
+    real = sa._mlp_and_pool
+
+    def tap(mlp, grouped, lead=0):
+        seen['grouped'] = grouped
+        seen['go'] = torch.randn(grouped.shape, generator=torch.Generator().manual_seed(5)).to(hip_device)
+        return (grouped * seen['go']).sum((1, 3))      # a linear read-out: its gradient is `go`
+    sa._mlp_and_pool = tap
+    outs = []
+    try:
+        for fused in (False, True, True):
+            gp.SAMPLE_GROUP_FUSED = fused
+            x = xyz.to(hip_device).requires_grad_(True)
+            f = feats.to(hip_device).requires_grad_(True)
+            centres, pooled, idx = sa(x * 1.0, f * 1.0)
+            (pooled.sum() + (centres * go_c).sum()).backward()
+            outs.append((centres.detach(), seen['grouped'].detach(), x.grad.clone(), f.grad.clone()))
+    finally:
+        gp.SAMPLE_GROUP_FUSED = True
+        sa._mlp_and_pool = real
+    want, got, again = outs
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    for a, b in ((got[2], want[2]), (got[3], want[3])):
+        assert b.abs().max().item() > 0
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item())
+    assert torch.equal(got[2], again[2]) and torch.equal(got[3], again[3])

@@ -396,15 +396,13 @@ def _replays_vs_eager(device, workload, replays, batch):
     for _ in range(replays):
         torch.cuda.synchronize()
         with torch.no_grad():      # the twin takes over the graph leg's state
-            off = 0
             assert [id(p) for p in bucket.params] == [id(p) for p in model_g.parameters()]
-            for pt, pg in zip(params, bucket.params):
+            for pt, pg, off in zip(params, bucket.params, bucket.offsets):   # (stack groups: not a running sum)
                 pt.copy_(pg)
                 n = pg.numel()
                 opt.state[pt] = dict(step=flat_state['step'].detach().clone().cpu().float(),
                                      exp_avg=flat_state['exp_avg'][off:off + n].view_as(pg).clone(),
                                      exp_avg_sq=flat_state['exp_avg_sq'][off:off + n].view_as(pg).clone())
-                off += n
             for bt, bg in zip(twin.buffers(), model_g.buffers()):
                 bt.copy_(bg)
             if semi_like:

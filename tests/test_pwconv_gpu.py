@@ -269,12 +269,18 @@ def test_weight_gradient_wide_shapes_and_strided_batches(cout, cin):
                                            (2, 1, 128, 64, 512), (3, 1, 100, 70, 96), (2, 1, 40, 33, 64),
                                            # wide layers: column blocks of one launch each
                                            (4, 2, 256, 256, 256), (2, 1, 256, 512, 128), (2, 1, 256, 259, 64),
-                                           (4, 2, 128, 515, 64), (2, 1, 200, 300, 96)])
+                                           (4, 2, 128, 515, 64), (2, 1, 200, 300, 96),
+                                           # the 1-D chains' own shapes (vote module, feature propagation,
+                                           # 8 scenes): TILED -- 64 x 64 blocks of the product, split-K
+                                           (8, 1, 256, 256, 1024), (8, 1, 259, 256, 1024), (8, 1, 256, 512, 512),
+                                           (8, 1, 256, 512, 1024), (12, 6, 128, 166, 512)])
 def test_layer_weight_gradient_matches_fp64(nb, ng, co, ci, p):
     """nesie_pw_wgrad: sum over batches and positions of dy . act(x)^T per weight group, with the
     activation recomputed on load, on batch-strided operands."""
     hip = _hip()
-    assert hip.pw_wgrad_supported(co, ci, p)
+    assert hip.pw_wgrad_supported(co, ci, p) or hip.pw_wgrad_tiled(nb, ng, co, ci, p)
+    if nb == 8:
+        assert hip.pw_wgrad_tiled(nb, ng, co, ci, p)
     g = torch.Generator(device=_dev()).manual_seed(co * 3 + ci + ng)
     dy_all = torch.randn(nb, co + 5, p, device=_dev(), generator=g)
     x_all = torch.randn(nb, ci + 3, p, device=_dev(), generator=g)
@@ -292,6 +298,9 @@ def test_layer_weight_gradient_matches_fp64(nb, ng, co, ci, p):
         full = torch.bmm(dy.double(), xd.transpose(1, 2))          # (nb, co, ci)
         ref = full.view(nb // ng, ng, co, ci).sum(0)
         assert (dw.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+        again = torch.empty_like(dw)                               # fixed-order partial sums: same bits
+        hip.pw_wgrad(dy, x, again, ng=ng, x_coef=coef if use_coef else None)
+        assert torch.equal(dw, again)
 
 
 @pytest.mark.parametrize('nb,ng,co,ci,p,in_place', [(6, 3, 128, 256, 256, False), (4, 1, 256, 128, 512, True),
@@ -583,8 +592,8 @@ def test_deferred_blend_into_fused_mini_pointnets(S, G, second_consumer):
     finally:
         fused_mlp.BlendMiniHeadFn.forward = staticmethod(real)
     torch.testing.assert_close(got[0], want[0], rtol=1e-4, atol=1e-4)
-    for a, b in ((got[1], want[1]), (got[2], want[2])):
-        torch.testing.assert_close(a, b, rtol=1e-3, atol=3e-4 * b.abs().max().item())
+    for a, b in ((got[1], want[1]), (got[2], want[2])):   # (two fp32 orders of the same sums)
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=6e-4 * b.abs().max().item())
     scale = max(b.abs().max().item() for b in want[3] if b is not None)
     for a, b in zip(got[3], want[3]):
         assert (a is None) == (b is None)
