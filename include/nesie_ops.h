@@ -133,6 +133,19 @@ int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsa
                                        const float *grad_out, const int *order,
                                        const int *sources, float *grad_features, void *stream);
 
+/* The tail of VoteModule.forward behind its last convolution (model_utils/vote_module.py:106-147
+ * with vote_per_seed = 1, with_res_feat, no vote_xyz_range): raw (B, 3+c, N) = [offset, residual]
+ * -> vote_points (B, N, 3) = seed_points + offset^T, vote_feats (B, c, N) = (seed_feats + residual)
+ * divided by its channel-wise L2 norm (normalise != 0), inv_norm (B, N) kept for the backward.
+ * Backward: g_feats (B, c, N) / g_points (B, N, 3), either may be NULL -> d_raw (B, 3+c, N) (rows
+ * 0..2 = g_points^T, rows 3.. = the gradient of seed_feats + residual). */
+int nesie_vote_finish_forward(int b, int c, int n, int normalise, const float *raw,
+                              const float *seed_points, const float *seed_feats, float *vote_points,
+                              float *vote_feats, float *inv_norm, void *stream);
+int nesie_vote_finish_backward(int b, int c, int n, int normalise, const float *g_feats,
+                               const float *g_points, const float *vote_feats, const float *inv_norm,
+                               float *d_raw, void *stream);
+
 /* QueryAndGroup over NETWORK-COMPUTED coordinates (vote aggregation groups the predicted votes
  * around centres sampled from them, nesie_head.py:243 -> point_sa_module.py:122-131,
  * group_points.py:98-110): the sampled centres straight from the (B, N, 3) array, and the

@@ -59,6 +59,8 @@ SIGNATURES = {
     "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_gather_rows3": [_I, _I, _I, _P, _P, _P, _P],
+    "nesie_vote_finish_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "nesie_vote_finish_backward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_xyz": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P],
     "nesie_group_max_pool_backward_add": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],

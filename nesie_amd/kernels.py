@@ -254,6 +254,33 @@ class HipKernels(_BNPoolMixin):
                       _ptr(scratch), _stream(idx))
         return order, sources
 
+    def vote_finish_forward(self, raw, seed_points, seed_feats, normalise):
+        """-> (vote_points (B, N, 3), vote_feats (B, C, N), inv_norm (B, N)) (nesie_vote_finish_forward)."""
+        _check(raw, seed_points, seed_feats); _f32(raw, seed_points, seed_feats)
+        b, c, n = seed_feats.shape
+        assert tuple(raw.shape) == (b, 3 + c, n) and tuple(seed_points.shape) == (b, n, 3)
+        vp, vf = torch.empty_like(seed_points), torch.empty_like(seed_feats)
+        inv = torch.empty(b, n, dtype=torch.float32, device=raw.device)
+        with torch.cuda.device(raw.device):
+            _lib.call("nesie_vote_finish_forward", b, c, n, int(bool(normalise)), _ptr(raw), _ptr(seed_points),
+                      _ptr(seed_feats), _ptr(vp), _ptr(vf), _ptr(inv), _stream(raw))
+        return vp, vf, inv
+
+    def vote_finish_backward(self, g_feats, g_points, vote_feats, inv_norm, normalise):
+        """-> d_raw (B, 3 + C, N) (nesie_vote_finish_backward); either gradient may be None."""
+        _check(vote_feats, inv_norm); _f32(vote_feats, inv_norm)
+        b, c, n = vote_feats.shape
+        for t, shape in ((g_feats, (b, c, n)), (g_points, (b, n, 3))):
+            if t is not None:
+                _check(t); _f32(t)
+                assert tuple(t.shape) == shape
+        d_raw = torch.empty(b, 3 + c, n, dtype=torch.float32, device=vote_feats.device)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(vote_feats.device):
+            _lib.call("nesie_vote_finish_backward", b, c, n, int(bool(normalise)), opt(g_feats), opt(g_points),
+                      _ptr(vote_feats), _ptr(inv_norm), _ptr(d_raw), _stream(vote_feats))
+        return d_raw
+
     def gather_rows3(self, xyz, sample):
         """xyz (B, N, 3), sample (B, M) int32 -> xyz[b, sample[b, m]] (B, M, 3)."""
         _check(xyz, sample); _f32(xyz); _i32(sample)
@@ -469,7 +496,7 @@ class HipKernels(_BNPoolMixin):
     def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len,
                             bn_z=None, bnb=None):
         """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c)
-        (zeroed by the caller) and adds sum(dy x rel) into d_wx (segs, c, 3).  bn_z / bnb: dy is
+        (zeroed by the caller) and WRITES sum(dy x rel) to d_wx (segs, c, 3).  bn_z / bnb: dy is
         the gradient of relu(bn(bn_z)) and the norm backward runs on the tile load
         (nesie_blend_conv_backward_bn; bnb (segs*c, 8) from ``pw_bnb_coef``)."""
         _check(dy, idx, weight, d_table); _f32(dy, weight, d_table); _i32(idx)
@@ -495,8 +522,8 @@ class HipKernels(_BNPoolMixin):
                 _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
                           _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part), segs, seg_len,
                           _stream(dy))
-            if part is not None:
-                d_wx += part.sum(0)
+            if part is not None:      # (d_wx arrives zero-filled from its caller: the sum overwrites it)
+                torch.sum(part, 0, out=d_wx)
 
     def blend_conv_bn_forward(self, table, idx, weight, rel, wx, gamma, beta, running_mean,
                               running_var, momentum, eps, out, save_mean, save_invstd, fwd_coef,

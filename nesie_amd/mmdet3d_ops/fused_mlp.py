@@ -588,7 +588,7 @@ class BlendMiniHeadFn(Function):
                                              ctx.needs_input_grad[11], ctx.slots[2])
         dgamma, dbeta = _dst(ctx.slots[0], c0, S * H0), _dst(ctx.slots[1], c0, S * H0)
         d_table = c0.new_zeros(b, m, pitch)
-        d_wx = c0.new_zeros(segs, h, 3)
+        d_wx = c0.new_empty(segs, h, 3)          # (written, not accumulated)
         if FOLD_NORM_BWD:
             bnb = backend.pw_bnb_coef(part, coef0, gamma0, float(B) * float(P), dgamma, dbeta)
             backend.blend_conv_backward(da0.view(B, S, H0, P), h, idx, weight, rel, d_table, d_wx,
@@ -806,8 +806,10 @@ class Stack1dFn(Function):
         tslots = ctx.slots
 
         def zero_bias(l):      # the bias in front of layer l's norm: gradient identically zero
+            # (its slot of the flat gradient vector was zero when the state was built and NOBODY ever
+            # writes it -- clip and all-reduce keep a zero zero -- so the slot itself is the gradient)
             sl = tslots[slots[l]['b']]
-            return sl.zero_() if sl is not None else torch.zeros_like(per_layer[l][1])
+            return sl if sl is not None else torch.zeros_like(per_layer[l][1])
         # a channel slice of a wider gradient (the outputs of several chains concatenated by their
         # consumer) is batch-strided: the layer kernels take a batch stride, no copy needed
         if not (S == 1 and layers[-1].bn is None and dout.stride(2) == 1 and dout.stride(1) == P):

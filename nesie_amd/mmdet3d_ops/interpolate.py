@@ -127,7 +127,7 @@ class BlendConv(Function):
         idx, weight, rel = ctx.saved_tensors
         segs, seg_len, b, m, pitch, h = ctx.dims
         d_table = dy.new_zeros(b, m, pitch)
-        d_wx = dy.new_zeros(segs, h, 3)
+        d_wx = dy.new_empty(segs, h, 3)          # (written, not accumulated)
         backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
                                             segs, seg_len)
         return d_table, d_wx, None, None, None, None, None, None

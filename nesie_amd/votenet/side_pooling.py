@@ -278,8 +278,16 @@ def fused_mini_pointnets(nets, c0, c0_stats):
     # of w come from ONE split (its backward is one concatenation; three overlapping uses of w
     # cost two zero-filled slice gradients and two additions)
     w_g, w_l = w.split(half, dim=2)
-    small = torch.matmul(w_g.unsqueeze(0), g + b3.view(1, S, half, 1)) \
-        + torch.matmul(w_l, b3.unsqueeze(-1)).view(1, S, H2, 1)
+    gx = g.reshape(B * S, half, g.shape[-1])
+    if not evaluating and fused_mlp.stack1d_supported(backend, gx, [(half, H2)], [None], S, which=fused_mlp.HEADS):
+        # ... as ONE bias-carrying layer of the layer kernel over the K proposals (weight group =
+        # net): W_g g + (W_g b3 + W_l b3); the bias is two tiny products of parameters
+        bias = torch.matmul(w, torch.cat([b3, b3], 1).unsqueeze(-1)).reshape(-1)          # (S * H2)
+        small = fused_mlp.Stack1dFn.apply(gx, (fused_mlp.Stack1dLayer(True, None),), S, w_g, bias) \
+            .view(B, S, H2, -1)
+    else:
+        small = torch.matmul(w_g.unsqueeze(0), g + b3.view(1, S, half, 1)) \
+            + torch.matmul(w_l, b3.unsqueeze(-1)).view(1, S, H2, 1)
     if evaluating:
         y, _ = fused_mlp.mini_tail_first(backend, c, small.contiguous(), w_l, G)
         coef1 = _norm.stacked_eval_coef(bn1s)

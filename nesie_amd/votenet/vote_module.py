@@ -11,6 +11,35 @@ from ..mmdet3d_ops import ConvModule, PointwiseConv1d
 from .losses import build_loss
 
 
+# Tests flip this to obtain the op-by-op tail of VoteModule.forward on the device.
+FUSED_FINISH = True
+
+
+class VoteFinishFn(torch.autograd.Function):
+    """(raw (B, 3+C, N), seed_points (B, N, 3), seed_feats (B, C, N)) -> (vote_points, vote_feats):
+    seed + offset, and the L2-normalised sum of seed and residual features (vote_module.py:106-147 for
+    one vote per seed).  Gradients: d_raw from one kernel, d_seed_feats = its feature rows (a view),
+    d_seed_points = the incoming gradient of the vote points."""
+
+    @staticmethod
+    def forward(ctx, raw, seed_points, seed_feats, normalise):
+        from ..kernels import backend_for
+        vp, vf, inv = backend_for(raw).vote_finish_forward(raw.contiguous(), seed_points.contiguous(),
+                                                           seed_feats.contiguous(), normalise)
+        ctx.normalise = normalise
+        ctx.save_for_backward(vf, inv)
+        return vp, vf
+
+    @staticmethod
+    def backward(ctx, g_points, g_feats):
+        from ..kernels import backend_for
+        vf, inv = ctx.saved_tensors
+        d_raw = backend_for(vf).vote_finish_backward(
+            None if g_feats is None else g_feats.contiguous(),
+            None if g_points is None else g_points.contiguous(), vf, inv, ctx.normalise)
+        return d_raw, g_points, d_raw[:, 3:], None
+
+
 class VoteModule(nn.Module):
     """``vote_per_seed`` votes per seed: a 1x1-conv stack, then one linear map whose output
     channels are laid out vote-major, ``[dx, dy, dz, residual feature (C)]`` per vote."""
@@ -57,7 +86,15 @@ class VoteModule(nn.Module):
             seed_points, seed_feats = seed_points[:, :self.num_points], seed_feats[..., :self.num_points]
         B, C, N = seed_feats.shape
         V = self.vote_per_seed
-        raw = self._vote_stack(seed_feats).view(B, V, self.per_vote, N)
+        raw3 = self._vote_stack(seed_feats)
+        from ..kernels import backend_for
+        if (V == 1 and self.with_res_feat and self.vote_xyz_range is None and FUSED_FINISH
+                and getattr(backend_for(seed_feats), 'name', '') == 'hip' and seed_feats.dtype == torch.float32
+                and torch.is_grad_enabled()):
+            # everything behind the last convolution as one launch per direction (csrc/vote.hip)
+            vote_points, vote_feats = VoteFinishFn.apply(raw3, seed_points, seed_feats, bool(self.norm_feats))
+            return vote_points, vote_feats, raw3[:, :3]
+        raw = raw3.view(B, V, self.per_vote, N)
         # one split: its backward is one concatenation (two slices cost two zero fills + an add)
         shift, residual = raw.split([3, self.per_vote - 3], dim=2) if self.with_res_feat \
             else (raw, None)                                              # (B, V, 3, N), (B, V, C, N)

@@ -206,7 +206,7 @@ class OracleKernels:
             d_table[:, :, face * seg_off:face * seg_off + c] += gp.transpose(1, 2)
             if d_wx is not None:
                 r = rel.view(b, k, segs, seg_len, 3)[:, :, face].reshape(b, k * seg_len, 3)
-                d_wx[face] += torch.matmul(dy[:, face], r).sum(0)
+                d_wx[face] = torch.matmul(dy[:, face], r).sum(0)      # (written, as the HIP wrapper does)
 
     def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight,
                                        grad_points):

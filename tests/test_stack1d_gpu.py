@@ -86,6 +86,45 @@ def test_vote_module_chain(hip_device):
     _compare(fused, plain, zero_bias={'vote_conv.0.conv.bias', 'vote_conv.1.conv.bias'})
 
 
+@pytest.mark.parametrize('norm_feats', [True, False])
+def test_vote_module_tail_as_one_kernel_matches_the_op_chain(hip_device, norm_feats):
+    """vote_module.VoteFinishFn (csrc/vote.hip: seed + offset, seed + residual features, L2
+    normalisation, and one backward kernel) vs the reference's add / permute / add / norm / div
+    chain under autograd (vote_module.py:106-147): outputs 1e-6, gradients of the seed features,
+    the seed coordinates and every parameter 1e-5 relative, with gradients arriving at all three
+    outputs."""
+    import copy
+    from nesie_amd.votenet import vote_module as vmod
+    torch.manual_seed(0)
+    vm = vmod.VoteModule(256, conv_channels=(256, 256), norm_feats=norm_feats).to(hip_device).train()
+    with torch.no_grad():
+        vm.conv_out.bias.normal_(0, 0.1)
+    g = torch.Generator(device=hip_device).manual_seed(1)
+    xyz0 = torch.rand(4, 1024, 3, device=hip_device, generator=g)
+    feats0 = torch.randn(4, 256, 1024, device=hip_device, generator=g)
+    go = [torch.randn(4, 1024, 3, device=hip_device, generator=g), torch.randn(4, 256, 1024, device=hip_device, generator=g),
+          torch.randn(4, 3, 1024, device=hip_device, generator=g)]
+    outs = []
+    try:
+        for fused in (False, True):
+            vmod.FUSED_FINISH = fused
+            m = copy.deepcopy(vm)
+            xyz, feats = xyz0.clone().requires_grad_(True), feats0.clone().requires_grad_(True)
+            res = m(xyz, feats)
+            sum((r * w).sum() for r, w in zip(res, go)).backward()
+            outs.append(([r.detach() for r in res], xyz.grad, feats.grad, {n: p.grad for n, p in m.named_parameters()}))
+    finally:
+        vmod.FUSED_FINISH = True
+    want, got = outs
+    for a, b in zip(got[0], want[0]):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-6)
+    for a, b in ((got[1], want[1]), (got[2], want[2])):
+        _close(a, b, 1e-5, 'input gradient')
+    for n in want[3]:
+        if want[3][n] is not None and float(want[3][n].abs().max()) > 0:
+            _close(got[3][n], want[3][n], 2e-5, n)
+
+
 def test_prediction_head_chain(hip_device):
     from nesie_amd.votenet import nesie_votenet_scannet_cfg
     from nesie_amd.votenet.nesie_head import NesieHead
