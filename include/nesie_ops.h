@@ -249,6 +249,20 @@ int nesie_blend_conv_backward_bn(int b, int c, int m, int n, const float *da, co
                                  const float *bnb, int pitch, int seg_off, const int *idx,
                                  const float *weight, const float *rel, float *d_table,
                                  float *d_wx, int segs, int seg_len, void *stream);
+
+/* The two backward entry points above WITHOUT float atomics (round 4): every 16-query group stores
+ * the row it has summed per seed into staging slots of its own (48 per group), a per-(scene, face)
+ * inverted index of the slots' seeds (nesie_inverted_index's kernel) lists each seed's slots in
+ * ascending order, and one wave per (scene, face, seed) adds them in that order and WRITES the
+ * d_table row -- bitwise reproducible, d_table needs no zero fill.  z / bnb both NULL: plain
+ * backward; both given: the norm backward on the tile load (as nesie_blend_conv_backward_bn).
+ * d_wx as above.  workspace: nesie_blend_conv_backward_workspace_bytes(b, c, n, segs) bytes. */
+size_t nesie_blend_conv_backward_workspace_bytes(int b, int c, int n, int segs);
+int nesie_blend_conv_backward_staged(int b, int c, int m, int n, const float *dy, const float *z,
+                                     const float *bnb, int pitch, int seg_off, const int *idx,
+                                     const float *weight, const float *rel, float *d_table,
+                                     float *d_wx, int segs, int seg_len, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 /* bnb[ch] = (scale, shift, a, mean, d1, e0, -, -) of a BatchNorm + ReLU backward from the partial
  * sums part [(channels) * nslots * 2] = (sum g, sum g zhat), the folded forward coefficients
  * z_coef [channels][4] and gamma; count = elements per channel; dgamma / dbeta written. */

@@ -47,6 +47,8 @@ SIGNATURES = {
                                  _P, _P],
     "nesie_blend_conv_backward": [_I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "nesie_blend_conv_backward_bn": [_I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    "nesie_blend_conv_backward_staged": [_I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P,
+                                         ctypes.c_size_t, _P],
     "nesie_pw_bnb_coef": [_I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P],
     "nesie_sort_vertices_forward": [_I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_points_in_boxes_batch": [_I, _I, _I, _P, _P, _P, _P],
@@ -145,6 +147,8 @@ def load():
     lib.nesie_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_blend_conv_bn_workspace_bytes.argtypes = [_I, _I, _I, _I]
     lib.nesie_blend_conv_bn_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_blend_conv_backward_workspace_bytes.argtypes = [_I, _I, _I, _I]
+    lib.nesie_blend_conv_backward_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_blend_conv_runs.argtypes = [_I, _I]
     lib.nesie_blend_conv_runs.restype = _I
     lib.nesie_mlp_stream_partials.argtypes = [_I, ctypes.c_longlong]

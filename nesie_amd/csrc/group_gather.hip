@@ -14,6 +14,7 @@
 // each row is written once; otherwise the same walk with float atomics to HBM
 // (the reference does the latter; sum order is not deterministic either way).
 #include "common.h"
+#include <stdlib.h>
 
 namespace nesie {
 
@@ -198,18 +199,22 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
 // run in ascending column order and the segmented sums of the backward are reproducible.
 constexpr int II_BLOCK = 1024;
 
+// n_ranked < n: the bins >= n_ranked collect entries nobody will read (the unused staging slots of
+// the blend backward, marked -1): a NEGATIVE index goes to bin n - 1 and those bins are not ranked
+// (their run can hold most of the entries; ranking is quadratic in the run length).
 __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
     int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
-    int *__restrict__ srcs, int *__restrict__ scratch_out) {
+    int *__restrict__ srcs, int *__restrict__ scratch_out, int n_ranked) {
   extern __shared__ int lds[];  // hist[n] then cursor[n]; scan scratch [II_BLOCK]
   int *cur = lds, *scratch = lds + n;
   const int bi = blockIdx.x, tid = threadIdx.x;
   const int *ix = idx + (size_t)bi * e_total;
   for (int j = tid; j < n; j += II_BLOCK) cur[j] = 0;
   __syncthreads();
+  const int neg = n_ranked < n ? n - 1 : 0;          // where a negative index goes
   for (int e = tid; e < e_total; e += II_BLOCK) {
     int s = ix[e];
-    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    s = s < 0 ? neg : (s >= n ? n - 1 : s);
     atomicAdd(&cur[s], 1);
   }
   __syncthreads();
@@ -238,19 +243,121 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
   int *tmp = scratch_out + (size_t)bi * e_total;
   for (int e = tid; e < e_total; e += II_BLOCK) {
     int s = ix[e];
-    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    s = s < 0 ? neg : (s >= n ? n - 1 : s);
     tmp[atomicAdd(&cur[s], 1)] = e;
   }
   __syncthreads();   // cur[s] is now the END of run s; run s starts where run s - 1 ends
   for (int i = tid; i < e_total; i += II_BLOCK) {
     const int e = tmp[i];
     int s = ix[e];
-    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    s = s < 0 ? neg : (s >= n ? n - 1 : s);
+    sr[i] = s;
+    if (s >= n_ranked) { ord[i] = e; continue; }     // (arrival order: never read)
     const int lo_s = s > 0 ? cur[s - 1] : 0, hi_s = cur[s];
     int rank = 0;
     for (int k = lo_s; k < hi_s; ++k) rank += tmp[k] < e ? 1 : 0;
     ord[lo_s + rank] = e;
-    sr[i] = s;
+  }
+}
+
+// The same index by a STABLE counting sort (n <= II_STABLE_N bins): no ranking pass.  Wave w of the
+// 16 owns a contiguous range of entries and keeps its own histogram row cnt[w][.] in LDS; after the
+// scan cnt[w][s] is where wave w's first entry of bin s goes (bin-major, wave-minor), and the wave
+// places its entries 64 at a time in ascending order: the lanes that hold the same bin find each
+// other with a ballot per distinct bin of the round and take consecutive positions in lane order.
+// The result is `order` ascending inside every run by construction -- what the ranking pass of
+// inverted_index_kernel computes in time quadratic in the run length (a seed of the blend backward's
+// staging index collects 1 500 slots: 0.4 ms per build there, 0.03 ms here).
+constexpr int II_STABLE_N = 2048, II_WAVES = II_BLOCK / 64;
+
+// span > 0 (the blend backward's staging index): the entries come in blocks of `span` whose VALID
+// bins are pairwise distinct (one 16-query group's seeds, ascending) with negative = unused entries:
+// the unused ones are skipped altogether, and a block is placed by ONE returning LDS add per lane --
+// no two lanes of a block share a cursor, blocks of a wave go in order, waves own their cursor rows:
+// still the stable order.  srcs behind the last valid position is filled with n (bisection-safe).
+__global__ __launch_bounds__(II_BLOCK) void inverted_index_stable_kernel(
+    int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
+    int *__restrict__ srcs, int n_ranked, int span) {
+  extern __shared__ int lds[];                       // cnt[II_WAVES][n], then scan scratch [II_BLOCK]
+  int *cnt = lds, *scratch = lds + II_WAVES * n;
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int *ix = idx + (size_t)bi * e_total;
+  const int neg = n_ranked < n ? n - 1 : 0;          // where a negative index goes
+  for (int j = tid; j < II_WAVES * n; j += II_BLOCK) cnt[j] = 0;
+  __syncthreads();
+  const int unit = span > 0 ? span : 64;
+  const int per = ((e_total + II_WAVES - 1) / II_WAVES + unit - 1) / unit * unit;   // entries per wave, whole rounds
+  const int e0 = wave * per, e1 = e0 + per < e_total ? e0 + per : e_total;
+  int *mine = cnt + wave * n;
+  for (int e = e0 + lane; e < e1; e += 64) {
+    int s = ix[e];
+    if (span > 0 && (s < 0 || s >= n_ranked)) continue;
+    s = s < 0 ? neg : (s >= n ? n - 1 : s);
+    atomicAdd(&mine[s], 1);
+  }
+  __syncthreads();
+  // totals per bin -> exclusive scan over the bins -> per-(wave, bin) start positions
+  const int bper = (n + II_BLOCK - 1) / II_BLOCK;    // bins per thread (contiguous)
+  const int b0 = tid * bper, b1 = b0 + bper < n ? b0 + bper : n;
+  int sum = 0;
+  for (int sbin = b0; sbin < b1; ++sbin)
+    for (int w = 0; w < II_WAVES; ++w) sum += cnt[w * n + sbin];
+  scratch[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < II_BLOCK; d <<= 1) {
+    const int v = tid >= d ? scratch[tid - d] : 0;
+    __syncthreads();
+    scratch[tid] += v;
+    __syncthreads();
+  }
+  int run = scratch[tid] - sum;                      // first position of this thread's first bin
+  for (int sbin = b0; sbin < b1; ++sbin)
+    for (int w = 0; w < II_WAVES; ++w) {
+      const int c = cnt[w * n + sbin];
+      cnt[w * n + sbin] = run;
+      run += c;
+    }
+  __syncthreads();
+  int *ord = order + (size_t)bi * e_total;
+  int *sr = srcs + (size_t)bi * e_total;
+  if (span > 0) {
+    const int total = scratch[II_BLOCK - 1];         // valid entries of the scene
+    for (int pos = total + tid; pos < e_total; pos += II_BLOCK) sr[pos] = n;
+    for (int base = e0; base < e1; base += span) {
+      const int e = base + lane;
+      if (lane < span && e < e1) {
+        const int sv = ix[e];
+        if (sv >= 0 && sv < n_ranked) {
+          const int pos = atomicAdd(&mine[sv], 1);   // (distinct bins inside a block: one lane per cursor)
+          ord[pos] = e;
+          sr[pos] = sv;
+        }
+      }
+    }
+    return;
+  }
+  volatile int *cur = mine;                          // this wave's cursors (only this wave touches them)
+  for (int base = e0; base < e1; base += 64) {
+    const int e = base + lane;
+    const bool live = e < e1;
+    int s = live ? ix[e] : 0;
+    s = s < 0 ? neg : (s >= n ? n - 1 : s);
+    unsigned long long todo = __ballot(live);
+    while (todo) {                                   // one trip per distinct bin of the round
+      const int leader = __builtin_ctzll(todo);
+      const int s0 = __builtin_amdgcn_readlane(s, leader);
+      const unsigned long long mask = __ballot(live && s == s0);
+      const int start = cur[s0];
+      if (live && s == s0) {
+        const int pos = start + __popcll(mask & ((1ull << lane) - 1ull));
+        ord[pos] = e;
+        sr[pos] = s0;
+      }
+      if (lane == leader) cur[s0] = start + __popcll(mask);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~mask;
+    }
   }
 }
 
@@ -453,8 +560,9 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
   return check_launch(W);
 }
 
-extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
-                                    int *sources, int *scratch, void *stream) {
+namespace nesie {
+int launch_inverted_index(int b, int n, long long e_total, const int *idx, int *order, int *sources,
+                          int *scratch, int n_ranked, hipStream_t s, int span) {
   const char *W = "inverted_index";
   NESIE_REQUIRE(b >= 0 && n >= 1 && e_total >= 0 && e_total < (1ll << 31), W);
   if (b == 0) return NESIE_OK;
@@ -463,10 +571,31 @@ extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *
     set_error("%s: %d source points (built for n <= 8192: one LDS histogram per scene)", W, n);
     return NESIE_ERR_UNSUPPORTED;
   }
+  static const int stable_on = getenv("NESIE_INDEX_STABLE") ? atoi(getenv("NESIE_INDEX_STABLE")) : 1;   // A/B switch
+  if (stable_on && n <= II_STABLE_N) {               // stable counting sort: ascending runs without a ranking pass
+    const size_t lds = ((size_t)II_WAVES * n + II_BLOCK) * sizeof(int);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)inverted_index_stable_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)II_WAVES * II_STABLE_N + II_BLOCK) * sizeof(int)));
+      attr = true;
+    }
+    NESIE_REQUIRE(span >= 0 && span <= 64 && (span == 0 || e_total % span == 0), W);
+    hipLaunchKernelGGL(inverted_index_stable_kernel, dim3(b), dim3(II_BLOCK), lds, s, n, (int)e_total, idx,
+                       order, sources, n_ranked, span);
+    return check_launch(W);
+  }
+  NESIE_REQUIRE(span == 0, W);
   const size_t lds = ((size_t)n + II_BLOCK) * sizeof(int);
-  hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, (hipStream_t)stream, n,
-                     (int)e_total, idx, order, sources, scratch);
+  hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, s, n, (int)e_total, idx, order,
+                     sources, scratch, n_ranked);
   return check_launch(W);
+}
+}  // namespace nesie
+
+extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
+                                    int *sources, int *scratch, void *stream) {
+  return launch_inverted_index(b, n, e_total, idx, order, sources, scratch, n, (hipStream_t)stream, 0);
 }
 
 extern "C" int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,

@@ -346,13 +346,23 @@ __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
 //     dZ = a g + (e0 - (z - mean) d1),  g = dA [fma(z, scale, shift) > 0],
 // with bnb[sg * C + ch] = (scale, shift, a, mean, d1, e0, -, -) (pw_bnb_coef_kernel, pwconv_wgrad.hip),
 // so the separate pass that read (dA, Z) and wrote dZ for this kernel to read disappears.
-template <int CPT, bool BNB>
+// STAGED (round 4): the row a wave has summed for one seed is not ADDED into d_table with float
+// atomics (whose arrival order differs from run to run, so the gradient of every MiniPointNet's
+// first convolution did) but STORED to a staging slot of its own: slot (16-query group, rank of
+// the seed inside the group's 48 sorted taps), 48 slots per group, `slot_seed` naming each slot's
+// seed (-1: unused).  A second kernel (blend_bwd_gather_kernel) owns one (scene, face, seed) per
+// wave and adds that seed's slots in ascending slot order, through the inverted index of slot_seed:
+// every d_table row is written once, in an order fixed by the taps alone.
+constexpr int BL_SLOTS = 48;   // staging slots per 16-query group (= its taps: the worst case)
+
+template <int CPT, bool BNB, bool STAGED>
 __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
     const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
     float *__restrict__ d_table, float *__restrict__ d_wx_part, int nb, int nruns,
-    const float *__restrict__ bnz, const float *__restrict__ bnb) {
+    const float *__restrict__ bnz, const float *__restrict__ bnb,
+    float *__restrict__ stage, int *__restrict__ slot_seed) {
   constexpr int C = CPT * 64;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
@@ -430,6 +440,21 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     float acc[CPT];
 #pragma unroll
     for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+    // STAGED: first slot of this wave's 16-query group, and the seeds emitted so far
+    const size_t gslot = STAGED ? ((size_t)((size_t)bi * segs + sg) * (per_seg / 16) + (r0 + q0) / 16) * BL_SLOTS : 0;
+    int rank = 0;
+    auto emit = [&]() {
+      if (STAGED) {
+        float *row = stage + (gslot + rank) * C + lane;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) row[e * 64] = acc[e];
+        if (lane == 0) slot_seed[gslot + rank] = cur;
+        ++rank;
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+      }
+    };
     for (int i0 = 0; i0 < 48; i0 += 8) {
       // phase A: eight taps' products, all loads independent (they overlap in the LDS queue)
       int seeds[8];
@@ -448,10 +473,7 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (seeds[i] != cur) {
-          if (cur >= 0) {
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
-          }
+          if (cur >= 0) emit();
           cur = seeds[i];
 #pragma unroll
           for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
@@ -460,8 +482,8 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
         for (int e = 0; e < CPT; ++e) acc[e] += x[i][e];
       }
     }
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+    emit();
+    if (STAGED && lane >= rank && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
   }
   if (d_wx_part) {
     // partial[b][run][s][c][3]: the four waves hold different queries of the same channels
@@ -476,6 +498,65 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     for (int i = threadIdx.x; i < C * 3; i += 256)
       dst[i] = (red[i] + red[C * 3 + i]) + (red[2 * C * 3 + i] + red[3 * C * 3 + i]);
   }
+}
+
+// Second half of the STAGED blend backward: one wave per (scene, face, seed).  (order, srcs) =
+// the inverted index of slot_seed per (scene, face) -- nesie_inverted_index's kernel with the seeds
+// as "source points" and the unused slots in an unranked bin of their own -- so order lists a
+// seed's staging slots in ASCENDING slot number.  The wave bisects srcs for its seed's run, adds
+// the rows (C floats each, dense 256-byte loads) in that order and writes the d_table row --
+// zeros for a seed no tap landed on: d_table needs no zero fill and meets no atomic.
+template <int CPT>
+__global__ __launch_bounds__(256) void blend_bwd_gather_kernel(
+    int m, int segs, int pitch, int seg_off, int slots_per_face, const float *__restrict__ stage,
+    const int *__restrict__ order, const int *__restrict__ srcs, float *__restrict__ d_table, int nb) {
+  constexpr int C = CPT * 64;
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long long)nb * segs * m) return;
+  const int seed = (int)(w % m), face = (int)((w / m) % (nb * segs));     // face = bi * segs + sg
+  const int bi = face / segs, sg = face % segs;
+  const int *sb = srcs + (size_t)face * slots_per_face, *ob = order + (size_t)face * slots_per_face;
+  int lo = 0, hi = slots_per_face;
+  while (lo < hi) {                                    // first sorted entry with source >= seed (uniform)
+    const int mid = (lo + hi) >> 1;
+    if (sb[mid] < seed) lo = mid + 1; else hi = mid;
+  }
+  int end = lo;
+  {
+    int l2 = lo, h2 = slots_per_face;
+    while (l2 < h2) {                                  // ... and the first with source > seed
+      const int mid = (l2 + h2) >> 1;
+      if (sb[mid] <= seed) l2 = mid + 1; else h2 = mid;
+    }
+    end = l2;
+  }
+  const float *base = stage + (size_t)face * slots_per_face * C + lane;
+  float acc[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+  int j = lo;
+  for (; j + 3 < end; j += 4) {                        // four rows in flight, added in order
+    float v[4][CPT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *row = base + (size_t)ob[j + u] * C;
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) v[u][e] = row[e * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) acc[e] += v[u][e];
+  }
+  for (; j < end; ++j) {
+    const float *row = base + (size_t)ob[j] * C;
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) acc[e] += row[e * 64];
+  }
+  float *dt = d_table + ((size_t)bi * m + seed) * pitch + (size_t)sg * seg_off + lane;
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) dt[e * 64] = acc[e];
 }
 
 // ---- blend + BatchNorm + ReLU fused by RECOMPUTATION ------------------------------------------
@@ -613,6 +694,9 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
     const float *__restrict__ fwd_coef, const float *__restrict__ bwd_coef,
     float *__restrict__ d_table, float *__restrict__ d_wx_part) {
   constexpr int C = CPT * 64;
+  constexpr bool STAGED = false;            // (this variant keeps the atomic rows: off the default path)
+  float *const stage = nullptr;
+  int *const slot_seed = nullptr;
   __shared__ float tile[C * (TS_Q + 1)];
   __shared__ int sj[TS_Q][3];
   __shared__ float sw[TS_Q][3];
@@ -697,6 +781,21 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
     float acc[CPT];
 #pragma unroll
     for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+    // STAGED: first slot of this wave's 16-query group, and the seeds emitted so far
+    const size_t gslot = STAGED ? ((size_t)((size_t)bi * segs + sg) * (per_seg / 16) + (r0 + q0) / 16) * BL_SLOTS : 0;
+    int rank = 0;
+    auto emit = [&]() {
+      if (STAGED) {
+        float *row = stage + (gslot + rank) * C + lane;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) row[e * 64] = acc[e];
+        if (lane == 0) slot_seed[gslot + rank] = cur;
+        ++rank;
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+      }
+    };
     for (int i0 = 0; i0 < 48; i0 += 8) {
       int seeds[8];
       float x[8][CPT];
@@ -713,10 +812,7 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (seeds[i] != cur) {
-          if (cur >= 0) {
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
-          }
+          if (cur >= 0) emit();
           cur = seeds[i];
 #pragma unroll
           for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
@@ -725,8 +821,8 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
         for (int e = 0; e < CPT; ++e) acc[e] += x[i][e];
       }
     }
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
+    emit();
+    if (STAGED && lane >= rank && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
   }
   if (d_wx_part) {
     __syncthreads();
@@ -867,10 +963,27 @@ extern "C" int nesie_blend_conv_runs(int n, int segs) {
   return segs >= 1 && n >= 0 ? cdiv(n / segs, BL_RUN) : 0;
 }
 
+// the inverted index of the staging slots (group_gather.hip)
+namespace nesie {
+int launch_inverted_index(int b, int n, long long e_total, const int *idx, int *order, int *sources,
+                          int *scratch, int n_ranked, hipStream_t s, int span);
+}
+
+// staging workspace of the STAGED backward: rows [b * segs * groups * 48][c] floats, then four int
+// arrays of b * segs * groups * 48 (slot_seed, order, srcs, scratch)
+static size_t blend_stage_slots(int b, int n, int segs) { return (size_t)b * (n / 16) * BL_SLOTS; }   // n / 16 groups in all
+
+extern "C" size_t nesie_blend_conv_backward_workspace_bytes(int b, int c, int n, int segs) {
+  if (b <= 0 || c <= 0 || n <= 0 || segs <= 0) return 0;
+  const size_t slots = blend_stage_slots(b, n, segs);
+  return slots * c * sizeof(float) + 4 * slots * sizeof(int);
+}
+
 static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, const float *dy,
                                     int pitch, int seg_off, const int *idx, const float *weight,
                                     const float *rel, float *d_table, float *d_wx, int segs,
-                                    int seg_len, const float *bnz, const float *bnb, void *stream) {
+                                    int seg_len, const float *bnz, const float *bnb, void *stream,
+                                    void *workspace = nullptr, size_t workspace_bytes = 0) {
   int st = blend_check(W, b, c, m, n, segs, seg_len, pitch, seg_off);
   if (st) return st;
   if (b == 0 || c == 0 || n == 0) return NESIE_OK;
@@ -885,20 +998,67 @@ static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, c
   const int nruns = cdiv(per_seg, BL_RUN);
   NESIE_REQUIRE((long long)nruns * b * segs < (1ll << 31), W);
   const dim3 grid((unsigned)(nruns * b * segs));
+  hipStream_t s = (hipStream_t)stream;
+  if (workspace) {   // STAGED: no float atomics, d_table written (not accumulated), reproducible
+    const size_t slots = blend_stage_slots(b, n, segs);
+    NESIE_REQUIRE(workspace_bytes >= nesie_blend_conv_backward_workspace_bytes(b, c, n, segs), W);
+    NESIE_REQUIRE(((uintptr_t)workspace & 15) == 0 && m + 1 <= 2048, W);     // (the stable index: <= 2048 bins)
+    const int slots_per_face = (per_seg / 16) * BL_SLOTS;
+    NESIE_REQUIRE((long long)slots_per_face < (1ll << 31) && (long long)b * segs * m < (1ll << 33), W);
+    float *stage = (float *)workspace;
+    int *slot_seed = (int *)(stage + slots * c), *order = slot_seed + slots, *srcs = order + slots,
+        *scratch = srcs + slots;
+#define LS(N)                                                                                      \
+  do {                                                                                             \
+    if (bnb)                                                                                       \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, true, true>), grid, dim3(256), 0, s,            \
+                         m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
+                         b, nruns, bnz, bnb, stage, slot_seed);                                    \
+    else                                                                                           \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, false, true>), grid, dim3(256), 0, s,           \
+                         m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
+                         b, nruns, bnz, bnb, stage, slot_seed);                                    \
+  } while (0)
+    if (c == 64) LS(1); else if (c == 128) LS(2); else if (c == 192) LS(3); else LS(4);
+#undef LS
+    // (scene, face) pairs are the "scenes" of the index; seeds 0 .. m - 1 ranked, bin m = unused slots
+    // (each group's BL_SLOTS slots hold distinct ascending seeds, then -1: the block-wise placement)
+    st = launch_inverted_index(b * segs, m + 1, slots_per_face, slot_seed, order, srcs, scratch, m, s, BL_SLOTS);
+    if (st) return st;
+    const long long waves = (long long)b * segs * m;
+#define LG(N) hipLaunchKernelGGL((blend_bwd_gather_kernel<N>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, \
+                                 m, segs, pitch, seg_off, slots_per_face, stage, order, srcs, d_table, b)
+    if (c == 64) LG(1); else if (c == 128) LG(2); else if (c == 192) LG(3); else LG(4);
+#undef LG
+    return check_launch(W);
+  }
 #define L(N)                                                                                       \
   do {                                                                                             \
     if (bnb)                                                                                       \
-      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, true, false>), grid, dim3(256), 0, s,           \
                          m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
-                         b, nruns, bnz, bnb);                                                      \
+                         b, nruns, bnz, bnb, (float *)nullptr, (int *)nullptr);                    \
     else                                                                                           \
-      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, \
+      hipLaunchKernelGGL((blend_bwd_rows_kernel<N, false, false>), grid, dim3(256), 0, s,          \
                          m, n, segs, seg_len, pitch, seg_off, dy, idx, weight, rel, d_table, d_wx, \
-                         b, nruns, bnz, bnb);                                                      \
+                         b, nruns, bnz, bnb, (float *)nullptr, (int *)nullptr);                    \
   } while (0)
   if (c == 64) L(1); else if (c == 128) L(2); else if (c == 192) L(3); else L(4);
 #undef L
   return check_launch(W);
+}
+
+// The same two entry points with the staging workspace: reproducible (no float atomics), d_table is
+// WRITTEN in full (no zero fill needed).  workspace = nesie_blend_conv_backward_workspace_bytes.
+extern "C" int nesie_blend_conv_backward_staged(int b, int c, int m, int n, const float *dy, const float *z,
+                                                const float *bnb, int pitch, int seg_off, const int *idx,
+                                                const float *weight, const float *rel, float *d_table,
+                                                float *d_wx, int segs, int seg_len, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+  const char *W = "blend_conv_backward_staged";
+  NESIE_REQUIRE(workspace && (z == nullptr) == (bnb == nullptr), W);
+  return blend_conv_backward_impl(W, b, c, m, n, dy, pitch, seg_off, idx, weight, rel, d_table, d_wx, segs,
+                                  seg_len, z, bnb, stream, workspace, workspace_bytes);
 }
 
 extern "C" int nesie_blend_conv_backward(int b, int c, int m, int n, const float *dy,

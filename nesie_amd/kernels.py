@@ -11,6 +11,7 @@ modules; every tensor must be contiguous; outputs are
 pre-allocated by the caller and written in place.
 """
 import contextlib
+import os
 
 import ctypes
 
@@ -493,12 +494,34 @@ class HipKernels(_BNPoolMixin):
                       _ptr(idx), _ptr(weight), opt(rel), opt(wx), _ptr(out), segs, seg_len,
                       int(out.shape[2]), c_offset, opt(stat_partial), _stream(table))
 
+    # Deterministic mode (NESIE_DETERMINISTIC=1 or ``set_deterministic(True)``): the blend backward --
+    # the one place where the step still adds floats with atomics -- stages its rows and gathers them
+    # per seed in a fixed order instead (nesie_blend_conv_backward_staged).  With it every gradient of
+    # a step is bitwise reproducible from run to run (tests/test_parity_gpu.py); it costs 0.25 ms of
+    # the 14.1 ms step (same-box A/B), so the default keeps the atomics, as the reference does
+    # everywhere (three_interpolate_cuda.cu:61-84, group_points_cuda.cu:10-31).
+    BLEND_STAGED = (os.environ.get('NESIE_DETERMINISTIC', '0') != '0'
+                    or os.environ.get('NESIE_BLEND_STAGED', '0') != '0')
+
+    @classmethod
+    def set_deterministic(cls, on=True):
+        """Bitwise-reproducible backward (see BLEND_STAGED); -> the previous setting."""
+        prev, cls.BLEND_STAGED = cls.BLEND_STAGED, bool(on)
+        return prev
+
+    def blend_backward_writes_table(self, c, n, segs, m):
+        """True when ``blend_conv_backward`` WRITES d_table in full (the staged form): the caller
+        then need not zero it."""
+        return self.BLEND_STAGED and c % 64 == 0 and c <= 256 and (n // segs) % 64 == 0 and m + 1 <= 2048
+
     def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len,
                             bn_z=None, bnb=None):
-        """dy (B, segs, c, n/segs); adds into d_table (B, M, pitch) columns [s*seg_off, +c)
-        (zeroed by the caller) and WRITES sum(dy x rel) to d_wx (segs, c, 3).  bn_z / bnb: dy is
-        the gradient of relu(bn(bn_z)) and the norm backward runs on the tile load
-        (nesie_blend_conv_backward_bn; bnb (segs*c, 8) from ``pw_bnb_coef``)."""
+        """dy (B, segs, c, n/segs) -> d_table (B, M, pitch) columns [s*seg_off, +c) and
+        sum(dy x rel) WRITTEN to d_wx (segs, c, 3).  bn_z / bnb: dy is the gradient of
+        relu(bn(bn_z)) and the norm backward runs on the tile load (bnb (segs*c, 8) from
+        ``pw_bnb_coef``).  Staged form (``blend_backward_writes_table``): no float atomics, d_table
+        written in full, bitwise reproducible (nesie_blend_conv_backward_staged); otherwise rows
+        are ADDED into d_table (zeroed by the caller) with atomics."""
         _check(dy, idx, weight, d_table); _f32(dy, weight, d_table); _i32(idx)
         b, m, pitch = d_table.shape
         n, c = idx.shape[1], dy.shape[2]
@@ -515,6 +538,14 @@ class HipKernels(_BNPoolMixin):
             if bnb is not None:
                 _check(bn_z, bnb); _f32(bn_z, bnb)
                 assert tuple(bn_z.shape) == tuple(dy.shape) and tuple(bnb.shape) == (segs * c, 8)
+            if self.blend_backward_writes_table(c, n, segs, m):
+                assert seg_off == c or segs == 1, 'staged form: one column block per face'
+                need = _lib.load().nesie_blend_conv_backward_workspace_bytes(b, c, n, segs)
+                ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
+                _lib.call("nesie_blend_conv_backward_staged", b, c, m, n, _ptr(dy), opt(bn_z), opt(bnb),
+                          pitch, seg_off, _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part),
+                          segs, seg_len, _ptr(ws), need, _stream(dy))
+            elif bnb is not None:
                 _lib.call("nesie_blend_conv_backward_bn", b, c, m, n, _ptr(dy), _ptr(bn_z), _ptr(bnb),
                           pitch, seg_off, _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part),
                           segs, seg_len, _stream(dy))
@@ -522,7 +553,7 @@ class HipKernels(_BNPoolMixin):
                 _lib.call("nesie_blend_conv_backward", b, c, m, n, _ptr(dy), pitch, seg_off,
                           _ptr(idx), _ptr(weight), opt(rel), _ptr(d_table), opt(part), segs, seg_len,
                           _stream(dy))
-            if part is not None:      # (d_wx arrives zero-filled from its caller: the sum overwrites it)
+            if part is not None:      # (d_wx arrives zero-filled or empty from its caller: the sum overwrites it)
                 torch.sum(part, 0, out=d_wx)
 
     def blend_conv_bn_forward(self, table, idx, weight, rel, wx, gamma, beta, running_mean,

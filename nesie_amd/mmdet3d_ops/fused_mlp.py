@@ -587,7 +587,8 @@ class BlendMiniHeadFn(Function):
         da0, part, dw3 = _mini_head_backward(backend, dc, dg, c0, coef0, arg, gamma0, w3, ctx.G,
                                              ctx.needs_input_grad[11], ctx.slots[2])
         dgamma, dbeta = _dst(ctx.slots[0], c0, S * H0), _dst(ctx.slots[1], c0, S * H0)
-        d_table = c0.new_zeros(b, m, pitch)
+        # (the staged backward writes every row; the atomic form adds into zeros)
+        d_table = (c0.new_empty if backend.blend_backward_writes_table(h, idx.shape[1], segs, m) else c0.new_zeros)(b, m, pitch)
         d_wx = c0.new_empty(segs, h, 3)          # (written, not accumulated)
         if FOLD_NORM_BWD:
             bnb = backend.pw_bnb_coef(part, coef0, gamma0, float(B) * float(P), dgamma, dbeta)

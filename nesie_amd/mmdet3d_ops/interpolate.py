@@ -126,7 +126,9 @@ class BlendConv(Function):
     def backward(ctx, dy, *unused):
         idx, weight, rel = ctx.saved_tensors
         segs, seg_len, b, m, pitch, h = ctx.dims
-        d_table = dy.new_zeros(b, m, pitch)
+        backend = backend_for(dy)
+        writes = getattr(backend, 'blend_backward_writes_table', lambda *a: False)(h, idx.shape[1], segs, m)
+        d_table = (dy.new_empty if writes else dy.new_zeros)(b, m, pitch)
         d_wx = dy.new_empty(segs, h, 3)          # (written, not accumulated)
         backend_for(dy).blend_conv_backward(dy.contiguous(), h, idx, weight, rel, d_table, d_wx,
                                             segs, seg_len)

@@ -347,6 +347,73 @@ def test_blend_conv_matches_oracle(oracle_kernels, hip_device, k, segs, g, h):
     torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(t1.grad.cpu(), t0.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(x1.grad.cpu(), x0.grad, rtol=1e-4, atol=2e-3)
+    # deterministic mode: the staged backward (no float atomics) -- same tolerance against the oracle,
+    # and a second evaluation gives the same bits
+    hip = kernels.backend_for(t1)
+    prev = hip.set_deterministic(True)
+    try:
+        assert hip.blend_backward_writes_table(h, idx.shape[1], segs, m)
+        res = []
+        for _ in range(2):
+            t2 = table.to(hip_device).requires_grad_(True)
+            x2 = wx.to(hip_device).requires_grad_(True)
+            ops.blend_conv(t2, x2, idx.to(hip_device), w.to(hip_device), rel.to(hip_device), segs, g).backward(go.to(hip_device))
+            res.append((t2.grad, x2.grad))
+    finally:
+        hip.set_deterministic(prev)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][0].cpu(), t0.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(res[0][1].cpu(), x0.grad, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("k,segs,g,h,hot", [(256, 6, 16, 256, 3), (128, 1, 64, 256, 1), (64, 6, 16, 128, 40)])
+def test_staged_blend_backward_is_reproducible_and_equals_the_atomic_form(hip_device, k, segs, g, h, hot):
+    """nesie_blend_conv_backward_staged with most taps on a few seeds (`hot`): a seed then collects
+    rows from hundreds of 16-query groups, other seeds none at all.  Three evaluations: same bits;
+    against a float64 scatter: rounding only; against the atomic form (NESIE_BLEND_STAGED=0's code
+    path, zero-filled table): summation order only; rows of seeds without taps are written as zeros
+    into a table that arrives full of NaN."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    prev = hip.set_deterministic(True)
+    try:
+        gen = torch.Generator().manual_seed(k + h)
+        b, m = 2, 96
+        n = k * segs * g
+        hot_idx = torch.randint(0, hot, (b, n, 3), generator=gen)
+        cold_idx = torch.randint(m // 2, m, (b, n, 3), generator=gen)
+        idx = torch.where(torch.rand(b, n, 3, generator=gen) < 0.7, hot_idx, cold_idx).int().to(hip_device)
+        w = torch.rand(b, n, 3, generator=gen).to(hip_device)
+        rel = torch.randn(b, n, 3, generator=gen).to(hip_device)
+        dy = torch.randn(b, segs, h, n // segs, generator=gen).to(hip_device)
+        outs = []
+        for _ in range(3):
+            d_table = torch.full((b, m, segs * h), float('nan'), device=hip_device)
+            d_wx = torch.empty(segs, h, 3, device=hip_device)
+            hip.blend_conv_backward(dy, h, idx, w, rel, d_table, d_wx, segs, g)
+            outs.append((d_table.clone(), d_wx.clone()))
+        assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
+        assert not torch.isnan(outs[0][0]).any()
+        # float64 scatter: query q of face s (output order s, k, g) <- taps of row (k * segs + s) * g + gi
+        want = torch.zeros(b, m, segs, h, dtype=torch.float64)
+        dyc = dy.double().cpu().view(b, segs, h, k, g)
+        idc = idx.cpu().long().view(b, k, segs, g, 3)
+        wc = w.double().cpu().view(b, k, segs, g, 3)
+        for bi in range(b):
+            for s_ in range(segs):
+                rows = idc[bi, :, s_].reshape(-1, 3)                           # (k * g, 3)
+                contrib = dyc[bi, s_].reshape(h, k * g).t().unsqueeze(1) * wc[bi, :, s_].reshape(-1, 3).unsqueeze(-1)
+                want[bi, :, s_].index_add_(0, rows.reshape(-1), contrib.reshape(-1, h))
+        err = (outs[0][0].double().cpu().view(b, m, segs, h) - want).abs().max().item()
+        assert err <= 3e-6 * want.abs().max().item(), err
+        assert float(outs[0][0][:, hot:m // 2].abs().max()) == 0.0          # seeds no tap landed on
+        hip.set_deterministic(False)
+        d_table = torch.zeros(b, m, segs * h, device=hip_device)
+        d_wx = torch.empty(segs, h, 3, device=hip_device)
+        hip.blend_conv_backward(dy, h, idx, w, rel, d_table, d_wx, segs, g)
+        torch.testing.assert_close(outs[0][0], d_table, rtol=1e-5, atol=1e-5 * float(d_table.abs().max()))
+        assert torch.equal(outs[0][1], d_wx)
+    finally:
+        hip.set_deterministic(prev)
 
 
 @pytest.mark.parametrize("mode", ["random", "identical", "disjoint", "aligned"])

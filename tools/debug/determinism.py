@@ -26,7 +26,11 @@ def main():
         for p in model.parameters():
             p.grad = None
         if workload == 'pretrain':
-            losses = model.forward_train(inp['points'], None, inp['gt'], None)
+            # (the index chain -- and with it the inverted indices of the scatter-adds -- ahead of the
+            # step, as bench.py's captured step has it)
+            pre = dict(indices=model.backbone.sample_and_group_indices(inp['points']),
+                       vote_targets=tuple(model.bbox_head.vote_targets_of(inp['points'], inp['gt'])))
+            losses = model.forward_train(inp['points'], None, inp['gt'], None, precomputed=pre)
         else:
             model.init_label_state(120, 1081, dev)
             losses = model.forward_train(inp['points_s'], inp['points_t'], inp['gt'], inp['use_label'],

@@ -9,6 +9,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 steps = sys.argv[1] if len(sys.argv) > 1 else '12'
 batch = sys.argv[2] if len(sys.argv) > 2 else '2'
 base = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'NESIE_FORCE_PG')}
+base['NESIE_DETERMINISTIC'] = os.environ.get('NESIE_DETERMINISTIC', '1')
 for name, extra, more in (('plain-a', {}, []), ('plain-b', {}, []), ('plain-eager', {}, ['--graph', '0']),
                           ('rccl', dict(NESIE_FORCE_PG='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541'), []),
                           ('rccl-eager', dict(NESIE_FORCE_PG='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29542'), ['--graph', '0'])):
