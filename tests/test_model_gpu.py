@@ -351,6 +351,28 @@ def test_fused_side_decode_matches_side2box(hip_device):
     torch.testing.assert_close(r1.grad, r2.grad, rtol=1e-4, atol=1e-5)
 
 
+def _run_children(cmd, env, timeout=300):
+    """subprocess.run(capture_output, text) for a bench.py launch that starts ranks of its own: the
+    whole process GROUP is killed on a time-out (a hung rank must not outlive the test holding the
+    GPU), and the time-out is short enough for the suite to report it instead of going silent."""
+    import os
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = proc.communicate()
+        raise AssertionError(f'{" ".join(cmd[-8:])} did not finish within {timeout} s; stderr tail: {err[-1500:]}')
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+
 def test_two_rank_step_rehearsal_on_one_gpu():
     """bench.py's N > 1 path end to end (graphs, pipelined index chain, flat gradient
     all-reduce between the two graphs, fused AdamW) with two ranks sharing this GPU; gloo stands
@@ -361,11 +383,10 @@ def test_two_rank_step_rehearsal_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NESIE_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
-    out = subprocess.run(
+    out = _run_children(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
          '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
-         '--gpus', '2', '--steps', '2', '--warmup', '1', '--cpu-baseline', '0'],
-        env=env, capture_output=True, text=True, timeout=600)
+         '--gpus', '2', '--steps', '2', '--warmup', '1', '--cpu-baseline', '0'], env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]            # rank 0 prints ONE line
@@ -388,10 +409,9 @@ def test_bare_bench_command_starts_its_own_ranks(workload, batch):
     env = {k: v for k, v in os.environ.items()
            if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     env['NESIE_DIST_BACKEND'] = 'gloo'
-    out = subprocess.run(
+    out = _run_children(
         [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
-         '1', '--cpu-baseline', '0', '--workload', workload, '--batch', str(batch)],
-        env=env, capture_output=True, text=True, timeout=900)
+         '1', '--cpu-baseline', '0', '--workload', workload, '--batch', str(batch)], env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -425,10 +445,10 @@ def test_rccl_all_reduce_runs_between_the_graph_replays_on_one_gpu():
     runs = {}
     for name, extra in (('plain', {}), ('rccl', dict(NESIE_FORCE_PG='1', MASTER_ADDR='127.0.0.1',
                                                      MASTER_PORT='29541'))):
-        out = subprocess.run(
+        out = _run_children(
             [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '47', '--warmup', '3',
              '--batch', '2', '--cpu-baseline', '0', '--parity-gate', '0', '--loss-trace', '1'],
-            env=dict(base, **extra), capture_output=True, text=True, timeout=900)
+            dict(base, **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
         assert len(lines) == 1, out.stdout[-2000:]
