@@ -490,12 +490,21 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     # thread_local: a process group's watchdog thread may query events while this thread captures
     mode = dict(capture_error_mode='thread_local')
-    with torch.cuda.graph(g1a, **mode):
-        phase1(current_indices())
-    with torch.cuda.graph(g1b, pool=g1a.pool(), **mode):
-        phase2()
-    with torch.cuda.graph(g2, pool=g1a.pool(), **mode):
-        update()
+    # one rank (no exchange between the phases): the whole step is ONE graph -- two replay boundaries
+    # less per step (NESIE_ONE_GRAPH=0: keep the three graphs of the multi-rank form, A/B)
+    one_graph = not comm.active and os.environ.get('NESIE_ONE_GRAPH', '1') != '0'
+    if one_graph:
+        with torch.cuda.graph(g1a, **mode):
+            phase1(current_indices())
+            phase2()
+            update()
+    else:
+        with torch.cuda.graph(g1a, **mode):
+            phase1(current_indices())
+        with torch.cuda.graph(g1b, pool=g1a.pool(), **mode):
+            phase2()
+        with torch.cuda.graph(g2, pool=g1a.pool(), **mode):
+            update()
     stage('step graphs captured')
     if pipelined:
         g_idx = torch.cuda.CUDAGraph()
@@ -525,6 +534,12 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                 ready.record(side)
         stage('input graph launched for the next step')
         comm.steps += 1
+        if one_graph:
+            if hasattr(opt, 'sync_hyper'):
+                opt.sync_hyper()     # a scheduler's new lr / wd reaches the captured update
+            g1a.replay()             # forward + backward + update
+            stage('step graph replayed')
+            return loss_out
         g1a.replay()                 # forward + head backward
         comm.launch(e_bb, e_all)     # the head's gradients travel ...
         g1b.replay()                 # ... while the backbone's backward computes
@@ -537,6 +552,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         stage('update graph replayed')
         return loss_out
     graph_step.eager = eager_step
+    graph_step.graphs_per_step = 1 if one_graph else 3
     graph_step.inputs, graph_step.optimizer, graph_step.comm = inputs, opt, comm
     return model, graph_step, bucket
 
@@ -789,6 +805,7 @@ def main():
                        # graph + backbone segment after it; 0 without a process group)
                        'collectives_per_step': step.comm.collectives / max(1, step.comm.steps),
                        'hip_graph': bool(args.graph),
+                       'graphs_per_step': getattr(step, 'graphs_per_step', None),
                        'index_chain_pipelined': bool(args.graph),
                        'grad_allreduce_bytes': bucket.nbytes(),
                        'grad_allreduce': 'two segments on a communication stream: head gradients '
