@@ -146,6 +146,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   constexpr int ROWS = MT + NT, PASSES = ROWS / 16;
   const bool vec = vec_ok != 0;  // float4 rows: p, batch stride and both bases 16-byte aligned
   float4 v[PASSES];
+#pragma unroll
+  for (int u = 0; u < PASSES; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_tile = [&](long long q0) {
     const long long q = q0 + (tid & 15) * 4;
     if (vec && q0 + WG_Q <= p1) {
@@ -155,6 +157,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
       for (int u = 0; u < PASSES; ++u) {
         const bool is_a = u * 16 < MT;                      // compile-time per pass
+        // a pass whose 16 rows all lie beyond Cin (Cin = 4 padded to 64 rows: three of four X
+        // passes) loads nothing: its LDS rows were zeroed once (a wave-uniform test)
+        if (!is_a && u * 16 - MT >= cin) continue;
         const int row = u * 16 + (tid >> 4) - (is_a ? 0 : MT);
         const int lim = is_a ? cout : cin;
         const int rr = row < lim ? row : lim - 1;
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
     for (int u = 0; u < PASSES; ++u) {
       const int r = u * 16 + (tid >> 4);
+      if (u * 16 >= MT && u * 16 - MT >= cin && q0 != p0) continue;     // (stays zero: written by the first tile)
       float *dst = (r < MT ? sa + r * WG_P : sb + (r - MT) * WG_P) + (tid & 15) * 4;
       *(float4 *)dst = v[u];
     }

@@ -60,7 +60,11 @@ class ReliableConvBboxHead(nn.Module):
         (Round 3 also ran the three output convolutions as one stacked 220-row layer inside the
         chain.  Values and gradients matched, but a step captured in a hipGraph with that layer
         aborted on replay while every launch of it replays fine on its own
-        (tools/debug/graph_ops.py, graph_bisect.py); not understood, so not shipped.)"""
+        (tools/debug/graph_ops.py, graph_bisect.py); not understood, so not shipped.  Round 4: the
+        220-row layer -- forward, input gradient, weight gradient -- between canaries, eager and in a
+        replayed graph of its own, touches nothing outside its buffers and equals float64
+        (tests/test_pwconv_gpu.py::test_ragged_220_row_output_layer_stays_inside_its_buffers): the
+        kernels' ragged-row guards are not the cause.)"""
         from ..kernels import backend_for
         from ..mmdet3d_ops import fused_mlp
         if (len(self.cls_conv_channels) or len(self.bbox_conv_channels) or len(self.heading_conv_channels)

@@ -645,3 +645,59 @@ def test_eval_mode_sa_stack_matches_the_module_by_module_path(c_in, mlp, ns):
                 m.running_mean.add_(0.25)
         again = sa(xyz, feats)[1]
     assert (again - outs[1]).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize('captured', [False, True])
+def test_ragged_220_row_output_layer_stays_inside_its_buffers(captured):
+    """The prediction head's three output convolutions stacked as ONE 220-row layer (20 + 198 + 2,
+    K = 128, 8 x 256 proposals) -- the form whose captured step aborted on replay in round 3 without
+    a root cause (bbox_module._fused).  Every buffer the launch touches sits between canaries:
+    input, weights, bias, output, and the input-gradient / weight-gradient launches of the same
+    shape; eager and inside a hipGraph replayed three times.  No canary may change and the values
+    must equal float64."""
+    hip = _hip()
+    dev = _dev()
+    nb, k, cout, p = 8, 128, 220, 256
+    g = torch.Generator(device=dev).manual_seed(220)
+    CAN = 4096
+
+    def guarded(*shape):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        buf = torch.full((n + 2 * CAN,), 12345.678, device=dev)
+        return buf, buf[CAN:CAN + n].view(*shape)
+    xb, x = guarded(nb, k, p)
+    wb, w = guarded(1, cout, k)
+    bb, bias = guarded(cout)
+    yb, y = guarded(nb, cout, p)
+    dxb, dx = guarded(nb, k, p)
+    dwb, dw = guarded(1, cout, k)
+    x.copy_(torch.randn(nb, k, p, device=dev, generator=g))
+    w.copy_(torch.randn(1, cout, k, device=dev, generator=g) / k ** 0.5)
+    bias.copy_(torch.randn(cout, device=dev, generator=g))
+    dy = torch.randn(nb, cout, p, device=dev, generator=g)
+
+    def launches():
+        hip.pw_layer_forward(x, w, y=y, bias=bias)
+        hip.pw_layer_forward(dy, w.transpose(1, 2), y=dx)
+        hip.pw_wgrad(dy, x, dw, x_coef=None)
+    launches()
+    torch.cuda.synchronize()
+    if captured:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            launches()
+        for _ in range(3):
+            y.zero_(); dx.zero_(); dw.zero_()
+            gr.replay()
+        torch.cuda.synchronize()
+    for name, buf, view in (('x', xb, x), ('w', wb, w), ('bias', bb, bias), ('y', yb, y), ('dx', dxb, dx), ('dw', dwb, dw)):
+        n = view.numel()
+        assert bool((buf[:CAN] == 12345.678).all()) and bool((buf[CAN + n:] == 12345.678).all()), name
+    ref = torch.matmul(w[0].double(), x.double()) + bias.double().view(1, -1, 1)
+    assert (y.double() - ref).abs().max().item() < 3e-5
+    ref_dx = torch.matmul(w[0].double().t(), dy.double())
+    assert (dx.double() - ref_dx).abs().max().item() < 3e-5 * max(1.0, ref_dx.abs().max().item())
+    ref_dw = torch.bmm(dy.double(), x.double().transpose(1, 2)).sum(0)
+    assert (dw[0].double() - ref_dw).abs().max().item() < 1e-4 * ref_dw.abs().max().item()
