@@ -551,6 +551,47 @@ int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, i
                          const float *pmax, const float *pmin, const uint8_t *amax,
                          const uint8_t *amin, const float *coef, int relu, float *pooled,
                          uint8_t *argmax, void *stream);
+/* ... also leaving the raw extremum each pooled value came from, zstar (nb, channels, p / group). */
+int nesie_pw_pool_finish_z(int nb, int ng, int channels, long long p, int group, int pool_group,
+                           const float *pmax, const float *pmin, const uint8_t *amax,
+                           const uint8_t *amin, const float *coef, int relu, float *pooled,
+                           uint8_t *argmax, float *zstar, void *stream);
+
+/* Backward of a POOLED TAIL -- last 1x1 conv (k -> c, bias-free) + training-mode BatchNorm + ReLU +
+ * max over the ns samples of every group (PointSAModule's shared MLP and _pool_features,
+ * point_sa_module.py:136-158, 277-289; autograd's max_pool2d / relu / batch_norm / conv2d backward
+ * chain in the reference) -- without the dense pre-pool tensor: the forward keeps only pooled,
+ * argmax and zstar, and with dZ = ghat + alpha + beta Z (per channel; ghat the pooled gradient at
+ * the arg-max, one non-zero per channel and group)
+ *   dA = W^T ghat + W^T alpha + (W^T diag(beta) W) A,   dW = sum ghat A^T + alpha s^T + diag(beta) W M,
+ *   s = sum A, M = sum A A^T,  A = relu(coef_prev . z_prev) the layer's operand (k, p) per batch element.
+ * nesie_pool_tail_supported: 1 when (k, c, p, ns) is built (k = 64, c = 128, ns in {16, 32, 64}).
+ * nesie_pool_tail_sizes: out[0] = reduction slots of the input-gradient launch (bn_part [k][out[0]][2]),
+ *   out[1] = partials of the weight-gradient pass.
+ * nesie_pool_tail_prepare: dgamma, dbeta [c] (written); ab [c][4] = (alpha, beta, gamma invstd, -);
+ *   ent [nb][m][c][2] = (masked pooled gradient, arg-max position as int bits);
+ *   wcat [k][c + k] = [W^T diag(gamma invstd) | W^T diag(beta) W]; c0 [k] = W^T alpha.
+ *   grad_pooled / pooled / zstar / argmax (nb, c, m); coef [c][4] = (scale, bias, mean, invstd) of
+ *   this layer's norm; w (c, k) row-major.
+ * nesie_pool_tail_dgrad: da (nb, k, p) = gradient of A, and in bn_part the two sums of the
+ *   PREVIOUS layer's norm backward (as nesie_pw_dgrad_bn_reduce leaves them).
+ * nesie_pool_tail_wgrad: dw (c, k) written; part_m [out[1]][k][k], part_s [out[1]][k],
+ *   part_w [out[1]][c][k], ms [k k + k] doubles are scratch. */
+int nesie_pool_tail_supported(int k, int c, long long p, int ns);
+int nesie_pool_tail_sizes(int nb, int k, int c, long long p, int *out);
+int nesie_pool_tail_prepare(int nb, int c, int m, int ns, int k, const float *grad_pooled,
+                            const float *pooled, const float *zstar, const uint8_t *argmax,
+                            const float *coef, const float *gamma, const float *w, float *dgamma,
+                            float *dbeta, float *ab, float *ent, float *wcat, float *c0,
+                            void *stream);
+int nesie_pool_tail_dgrad(int nb, int k, int c, long long p, int ns, const float *z_prev,
+                          long long z_bstride, const float *coef_prev, const float *wcat,
+                          const float *c0, const float *ent, float *da, long long da_bstride,
+                          float *bn_part, void *stream);
+int nesie_pool_tail_wgrad(int nb, int k, int c, long long p, int ns, const float *z_prev,
+                          long long z_bstride, const float *coef_prev, const float *ent,
+                          const float *ab, const float *w, float *part_m, float *part_s,
+                          float *part_w, double *ms, float *dw, void *stream);
 
 /* Weight gradient of the same layers: dw[g][co][ci] = sum over the batches n of group g (n % ng
  * == g) and all positions of dy[n][co][pos] * act(x[n][ci][pos]), act as in

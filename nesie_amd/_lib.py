@@ -111,6 +111,13 @@ SIGNATURES = {
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "nesie_pw_pool_finish": [_I, _I, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P,
                              _P],
+    "nesie_pw_pool_finish_z": [_I, _I, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P,
+                               _P, _P],
+    "nesie_pool_tail_sizes": [_I, _I, _I, ctypes.c_longlong, _P],
+    "nesie_pool_tail_prepare": [_I, _I, _I, _I, _I] + [_P] * 14,
+    "nesie_pool_tail_dgrad": [_I, _I, _I, ctypes.c_longlong, _I, _P, ctypes.c_longlong, _P, _P, _P, _P,
+                              _P, ctypes.c_longlong, _P, _P],
+    "nesie_pool_tail_wgrad": [_I, _I, _I, ctypes.c_longlong, _I, _P, ctypes.c_longlong] + [_P] * 10,
     "nesie_bn_relu_forward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
                               _P, _P, _P, _I, _P, _I, _P, ctypes.c_size_t, _P],
     "nesie_bn_relu_backward": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
@@ -167,6 +174,8 @@ def load():
     lib.nesie_pw_supported.restype = _I
     lib.nesie_pw_stat_slots.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
     lib.nesie_pw_stat_slots.restype = _I
+    lib.nesie_pool_tail_supported.argtypes = [_I, _I, ctypes.c_longlong, _I]
+    lib.nesie_pool_tail_supported.restype = _I
     lib.nesie_abi_version.restype = _I
     lib.nesie_set_distance_form.argtypes = [_I]
     lib.nesie_set_distance_form.restype = _I

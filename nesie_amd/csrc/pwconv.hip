@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(
     long long total, int channels, int ng, int groups, int nsub, int pg, const float *__restrict__ pmax,
     const float *__restrict__ pmin, const uint8_t *__restrict__ amax,
     const uint8_t *__restrict__ amin, const float *__restrict__ coef, float lo,
-    float *__restrict__ pooled, uint8_t *__restrict__ arg) {
+    float *__restrict__ pooled, uint8_t *__restrict__ arg, float *__restrict__ zstar) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (row, group)
   if (i >= total) return;
   const long long row = i / groups;
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void pw_pool_finish_kernel(
   }
   pooled[i] = coef ? fmaxf(__builtin_fmaf(e, sc, bi), lo) : e;
   arg[i] = (uint8_t)at;
+  if (zstar) zstar[i] = e;      // the raw extremum (a pooled tail's backward needs its zhat)
 }
 
 // tile geometry of a (K, Cout) layer
@@ -306,10 +307,10 @@ extern "C" int nesie_pw_stats_finalize(int channels, int cout, int nslots, const
   return check_launch(W);
 }
 
-extern "C" int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, int pool_group,
-                                    const float *pmax, const float *pmin, const uint8_t *amax,
-                                    const uint8_t *amin, const float *coef, int relu,
-                                    float *pooled, uint8_t *argmax, void *stream) {
+static int pw_pool_finish_impl(int nb, int ng, int channels, long long p, int group, int pool_group,
+                               const float *pmax, const float *pmin, const uint8_t *amax,
+                               const uint8_t *amin, const float *coef, int relu,
+                               float *pooled, uint8_t *argmax, float *zstar, void *stream) {
   const char *W = "pw_pool_finish";
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && channels >= 1 && p >= 0 && group >= 1, W);
   if (nb == 0 || p == 0) return NESIE_OK;
@@ -318,6 +319,24 @@ extern "C" int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, i
   const long long total = (long long)nb * channels * (p / group);
   hipLaunchKernelGGL(pw_pool_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      total, channels, ng, (int)(p / group), group / pool_group, pool_group, pmax, pmin,
-                     amax, amin, coef, relu ? 0.f : -__builtin_inff(), pooled, argmax);
+                     amax, amin, coef, relu ? 0.f : -__builtin_inff(), pooled, argmax, zstar);
   return check_launch(W);
+}
+
+extern "C" int nesie_pw_pool_finish(int nb, int ng, int channels, long long p, int group, int pool_group,
+                                    const float *pmax, const float *pmin, const uint8_t *amax,
+                                    const uint8_t *amin, const float *coef, int relu,
+                                    float *pooled, uint8_t *argmax, void *stream) {
+  return pw_pool_finish_impl(nb, ng, channels, p, group, pool_group, pmax, pmin, amax, amin, coef, relu,
+                             pooled, argmax, nullptr, stream);
+}
+
+// ... and the raw extremum each pooled value came from (nb, channels, p / group)
+extern "C" int nesie_pw_pool_finish_z(int nb, int ng, int channels, long long p, int group, int pool_group,
+                                      const float *pmax, const float *pmin, const uint8_t *amax,
+                                      const uint8_t *amin, const float *coef, int relu,
+                                      float *pooled, uint8_t *argmax, float *zstar, void *stream) {
+  NESIE_REQUIRE(zstar, "pw_pool_finish_z");
+  return pw_pool_finish_impl(nb, ng, channels, p, group, pool_group, pmax, pmin, amax, amin, coef, relu,
+                             pooled, argmax, zstar, stream);
 }

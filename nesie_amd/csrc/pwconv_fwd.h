@@ -130,6 +130,12 @@ enum : int {
   PW_BIAS = 32,     // Y += bias[m]
   PW_AFFINE = 64,   // operand = max(scale * x + bias, lo)
   PW_BNRED = 128,   // Y is the gradient of relu(bn(Z)): partial sums of g = Y [bn(Z) > 0] and g * zhat
+  // The first SPC = 128 / 256 operand rows are not loaded but BUILT: row c holds one value per group
+  // of ns positions, sp_ent[n][group][c] = (value, position inside the group), zero elsewhere -- the
+  // gradient a max-pool hands back (input gradient of a pooled tail, pool_tail.hip).  The loaded
+  // operand (x, in_coef) supplies rows SPC .. K - 1; K = KH * KT exactly.
+  PW_SPARSE128 = 256,
+  PW_SPARSE256 = 512,
 };
 
 struct PwFwd {
@@ -145,6 +151,7 @@ struct PwFwd {
   const float *bn_coef; float *bn_part;    // ... its [ng * cout][4] (scale, bias, mean, invstd); [ng * cout][nslots][2]
   int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout
   int xcd_map;         // the nhalf workgroups of a tile stream sit on ONE XCD (grid % (8 nhalf) == 0)
+  const float2 *sp_ent; int sp_ns_shift, sp_groups;   // PW_SPARSE*: entries, log2(ns), groups per batch element
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -194,6 +201,8 @@ void pw_fwd_kernel(const PwFwd a) {
   constexpr bool EVEN = NCH == NX * NT;
   constexpr int ROWSTEP = NT / CPR;                      // rows between two slots of a thread
   constexpr int CROWS = WR * RW * 16;                    // output rows per workgroup
+  constexpr int SPC = (EPI & PW_SPARSE128) ? 128 : (EPI & PW_SPARSE256) ? 256 : 0;   // built operand rows
+  static_assert(SPC % ROWSTEP == 0 && (SPC == 0 || (NCH == NX * NT && SPC < KH * KT)), "sparse rows");
   static_assert(NT % CPR == 0 && (PG == 16 || PG == 32), "tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   STAMP_WG(0)
@@ -269,9 +278,14 @@ void pw_fwd_kernel(const PwFwd a) {
       for (int i = 0; i < NX; ++i) {
         int row = kh * KT + slot_row(i) + srow;
         row = row < k ? row : k - 1;
-        cof[kh][i] = *(const float2 *)(a.in_coef + ((size_t)g * k + row) * 4);
+        if (SPC > 0) row = row >= SPC ? row - SPC : 0;   // (slots of built rows never use theirs)
+        cof[kh][i] = *(const float2 *)(a.in_coef + ((size_t)g * (k - SPC) + row) * 4);
       }
   }
+  // built rows: entry of (group of this lane's 16-byte chunk, row srow) relative to the tile's first
+  // group and the slot's first row; and the chunk's first position inside its group
+  const unsigned sp_voff = SPC > 0 ? (unsigned)(((((4 * scol) >> a.sp_ns_shift) * SPC) + srow) * 8) : 0u;
+  const int sp_pos0 = SPC > 0 ? ((4 * scol) & ((1 << a.sp_ns_shift) - 1)) : 0;
   const int tpb = a.tiles_per_batch, nwg = a.nwg_g;
   const int ntiles = (a.nb / a.ng) * tpb;
 
@@ -302,7 +316,16 @@ void pw_fwd_kernel(const PwFwd a) {
   // the sub-tile does not exist, read the first words of the tensor instead
   auto load_slot = [&](auto ic, auto khc, const Cursor &c, bool live) {
     constexpr int i = decltype(ic)::value, kh = decltype(khc)::value;
-    const float *xb = a.x + (size_t)(g + a.ng * c.q) * a.x_bs + (size_t)c.r * PT + (size_t)(kh * KT) * p;
+    if constexpr (SPC > 0 && kh * KT + slot_row(i) < SPC) {
+      // wave-uniform: first entry of the tile's first group, row kh KT + slot_row(i)
+      const float2 *eb = a.sp_ent + ((size_t)(g + a.ng * c.q) * a.sp_groups + (size_t)(((long long)c.r * PT) >> a.sp_ns_shift)) * SPC
+                         + (kh * KT + slot_row(i));
+      const float2 e = *(const float2 *)((const char *)(live ? eb : a.sp_ent) + (live ? sp_voff : 0u));
+      stg[i][0] = e.x;
+      stg[i][1] = e.y;
+      return;
+    }
+    const float *xb = a.x + (size_t)(g + a.ng * c.q) * a.x_bs + (size_t)c.r * PT + (long long)(kh * KT - SPC) * p;
     if constexpr (kh < KH - 1) {
       const float *xs = live ? xb + (size_t)slot_row(i) * p : a.x;   // wave-uniform
       stg[i] = load16_saddr(live ? voff0 : 0u, xs);
@@ -314,7 +337,14 @@ void pw_fwd_kernel(const PwFwd a) {
   auto write_slot = [&](auto ic, auto khc, int buf) {
     constexpr int i = decltype(ic)::value;
     f32x4 q = stg[i];
-    if constexpr ((EPI & PW_AFFINE) != 0) {
+    if constexpr (SPC > 0 && decltype(khc)::value * KT + slot_row(i) < SPC) {
+      const int at = __float_as_int(q[1]) - sp_pos0;
+      const float v = q[0];
+      q[0] = at == 0 ? v : 0.f;
+      q[1] = at == 1 ? v : 0.f;
+      q[2] = at == 2 ? v : 0.f;
+      q[3] = at == 3 ? v : 0.f;
+    } else if constexpr ((EPI & PW_AFFINE) != 0) {
       const float2 co = cof[decltype(khc)::value][i];
       const float lo = a.in_lo;
       q[0] = fmaxf(__builtin_fmaf(q[0], co.x, co.y), lo);
@@ -340,7 +370,9 @@ void pw_fwd_kernel(const PwFwd a) {
   // pwbench stamps).  A pooled tail WITHOUT a store keeps the identity order: position 16 quad + 4 r + e,
   // the lane's 16 values ARE a pooling group; with a store the four quads of a channel share every
   // group and reduce it with two cross-lane exchanges.
-  constexpr bool PERM = !(EPI & PW_POOL) || (EPI & PW_STORE);   // (a pooled tail that stores nothing keeps lane-local groups)
+  // (a pooled tail that stores nothing keeps lane-local groups -- unless it also leaves statistics:
+  // SA tails, whose sums then run in the order of the storing variant, bit for bit)
+  constexpr bool PERM = !(EPI & PW_POOL) || (EPI & (PW_STORE | PW_STATS));
   constexpr int RS = PERM ? 16 : 4;           // positions between accumulator registers r and r + 1
   const int q0 = wc * 64 + (PERM ? 4 : 16) * quad;   // this lane's first position inside a tile
   // byte offset of (row m, position q0) from the tile's first output word, per row set
@@ -724,6 +756,8 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
     if (base == PW_POOL && pg == 16) GOW(PW_AFFINE | PW_POOL, 16);
     if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16)
       GOW(PW_AFFINE | PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
+    if (base == (PW_STATS | PW_POOL | PW_POOLMIN) && pg == 16) GOW(PW_AFFINE | PW_STATS | PW_POOL | PW_POOLMIN, 16);
+    if (base == (PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32) GOW(PW_AFFINE | PW_STATS | PW_POOL | PW_POOLMIN, 32);
     if (base == (PW_STORE | PW_POOL) && pg == 32) GOW(PW_AFFINE | PW_STORE | PW_POOL, 32);
     if (base == PW_POOL && pg == 32) GOW(PW_AFFINE | PW_POOL, 32);
     if (base == (PW_STORE | PW_STATS | PW_POOL | PW_POOLMIN) && pg == 32)
@@ -741,6 +775,19 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
 #undef GO
 #undef GOW
 #undef GO1
+}
+
+// the one prologue / epilogue combination of a pooled tail's input gradient (built operand rows)
+template <int KT16, int KH, int WR, int WC, int RW, int SPBIT>
+static int pw_launch_sparse(const PwFwd &a, int grid, size_t lds, hipStream_t s) {
+  auto kern = pw_fwd_kernel<KT16, KH, WR, WC, RW, PW_STORE | PW_BIAS | PW_AFFINE | PW_BNRED | SPBIT, 16, false>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WR * WC * 64), lds, s, a);
+  return NESIE_OK;
 }
 
 #define PW_GEOM_NAME(KT16, KH, WR, WC, RW) pw_launch_##KT16##_##KH##_##WR##_##WC##_##RW

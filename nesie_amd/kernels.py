@@ -1157,18 +1157,68 @@ class HipKernels(_BNPoolMixin):
                       opt(beta), opt(running_mean), opt(running_var), float(momentum), float(eps),
                       _ptr(coef), opt(chan_bias), _stream(coef))
 
-    def pw_pool_finish(self, ng, p, group, pool_group, pool_out, coef, relu, pooled, argmax):
+    def pw_pool_finish(self, ng, p, group, pool_group, pool_out, coef, relu, pooled, argmax, zstar=None):
         """partial extrema (NB, C, P / pool_group) -> pooled (NB, C, P / group) float,
-        argmax uint8 (position inside the group)."""
+        argmax uint8 (position inside the group); zstar (optional, like pooled): the raw extremum."""
         pmax, pmin, amax, amin = pool_out
         _check(pmax, amax, pooled, argmax); _f32(pmax, pooled)
         nb, c = pooled.shape[:2]
         assert pooled.numel() == nb * c * (p // group) and argmax.dtype == torch.uint8
         opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
         with torch.cuda.device(pooled.device):
+            if zstar is not None:
+                _check(zstar); _f32(zstar)
+                assert zstar.numel() == pooled.numel()
+                _lib.call("nesie_pw_pool_finish_z", nb, ng, c, p, group, pool_group, _ptr(pmax), opt(pmin),
+                          _ptr(amax), opt(amin), opt(coef), int(bool(relu)), _ptr(pooled),
+                          _ptr(argmax), _ptr(zstar), _stream(pooled))
+                return
             _lib.call("nesie_pw_pool_finish", nb, ng, c, p, group, pool_group, _ptr(pmax), opt(pmin),
                       _ptr(amax), opt(amin), opt(coef), int(bool(relu)), _ptr(pooled),
                       _ptr(argmax), _stream(pooled))
+
+    # ---- pooled tail without the dense pre-pool tensor (csrc/pool_tail.hip) ---------------------
+    def pool_tail_supported(self, k, c, p, ns):
+        return bool(_lib.load().nesie_pool_tail_supported(int(k), int(c), int(p), int(ns)))
+
+    def pool_tail_backward(self, g, pooled, zstar, argmax, coef, gamma, w, z_prev, coef_prev, ns,
+                           dgamma, dbeta, dw=None):
+        """Backward of conv (k -> c) + BatchNorm + ReLU + max over groups of ``ns`` positions from
+        the pooled gradient g (NB, C, M), what the forward kept (pooled, zstar, argmax (NB, C, M),
+        coef (C, 4)) and the layer's operand in raw form (z_prev (NB, K, P) with its folded
+        coefficients coef_prev (K, 4)).  Writes dgamma, dbeta (C,) and dw (C, K) (None: skipped);
+        returns (da (NB, K, P), partials of the previous norm's backward (K, slots, 2))."""
+        _check(g, pooled, zstar, argmax, coef, gamma, w, z_prev, coef_prev, dgamma, dbeta)
+        _f32(g, pooled, zstar, coef, gamma, w, z_prev, coef_prev, dgamma, dbeta)
+        nb, c, m = g.shape
+        k, p = z_prev.shape[1], z_prev.shape[2]
+        assert tuple(z_prev.shape) == (nb, k, p) and p == m * ns and tuple(w.shape) == (c, k)
+        assert argmax.dtype == torch.uint8 and tuple(coef.shape) == (c, 4) and tuple(coef_prev.shape) == (k, 4)
+        assert z_prev.stride(2) == 1 and z_prev.stride(1) == p
+        dev = g.device
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        sizes = (ctypes.c_int * 2)()
+        _lib.call("nesie_pool_tail_sizes", nb, k, c, p, ctypes.addressof(sizes))
+        nslots, nparts = int(sizes[0]), int(sizes[1])
+        ab, ent, wcat, c0 = f(c, 4), f(nb, m, c, 2), f(k, c + k), f(k)
+        da, part = f(nb, k, p), f(k, nslots, 2)
+        zbs = z_prev.stride(0) if nb > 1 else k * p
+        with torch.cuda.device(dev):
+            st = _stream(g)
+            _lib.call("nesie_pool_tail_prepare", nb, c, m, ns, k, _ptr(g), _ptr(pooled), _ptr(zstar),
+                      _ptr(argmax), _ptr(coef), _ptr(gamma), _ptr(w), _ptr(dgamma), _ptr(dbeta),
+                      _ptr(ab), _ptr(ent), _ptr(wcat), _ptr(c0), st)
+            _lib.call("nesie_pool_tail_dgrad", nb, k, c, p, ns, _ptr(z_prev), zbs, _ptr(coef_prev),
+                      _ptr(wcat), _ptr(c0), _ptr(ent), _ptr(da), k * p, _ptr(part), st)
+            if dw is not None:
+                _check(dw); _f32(dw)
+                assert dw.numel() == c * k
+                part_m, part_s, part_w = f(nparts, k, k), f(nparts, k), f(nparts, c, k)
+                ms = torch.empty(k * k + k, dtype=torch.float64, device=dev)
+                _lib.call("nesie_pool_tail_wgrad", nb, k, c, p, ns, _ptr(z_prev), zbs, _ptr(coef_prev),
+                          _ptr(ent), _ptr(ab), _ptr(w), _ptr(part_m), _ptr(part_s), _ptr(part_w),
+                          _ptr(ms), _ptr(dw), st)
+        return da, part
 
     def mlp_stat_finalize(self, part, count, gamma, beta, running_mean, running_var, momentum, eps,
                           coef, channel_major=False):

@@ -107,6 +107,10 @@ def _wgrad_aten(backend, dy, x, x_coef, ng):
 # NESIE_FOLD_NORM_BWD=0: A/B switch -- the BatchNorm + ReLU backward's apply pass runs as its own
 # launch (nesie_bn_relu_backward_apply) in front of the weight gradient instead of inside it
 FOLD_NORM_BWD = _os.environ.get('NESIE_FOLD_NORM_BWD', '1') != '0'
+# the pooled last layer of an SA stack without its dense pre-pool tensor (csrc/pool_tail.hip): the
+# forward keeps (pooled, arg-max, raw extremum) only, the backward goes through
+# dZ = sparse + alpha + beta Z.  0: the dense form (A/B switch)
+POOL_TAIL = _os.environ.get('NESIE_POOL_TAIL', '1') != '0'
 
 
 def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_w, ng=1, need_dz=True,
@@ -165,9 +169,10 @@ class SAStackFn(Function):
             cout, cin = w.shape[0], w.shape[1]
             w2 = w.reshape(1, cout, cin)
             src = x3 if l == 0 else ys[-1]
-            y = x.new_empty(B, cout, P)
-            new_coef = x.new_empty(cout, 4)
             last = l == L - 1
+            tail = bool(last and l > 0 and POOL_TAIL and backend.pool_tail_supported(cin, cout, P, ns))
+            y = None if tail else x.new_empty(B, cout, P)     # (tail: the raw output is never written)
+            new_coef = x.new_empty(cout, 4)
             if l == 0 and cin <= 8 and not last:
                 part = x.new_empty(backend.mlp_stream_parts(B, P), cout, 2)
                 backend.mlp_stream_forward(src, w2[0].contiguous(), y, part)
@@ -186,10 +191,14 @@ class SAStackFn(Function):
             coef = new_coef
             ys.append(y)
             coefs.append(coef)
-        cl = ys[-1].shape[1]
+        cl = params[3 * (L - 1)].shape[0]
         pooled = x.new_empty(B, cl, M)
         argmax = torch.empty(B, cl, M, dtype=torch.uint8, device=x.device)
-        backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax)
+        ctx.tail = ys[-1] is None
+        if ctx.tail:
+            ys[-1] = x.new_empty(B, cl, M)            # the raw extremum behind every pooled value
+        backend.pw_pool_finish(1, P, ns, pool_group, pool_out, coef, True, pooled, argmax,
+                               zstar=ys[-1] if ctx.tail else None)
         ctx.L, ctx.ns, ctx.fixed_lead = L, ns, int(fixed_lead)
         # gradient slots of (weight, gamma, beta) per layer -- only when a backward will follow
         ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[3 + j] else None for j, t in enumerate(params)]
@@ -208,19 +217,32 @@ class SAStackFn(Function):
         B, c0, P = x3.shape
         M = P // ns
         grads = [None] * (3 * L)
-        # last layer: BatchNorm + ReLU + max backward into the dense raw-output gradient
         yl = ys[-1]
         cl = yl.shape[1]
-        dy = torch.empty_like(yl)
         slots = ctx.slots
         dgamma, dbeta = _dst(slots[3 * (L - 1) + 1], g, cl), _dst(slots[3 * (L - 1) + 2], g, cl)
-        backend.bn_relu_maxpool_backward(g.contiguous(), argmax, yl.view(B, cl, M, ns), pooled,
-                                         params[3 * (L - 1) + 1], None, coefs[-1],
-                                         dy.view(B, cl, M, ns), dgamma, dbeta)
         grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dgamma, dbeta
         dx = None
         pending = None          # (da, part) of the layer whose norm backward has not been applied yet
-        for l in range(L - 1, -1, -1):
+        top = L - 1
+        if ctx.tail:
+            # last layer without its dense tensors: yl is the raw extremum per (channel, group)
+            wl = params[3 * (L - 1)]
+            need_w = ctx.needs_input_grad[3 + 3 * (L - 1)]
+            dwl = _dst(slots[3 * (L - 1)], g, cl, wl.shape[1]) if need_w else None
+            pending = backend.pool_tail_backward(g.contiguous(), pooled, yl, argmax, coefs[-1],
+                                                 params[3 * (L - 1) + 1], wl.reshape(cl, wl.shape[1]),
+                                                 ys[L - 2], coefs[L - 2], ns, dgamma, dbeta, dw=dwl)
+            if need_w:
+                grads[3 * (L - 1)] = dwl.view_as(wl)
+            top = L - 2
+        else:
+            # last layer: BatchNorm + ReLU + max backward into the dense raw-output gradient
+            dy = torch.empty_like(yl)
+            backend.bn_relu_maxpool_backward(g.contiguous(), argmax, yl.view(B, cl, M, ns), pooled,
+                                             params[3 * (L - 1) + 1], None, coefs[-1],
+                                             dy.view(B, cl, M, ns), dgamma, dbeta)
+        for l in range(top, -1, -1):
             w = params[3 * l]
             cout, cin = w.shape[0], w.shape[1]
             w2 = w.reshape(cout, cin)

@@ -701,3 +701,74 @@ def test_ragged_220_row_output_layer_stays_inside_its_buffers(captured):
     assert (dx.double() - ref_dx).abs().max().item() < 3e-5 * max(1.0, ref_dx.abs().max().item())
     ref_dw = torch.bmm(dy.double(), x.double().transpose(1, 2)).sum(0)
     assert (dw[0].double() - ref_dw).abs().max().item() < 1e-4 * ref_dw.abs().max().item()
+
+
+@pytest.mark.parametrize('nb,m,ns,k,c', [(3, 40, 64, 64, 128), (2, 96, 32, 64, 128), (2, 132, 16, 64, 128),
+                                         (1, 10, 64, 64, 128)])
+def test_pooled_tail_backward_without_the_dense_tensors_matches_float64(nb, m, ns, k, c):
+    """csrc/pool_tail.hip: conv (k -> c) + training BatchNorm + ReLU + max over ns from what the
+    forward kept (pooled, arg-max, raw extremum) against autograd in float64 on the literal chain,
+    negative norm scales included; and bit-identical on a second run (no atomics)."""
+    be, dev = _hip(), _dev()
+    p = m * ns
+    assert be.pool_tail_supported(k, c, p, ns)
+    g = torch.Generator(device=dev).manual_seed(nb * 1000 + ns)
+    z_prev = torch.randn(nb, k, p, device=dev, generator=g)
+    coef_prev = torch.zeros(k, 4, device=dev)
+    coef_prev[:, 0] = torch.empty(k, device=dev).uniform_(-1.2, 1.5, generator=g)   # scale
+    coef_prev[:, 1] = torch.randn(k, device=dev, generator=g) * 0.3                  # bias
+    coef_prev[:, 2] = torch.randn(k, device=dev, generator=g) * 0.1                  # mean
+    coef_prev[:, 3] = torch.empty(k, device=dev).uniform_(0.5, 2.0, generator=g)     # invstd
+    w = torch.randn(c, k, device=dev, generator=g) * 0.2
+    gamma = torch.empty(c, device=dev).uniform_(-1.0, 1.5, generator=g)
+    beta = torch.randn(c, device=dev, generator=g) * 0.3
+    gpool = torch.randn(nb, c, m, device=dev, generator=g)
+    eps = 1e-5
+
+    # float64 literal chain (the previous layer's activation is an input here: A = relu(s z + b))
+    zp = z_prev.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = torch.relu(zp * coef_prev[:, 0].double().view(1, k, 1) + coef_prev[:, 1].double().view(1, k, 1))
+    a.retain_grad()
+    z = torch.einsum('ck,nkp->ncp', wd, a)
+    mean, var = z.mean(dim=(0, 2)), z.var(dim=(0, 2), unbiased=False)
+    invstd = (var + eps).rsqrt()
+    y = torch.relu((z - mean.view(1, c, 1)) * (invstd * gd).view(1, c, 1) + bd.view(1, c, 1))
+    pooled64 = y.view(nb, c, m, ns).max(dim=-1).values
+    (pooled64 * gpool.double()).sum().backward()
+
+    # what the forward keeps: folded coefficients from the float64 statistics, pooled, arg-max, z*
+    coef = torch.stack([invstd * gd, bd - mean * invstd * gd, mean, invstd], 1).detach().float().contiguous()
+    zf = z.detach().float().view(nb, c, m, ns)
+    sel = torch.where((coef[:, 0] >= 0).view(1, c, 1, 1), zf, -zf)
+    argmax = sel.argmax(dim=-1)
+    zstar = zf.gather(-1, argmax.unsqueeze(-1)).squeeze(-1).contiguous()
+    pooled = torch.relu(zstar * coef[:, 0].view(1, c, 1) + coef[:, 1].view(1, c, 1)).contiguous()
+    argmax = argmax.to(torch.uint8).contiguous()
+
+    def run():
+        dgamma, dbeta, dw = (torch.full((c,), float('nan'), device=dev), torch.full((c,), float('nan'), device=dev),
+                             torch.full((c, k), float('nan'), device=dev))
+        da, part = be.pool_tail_backward(gpool, pooled, zstar, argmax, coef, gamma, w, z_prev, coef_prev, ns,
+                                         dgamma, dbeta, dw=dw)
+        torch.cuda.synchronize()
+        return da, part, dgamma, dbeta, dw
+
+    da, part, dgamma, dbeta, dw = run()
+    scale = lambda t: t.abs().max().item()  # noqa: E731
+    torch.testing.assert_close(dgamma.double(), gd.grad, rtol=1e-4, atol=1e-5 * scale(gd.grad))
+    torch.testing.assert_close(dbeta.double(), bd.grad, rtol=1e-4, atol=1e-5 * scale(bd.grad))
+    torch.testing.assert_close(da.double(), a.grad, rtol=1e-3, atol=2e-5 * scale(a.grad))
+    torch.testing.assert_close(dw.double(), wd.grad, rtol=1e-3, atol=1e-4 * scale(wd.grad))
+    # the reduction of the previous layer's norm backward: sum g, sum g zhat with g = dA [A > 0]
+    mask = (a.detach() > 0).double()
+    g2 = a.grad * mask
+    zhat = (z_prev.double() - coef_prev[:, 2].double().view(1, k, 1)) * coef_prev[:, 3].double().view(1, k, 1)
+    sums = part.double().sum(dim=1)
+    want0, want1 = g2.sum(dim=(0, 2)), (g2 * zhat).sum(dim=(0, 2))
+    torch.testing.assert_close(sums[:, 0], want0, rtol=1e-3, atol=1e-4 * scale(want0))
+    torch.testing.assert_close(sums[:, 1], want1, rtol=1e-3, atol=1e-4 * scale(want1))
+    again = run()
+    for t0, t1 in zip((da, part, dgamma, dbeta, dw), again):
+        assert torch.equal(t0, t1)
