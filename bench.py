@@ -509,8 +509,19 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     if pipelined:
         g_idx = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_idx, stream=side, **mode):
-            fresh, fresh_votes = input_only_work()
-            copy_tensors(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
+            if os.environ.get('NESIE_DIAG_SIDE_DUMMY'):   # diagnostic only: N tiny kernels instead of the chain
+                dummy = torch.zeros(64, device=device)
+                for _ in range(int(os.environ['NESIE_DIAG_SIDE_DUMMY'])):
+                    dummy.add_(1.0)
+            elif os.environ.get('NESIE_DIAG_SIDE_FPS_ONLY'):   # diagnostic only: the four sampling launches alone
+                from nesie_amd.mmdet3d_ops.furthest_point_sample import FurthestPointSampling
+                lev = pts[..., :3].contiguous()
+                for npoint in (2048, 1024, 512, 256):
+                    pick = FurthestPointSampling.apply(lev, npoint)
+                    lev = lev.gather(1, pick.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            else:
+                fresh, fresh_votes = input_only_work()
+                copy_tensors(flat(idx_next) + votes_next, flat(fresh) + fresh_votes)
         ready, copied = torch.cuda.Event(), torch.cuda.Event()
         stage('input graph captured')
         with torch.cuda.stream(side):
