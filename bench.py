@@ -745,9 +745,18 @@ def main():
         # (the per-element transform is not counted); reads dA, Z, X once, writes dZ once
         nb, co, p = da.shape
         return 2.0 * nb * co * x.shape[1] * p, nb * (3 * co + x.shape[1]) * p * 4, nb * p
+    def tail_flop(g, pooled, zstar, argmax, coef, gamma, w, z_prev, coef_prev, ns, *a, **kw):
+        # backward of a pooled tail without its dense tensors (csrc/pool_tail.hip), ALL its launches as
+        # one entry: the layer's input gradient + weight gradient, 2 x 2 nb c k p (what it issues is
+        # 2 nb (k + c) k p built-row product + 2 nb k k p Gram product: the same count at c = 2 k);
+        # reads the operand's raw form twice, writes dA once
+        nb, k, p = z_prev.shape
+        c = w.shape[0]
+        return 4.0 * nb * c * k * p, 3 * nb * k * p * 4, nb * p
     gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
                    GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop),
-                   GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop))
+                   GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop),
+                   GemmTimer(hip, 'pool_tail_backward', tail_flop))
     bn_apply_timer = KernelTimer(hip, 'bn_relu_backward_apply', lambda dy, *_: dy.numel() == mid)
     timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer, bn_apply_timer) + gemm_timers
 
@@ -847,6 +856,10 @@ def main():
         # on the operand load from (dA, Z) and written once): 4 tensor passes per launch instead of 2,
         # HBM co-bound -- priced on their own below, and shown inside the family as well
         n_wf, ms_wf, fl_wf, by_wf = gemm_timers[3].totals()
+        # the pooled tail's backward (built-row input gradient + Gram / sparse weight gradient + its small
+        # launches, timed as ONE entry; of its 3 operand passes the 2 of the layer-kernel launch are in the
+        # PMC family rows)
+        n_t, ms_t, fl_t, by_t = gemm_timers[4].totals()
         # ... and the same kernels on the 1-D per-seed / per-proposal chains (vote module, prediction
         # trunk, feature propagation, score heads): 8 x 256 .. 1024 positions, launch-bound
         sn, sms, sfl, sby = (sum(v) for v in zip(*(t.totals(big=False) for t in gemm_timers)))
@@ -854,8 +867,8 @@ def main():
             per_step = lambda v: v / eager_steps  # noqa: E731
             # THE entry: every launch of the family -- large plain launches, the weight-gradient launches
             # that carry the norm backward's streaming half, and the small launch-bound 1-D-chain launches
-            fl_all, ms_all = fl_l + fl_w + fl_wf + sfl, ms_l + ms_w + ms_wf + sms
-            n_all = n_l + n_w + n_wf + sn
+            fl_all, ms_all = fl_l + fl_w + fl_wf + fl_t + sfl, ms_l + ms_w + ms_wf + ms_t + sms
+            n_all = n_l + n_w + n_wf + n_t + sn
             tf_all = fl_all / (ms_all * 1e-3) / 1e12
             tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
             # HBM bytes of the family as rocprofv3 counted them (separate --pmc FETCH_SIZE / WRITE_SIZE
@@ -877,7 +890,7 @@ def main():
                                     f'(sha256 {str(t.get("lib_sha256"))[:12]}.. vs loaded {lib_sha[:12]}..): not quoted')
                 else:
                     traffic = {'fetch_corrected_plus_write_bytes_per_step': t['family_bytes_per_step'],
-                               'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf),   # (PMC rows include the fused weight-gradient launches)
+                               'over_algorithmic': t['family_bytes_per_step'] / per_step(by_l + by_w + by_wf + by_t * 2 / 3),   # (PMC rows include the fused weight-gradient launches and the pooled tail's layer-kernel launch)
                                # the family's largest launch by bytes, counted / algorithmic
                                'largest_launch_over_algorithmic': (
                                    (t['largest_launch']['fetch_corrected_bytes'] + t['largest_launch']['write_bytes'])
@@ -893,8 +906,10 @@ def main():
                 'bound': 'mfma', 'achieved': tf_all, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf_all / MFMA_F32_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_note': traffic_note,
-                'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf),   # launches over >= 32768 positions
-                'algorithmic_hbm_gbs': (by_l + by_w + by_wf) / ((ms_l + ms_w + ms_wf) * 1e-3) / 1e9,
+                'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf + by_t),   # launches over >= 32768 positions
+                'algorithmic_hbm_gbs': (by_l + by_w + by_wf + by_t) / ((ms_l + ms_w + ms_wf + ms_t) * 1e-3) / 1e9,
+                'pooled_tail_backward': ({'entries_per_step': per_step(n_t), 'ms_per_step': per_step(ms_t),
+                                          'tflops': fl_t / (ms_t * 1e-3) / 1e12} if ms_t else None),
                 'launches_per_step': per_step(n_all),
                 'family_ms_per_step': per_step(ms_all),
                 'avg_launch_ms': ms_all / n_all,
