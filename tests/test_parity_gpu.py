@@ -48,10 +48,10 @@ FULL_SIZE_SLACK = {
     # kernel's partial sums equal a float64 sum of ITS inputs to 2.4e-7.  dgamma and the last
     # conv's weight gradient do not move (xhat ~ 0, a ~ 0 there).  Which activation sits on the
     # kink depends on the summation order (NESIE_PW_ONE_PER_CU=1 moves it out of this net), so the
-    # family is named, the excursion bounded, and at most TWO of the seven nets (<= 6 tensors each) may
-    # use it (the scatter-add backward kernels add with float atomics in no fixed order, so which
-    # activation sits on the kink can differ between two runs of the same code):
-    r'^bbox_head\.grid_conv\.mlps_before\.\d\.(first|second)_conv\.[013]\.(weight|bias)$': (2e-2, 12),
+    # family is named, the excursion bounded, and ONE of the seven nets (<= 6 tensors) may use it.
+    # (Round 3 allowed two nets because the scatter-add backward kernels added with float atomics in no
+    # fixed order; the test now runs the HIP leg in deterministic mode, where nothing varies from run to run.)
+    r'^bbox_head\.grid_conv\.mlps_before\.\d\.(first|second)_conv\.[013]\.(weight|bias)$': (2e-2, 6),
 }
 
 
@@ -76,7 +76,7 @@ def _check_per_parameter(worst, slack):
     for pat, names in used.items():
         print('counted exception used by:', names)
         nets = {re.sub(r'\.(first|second)_conv\..*', '', x) for x in names}
-        if len(names) > slack[pat][1] or len(nets) > 2:
+        if len(names) > slack[pat][1] or len(nets) > 1:
             bad += [(x, 'counted exception over its budget', '', '') for x in names]
     for b in bad:
         print('per-parameter bound exceeded:', *b)
@@ -147,7 +147,11 @@ def test_full_size_step_losses_and_gradients_match_the_cpu_oracle(oracle_kernels
     gmodel = copy.deepcopy(model).to(hip_device)
     with kernels.use_backend(oracle_kernels):
         cpu_l, cpu_g = _small.train_step_losses(model, pts, boxes, labels)
-    gpu_l, gpu_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
+    was = kernels.HipKernels.set_deterministic(True)     # fixed-order backward: the outcome is the code's, not the run's
+    try:
+        gpu_l, gpu_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
+    finally:
+        kernels.HipKernels.set_deterministic(was)
     assert len(ref_l) == 8
     for k, v in ref_l.items():
         assert abs(float(gpu_l[k].sum()) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(gpu_l[k].sum()), v)
@@ -355,8 +359,11 @@ def test_full_size_student_teacher_step_matches_the_cpu_oracle(oracle_kernels, h
     rel = ((g - w).norm() / w.norm()).item()
     print(f'{kind} full size: pseudo boxes per scene {per_scene.tolist()}, '
           f'flat gradient rel. L2 {rel:.3e}')
-    # two fp32 evaluations against each other (no fp64 referee exists for the student/teacher
-    # step): on the supervised full-size step each sits 2e-3 .. 3.5e-3 from fp64
+    # two fp32 evaluations against each other with NOTHING replayed (each leg samples its own votes
+    # and blends its own 3-NN taps: measured 4.0e-3 for SAQE, 1.06e-2 for Nesie, where a few taps flip).
+    # The same step with the decisions replayed is held to 5e-3 at B = 8 / 16 by
+    # test_student_teacher_step_at_the_baseline_batch_sizes_matches_the_cpu_oracle (measured 2.0e-3 / 3.3e-3);
+    # on the supervised full-size step each fp32 leg sits 3.4e-3 .. 3.5e-3 from fp64
     assert rel < 1.5e-2, rel
 
 
