@@ -289,19 +289,6 @@ void pw_fwd_kernel(const PwFwd a) {
   const int tpb = a.tiles_per_batch, nwg = a.nwg_g;
   const int ntiles = (a.nb / a.ng) * tpb;
 
-  // The launch-time loads (W) are waited for HERE: left alone, the compiler puts their vmcnt(0)
-  // in front of the first use inside the tile loop, where it also drains the operand loads.
-#pragma unroll
-  for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-    for (int kk = 0; kk < KH * KQ; ++kk) asm volatile("" : "+v"(wreg[rw][kk]));
-  if (EPI & PW_AFFINE) {
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-      for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(cof[kh][i].x), "+v"(cof[kh][i].y));
-  }
-
   // ---- the stream of sub-tiles this workgroup stages: (tile, kh) in execution order
   struct Cursor { int t, q, r, kh; };                    // tile index, (batch of the group, tile of the batch), sub-tile
   const int dq = nwg / tpb, dr = nwg % tpb;
@@ -393,7 +380,6 @@ void pw_fwd_kernel(const PwFwd a) {
     if (EPI & PW_BNRED) {
       const int m = c0 + (wr * RW + rw) * 16 + l16;
       if (!RAGGED || m < cout) zc[rw] = *(const float4 *)(a.bn_coef + ((size_t)g * cout + m) * 4);
-      asm volatile("" : "+v"(zc[rw].x), "+v"(zc[rw].y), "+v"(zc[rw].z), "+v"(zc[rw].w));
     }
   }
   auto row_ok = [&](int rw) { return !RAGGED || c0 + (wr * RW + rw) * 16 + l16 < cout; };
@@ -416,7 +402,6 @@ void pw_fwd_kernel(const PwFwd a) {
     for (int r = 0; r < 4; ++r) rbias[rw][r] = 0.f;
     if (EPI & PW_BIAS) {
       if (row_ok(rw)) cbias[rw] = a.bias[g * cout + c0 + (wr * RW + rw) * 16 + l16];
-      asm volatile("" : "+v"(cbias[rw]));
     }
   }
   auto load_row_bias = [&](int n, long long p0) {
@@ -571,6 +556,25 @@ void pw_fwd_kernel(const PwFwd a) {
   using KH0 = std::integral_constant<int, 0>;
   using KH1 = std::integral_constant<int, (KH > 1 ? 1 : 0)>;   // sub-tile 1 is (tile 0, kh 1) or (tile 1, kh 0)
   static_for<0, NX>([&](auto ic) { load_slot(ic, KH0{}, cur, cur.t < ntiles); });
+  // The launch-time loads (W, coefficients) are waited for HERE -- behind the first operand loads, which
+  // are younger and stay in flight: left alone, the compiler puts their vmcnt(0) in front of the first
+  // use inside the tile loop, where it also drains the operand loads.  (Round 3 waited BEFORE the first
+  // operand loads: every launch began with two memory latencies back to back.)
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+    for (int kk = 0; kk < KH * KQ; ++kk) asm volatile("" : "+v"(wreg[rw][kk]));
+  if (EPI & PW_AFFINE) {
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(cof[kh][i].x), "+v"(cof[kh][i].y));
+  }
+#pragma unroll
+  for (int rw = 0; rw < RW; ++rw) {
+    if (EPI & PW_BNRED) asm volatile("" : "+v"(zc[rw].x), "+v"(zc[rw].y), "+v"(zc[rw].z), "+v"(zc[rw].w));
+    if (EPI & PW_BIAS) asm volatile("" : "+v"(cbias[rw]));
+  }
   static_for<0, NX>([&](auto ic) { write_slot(ic, KH0{}, 0); });
   advance(nxt);
   static_for<0, NX>([&](auto ic) { load_slot(ic, KH1{}, nxt, nxt.t < ntiles); });
