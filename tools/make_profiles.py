@@ -49,7 +49,7 @@ def main():
     small_ms = sum(float(r['TotalDurationNs']) for r in rows if float(r['AverageNs']) < 12000) / STEPS / 1e6
     hdr = [
         f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --cpu-baseline 0   (1x MI355X, {tag}, tools/prof_round.sh; libnesie_hip.so sha256 {sha[:16]}..)",
-        f"bench line under the profiler: value={b['value']:.1f} scenes/s  ms_per_step={b['ms_per_step']:.2f}; without it, same box (profiles/{tag}_bench_line.json): {clean['value']:.1f} scenes/s, {clean['ms_per_step']:.2f} ms",
+        f"bench line under the profiler: value={b['value']:.1f} scenes/s  ms_per_step={b['ms_per_step']:.2f}; without it (profiles/{tag}_bench_line.json): {clean['value']:.1f} scenes/s, {clean['ms_per_step']:.2f} ms",
         "The process runs 20 training steps in all (2 eager warm-up steps before capture, 3 warm-up, 10 timed, 5 un-captured for the HIP-event",
         "timings of the roofline entries) plus the parity gate's one B=2 step on each leg; per-step = total / 20.  FPS, ball query, inverted indices, FP taps and",
         f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms of kernel time, mostly one CU per scene: overlapped, at a measured cost of 0.65 - 0.75 ms to the step, DESIGN.md section 9 item 6).",
