@@ -387,9 +387,21 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
                                        precomputed=pre)
         return model.forward_train(pts, None, gt, None, precomputed=pre)
 
+    # While the forward pass runs, the side stream's sampling kernels for the NEXT batch hold one CU per
+    # scene and XCD (1024 threads, 160 KB of LDS: nothing else fits beside them), and a one-round
+    # persistent grid sized for all 32 CUs of an XCD then has two workgroups that find no CU until the
+    # round ends: the forward's persistent grids are sized for the CUs
+    # that are left.  NESIE_FWD_CUS: A/B switch (256 = the whole chip)
+    budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', '248')) if (graph and on_gpu) else 256}
+
     def phase1(pre=None):       # forward + the head's backward
         bucket.begin()
-        total = model.parse_losses(forward_losses(pre))
+        if on_gpu and budget['cus'] != 256:
+            with kernels.HipKernels.cu_budget(budget['cus']):
+                losses = forward_losses(pre)
+        else:
+            losses = forward_losses(pre)
+        total = model.parse_losses(losses)
         cut['boundary'] = model.take_head_inputs()
         cut['grads'] = dp.backward_head(total, cut['boundary'], head_params)
         bucket.collect(n_bb, None)
@@ -563,6 +575,7 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
         stage('update graph replayed')
         return loss_out
     graph_step.eager = eager_step
+    graph_step.forward_cu_budget = budget
     graph_step.graphs_per_step = 1 if one_graph else 3
     graph_step.inputs, graph_step.optimizer, graph_step.comm = inputs, opt, comm
     return model, graph_step, bucket
@@ -785,9 +798,14 @@ def main():
         t.enabled = True
     eager = getattr(step, 'eager', step)
     eager_steps = min(args.steps, 5)
+    # (nothing runs beside these launches: they are timed with grids sized for the whole chip, not for
+    # the CUs the replayed step's forward leaves to the sampling kernels)
+    fwd_budget = getattr(step, 'forward_cu_budget', None) or {'cus': 256}
+    budget_in_step, fwd_budget['cus'] = fwd_budget['cus'], 256
     for _ in range(eager_steps):
         eager()
     torch.cuda.synchronize()
+    fwd_budget['cus'] = budget_in_step
     for t in timers:
         t.enabled = False
     if world > 1:
@@ -827,6 +845,7 @@ def main():
                        'hip_graph': bool(args.graph),
                        'graphs_per_step': getattr(step, 'graphs_per_step', None),
                        'index_chain_pipelined': bool(args.graph),
+                       'forward_cu_budget': (getattr(step, 'forward_cu_budget', None) or {'cus': 256})['cus'],
                        'grad_allreduce_bytes': bucket.nbytes(),
                        'grad_allreduce': 'two segments on a communication stream: head gradients '
                                          'during the backbone backward graph, backbone gradients after it',
@@ -912,6 +931,9 @@ def main():
                                           'tflops': fl_t / (ms_t * 1e-3) / 1e12} if ms_t else None),
                 'launches_per_step': per_step(n_all),
                 'family_ms_per_step': per_step(ms_all),
+                'grids': ('timed alone, persistent grids sized for all 256 CUs; inside the replayed step the FORWARD '
+                          f'launches are sized for {budget_in_step} CUs (the next batch\'s sampling kernels hold one '
+                          'CU per XCD meanwhile)' if budget_in_step != 256 else 'sized for all 256 CUs'),
                 'avg_launch_ms': ms_all / n_all,
                 'algorithmic_flops_per_launch': fl_all / n_all,
                 # sub-entry: the launches over >= 32768 positions WITHOUT the fused norm-backward ones

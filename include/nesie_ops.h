@@ -50,6 +50,13 @@ const char *nesie_last_error(void); /* thread-local, never NULL */
  * oracle has the same switch (oracle_set_distance_form). */
 int nesie_set_distance_form(int form);
 int nesie_get_distance_form(void);
+/* CUs the persistent grids of the layer / weight-gradient kernels are sized for (default 256 = the
+ * chip).  A caller that runs other long-lived work beside them -- the next batch's furthest point
+ * sampling holds one CU per scene and XCD for milliseconds (furthest_point_sample_cuda.cu's one block
+ * per batch element) -- sizes them for the CUs that are left, so that no workgroup of a one-round
+ * grid waits for a CU that will not come free.  n % 8 == 0 (one XCD-balanced grid). */
+int nesie_set_cu_count(int n);
+int nesie_get_cu_count(void);
 
 /* mmdet3d/ops/furthest_point_sample/src/furthest_point_sample.cpp:32-58
  * furthest_point_sampling_wrapper(b, n, m, points[B,N,3], temp[B,N], idx[B,M]).

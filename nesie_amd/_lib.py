@@ -181,6 +181,10 @@ def load():
     lib.nesie_set_distance_form.restype = _I
     lib.nesie_get_distance_form.argtypes = []
     lib.nesie_get_distance_form.restype = _I
+    lib.nesie_set_cu_count.argtypes = [_I]
+    lib.nesie_set_cu_count.restype = _I
+    lib.nesie_get_cu_count.argtypes = []
+    lib.nesie_get_cu_count.restype = _I
     lib.nesie_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib

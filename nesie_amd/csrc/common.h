@@ -10,6 +10,7 @@ namespace nesie {
 
 void set_error(const char *fmt, ...);
 int distance_form();   // 0 (default), 1, 2: see sqdist_form
+int cu_count();        // CUs the persistent grids are sized for (nesie_set_cu_count; 256)
 
 inline int check_launch(const char *what) {
   hipError_t e = hipGetLastError();

@@ -345,7 +345,7 @@ static bool pt_geometry(int k, int c, PtGeom *o) {
 static int pt_ns_shift(int ns) { return ns == 16 ? 4 : ns == 32 ? 5 : ns == 64 ? 6 : -1; }
 static int pt_dgrad_groups(const PtGeom &g, int nb, long long p) {
   const long long tiles = (long long)nb * (p / (64 * g.wc));
-  long long nwg = 256 * g.per_cu;
+  long long nwg = (long long)cu_count() * g.per_cu;
   return (int)(nwg < tiles ? nwg : tiles);
 }
 static int pt_gram_groups(int nb, long long p) {

@@ -154,7 +154,7 @@ extern "C" int nesie_pw_supported(int k, int cout, long long p) {
 // workgroups per weight group of a launch
 static int pw_groups(const PwGeom &g, int nb, int ng, long long p) {
   const long long tiles = (long long)(nb / ng) * cdiv(p, g.pt);
-  long long nwg = 256 * g.per_cu / (ng * g.nhalf);
+  long long nwg = (long long)cu_count() * g.per_cu / (ng * g.nhalf);
   if (nwg < 1) nwg = 1;
   if (nwg > tiles) nwg = tiles;
   // several row blocks per tile: a grid that is a multiple of 8 * nhalf lets the row blocks of a

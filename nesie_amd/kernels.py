@@ -114,6 +114,22 @@ class HipKernels(_BNPoolMixin):
     def get_distance_form():
         return _lib.load().nesie_get_distance_form()
 
+    @staticmethod
+    @contextlib.contextmanager
+    def cu_budget(n):
+        """Inside: the persistent grids of the layer / weight-gradient kernels are sized for ``n``
+        CUs instead of the chip's 256 (``nesie_set_cu_count``) -- for launches that run beside
+        long-lived workgroups of another stream (the next batch's furthest point sampling holds
+        one CU per scene and XCD).  Host-side sizing only: a captured graph keeps what it was
+        captured with."""
+        lib = _lib.load()
+        before = lib.nesie_get_cu_count()
+        _lib.call("nesie_set_cu_count", int(n))
+        try:
+            yield
+        finally:
+            _lib.call("nesie_set_cu_count", before)
+
     @classmethod
     def _index_for(cls, xyz, b, n):
         hit = cls._spatial_index.get(xyz.device)

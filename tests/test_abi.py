@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_every_compute_entry_point():
     compute = [n for n in declared_symbols()
                if n not in ("nesie_abi_version", "nesie_last_error",
-                            "nesie_set_distance_form", "nesie_get_distance_form",
+                            "nesie_set_distance_form", "nesie_get_distance_form", "nesie_set_cu_count", "nesie_get_cu_count",
                             "nesie_fps_workspace_bytes", "nesie_fps_leaves_index",
                             "nesie_bn_workspace_bytes",
                             "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_pw_wgrad_supported", "nesie_pw_wgrad_tiled", "nesie_pool_tail_supported",

@@ -772,3 +772,44 @@ def test_pooled_tail_backward_without_the_dense_tensors_matches_float64(nb, m, n
     again = run()
     for t0, t1 in zip((da, part, dgamma, dbeta, dw), again):
         assert torch.equal(t0, t1)
+
+
+def test_persistent_grids_sized_for_fewer_cus_give_the_same_layer():
+    """``HipKernels.cu_budget`` (nesie_set_cu_count): the layer / weight-gradient launches sized for 248
+    CUs -- what bench.py does while the next batch's sampling kernels hold one CU per XCD -- walk the
+    same tiles with fewer workgroups: outputs bit-identical, statistics and the weight gradient equal
+    to rounding, fewer statistic slots; the setting is restored on exit."""
+    hip, dev = _hip(), _dev()
+    from nesie_amd.kernels import HipKernels
+    g = torch.Generator(device=dev).manual_seed(7)
+    nb, k, cout, p = 8, 128, 256, 32768
+    x = torch.randn(nb, k, p, device=dev, generator=g)
+    w = torch.randn(1, cout, k, device=dev, generator=g) / k ** 0.5
+    gamma, beta = torch.rand(cout, device=dev, generator=g) + 0.5, torch.randn(cout, device=dev, generator=g)
+
+    def run():
+        slots = hip.pw_stat_slots(nb, 1, k, cout, p)
+        y, part = torch.empty(nb, cout, p, device=dev), torch.zeros(1, slots, cout, 4, device=dev)
+        hip.pw_layer_forward(x, w, y=y, stat_part=part)
+        coef = torch.empty(cout, 4, device=dev)
+        hip.pw_stats_finalize(part, gamma, beta, None, None, 0.1, 1e-5, coef)
+        dw = torch.empty(1, cout, k, device=dev)
+        hip.pw_wgrad(y, x, dw)
+        torch.cuda.synchronize()
+        return slots, y, coef, dw
+
+    full = run()
+    assert _lib_cu_count() == 256
+    with HipKernels.cu_budget(248):
+        assert _lib_cu_count() == 248
+        less = run()
+    assert _lib_cu_count() == 256
+    assert less[0] < full[0]
+    assert torch.equal(less[1], full[1])
+    torch.testing.assert_close(less[2], full[2], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(less[3], full[3], rtol=1e-4, atol=1e-4 * full[3].abs().max().item())
+
+
+def _lib_cu_count():
+    from nesie_amd import _lib
+    return _lib.load().nesie_get_cu_count()
