@@ -392,7 +392,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # persistent grid sized for all 32 CUs of an XCD then has two workgroups that find no CU until the
     # round ends: the forward's persistent grids are sized for the CUs
     # that are left.  NESIE_FWD_CUS: A/B switch (256 = the whole chip)
-    budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', '248')) if (graph and on_gpu) else 256}
+    # (the un-captured form of the step sizes them the same way: tests compare the two forms bit for bit)
+    budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', '248')) if on_gpu else 256}
 
     def phase1(pre=None):       # forward + the head's backward
         bucket.begin()

@@ -420,11 +420,14 @@ def _replays_vs_eager(device, workload, replays, batch):
         torch.cuda.synchronize()
         for p in params:
             p.grad = None
-        if semi_like:
-            losses = twin.forward_train(inp['points_s'], inp['points_t'], inp['gt'],
-                                        inp['use_label'], inp['meta_s'], inp['meta_t'], inp['rows'])
-        else:
-            losses = twin.forward_train(inp['points'], None, inp['gt'], None)
+        # (the replayed step launches its forward with the persistent grids sized for the CUs the next
+        # batch's sampling leaves free, bench.py: the twin's partial sums must be grouped the same way)
+        with kernels.HipKernels.cu_budget(step_g.forward_cu_budget['cus']):
+            if semi_like:
+                losses = twin.forward_train(inp['points_s'], inp['points_t'], inp['gt'],
+                                            inp['use_label'], inp['meta_s'], inp['meta_t'], inp['rows'])
+            else:
+                losses = twin.forward_train(inp['points'], None, inp['gt'], None)
         twin.parse_losses(losses).backward()
         torch.nn.utils.clip_grad_norm_(params, max_norm=10, norm_type=2)
         gtop = max(p.grad.abs().max().item() for p in params if p.grad is not None)
