@@ -391,10 +391,14 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # scene and XCD (1024 threads, 160 KB of LDS: nothing else fits beside them), and a one-round
     # persistent grid sized for all 32 CUs of an XCD then has two workgroups that find no CU until the
     # round ends: the forward's persistent grids are sized for the CUs
-    # that are left (B = 8: 248; B = 16: 240, measured best for each).  NESIE_FWD_CUS: A/B switch (256 = the whole chip)
+    # that are left.  NESIE_FWD_CUS: A/B switch (256 = the whole chip)
     # (the un-captured form of the step sizes them the same way: tests compare the two forms bit for bit)
-    # (one sampling workgroup per scene, dealt round-robin over the 8 XCDs: ceil(batch / 8) CUs per XCD)
-    left = max(256 - 8 * ((batch + 7) // 8), 192)
+    # (one sampling workgroup per scene, dealt round-robin over the 8 XCDs: ceil(batch / 8) CUs per XCD,
+    # plus two more per XCD: the 2-per-CU layer launches still stall beside the sampling with one CU
+    # spare -- 131 us against 104 us with three, tools/debug/fps_interference.py -- and the sweep of the
+    # whole step agrees: 232 at 8 scenes (256: 13.42, 248: 13.26, 232: 13.15, 224: 13.19, 216: 13.26 ms),
+    # 224 at 16 (240: 36.17, 224: 35.64, 208: 36.07 ms))
+    left = max(256 - 16 - 8 * ((batch + 7) // 8), 192)
     budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', str(left))) if on_gpu else 256}
 
     def phase1(pre=None):       # forward + the head's backward

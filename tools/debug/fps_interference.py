@@ -64,11 +64,14 @@ def main():
 
     FurthestPointSampling.apply(pts, 2048)
     torch.cuda.synchronize()
-    print(f'{"kernel":62s} {"alone us":>9s} {"beside FPS us":>13s} {"ratio":>6s}')
-    for name, fn in cases.items():
-        n = 30 if 'launch-bound' not in name and '1-D' not in name else 200
-        t0, t1 = timed(fn, n), busy(fn, n)
-        print(f'{name:62s} {t0:9.1f} {t1:13.1f} {t1 / t0:6.2f}')
+    for cus in [int(a) for a in sys.argv[1:]] or (256, 248):
+        print(f'persistent grids sized for {cus} CUs (HipKernels.cu_budget)')
+        print(f'{"kernel":62s} {"alone us":>9s} {"beside FPS us":>13s} {"ratio":>6s}')
+        with kernels.HipKernels.cu_budget(cus):
+            for name, fn in cases.items():
+                n = 30 if 'launch-bound' not in name and '1-D' not in name else 200
+                t0, t1 = timed(fn, n), busy(fn, n)
+                print(f'{name:62s} {t0:9.1f} {t1:13.1f} {t1 / t0:6.2f}')
 
 
 if __name__ == '__main__':
