@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void pt_wcat_kernel(int c_sp, int k, const flo
   }
 }
 
-// One pass over A = relu(scale x + bias) (K x P per batch element), 32-position tiles:
+// One pass over A = relu(scale x + bias) (K x P per batch element), 64-position tiles (32-position
+// tiles: one barrier per 8 KB, 119 us for SA1's 268 MB):
 //   part_m[rank] += A_tile A_tile^T          (fp32 MFMA, as pw_wgrad_kernel with both operands the same tile)
 //   part_s[rank] += row sums
 //   part_w[rank][c] += g[c] A[:, position of c's entry]    for every entry of the tile's group(s)
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void pt_gram_kernel(int nb, long long p, const
                                                       int groups, float *__restrict__ part_m,
                                                       float *__restrict__ part_s,
                                                       float *__restrict__ part_w, int nwg) {
-  constexpr int K = 16 * K16, PT = 32, PITCH = PT + 4, CPR = PT / 4, NT = 512;
+  constexpr int K = 16 * K16, PT = 64, PITCH = PT + 4, CPR = PT / 4, NT = 512;
   constexpr int NX = K * CPR / NT;
   static_assert(K * CPR % NT == 0, "tile");
   constexpr int WM = 2, WN = 4, MB = K16 / WM, NB = K16 / WN;
@@ -190,8 +191,7 @@ __global__ __launch_bounds__(512) void pt_gram_kernel(int nb, long long p, const
 #pragma unroll
   for (int kk = 0; kk < KPER; ++kk) wacc[kk] = 0.f;
 
-  const int ns_mask = (1 << ns_shift) - 1;
-  const int two = ns_shift < 5 ? 1 : 0;          // 16-position groups: two per tile
+  const int ngt = 64 >> ns_shift;                // groups per tile: 1 (ns = 64), 2 or 4
   float *b0 = lds, *b1 = lds + TILE;
   int t = rank;
   if (t < ntiles) {
@@ -201,16 +201,17 @@ __global__ __launch_bounds__(512) void pt_gram_kernel(int nb, long long p, const
   }
   for (; t < ntiles; t += nwg) {
     const int n = t / tpb, p0 = (t % tpb) * PT;
-    // this tile's entries (consumed behind the MFMAs)
+    // this tile's entries (consumed behind the MFMAs): one per channel and group of the tile
     const float2 *eb = ent + ((size_t)n * groups + (p0 >> ns_shift)) * CSP + cw * 64 + lane;
-    const float2 e0 = eb[0];
-    const float2 e1 = two ? eb[CSP] : make_float2(0.f, __int_as_float(1 << 20));
+    float2 e[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) e[gi] = gi < ngt ? eb[(size_t)gi * CSP] : make_float2(0.f, 0.f);
     lgkm_wait<0>();
     __builtin_amdgcn_s_barrier();
     const unsigned la = lds_addr(b0) + (unsigned)(((wm * MB * 16 + l16) * PITCH + 4 * quad) * 4);
     const unsigned lb = lds_addr(b0) + (unsigned)(((wn * NB * 16 + l16) * PITCH + 4 * quad) * 4);
     f32x4 fa[MB], fb[NB];
-    static_for<0, 2>([&](auto pgc) {
+    static_for<0, PT / 16>([&](auto pgc) {
       constexpr int pg = decltype(pgc)::value;
       static_for<0, MB>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -234,19 +235,16 @@ __global__ __launch_bounds__(512) void pt_gram_kernel(int nb, long long p, const
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    // sparse product: the entry of (channel, group) lies in this tile when its position does
+    // sparse product: every entry of the tile's group(s) lies inside the tile
     {
-      const int rel0 = p0 & ns_mask;            // (non-zero only for 64-position groups)
       const float *col = b0 + (kw * KPER) * PITCH;
-      const int ra = __float_as_int(e0.y) - rel0;
-      if ((unsigned)ra < 32u) {
 #pragma unroll
-        for (int kk = 0; kk < KPER; ++kk) wacc[kk] = __builtin_fmaf(e0.x, col[kk * PITCH + ra], wacc[kk]);
-      }
-      const int rb = __float_as_int(e1.y) + 16;
-      if ((unsigned)rb < 32u) {
+      for (int gi = 0; gi < 4; ++gi) {
+        if (gi < ngt) {                           // (uniform)
+          const int rel = __float_as_int(e[gi].y) + (gi << ns_shift);
 #pragma unroll
-        for (int kk = 0; kk < KPER; ++kk) wacc[kk] = __builtin_fmaf(e1.x, col[kk * PITCH + rb], wacc[kk]);
+          for (int kk = 0; kk < KPER; ++kk) wacc[kk] = __builtin_fmaf(e[gi].x, col[kk * PITCH + rel], wacc[kk]);
+        }
       }
     }
     write_tile(b1);
@@ -267,10 +265,9 @@ __global__ __launch_bounds__(512) void pt_gram_kernel(int nb, long long p, const
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     float v = rs[i];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if ((tid & 7) == 0) part_s[(size_t)rank * K + (i * NT + tid) / CPR] = v;
+#pragma unroll
+    for (int o = 1; o < CPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & (CPR - 1)) == 0) part_s[(size_t)rank * K + (i * NT + tid) / CPR] = v;
   }
   float *wd = part_w + ((size_t)rank * CSP + cw * 64 + lane) * K + kw * KPER;
 #pragma unroll
@@ -349,7 +346,7 @@ static int pt_dgrad_groups(const PtGeom &g, int nb, long long p) {
   return (int)(nwg < tiles ? nwg : tiles);
 }
 static int pt_gram_groups(int nb, long long p) {
-  const long long tiles = (long long)nb * (p / 32);
+  const long long tiles = (long long)nb * (p / 64);
   return (int)(tiles < 512 ? tiles : 512);
 }
 
@@ -432,7 +429,7 @@ extern "C" int nesie_pool_tail_wgrad(int nb, int k, int c, long long p, int ns, 
   hipStream_t s = (hipStream_t)stream;
   const int nwg = pt_gram_groups(nb, p);
   const int shift = pt_ns_shift(ns);
-  const size_t lds = (size_t)2 * k * 36 * sizeof(float);
+  const size_t lds = (size_t)2 * k * 68 * sizeof(float);
 #define GRAM(K16, C)                                                                                     \
   hipLaunchKernelGGL((pt_gram_kernel<K16, C>), dim3(nwg), dim3(512), lds, s, nb, p, z_prev, z_bstride,   \
                      coef_prev, (const float2 *)ent, shift, (int)(p / ns), part_m, part_s, part_w, nwg)
