@@ -200,15 +200,72 @@ class ResidentScenes:
             (flip_h, flip_v, angle, scale, trans)
 
     # ---- batch assembly -----------------------------------------------------------------
+    # ---- host-drawn decisions, staged through ONE pinned buffer -------------------------------
+    def new_staging(self, batch, num_points=40000):
+        """Buffers for a batch whose decisions are drawn on the HOST in the reference's order
+        (``draw_like_reference``, numpy): B x num_points pool rows (int32), the B x 20 point
+        transforms and the B x T x 7 augmented boxes (float32), packed in one int32 array so that
+        one DMA copy brings them over.
+        -> dict(host=[pinned array, pinned array] (double buffer), dev=device array, ...)."""
+        T = self.box_pad.shape[1]
+        words = batch * (num_points + 20 + T * 7)
+        pin = self.device.type == 'cuda'
+        return dict(host=[torch.empty(words, dtype=torch.int32, pin_memory=pin) for _ in range(2)],
+                    dev=torch.empty(words, dtype=torch.int32, device=self.device), n=num_points,
+                    batch=batch, boxes=T)
+
+    def _staging_views(self, buf, staging):
+        B, n, T = staging['batch'], staging['n'], staging['boxes']
+        rows = buf[:B * n].view(B, n)
+        xform = buf[B * n:B * (n + 20)].view(torch.float32).view(B, 20)
+        boxes = buf[B * (n + 20):].view(torch.float32).view(B, T, 7)
+        return rows, xform, boxes
+
+    def stage_draws(self, staging, which, scene_ids, rng, **ranges):
+        """Draw one batch's decisions for ``scene_ids`` (host ints) with ``rng`` exactly as the
+        reference's pipeline would (IndoorPointSample, RandomFlip3D, GlobalRotScaleTrans), apply
+        them to the boxes and fold them into the point transform -- all on the host, as the
+        reference's data-loader workers do -- and write the result into pinned buffer ``which``."""
+        rows, xform, boxes = self._staging_views(staging['host'][which], staging)
+        host = self._host_tables()
+        draws = [draw_like_reference(rng, int(self.counts[sid]), staging['n'], **ranges) for sid in scene_ids]
+        for i, (sid, d) in enumerate(zip(scene_ids, draws)):
+            rows[i] = torch.from_numpy(d.choices + int(self.offsets[sid]))
+        ids = torch.as_tensor(list(scene_ids))
+        f32 = dict(dtype=torch.float32)
+        flip_h, flip_v = torch.tensor([d.flip_h for d in draws]), torch.tensor([d.flip_v for d in draws])
+        angle, scale = torch.tensor([d.angle for d in draws], **f32), torch.tensor([d.scale for d in draws], **f32)
+        trans = torch.tensor(np.stack([d.trans for d in draws]), **f32)
+        one = torch.ones_like(angle)
+        xform.copy_(torch.cat([host['align'][ids], torch.where(flip_h, -one, one)[:, None],
+                               torch.where(flip_v, -one, one)[:, None], torch.cos(angle)[:, None],
+                               torch.sin(angle)[:, None], scale[:, None], trans], dim=1))
+        boxes.copy_(self._augment_boxes(host['box_pad'][ids], host['box_valid'][ids], flip_h, flip_v,
+                                        angle, scale, trans))
+
+    def _host_tables(self):
+        if getattr(self, '_host', None) is None:
+            self._host = dict(align=self.align.cpu(), box_pad=self.box_pad.cpu(), box_valid=self.box_valid.cpu())
+        return self._host
+
     def assemble_batch(self, scene_ids, draws=None, num_points=40000, generator=None,
-                       noise=None, **ranges):
+                       noise=None, staging=None, **ranges):
         """-> points (B, n, 4) = (x, y, z, height) and the ground truth as the head's GTBatch
         (boxes (B,T,7) bottom-origin, labels, count, valid), all on the device, no host
         synchronisation.  ``scene_ids``: list or device tensor; ``draws``: list of
         ``AugmentDraws`` (reference order) or None = draw on the device; with ``noise``
         (``new_noise``) and ``scene_ids`` a static device tensor the call makes no random-number
-        and no host-side call and is capturable in a hipGraph."""
+        and no host-side call and is capturable in a hipGraph; so it is with ``staging``
+        (``new_staging`` / ``stage_draws``: the decisions drawn AND applied to boxes / transforms on
+        the host in the reference's order and brought over by one copy -- the device runs the
+        gather kernel and three small index gathers, nothing else)."""
         from .votenet.nesie_head import GTBatch
+        if staging is not None:     # drawn and applied on the host, already copied into staging['dev']
+            ids = torch.as_tensor(scene_ids, device=self.device)
+            choices, xform, boxes = self._staging_views(staging['dev'], staging)
+            out = torch.empty(choices.shape[0], choices.shape[1], 4, dtype=torch.float32, device=self.device)
+            backend_for(self.pool).scene_assemble(self.pool, self.height, choices, xform, out)
+            return out, GTBatch(boxes, self.label_pad[ids], self.box_count_dev[ids], self.box_valid[ids])
         if draws is None:
             choices, xform, dec = self.draw_on_device(scene_ids, num_points, generator,
                                                       noise=noise, **ranges)

@@ -126,3 +126,27 @@ def test_identity_transform_returns_the_sampled_rows(oracle_kernels):
     floor = np.percentile(xyz[:, 2], 0.99)
     np.testing.assert_array_equal(pts[0, :, 3].numpy(), (xyz[::-1, 2] - floor).astype(np.float32))
     assert boxes[0].shape == (0, 7)
+
+
+def test_host_staged_draws_give_the_same_batch_as_the_draw_objects(oracle_kernels):
+    """``stage_draws`` (numpy draws in the reference's order, packed into one pinned buffer) +
+    ``assemble_batch(staging=...)`` = ``assemble_batch(draws=[AugmentDraws ...])`` with the same
+    generator state: points, boxes, labels, validity -- bit for bit."""
+    ranges = dict(rot_range=(-0.087266, 0.087266), scale_range=(0.9, 1.1), translation_std=(0.1, 0.1, 0.05))
+    with kernels.use_backend(oracle_kernels):
+        scenes = ResidentScenes("cpu")
+        for seed, n in [(1, 5000), (2, 900), (3, 2500)]:
+            raw6, align, gt, labels = golden_inputs.raw_scene(seed, n, False)
+            scenes.add_scene(raw6[:, :3], align, gt, labels)
+        scenes.finalize()
+        ids, n_pts = [2, 0, 1], 1024
+        rng = np.random.RandomState(77)
+        draws = [draw_like_reference(rng, int(scenes.counts[s]), n_pts, **ranges) for s in ids]
+        want_p, want_g = scenes.assemble_batch(ids, draws)
+        staging = scenes.new_staging(len(ids), n_pts)
+        scenes.stage_draws(staging, 1, ids, np.random.RandomState(77), **ranges)
+        staging['dev'].copy_(staging['host'][1])
+        got_p, got_g = scenes.assemble_batch(ids, staging=staging)
+    assert torch.equal(got_p, want_p)
+    assert torch.equal(got_g.boxes, want_g.boxes) and torch.equal(got_g.labels, want_g.labels)
+    assert torch.equal(got_g.valid, want_g.valid) and torch.equal(got_g.count, want_g.count)

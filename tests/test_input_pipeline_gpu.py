@@ -66,3 +66,29 @@ def test_device_drawn_batches_feed_the_training_step(hip_device):
     total = model.parse_losses(losses)
     total.backward()
     assert torch.isfinite(total)
+
+
+def test_host_staged_draws_on_the_gpu_equal_the_draw_objects(hip_device):
+    """``stage_draws`` (decisions drawn and applied on the host, one pinned buffer, one copy) against
+    ``assemble_batch(draws=...)`` with the same generator state on the device: the same rows of the
+    pool, points to float rounding of the transform (host cos / sin vs the device's), boxes too."""
+    from tests.test_input_pipeline_cpu import draw_like_reference
+    ranges = dict(rot_range=(-0.087266, 0.087266), scale_range=(0.9, 1.1), translation_std=(0.1, 0.1, 0.05))
+    scenes = ResidentScenes(hip_device)
+    for seed, n in [(1, 5000), (2, 900), (3, 2500)]:
+        raw6, align, gt, labels = golden_inputs.raw_scene(seed, n, False)
+        scenes.add_scene(raw6[:, :3], align, gt, labels)
+    scenes.finalize()
+    ids, n_pts = [2, 0, 1], 2048
+    rng = np.random.RandomState(5)
+    draws = [draw_like_reference(rng, int(scenes.counts[s]), n_pts, **ranges) for s in ids]
+    want_p, want_g = scenes.assemble_batch(ids, draws)
+    staging = scenes.new_staging(len(ids), n_pts)
+    assert staging['host'][0].is_pinned()
+    scenes.stage_draws(staging, 0, ids, np.random.RandomState(5), **ranges)
+    staging['dev'].copy_(staging['host'][0], non_blocking=True)
+    got_p, got_g = scenes.assemble_batch(torch.tensor(ids, device=hip_device), staging=staging)
+    torch.testing.assert_close(got_p, want_p, rtol=0, atol=2e-6)
+    torch.testing.assert_close(got_g.boxes, want_g.boxes, rtol=0, atol=2e-6)
+    assert torch.equal(got_g.labels, want_g.labels) and torch.equal(got_g.valid, want_g.valid)
+    assert torch.equal(got_g.count, want_g.count)
