@@ -80,3 +80,27 @@ def test_package_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), \
                     f"{f} imports the oracle"
+
+
+def test_cu_budget_is_validated_and_restored():
+    """nesie_set_cu_count: host-side sizing state only (no GPU call): multiples of 8 in [8, 256],
+    anything else is refused with the usual status + message; HipKernels.cu_budget restores the
+    previous value on exit, also when the body raises."""
+    import pytest
+    from nesie_amd.kernels import HipKernels
+    lib = _lib.load()
+    assert lib.nesie_get_cu_count() == 256
+    for bad in (0, 4, 100, 260, -8):
+        with pytest.raises(RuntimeError, match="set_cu_count"):
+            _lib.call("nesie_set_cu_count", bad)
+    assert lib.nesie_get_cu_count() == 256
+    with HipKernels.cu_budget(232):
+        assert lib.nesie_get_cu_count() == 232
+        with HipKernels.cu_budget(248):
+            assert lib.nesie_get_cu_count() == 248
+        assert lib.nesie_get_cu_count() == 232
+    assert lib.nesie_get_cu_count() == 256
+    with pytest.raises(ValueError):
+        with HipKernels.cu_budget(224):
+            raise ValueError("body failed")
+    assert lib.nesie_get_cu_count() == 256
