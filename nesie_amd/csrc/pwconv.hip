@@ -230,6 +230,8 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   a.pool_max = pool_max_out; a.pool_min = pool_min_out; a.arg_max = arg_max_out; a.arg_min = arg_min_out;
   a.bn_z = bn_z; a.bnz_bs = bnz_bstride; a.bn_coef = bn_coef; a.bn_part = bn_part;
   a.stamps = nullptr;
+  static const int w_stage = [] { const char *e = getenv("NESIE_PW_WSTAGE"); return e ? atoi(e) : 1; }();
+  a.w_stage = w_stage;
 #ifdef PW_STAMP
   a.stamps = g_pw_stamps;
 #endif

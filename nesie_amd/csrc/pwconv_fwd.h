@@ -152,6 +152,7 @@ struct PwFwd {
   int tiles_per_batch, nwg_g, nhalf;       // nhalf: workgroups per tile along Cout
   int xcd_map;         // the nhalf workgroups of a tile stream sit on ONE XCD (grid % (8 nhalf) == 0)
   const float2 *sp_ent; int sp_ns_shift, sp_groups;   // PW_SPARSE*: entries, log2(ns), groups per batch element
+  int w_stage;         // 1: row-major weights come in through LDS (NESIE_PW_WSTAGE=0: lane loads, A/B switch)
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -258,15 +259,61 @@ void pw_fwd_kernel(const PwFwd a) {
   const unsigned lw0 = lds_addr(lds) + (unsigned)((srow * PT + scol * 4) * 4);
 
   // this wave's rows of W, for the whole launch: lane (l16, quad) holds W[m][kh KT + 4 kk + quad]
+  // Row-major weights (forward launches: w_cs == 1) come in THROUGH LDS: fetched lane by lane those KH KQ
+  // words per lane are KH KQ load instructions that each touch 16 rows -- 8 192 cache-line requests per
+  // workgroup, 7.5 us of a 23 us one-tile launch and 10 us of every larger one (tools/pwbench stamps:
+  // loop start 9.4 us after entry, 1.9 us with the loads stubbed out).  Instead every wave copies its
+  // 16 RW rows of a K sub-tile with 16-byte loads (a row = KT contiguous floats) into a block of its own
+  // inside the operand buffers, which are not in use yet, and reads its words back; columns are
+  // XOR-swizzled by the row (word k ^ 4 (row & 15)) so that the 16 rows x 4 words of a read hit 64
+  // banks.  Same values, same order of the products: bit-identical results.  (The transposed views of the
+  // input-gradient launches keep their lane loads: there a load instruction touches 4 lines, not 16, and the
+  // same staging with a word-by-word scatter into the block was slower: 13.17 vs 13.02 ms for the step.)
   float wreg[RW][KH * KQ];
+  // (sub-tiles of 64 or 128 rows: the swizzle stays inside a row; the 96- and 144-row geometries keep the lane loads)
+  const bool w_rows = KT % 64 == 0 && (a.w_stage & 1) && a.w_cs == 1 && (a.w_rs & 3) == 0 && (a.w_gs & 3) == 0 && ((uintptr_t)a.w & 15) == 0;   // (uniform)
+  if (w_rows) {
+    static_assert(WR * WC * RW * 16 <= 2 * PT, "the waves' blocks fit the two operand buffers");
+    constexpr int WROWS = RW * 16, C4 = KT / 4, NL = (WROWS * C4 + 63) / 64;
+    float *wl = lds + wave * (WROWS * KT);
+    const int m0 = c0 + wr * WROWS;
+    const float *wg0 = a.w + (size_t)g * a.w_gs + (size_t)m0 * a.w_rs;
 #pragma unroll
-  for (int rw = 0; rw < RW; ++rw) {
-    const int m = c0 + (wr * RW + rw) * 16 + l16;
-    const float *wg = a.w + (size_t)g * a.w_gs + (size_t)m * a.w_rs;
+    for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-    for (int kk = 0; kk < KH * KQ; ++kk) {
-      const int kx = 4 * kk + quad;
-      wreg[rw][kk] = (m < cout && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
+      for (int i = 0; i < NL; ++i) {
+        const int f = i * 64 + lane, row = f / C4, c4 = f % C4, kcol = kh * KT + 4 * c4;
+        if (NL * 64 == WROWS * C4 || f < WROWS * C4) {
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m0 + row < cout) {
+            const float *src = wg0 + (size_t)row * a.w_rs + kcol;
+            if (kcol + 3 < k) {
+              v = *(const f32x4 *)src;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = kcol + e < k ? src[e] : 0.f;
+            }
+          }
+          *(f32x4 *)(wl + row * KT + ((4 * c4) ^ (4 * (row & 15)))) = v;
+        }
+      }
+#pragma unroll
+      for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk)
+          wreg[rw][kh * KQ + kk] = wl[(rw * 16 + l16) * KT + ((4 * kk + quad) ^ (4 * l16))];
+    }
+    __syncthreads();      // the blocks lie in the operand buffers: nobody stages a tile before every wave has read
+  } else {
+#pragma unroll
+    for (int rw = 0; rw < RW; ++rw) {
+      const int m = c0 + (wr * RW + rw) * 16 + l16;
+      const float *wg = a.w + (size_t)g * a.w_gs + (size_t)m * a.w_rs;
+#pragma unroll
+      for (int kk = 0; kk < KH * KQ; ++kk) {
+        const int kx = 4 * kk + quad;
+        wreg[rw][kk] = (m < cout && kx < k) ? wg[(size_t)kx * a.w_cs] : 0.f;
+      }
     }
   }
   // (scale, bias) of the previous layer's folded BatchNorm for the rows of every staging slot

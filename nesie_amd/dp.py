@@ -62,21 +62,26 @@ class FlatGradBucket:
                     and all(p.shape == g[0].shape for p in g)):
                 groups.append(g)
                 seen.update(id(p) for p in g)
-        total = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        # every parameter (and every group) starts on a 16-byte boundary: the layer kernel fetches
+        # row-major weights with 16-byte loads (a 259-float bias in front would shift every later
+        # weight by 12 bytes); the gaps hold zeros in both flat vectors and stay zero
+        align = lambda o: -(-o // 4) * 4  # noqa: E731
         where, off = {}, 0
         for p in self.params:                       # ungrouped, in model order
             if id(p) not in seen:
+                off = align(off)
                 where[id(p)] = off
                 off += p.numel()
         self.group_spans = []                       # (offset, S, numel of one member, shape)
         for g in groups:
+            off = align(off)
             self.group_spans.append((off, len(g), g[0].numel(), tuple(g[0].shape), g))
             for p in g:
                 where[id(p)] = off
                 off += p.numel()
-        assert off == total
+        total = align(off)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
         self.offsets = [where[id(p)] for p in self.params]
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
