@@ -524,8 +524,9 @@ int main(int argc, char **argv) {
     };
     const long long xbs = getenv("PW_XSTRIDE0") ? 0 : (long long)s.k * s.p;   // every batch reads X[0]: operand from cache
     auto own = [&](const float *coef, int relu, float *y, float *part, int pg, int pmin) {
+      static const bool wt = getenv("PW_WT") != nullptr;   // PW_WT: the weights as a transposed view (input-gradient launches)
       int st = nesie_pw_layer_forward(s.nb, s.ng, s.k, s.cout, s.p, dx, xbs, dw, (long long)s.cout * s.k,
-                                      s.k, 1, coef, relu, nullptr, 0, nullptr, y, (long long)s.cout * s.p, part, pg, pmin,
+                                      wt ? 1 : s.k, wt ? s.cout : 1, coef, relu, nullptr, 0, nullptr, y, (long long)s.cout * s.p, part, pg, pmin,
                                       dpmax, dpmin, damax, damin, 0);
       if (st) { printf("nesie error %d: %s\n", st, nesie_last_error()); exit(1); }
     };
@@ -547,6 +548,18 @@ int main(int argc, char **argv) {
         long long mx[3] = {0, 0, 0}, mn[3] = {1ll << 60, 1ll << 60, 1ll << 60}; double av[3] = {0, 0, 0};
         for (int b = 0; b < 1024; ++b) if (hs[512 + b * 4]) for (int k = 0; k < 3; ++k) {
           const long long v = hs[512 + b * 4 + k] - t0; mx[k] = v > mx[k] ? v : mx[k]; mn[k] = v < mn[k] ? v : mn[k]; av[k] += (double)v / nwgs; }
+        if (getenv("PW_XCD_STATS")) {   // loop start / end per XCD (block index mod 8) and per eighth of the grid
+          for (int x = 0; x < 8; ++x) {
+            double a1 = 0, a2 = 0, m2 = 0; int c = 0;
+            for (int b = x; b < 1024; b += 8) if (hs[512 + b * 4]) { a1 += (hs[512 + b * 4 + 1] - t0) * .01; const double e = (hs[512 + b * 4 + 2] - t0) * .01; a2 += e; m2 = e > m2 ? e : m2; ++c; }
+            if (c) printf("  xcd %d: %3d workgroups, loop start mean %.2f, loop end mean %.2f max %.2f us\n", x, c, a1 / c, a2 / c, m2);
+          }
+          for (int part = 0; part < 8; ++part) {
+            double a0 = 0, a1 = 0, a2 = 0, m2 = 0; int c = 0;
+            for (int b = part * nwgs / 8; b < (part + 1) * nwgs / 8; ++b) if (hs[512 + b * 4]) { a0 += (hs[512 + b * 4] - t0) * .01; a1 += (hs[512 + b * 4 + 1] - t0) * .01; const double e = (hs[512 + b * 4 + 2] - t0) * .01; a2 += e; m2 = e > m2 ? e : m2; ++c; }
+            if (c) printf("  blocks %4d..%4d: entry %.2f, loop start %.2f, loop end mean %.2f max %.2f us\n", part * nwgs / 8, (part + 1) * nwgs / 8 - 1, a0 / c, a1 / c, a2 / c, m2);
+          }
+        }
         printf("%d workgroups; us since the first entry (min / mean / max): entry %.2f %.2f %.2f | loop start %.2f %.2f %.2f | loop end %.2f %.2f %.2f\n", nwgs,
                mn[0] * .01, av[0] * .01, mx[0] * .01, mn[1] * .01, av[1] * .01, mx[1] * .01, mn[2] * .01, av[2] * .01, mx[2] * .01);
       }
