@@ -126,7 +126,10 @@ class FlatTrainState(FlatGradBucket):
         super().__init__(params, stack_groups)
         from . import grad_slots
         ref = self.params[0]
-        flat_p = torch.empty(self.flat.numel(), dtype=ref.dtype, device=ref.device)
+        # zeros, not empty: the 16-byte alignment gaps between parameters are part of the vector the
+        # optimiser, the norm and the all-reduce walk -- they must hold 0 (and then stay 0: gradient
+        # 0, moments 0, decay of 0)
+        flat_p = torch.zeros(self.flat.numel(), dtype=ref.dtype, device=ref.device)
         self.views, self.grad_views = [], []
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
@@ -151,17 +154,25 @@ class FlatTrainState(FlatGradBucket):
         grad_slots.begin(self)
 
     def split_after(self, first_params):
-        """-> (number of parameters, number of elements) of the leading block ``first_params``
-        (which must be a prefix of the bucket's parameter order AND of its layout, e.g.
-        ``model.backbone``: no member of a stack group)."""
+        """-> (number of parameters, LAYOUT extent in elements) of the leading block
+        ``first_params`` (which must be a prefix of the bucket's parameter order AND of its layout,
+        e.g. ``model.backbone``: no member of a stack group).  The extent is where the block ends
+        in the flat vectors, alignment gaps included and rounded up to the next 16-byte boundary
+        (= where the next parameter starts), so [0, extent) and [extent, total) are the two
+        all-reduce segments."""
         first = [p for p in first_params if p.requires_grad]
         assert [id(p) for p in first] == [id(p) for p in self.params[:len(first)]], \
             'not a prefix of the bucket'
-        elems = sum(p.numel() for p in first)
-        assert sorted(self.offsets[:len(first)]) == self.offsets[:len(first)] and \
-            (not first or self.offsets[len(first) - 1] + first[-1].numel() == elems), \
-            'the leading block is not contiguous in the flat layout'
-        return len(first), elems
+        if not first:
+            return 0, 0
+        n = len(first)
+        extent = -(-(self.offsets[n - 1] + first[-1].numel()) // 4) * 4
+        assert sorted(self.offsets[:n]) == self.offsets[:n], \
+            'the leading block is not laid out in parameter order'
+        assert all(o >= extent for o in self.offsets[n:]) and \
+            all(o >= extent for o, *_ in self.group_spans), \
+            'a later parameter or a stack group lies inside the leading block'
+        return n, min(extent, self.flat.numel())
 
     def collect(self, lo=0, hi=None):
         """Gather the gradients of parameters [lo, hi) (default: all) into the flat vector."""

@@ -829,10 +829,13 @@ class Stack1dFn(Function):
         tslots = ctx.slots
 
         def zero_bias(l):      # the bias in front of layer l's norm: gradient identically zero
-            # (its slot of the flat gradient vector was zero when the state was built and NOBODY ever
-            # writes it -- clip and all-reduce keep a zero zero -- so the slot itself is the gradient)
+            # With a slot in the flat gradient vector the answer is None: FlatTrainState.collect()
+            # zero-fills every parameter that got no gradient (one multi-tensor fill for all of
+            # them), so whatever an earlier step, another path or a loaded vector left in the slot
+            # is overwritten in every step.  Without a flat state: a zero tensor, as ATen returns
+            # (a None would make a per-parameter optimiser skip the parameter).
             sl = tslots[slots[l]['b']]
-            return sl if sl is not None else torch.zeros_like(per_layer[l][1])
+            return None if sl is not None else torch.zeros_like(per_layer[l][1])
         # a channel slice of a wider gradient (the outputs of several chains concatenated by their
         # consumer) is batch-strided: the layer kernels take a batch stride, no copy needed
         if not (S == 1 and layers[-1].bn is None and dout.stride(2) == 1 and dout.stride(1) == P):

@@ -137,3 +137,69 @@ def test_per_parameter_optimizer_state_follows_the_layout(tmp_path):
     got, old = fresh.state[state.flat_param], opt.state[state.flat_param]
     torch.testing.assert_close(got['exp_avg'], old['exp_avg'], rtol=1e-6, atol=1e-8)
     torch.testing.assert_close(got['exp_avg_sq'], old['exp_avg_sq'], rtol=1e-6, atol=1e-8)
+
+
+def _gap_mask(state):
+    used = torch.zeros(state.flat.numel(), dtype=torch.bool)
+    for p, o in zip(state.params, state.offsets):
+        used[o:o + p.numel()] = True
+    return ~used
+
+
+def test_alignment_gaps_hold_zeros_in_both_flat_vectors_and_stay_zero():
+    """Every parameter starts on a 16-byte boundary; the gaps are part of the vectors the optimiser,
+    the clip and the all-reduce walk, so they must be 0 after construction (torch.empty would hand
+    back recycled memory on the GPU) and after optimiser steps."""
+    torch.manual_seed(1)
+    mods = [torch.nn.Linear(3, 3), torch.nn.Linear(3, 5), torch.nn.Linear(5, 2)]   # numels 9, 3, 15, 5, 10, 2
+    params = [p for m in mods for p in m.parameters()]
+    state = dp.FlatTrainState(params)
+    gaps = _gap_mask(state)
+    assert int(gaps.sum()) > 0 and all(o % 4 == 0 for o in state.offsets)
+    assert torch.all(state.flat_param.data[gaps] == 0) and torch.all(state.flat[gaps] == 0)
+    opt = torch.optim.AdamW([state.flat_param], lr=1e-2, weight_decay=0.1)
+    x = torch.randn(4, 3)
+    for _ in range(3):
+        state.begin()
+        mods[2](mods[1](mods[0](x))).square().sum().backward()
+        state.collect()
+        opt.step()
+        assert torch.all(state.flat_param.data[gaps] == 0) and torch.all(state.flat[gaps] == 0)
+    assert torch.isfinite(state.flat_param.data).all()
+
+
+def test_split_after_returns_the_layout_extent_of_a_prefix_with_ragged_sizes():
+    """The segment boundary of the two-part all-reduce is a LAYOUT offset: a leading block holding a
+    3-element parameter ends on the next 16-byte boundary, not at the sum of its sizes."""
+    torch.manual_seed(2)
+    pre = torch.nn.Linear(3, 3)      # weight 9 (-> 12), bias 3 (-> 16)
+    rest = [torch.nn.Linear(3, 4), torch.nn.Linear(3, 4)]
+    params = list(pre.parameters()) + [p for m in rest for p in m.parameters()]
+    state = dp.FlatTrainState(params, stack_groups=[[m.weight for m in rest], [m.bias for m in rest]])
+    n, extent = state.split_after(pre.parameters())
+    assert (n, extent) == (2, 16)
+    assert all(o >= extent for o in state.offsets[n:]) and extent % 4 == 0
+    # a block that is not a layout prefix is refused: a member of a stack group lies behind the others
+    twin = dp.FlatTrainState([p for m in rest for p in m.parameters()] + list(pre.parameters()),
+                             stack_groups=[[m.weight for m in rest]])
+    try:
+        twin.split_after(list(rest[0].parameters()))
+        raise SystemExit('expected an assertion')
+    except AssertionError:
+        pass
+
+
+def test_collect_overwrites_a_poisoned_slot_of_a_parameter_that_got_no_gradient():
+    """A parameter whose backward returns None (the conv bias in front of a norm in Stack1dFn:
+    identically zero) is zero-filled by collect() in EVERY step, whatever sat in its slot."""
+    pre, nets, params = _toy()
+    state = dp.FlatTrainState(params)
+    state.flat.fill_(float('nan'))
+    x = torch.randn(3, 5)
+    state.begin()
+    nets[0](pre(x)).sum().backward()          # nets[1], nets[2] are not reached
+    state.collect()
+    for p, o in zip(state.params, state.offsets):
+        g = state.flat[o:o + p.numel()]
+        reached = any(p is q for m in (pre, nets[0]) for q in m.parameters())
+        assert torch.isfinite(g).all() and (reached or torch.all(g == 0))
