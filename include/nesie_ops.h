@@ -129,13 +129,21 @@ int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample
                                    void *stream);
 /* Same result through an inverted index of idx: order[B, M*ns] = the grouped columns sorted
  * by their source point, sources[B, M*ns] = that point for each (nesie_inverted_index builds
- * both, n <= 8192).  Lanes own sorted entries, a segmented scan inside each wave sums the runs;
+ * both; any n: n <= 2048 by a stable counting sort in one workgroup per scene, larger n in windows
+ * of 8192 source points per workgroup).  Lanes own sorted entries, a segmented scan inside each wave sums the runs;
  * every run is summed by exactly ONE wave (the one that holds its first entry follows it through
  * the next chunks) and added into grad_features (zeroed by the caller) by one lane: no float
  * atomics.  Inside a run the columns are in ascending order (scratch[B, M*ns] holds the
  * arrival-order placement that the second pass ranks), so the sums are bitwise reproducible. */
 int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
                          int *sources, int *scratch, void *stream);
+/* nesie_group_points_backward / nesie_gather_points_grad_wrapper (nsample = 1) through the same
+ * index: grad_points (B,C,N, zeroed) += grad_out (B,C,npoints,nsample), every point's run summed by
+ * one wave in ascending column order (replaces the atomicAdd of group_points_cuda.cu:10-31 and
+ * gather_points_cuda.cu:51-70 with a defined order). */
+int nesie_group_points_backward_csr(int b, int c, int n, int npoints, int nsample,
+                                    const float *grad_out, const int *order, const int *sources,
+                                    float *grad_points, void *stream);
 int nesie_query_and_group_backward_csr(int b, int c, int n, int npoints, int nsample,
                                        const float *grad_out, const int *order,
                                        const int *sources, float *grad_features, void *stream);
@@ -257,11 +265,13 @@ int nesie_blend_conv_backward_bn(int b, int c, int m, int n, const float *da, co
                                  const float *weight, const float *rel, float *d_table,
                                  float *d_wx, int segs, int seg_len, void *stream);
 
-/* The two backward entry points above WITHOUT float atomics (round 4): every 16-query group stores
- * the row it has summed per seed into staging slots of its own (48 per group), a per-(scene, face)
- * inverted index of the slots' seeds (nesie_inverted_index's kernel) lists each seed's slots in
- * ascending order, and one wave per (scene, face, seed) adds them in that order and WRITES the
- * d_table row -- bitwise reproducible, d_table needs no zero fill.  z / bnb both NULL: plain
+/* The two backward entry points above WITHOUT float atomics (round 4; the default of the python
+ * layer since round 5): every 16-query group stores the row it has summed per seed into staging
+ * slots of its own (48 per group), a counting sort per chunk of 128 groups lists each seed's slots
+ * in ascending order (chunk-major, with the run starts), and one wave per (scene, face, seed) walks
+ * the chunks, adds its rows in that order and WRITES the d_table row -- bitwise reproducible,
+ * d_table needs no zero fill.  Needs m <= 2047 seeds, pitch and seg_off multiples of 4, d_table
+ * 16-byte aligned.  z / bnb both NULL: plain
  * backward; both given: the norm backward on the tile load (as nesie_blend_conv_backward_bn).
  * d_wx as above.  workspace: nesie_blend_conv_backward_workspace_bytes(b, c, n, segs) bytes. */
 size_t nesie_blend_conv_backward_workspace_bytes(int b, int c, int n, int segs);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "nesie_three_interpolate_grad_csr": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nesie_group_points_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_gather_rows3": [_I, _I, _I, _P, _P, _P, _P],
     "nesie_vote_finish_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "nesie_vote_finish_backward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],

@@ -198,29 +198,42 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
 // ranks every entry inside its run (runs are short: M ns / N on average), so `order` lists each
 // run in ascending column order and the segmented sums of the backward are reproducible.
 constexpr int II_BLOCK = 1024;
+constexpr int II_WINDOW = 8192;     // source points per workgroup (LDS histogram + cursor)
 
-// n_ranked < n: the bins >= n_ranked collect entries nobody will read (the unused staging slots of
-// the blend backward, marked -1): a NEGATIVE index goes to bin n - 1 and those bins are not ranked
-// (their run can hold most of the entries; ranking is quadratic in the run length).
+// Any n (round 5): workgroup (scene, window w) owns the source points [w * II_WINDOW, + II_WINDOW):
+// it first counts the entries that belong to EARLIER windows (that many positions of order / srcs lie
+// in front of its own), then sorts its own entries as before.  Every window reads the whole index
+// row, so the cost grows with the window count -- 5 windows at 40 000 points; the step itself only
+// ever inverts indices over <= 2 048 points (the 40 000-point level carries no feature gradient).
 __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
     int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
-    int *__restrict__ srcs, int *__restrict__ scratch_out, int n_ranked) {
-  extern __shared__ int lds[];  // hist[n] then cursor[n]; scan scratch [II_BLOCK]
-  int *cur = lds, *scratch = lds + n;
+    int *__restrict__ srcs, int *__restrict__ scratch_out) {
+  extern __shared__ int lds[];  // cursor[bins]; scan scratch [II_BLOCK]; base counter
+  const int lo_pt = blockIdx.y * II_WINDOW;
+  const int bins = n - lo_pt < II_WINDOW ? n - lo_pt : II_WINDOW;
+  int *cur = lds, *scratch = lds + bins, *before = scratch + II_BLOCK;
   const int bi = blockIdx.x, tid = threadIdx.x;
   const int *ix = idx + (size_t)bi * e_total;
-  for (int j = tid; j < n; j += II_BLOCK) cur[j] = 0;
+  for (int j = tid; j < bins; j += II_BLOCK) cur[j] = 0;
+  if (tid == 0) *before = 0;
   __syncthreads();
-  const int neg = n_ranked < n ? n - 1 : 0;          // where a negative index goes
+  int mine_before = 0;
   for (int e = tid; e < e_total; e += II_BLOCK) {
     int s = ix[e];
-    s = s < 0 ? neg : (s >= n ? n - 1 : s);
-    atomicAdd(&cur[s], 1);
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    if (s < lo_pt) ++mine_before;
+    else if (s < lo_pt + bins) atomicAdd(&cur[s - lo_pt], 1);
+  }
+  if (lo_pt > 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine_before += __shfl_xor(mine_before, off, 64);
+    if ((tid & 63) == 0 && mine_before) atomicAdd(before, mine_before);
   }
   __syncthreads();
-  // exclusive scan over n bins: each thread owns a contiguous chunk
-  const int per = (n + II_BLOCK - 1) / II_BLOCK;
-  const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+  const int base = *before;
+  // exclusive scan over the bins: each thread owns a contiguous chunk
+  const int per = (bins + II_BLOCK - 1) / II_BLOCK;
+  const int lo = tid * per, hi = lo + per < bins ? lo + per : bins;
   int sum = 0;
   for (int j = lo; j < hi; ++j) sum += cur[j];
   scratch[tid] = sum;
@@ -231,10 +244,10 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
     scratch[tid] += v;
     __syncthreads();
   }
-  int run = scratch[tid] - sum;  // exclusive prefix of this chunk
+  int run = base + scratch[tid] - sum;  // first position of this chunk
   for (int j = lo; j < hi; ++j) {
     const int cnt = cur[j];
-    cur[j] = run;  // becomes the cursor of point j
+    cur[j] = run;  // becomes the cursor of point lo_pt + j
     run += cnt;
   }
   __syncthreads();
@@ -243,17 +256,17 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
   int *tmp = scratch_out + (size_t)bi * e_total;
   for (int e = tid; e < e_total; e += II_BLOCK) {
     int s = ix[e];
-    s = s < 0 ? neg : (s >= n ? n - 1 : s);
-    tmp[atomicAdd(&cur[s], 1)] = e;
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
+    if (s >= lo_pt && s < lo_pt + bins) tmp[atomicAdd(&cur[s - lo_pt], 1)] = e;
   }
-  __syncthreads();   // cur[s] is now the END of run s; run s starts where run s - 1 ends
-  for (int i = tid; i < e_total; i += II_BLOCK) {
+  __syncthreads();   // cur[j] is now the END of run j; run j starts where run j - 1 ends (run 0: at base)
+  const int total = cur[bins - 1];
+  for (int i = base + tid; i < total; i += II_BLOCK) {
     const int e = tmp[i];
     int s = ix[e];
-    s = s < 0 ? neg : (s >= n ? n - 1 : s);
-    sr[i] = s;
-    if (s >= n_ranked) { ord[i] = e; continue; }     // (arrival order: never read)
-    const int lo_s = s > 0 ? cur[s - 1] : 0, hi_s = cur[s];
+    s = (s < 0 ? 0 : (s >= n ? n - 1 : s)) - lo_pt;
+    sr[i] = s + lo_pt;
+    const int lo_s = s > 0 ? cur[s - 1] : base, hi_s = cur[s];
     int rank = 0;
     for (int k = lo_s; k < hi_s; ++k) rank += tmp[k] < e ? 1 : 0;
     ord[lo_s + rank] = e;
@@ -266,34 +279,25 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_kernel(
 // places its entries 64 at a time in ascending order: the lanes that hold the same bin find each
 // other with a ballot per distinct bin of the round and take consecutive positions in lane order.
 // The result is `order` ascending inside every run by construction -- what the ranking pass of
-// inverted_index_kernel computes in time quadratic in the run length (a seed of the blend backward's
-// staging index collects 1 500 slots: 0.4 ms per build there, 0.03 ms here).
+// inverted_index_kernel computes in time quadratic in the run length.
 constexpr int II_STABLE_N = 2048, II_WAVES = II_BLOCK / 64;
 
-// span > 0 (the blend backward's staging index): the entries come in blocks of `span` whose VALID
-// bins are pairwise distinct (one 16-query group's seeds, ascending) with negative = unused entries:
-// the unused ones are skipped altogether, and a block is placed by ONE returning LDS add per lane --
-// no two lanes of a block share a cursor, blocks of a wave go in order, waves own their cursor rows:
-// still the stable order.  srcs behind the last valid position is filled with n (bisection-safe).
 __global__ __launch_bounds__(II_BLOCK) void inverted_index_stable_kernel(
     int n, int e_total, const int *__restrict__ idx, int *__restrict__ order,
-    int *__restrict__ srcs, int n_ranked, int span) {
+    int *__restrict__ srcs) {
   extern __shared__ int lds[];                       // cnt[II_WAVES][n], then scan scratch [II_BLOCK]
   int *cnt = lds, *scratch = lds + II_WAVES * n;
   const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int *ix = idx + (size_t)bi * e_total;
-  const int neg = n_ranked < n ? n - 1 : 0;          // where a negative index goes
   for (int j = tid; j < II_WAVES * n; j += II_BLOCK) cnt[j] = 0;
   __syncthreads();
-  const int unit = span > 0 ? span : 64;
-  const int per = ((e_total + II_WAVES - 1) / II_WAVES + unit - 1) / unit * unit;   // entries per wave, whole rounds
+  const int per = ((e_total + II_WAVES - 1) / II_WAVES + 63) / 64 * 64;   // entries per wave, whole rounds
   const int e0 = wave * per, e1 = e0 + per < e_total ? e0 + per : e_total;
   int *mine = cnt + wave * n;
   for (int e = e0 + lane; e < e1; e += 64) {
     int s = ix[e];
-    if (span > 0 && (s < 0 || s >= n_ranked)) continue;
-    s = s < 0 ? neg : (s >= n ? n - 1 : s);
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
     atomicAdd(&mine[s], 1);
   }
   __syncthreads();
@@ -321,28 +325,12 @@ __global__ __launch_bounds__(II_BLOCK) void inverted_index_stable_kernel(
   __syncthreads();
   int *ord = order + (size_t)bi * e_total;
   int *sr = srcs + (size_t)bi * e_total;
-  if (span > 0) {
-    const int total = scratch[II_BLOCK - 1];         // valid entries of the scene
-    for (int pos = total + tid; pos < e_total; pos += II_BLOCK) sr[pos] = n;
-    for (int base = e0; base < e1; base += span) {
-      const int e = base + lane;
-      if (lane < span && e < e1) {
-        const int sv = ix[e];
-        if (sv >= 0 && sv < n_ranked) {
-          const int pos = atomicAdd(&mine[sv], 1);   // (distinct bins inside a block: one lane per cursor)
-          ord[pos] = e;
-          sr[pos] = sv;
-        }
-      }
-    }
-    return;
-  }
   volatile int *cur = mine;                          // this wave's cursors (only this wave touches them)
   for (int base = e0; base < e1; base += 64) {
     const int e = base + lane;
     const bool live = e < e1;
     int s = live ? ix[e] : 0;
-    s = s < 0 ? neg : (s >= n ? n - 1 : s);
+    s = s < 0 ? 0 : (s >= n ? n - 1 : s);
     unsigned long long todo = __ballot(live);
     while (todo) {                                   // one trip per distinct bin of the round
       const int leader = __builtin_ctzll(todo);
@@ -560,17 +548,31 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
   return check_launch(W);
 }
 
+// group_points / gather_points backward through an inverted index of idx (nesie_inverted_index):
+// what nesie_group_points_backward adds with float atomics (LDS or HBM), in an order fixed by the
+// index alone.  grad_points must be zero on entry.
+extern "C" int nesie_group_points_backward_csr(int b, int c, int n, int npoints, int nsample,
+                                               const float *grad_out, const int *order,
+                                               const int *sources, float *grad_points, void *stream) {
+  const char *W = "group_points_backward_csr";
+  NESIE_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, W);
+  const long long e_total = (long long)npoints * nsample;
+  if (b == 0 || n == 0 || c == 0 || e_total == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_out && order && sources && grad_points, W);
+  NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
+                     dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total, (long long)c * e_total, 1,
+                     grad_out, (const float *)nullptr, order, sources, grad_points);
+  return check_launch(W);
+}
+
 namespace nesie {
 int launch_inverted_index(int b, int n, long long e_total, const int *idx, int *order, int *sources,
-                          int *scratch, int n_ranked, hipStream_t s, int span) {
+                          int *scratch, hipStream_t s) {
   const char *W = "inverted_index";
   NESIE_REQUIRE(b >= 0 && n >= 1 && e_total >= 0 && e_total < (1ll << 31), W);
   if (b == 0) return NESIE_OK;
   NESIE_REQUIRE(idx && order && sources && scratch, W);
-  if (n > 8192) {
-    set_error("%s: %d source points (built for n <= 8192: one LDS histogram per scene)", W, n);
-    return NESIE_ERR_UNSUPPORTED;
-  }
   static const int stable_on = getenv("NESIE_INDEX_STABLE") ? atoi(getenv("NESIE_INDEX_STABLE")) : 1;   // A/B switch
   if (stable_on && n <= II_STABLE_N) {               // stable counting sort: ascending runs without a ranking pass
     const size_t lds = ((size_t)II_WAVES * n + II_BLOCK) * sizeof(int);
@@ -580,22 +582,22 @@ int launch_inverted_index(int b, int n, long long e_total, const int *idx, int *
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)II_WAVES * II_STABLE_N + II_BLOCK) * sizeof(int)));
       attr = true;
     }
-    NESIE_REQUIRE(span >= 0 && span <= 64 && (span == 0 || e_total % span == 0), W);
     hipLaunchKernelGGL(inverted_index_stable_kernel, dim3(b), dim3(II_BLOCK), lds, s, n, (int)e_total, idx,
-                       order, sources, n_ranked, span);
+                       order, sources);
     return check_launch(W);
   }
-  NESIE_REQUIRE(span == 0, W);
-  const size_t lds = ((size_t)n + II_BLOCK) * sizeof(int);
-  hipLaunchKernelGGL(inverted_index_kernel, dim3(b), dim3(II_BLOCK), lds, s, n, (int)e_total, idx, order,
-                     sources, scratch, n_ranked);
+  const int windows = cdiv(n, II_WINDOW);
+  NESIE_REQUIRE(windows <= 65535, W);
+  const size_t lds = ((size_t)(n < II_WINDOW ? n : II_WINDOW) + II_BLOCK + 1) * sizeof(int);
+  hipLaunchKernelGGL(inverted_index_kernel, dim3(b, windows), dim3(II_BLOCK), lds, s, n, (int)e_total, idx, order,
+                     sources, scratch);
   return check_launch(W);
 }
 }  // namespace nesie
 
 extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
                                     int *sources, int *scratch, void *stream) {
-  return launch_inverted_index(b, n, e_total, idx, order, sources, scratch, n, (hipStream_t)stream, 0);
+  return launch_inverted_index(b, n, e_total, idx, order, sources, scratch, (hipStream_t)stream);
 }
 
 extern "C" int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,

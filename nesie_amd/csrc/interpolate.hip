@@ -443,12 +443,22 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
     // STAGED: first slot of this wave's 16-query group, and the seeds emitted so far
     const size_t gslot = STAGED ? ((size_t)((size_t)bi * segs + sg) * (per_seg / 16) + (r0 + q0) / 16) * BL_SLOTS : 0;
     int rank = 0;
+    if (STAGED) {
+      // the group's distinct seeds in ascending order name its staging slots: lane i of the sorted
+      // keys opens a slot when its seed differs from lane i - 1's; ONE store instruction per group
+      const int sd = lane < 48 ? (int)(key >> 6) : -1;
+      const int sp = __shfl_up(sd, 1, 64);
+      const bool first = lane < 48 && (lane == 0 || sd != sp);
+      const unsigned long long fm = __ballot(first);
+      const int nvalid = __popcll(fm);
+      if (first) slot_seed[gslot + __popcll(fm & ((1ull << lane) - 1ull))] = sd;
+      if (lane >= nvalid && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
+    }
     auto emit = [&]() {
       if (STAGED) {
         float *row = stage + (gslot + rank) * C + lane;
 #pragma unroll
         for (int e = 0; e < CPT; ++e) row[e * 64] = acc[e];
-        if (lane == 0) slot_seed[gslot + rank] = cur;
         ++rank;
       } else {
 #pragma unroll
@@ -483,7 +493,6 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
       }
     }
     emit();
-    if (STAGED && lane >= rank && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
   }
   if (d_wx_part) {
     // partial[b][run][s][c][3]: the four waves hold different queries of the same channels
@@ -500,63 +509,156 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
   }
 }
 
-// Second half of the STAGED blend backward: one wave per (scene, face, seed).  (order, srcs) =
-// the inverted index of slot_seed per (scene, face) -- nesie_inverted_index's kernel with the seeds
-// as "source points" and the unused slots in an unranked bin of their own -- so order lists a
-// seed's staging slots in ASCENDING slot number.  The wave bisects srcs for its seed's run, adds
-// the rows (C floats each, dense 256-byte loads) in that order and writes the d_table row --
-// zeros for a seed no tap landed on: d_table needs no zero fill and meets no atomic.
+// Second half of the STAGED blend backward (round 5 form).  The staging slots of one (scene, face)
+// are indexed by SEED in two steps that never leave the chip-wide grid idle:
+//   blend_slot_index_kernel: one 1024-thread workgroup per CHUNK of SI_GROUPS 16-query groups
+//     (6 144 slots; 4 chunks per side face, 16 per box grid: 192 / 128 workgroups where the
+//     round-4 index ran one workgroup per face) counting-sorts its chunk's valid slots by seed --
+//     per-wave histogram rows in LDS (a group's valid seeds are pairwise distinct, so a group is
+//     counted and later placed by one LDS add per lane), block scan, placement in group order: the
+//     STABLE order, every seed's run ascending in slot number -- and leaves `order` (the chunk's
+//     slots seed-major) and `offs` (m + 1 run starts per chunk);
+//   blend_bwd_gather_kernel: one wave per (scene, face, seed) walks the chunks in order, reads its
+//     run bounds from `offs` (no bisection: the round-4 kernel spent 2 x 15 dependent L2 loads per
+//     wave finding them), adds the rows in ascending slot order and WRITES the d_table row (zeros
+//     for a seed no tap landed on): d_table needs no zero fill and meets no atomic, and the sum
+//     order is fixed by the taps alone.
+constexpr int SI_GROUPS = 128;                         // 16-query groups per index workgroup
+constexpr int SI_BLOCK = 1024, SI_WAVES = SI_BLOCK / 64;
+constexpr int SI_MAX_BINS = 2048;                      // seeds + 1 (LDS: 16 histogram rows)
+
+__global__ __launch_bounds__(SI_BLOCK) void blend_slot_index_kernel(
+    int m, int groups_per_face, int nchunk, const int *__restrict__ slot_seed,
+    int *__restrict__ order, int *__restrict__ offs) {
+  extern __shared__ int si_lds[];                      // cnt[SI_WAVES][m], then scan scratch [SI_BLOCK]
+  int *cnt = si_lds, *scratch = si_lds + SI_WAVES * m;
+  const int face = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g0 = chunk * SI_GROUPS;
+  const int g1 = g0 + SI_GROUPS < groups_per_face ? g0 + SI_GROUPS : groups_per_face;
+  const int *ss = slot_seed + (size_t)face * groups_per_face * BL_SLOTS;
+  for (int j = tid; j < SI_WAVES * m; j += SI_BLOCK) cnt[j] = 0;
+  __syncthreads();
+  constexpr int GPW = SI_GROUPS / SI_WAVES;            // groups per wave, consecutive
+  int *mine = cnt + wave * m;
+  int sv[GPW];
+#pragma unroll
+  for (int u = 0; u < GPW; ++u) {
+    const int g = g0 + wave * GPW + u;
+    int v = -1;
+    if (g < g1 && lane < BL_SLOTS) v = ss[(size_t)g * BL_SLOTS + lane];
+    sv[u] = (v >= 0 && v < m) ? v : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < GPW; ++u)
+    if (sv[u] >= 0) atomicAdd(&mine[sv[u]], 1);        // (distinct bins inside a group)
+  __syncthreads();
+  // totals per bin -> exclusive scan over the bins -> per-(wave, bin) start positions
+  const int bper = (m + SI_BLOCK - 1) / SI_BLOCK;      // bins per thread (contiguous)
+  const int b0 = tid * bper, b1 = b0 + bper < m ? b0 + bper : m;
+  int sum = 0;
+  for (int sbin = b0; sbin < b1; ++sbin)
+    for (int w = 0; w < SI_WAVES; ++w) sum += cnt[w * m + sbin];
+  scratch[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < SI_BLOCK; d <<= 1) {
+    const int v = tid >= d ? scratch[tid - d] : 0;
+    __syncthreads();
+    scratch[tid] += v;
+    __syncthreads();
+  }
+  int *of = offs + ((size_t)face * nchunk + chunk) * (m + 1);
+  int run = scratch[tid] - sum;                        // first position of this thread's first bin
+  for (int sbin = b0; sbin < b1; ++sbin) {
+    of[sbin] = run;
+    for (int w = 0; w < SI_WAVES; ++w) {
+      const int c = cnt[w * m + sbin];
+      cnt[w * m + sbin] = run;
+      run += c;
+    }
+  }
+  if (tid == SI_BLOCK - 1) of[m] = scratch[SI_BLOCK - 1];
+  __syncthreads();
+  int *ord = order + ((size_t)face * nchunk + chunk) * (SI_GROUPS * BL_SLOTS);
+#pragma unroll
+  for (int u = 0; u < GPW; ++u) {                      // groups in order: the stable placement
+    if (sv[u] >= 0) {
+      const int pos = atomicAdd(&mine[sv[u]], 1);      // (one lane per cursor inside a group)
+      ord[pos] = (g0 + wave * GPW + u) * BL_SLOTS + lane;
+    }
+  }
+}
+
+// lane = CPT consecutive channels (one 4 * CPT-byte load per row and lane: 1 KB rows move as ONE
+// 16-byte-per-lane instruction at C = 256)
 template <int CPT>
 __global__ __launch_bounds__(256) void blend_bwd_gather_kernel(
-    int m, int segs, int pitch, int seg_off, int slots_per_face, const float *__restrict__ stage,
-    const int *__restrict__ order, const int *__restrict__ srcs, float *__restrict__ d_table, int nb) {
+    int m, int segs, int pitch, int seg_off, int slots_per_face, int nchunk,
+    const float *__restrict__ stage, const int *__restrict__ order, const int *__restrict__ offs,
+    float *__restrict__ d_table, int nb) {
   constexpr int C = CPT * 64;
+  // CPT floats per lane as one load (CPT = 3 is padded to 16 bytes as a vector type: three scalars)
+  struct Row {
+    float v[CPT];
+    __device__ __forceinline__ void load(const float *p) {
+      if constexpr (CPT == 4) { const float4 t = *(const float4 *)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      else if constexpr (CPT == 2) { const float2 t = *(const float2 *)p; v[0] = t.x; v[1] = t.y; }
+      else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) v[e] = p[e];
+      }
+    }
+    __device__ __forceinline__ void store(float *p) const {
+      if constexpr (CPT == 4) *(float4 *)p = make_float4(v[0], v[1], v[2], v[3]);
+      else if constexpr (CPT == 2) *(float2 *)p = make_float2(v[0], v[1]);
+      else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) p[e] = v[e];
+      }
+    }
+  };
   const int lane = threadIdx.x & 63;
   const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= (long long)nb * segs * m) return;
-  const int seed = (int)(w % m), face = (int)((w / m) % (nb * segs));     // face = bi * segs + sg
+  // seed fastest: the four waves of a workgroup write neighbouring d_table rows
+  const int seed = (int)(w % m), face = (int)(w / m);                      // face = bi * segs + sg
   const int bi = face / segs, sg = face % segs;
-  const int *sb = srcs + (size_t)face * slots_per_face, *ob = order + (size_t)face * slots_per_face;
-  int lo = 0, hi = slots_per_face;
-  while (lo < hi) {                                    // first sorted entry with source >= seed (uniform)
-    const int mid = (lo + hi) >> 1;
-    if (sb[mid] < seed) lo = mid + 1; else hi = mid;
+  // run bounds of this seed in every chunk: lane c holds chunk c's (lo, hi)
+  int lo = 0, hi = 0;
+  if (lane < nchunk) {
+    const int *of = offs + ((size_t)face * nchunk + lane) * (m + 1) + seed;
+    lo = of[0]; hi = of[1];
   }
-  int end = lo;
-  {
-    int l2 = lo, h2 = slots_per_face;
-    while (l2 < h2) {                                  // ... and the first with source > seed
-      const int mid = (l2 + h2) >> 1;
-      if (sb[mid] <= seed) l2 = mid + 1; else h2 = mid;
+  const float *base = stage + (size_t)face * slots_per_face * C + lane * CPT;
+  Row acc;
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) acc.v[e] = 0.f;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int l = __builtin_amdgcn_readlane(lo, ch), h = __builtin_amdgcn_readlane(hi, ch);
+    const int *ob = order + ((size_t)face * nchunk + ch) * (SI_GROUPS * BL_SLOTS);
+    for (int j0 = l; j0 < h; j0 += 64) {               // (a seed rarely has more than 64 slots per chunk)
+      const int cntj = h - j0 < 64 ? h - j0 : 64;
+      const int myslot = lane < cntj ? ob[j0 + lane] : 0;
+      int u = 0;
+      for (; u + 3 < cntj; u += 4) {                   // four rows in flight, added in order
+        Row v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k].load(base + (size_t)__builtin_amdgcn_readlane(myslot, u + k) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) acc.v[e] += v[k].v[e];
+      }
+      for (; u < cntj; ++u) {
+        Row v;
+        v.load(base + (size_t)__builtin_amdgcn_readlane(myslot, u) * C);
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc.v[e] += v.v[e];
+      }
     }
-    end = l2;
   }
-  const float *base = stage + (size_t)face * slots_per_face * C + lane;
-  float acc[CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
-  int j = lo;
-  for (; j + 3 < end; j += 4) {                        // four rows in flight, added in order
-    float v[4][CPT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float *row = base + (size_t)ob[j + u] * C;
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) v[u][e] = row[e * 64];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) acc[e] += v[u][e];
-  }
-  for (; j < end; ++j) {
-    const float *row = base + (size_t)ob[j] * C;
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) acc[e] += row[e * 64];
-  }
-  float *dt = d_table + ((size_t)bi * m + seed) * pitch + (size_t)sg * seg_off + lane;
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) dt[e * 64] = acc[e];
+  acc.store(d_table + ((size_t)bi * m + seed) * pitch + (size_t)sg * seg_off + lane * CPT);
 }
 
 // ---- blend + BatchNorm + ReLU fused by RECOMPUTATION ------------------------------------------
@@ -784,12 +886,22 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
     // STAGED: first slot of this wave's 16-query group, and the seeds emitted so far
     const size_t gslot = STAGED ? ((size_t)((size_t)bi * segs + sg) * (per_seg / 16) + (r0 + q0) / 16) * BL_SLOTS : 0;
     int rank = 0;
+    if (STAGED) {
+      // the group's distinct seeds in ascending order name its staging slots: lane i of the sorted
+      // keys opens a slot when its seed differs from lane i - 1's; ONE store instruction per group
+      const int sd = lane < 48 ? (int)(key >> 6) : -1;
+      const int sp = __shfl_up(sd, 1, 64);
+      const bool first = lane < 48 && (lane == 0 || sd != sp);
+      const unsigned long long fm = __ballot(first);
+      const int nvalid = __popcll(fm);
+      if (first) slot_seed[gslot + __popcll(fm & ((1ull << lane) - 1ull))] = sd;
+      if (lane >= nvalid && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
+    }
     auto emit = [&]() {
       if (STAGED) {
         float *row = stage + (gslot + rank) * C + lane;
 #pragma unroll
         for (int e = 0; e < CPT; ++e) row[e * 64] = acc[e];
-        if (lane == 0) slot_seed[gslot + rank] = cur;
         ++rank;
       } else {
 #pragma unroll
@@ -822,7 +934,6 @@ __global__ __launch_bounds__(256) void blend_bn_bwd_rows_kernel(
       }
     }
     emit();
-    if (STAGED && lane >= rank && lane < BL_SLOTS) slot_seed[gslot + lane] = -1;     // the unused slots
   }
   if (d_wx_part) {
     __syncthreads();
@@ -963,20 +1074,18 @@ extern "C" int nesie_blend_conv_runs(int n, int segs) {
   return segs >= 1 && n >= 0 ? cdiv(n / segs, BL_RUN) : 0;
 }
 
-// the inverted index of the staging slots (group_gather.hip)
-namespace nesie {
-int launch_inverted_index(int b, int n, long long e_total, const int *idx, int *order, int *sources,
-                          int *scratch, int n_ranked, hipStream_t s, int span);
-}
-
-// staging workspace of the STAGED backward: rows [b * segs * groups * 48][c] floats, then four int
-// arrays of b * segs * groups * 48 (slot_seed, order, srcs, scratch)
+// staging workspace of the STAGED backward: rows [b * segs * groups * 48][c] floats, then
+// slot_seed and order (one int per slot each; order chunk-major, SI_GROUPS * 48 per chunk) and the
+// run starts offs [faces * chunks][SI_MAX_BINS]
 static size_t blend_stage_slots(int b, int n, int segs) { return (size_t)b * (n / 16) * BL_SLOTS; }   // n / 16 groups in all
+static int blend_index_chunks(int n, int segs) { return cdiv(n / segs / 16, SI_GROUPS); }
 
 extern "C" size_t nesie_blend_conv_backward_workspace_bytes(int b, int c, int n, int segs) {
   if (b <= 0 || c <= 0 || n <= 0 || segs <= 0) return 0;
   const size_t slots = blend_stage_slots(b, n, segs);
-  return slots * c * sizeof(float) + 4 * slots * sizeof(int);
+  const size_t order_ints = (size_t)b * segs * blend_index_chunks(n, segs) * SI_GROUPS * BL_SLOTS;
+  const size_t offs_ints = (size_t)b * segs * blend_index_chunks(n, segs) * SI_MAX_BINS;
+  return slots * c * sizeof(float) + (slots + order_ints + offs_ints) * sizeof(int);
 }
 
 static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, const float *dy,
@@ -1002,12 +1111,15 @@ static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, c
   if (workspace) {   // STAGED: no float atomics, d_table written (not accumulated), reproducible
     const size_t slots = blend_stage_slots(b, n, segs);
     NESIE_REQUIRE(workspace_bytes >= nesie_blend_conv_backward_workspace_bytes(b, c, n, segs), W);
-    NESIE_REQUIRE(((uintptr_t)workspace & 15) == 0 && m + 1 <= 2048, W);     // (the stable index: <= 2048 bins)
-    const int slots_per_face = (per_seg / 16) * BL_SLOTS;
-    NESIE_REQUIRE((long long)slots_per_face < (1ll << 31) && (long long)b * segs * m < (1ll << 33), W);
+    NESIE_REQUIRE(((uintptr_t)workspace & 15) == 0 && m + 1 <= SI_MAX_BINS, W);     // (the index: <= 2048 bins)
+    NESIE_REQUIRE(pitch % 4 == 0 && seg_off % 4 == 0 && ((uintptr_t)d_table & 15) == 0, W);   // (vector row stores)
+    const int groups_per_face = per_seg / 16, slots_per_face = groups_per_face * BL_SLOTS;
+    const int nchunk = blend_index_chunks(n, segs);
+    NESIE_REQUIRE(nchunk <= 64 && (long long)b * segs * nchunk < (1ll << 31) &&
+                  (long long)b * segs * m < (1ll << 33), W);
     float *stage = (float *)workspace;
-    int *slot_seed = (int *)(stage + slots * c), *order = slot_seed + slots, *srcs = order + slots,
-        *scratch = srcs + slots;
+    int *slot_seed = (int *)(stage + slots * c), *order = slot_seed + slots,
+        *offs = order + (size_t)b * segs * nchunk * SI_GROUPS * BL_SLOTS;
 #define LS(N)                                                                                      \
   do {                                                                                             \
     if (bnb)                                                                                       \
@@ -1021,13 +1133,20 @@ static int blend_conv_backward_impl(const char *W, int b, int c, int m, int n, c
   } while (0)
     if (c == 64) LS(1); else if (c == 128) LS(2); else if (c == 192) LS(3); else LS(4);
 #undef LS
-    // (scene, face) pairs are the "scenes" of the index; seeds 0 .. m - 1 ranked, bin m = unused slots
-    // (each group's BL_SLOTS slots hold distinct ascending seeds, then -1: the block-wise placement)
-    st = launch_inverted_index(b * segs, m + 1, slots_per_face, slot_seed, order, srcs, scratch, m, s, BL_SLOTS);
-    if (st) return st;
+    {
+      const size_t lds = ((size_t)SI_WAVES * m + SI_BLOCK) * sizeof(int);
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void *)blend_slot_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(((size_t)SI_WAVES * SI_MAX_BINS + SI_BLOCK) * sizeof(int)));
+        attr = true;
+      }
+      hipLaunchKernelGGL(blend_slot_index_kernel, dim3((unsigned)(b * segs * nchunk)), dim3(SI_BLOCK), lds, s,
+                         m, groups_per_face, nchunk, slot_seed, order, offs);
+    }
     const long long waves = (long long)b * segs * m;
 #define LG(N) hipLaunchKernelGGL((blend_bwd_gather_kernel<N>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, \
-                                 m, segs, pitch, seg_off, slots_per_face, stage, order, srcs, d_table, b)
+                                 m, segs, pitch, seg_off, slots_per_face, nchunk, stage, order, offs, d_table, b)
     if (c == 64) LG(1); else if (c == 128) LG(2); else if (c == 192) LG(3); else LG(4);
 #undef LG
     return check_launch(W);

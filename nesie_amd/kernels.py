@@ -337,6 +337,17 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_query_and_group_backward_csr", b, c, n, m, ns, _ptr(grad_out),
                       _ptr(order), _ptr(offsets), _ptr(grad_features), _stream(grad_out))
 
+    def group_points_backward_csr(self, grad_out, order, sources, grad_points):
+        """grad_points (B,C,N, zeroed) += grad_out (B,C,M,ns) through (order, sources) =
+        inverted_index(idx (B,M,ns), N): no float atomics (nesie_group_points_backward_csr)."""
+        _check(grad_out, order, sources, grad_points); _f32(grad_out, grad_points); _i32(order, sources)
+        b, c, n = grad_points.shape
+        m, ns = grad_out.shape[2], grad_out.shape[3]
+        assert grad_out.shape[:2] == (b, c) and tuple(order.shape) == (b, m * ns) == tuple(sources.shape)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("nesie_group_points_backward_csr", b, c, n, m, ns, _ptr(grad_out), _ptr(order),
+                      _ptr(sources), _ptr(grad_points), _stream(grad_out))
+
     def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
         _check(unknown, known, dist2, idx); _f32(unknown, known, dist2); _i32(idx)
         assert unknown.numel() == b * n * 3 and known.numel() == b * m * 3
@@ -510,25 +521,34 @@ class HipKernels(_BNPoolMixin):
                       _ptr(idx), _ptr(weight), opt(rel), opt(wx), _ptr(out), segs, seg_len,
                       int(out.shape[2]), c_offset, opt(stat_partial), _stream(table))
 
-    # Deterministic mode (NESIE_DETERMINISTIC=1 or ``set_deterministic(True)``): the blend backward --
-    # the one place where the step still adds floats with atomics -- stages its rows and gathers them
-    # per seed in a fixed order instead (nesie_blend_conv_backward_staged).  With it every gradient of
-    # a step is bitwise reproducible from run to run (tests/test_parity_gpu.py); it costs 0.25 ms of
-    # the 14.1 ms step (same-box A/B), so the default keeps the atomics, as the reference does
-    # everywhere (three_interpolate_cuda.cu:61-84, group_points_cuda.cu:10-31).
-    BLEND_STAGED = (os.environ.get('NESIE_DETERMINISTIC', '0') != '0'
-                    or os.environ.get('NESIE_BLEND_STAGED', '0') != '0')
+    # Deterministic backward -- THE DEFAULT since round 5 (NESIE_DETERMINISTIC=0 or
+    # ``set_deterministic(False)`` restores the reference's atomicAdd scatters,
+    # three_interpolate_cuda.cu:61-84, group_points_cuda.cu:10-31): every scatter-add of the backward
+    # pass runs in an order fixed by the indices alone --
+    #  * the blend backward stages its rows and gathers them per seed (nesie_blend_conv_backward_staged);
+    #  * group_points / QueryAndGroup / gather_points / three_interpolate backward go through an
+    #    inverted index of their indices (``scatter_index``), built on the spot when the caller did
+    #    not hand one over (any number of source points);
+    # so two runs of the same step give the same bits in every gradient (tests/test_parity_gpu.py).
+    DETERMINISTIC = os.environ.get('NESIE_DETERMINISTIC', '1') != '0'
 
     @classmethod
     def set_deterministic(cls, on=True):
-        """Bitwise-reproducible backward (see BLEND_STAGED); -> the previous setting."""
-        prev, cls.BLEND_STAGED = cls.BLEND_STAGED, bool(on)
+        """Bitwise-reproducible backward (see DETERMINISTIC); -> the previous setting."""
+        prev, cls.DETERMINISTIC = cls.DETERMINISTIC, bool(on)
         return prev
+
+    def scatter_index(self, idx, n):
+        """(order, sources) = inverted_index(idx, n) when the deterministic backward is on and the
+        caller has none, else None (-> the atomic kernels)."""
+        if not self.DETERMINISTIC:
+            return None
+        return self.inverted_index(idx.contiguous(), n)
 
     def blend_backward_writes_table(self, c, n, segs, m):
         """True when ``blend_conv_backward`` WRITES d_table in full (the staged form): the caller
         then need not zero it."""
-        return self.BLEND_STAGED and c % 64 == 0 and c <= 256 and (n // segs) % 64 == 0 and m + 1 <= 2048
+        return self.DETERMINISTIC and c % 64 == 0 and c <= 256 and (n // segs) % 64 == 0 and m + 1 <= 2048
 
     def blend_conv_backward(self, dy, seg_off, idx, weight, rel, d_table, d_wx, segs, seg_len,
                             bn_z=None, bnb=None):
@@ -554,6 +574,11 @@ class HipKernels(_BNPoolMixin):
             if bnb is not None:
                 _check(bn_z, bnb); _f32(bn_z, bnb)
                 assert tuple(bn_z.shape) == tuple(dy.shape) and tuple(bnb.shape) == (segs * c, 8)
+            if self.DETERMINISTIC and not self.blend_backward_writes_table(c, n, segs, m):
+                raise RuntimeError(
+                    f'blend_conv_backward: no fixed-order form for c={c}, {n // segs} queries per face, '
+                    f'{m} seeds (needs c in 64..256 step 64, faces of whole 64-query tiles, <= 2047 '
+                    'seeds); HipKernels.set_deterministic(False) selects the atomic scatter')
             if self.blend_backward_writes_table(c, n, segs, m):
                 assert seg_off == c or segs == 1, 'staged form: one column block per face'
                 need = _lib.load().nesie_blend_conv_backward_workspace_bytes(b, c, n, segs)

@@ -31,8 +31,13 @@ class GroupingOperation(Function):
         B, C, npoint, nsample = grad_out.size()
         grad_features = grad_out.new_zeros((B, C, N))
         grad_out_data = grad_out.data.contiguous()
-        backend_for(grad_out_data).group_points_backward(
-            B, C, N, npoint, nsample, grad_out_data, idx, grad_features.data)
+        backend = backend_for(grad_out_data)
+        csr = _scatter_index(backend, idx, N)
+        if csr is not None:     # fixed-order scatter (group_points_cuda.cu:10-31 adds with atomicAdd)
+            backend.group_points_backward_csr(grad_out_data, csr[0], csr[1], grad_features.data)
+        else:
+            backend.group_points_backward(B, C, N, npoint, nsample, grad_out_data, idx,
+                                          grad_features.data)
         return grad_features, None
 
 
@@ -40,13 +45,20 @@ grouping_operation = GroupingOperation.apply
 group_points = grouping_operation  # the name mmdet3d.ops re-exports
 
 
+def _scatter_index(backend, idx, n):
+    """The inverted index a backward builds for itself when nobody handed one over and the back
+    end runs its scatters in a fixed order (``HipKernels.DETERMINISTIC``, the default)."""
+    build = getattr(backend, 'scatter_index', None)
+    return None if build is None else build(idx, n)
+
+
 def inverted_index(idx, n):
     """idx (B, M, ns) int32 source-point indices -> (order, sources), both (B, M*ns) int32 = the
     grouped columns sorted by source point and that point for each, or None when the back end
-    has no index builder for this size.  Pure index work: depends on coordinates only, so it is built ahead
+    has no index builder.  Pure index work: depends on coordinates only, so it is built ahead
     of the step with the ball query."""
     backend = backend_for(idx)
-    if not hasattr(backend, 'inverted_index') or n > 8192:
+    if not hasattr(backend, 'inverted_index'):
         return None
     return backend.inverted_index(idx.contiguous(), n)
 
@@ -76,13 +88,11 @@ class QueryGroupCat(Function):
         c, n = ctx.cn
         grad_out = grad_out.contiguous()
         backend = backend_for(grad_out)
-        if ctx.has_csr and hasattr(backend, 'query_and_group_backward_csr'):
-            order, offsets = ctx.saved_tensors[1:]
-            grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
-            backend.query_and_group_backward_csr(grad_out, idx.shape, order, offsets,
-                                                 grad_features)
+        csr = ctx.saved_tensors[1:] if ctx.has_csr else _scatter_index(backend, idx, n)
+        grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
+        if csr and hasattr(backend, 'query_and_group_backward_csr'):
+            backend.query_and_group_backward_csr(grad_out, idx.shape, csr[0], csr[1], grad_features)
         else:
-            grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
             backend.query_and_group_backward(grad_out, idx, grad_features)
         return None, None, grad_features, None, None, None
 
@@ -147,7 +157,7 @@ def sample_query_group_supported(points_xyz, features, grouper):
             and grouper.use_xyz
             and not grouper.return_grouped_xyz and not grouper.return_grouped_idx
             and points_xyz.dtype == torch.float32 and features.dtype == torch.float32
-            and points_xyz.shape[1] <= 8192 and torch.is_grad_enabled()
+            and points_xyz.shape[1] <= 8192 and torch.is_grad_enabled()      # (qg_xyz_bwd: one thread per point)
             and (points_xyz.requires_grad or features.requires_grad))
 
 

@@ -57,6 +57,8 @@ class ThreeInterpolate(Function):
         grad_features = grad_out.new_zeros((B, c, m))
         grad_out_data = grad_out.data.contiguous()
         backend = backend_for(grad_out_data)
+        if csr is None and getattr(backend, 'scatter_index', None) is not None:
+            csr = backend.scatter_index(idx, m)     # fixed-order scatter (three_interpolate_cuda.cu:61-84: atomicAdd)
         if csr is not None and hasattr(backend, 'three_interpolate_grad_csr'):
             backend.three_interpolate_grad_csr(grad_out_data, weight, csr[0], csr[1],
                                                grad_features.data)

@@ -718,10 +718,7 @@ def test_query_group_cat_matches_the_literal_chain(oracle_kernels, hip_device, n
     # bitwise equal, and equal to the scatter form within summation order
     from nesie_amd.mmdet3d_ops.group_points import inverted_index
     idx_d = idx.to(hip_device)
-    csr = inverted_index(idx_d, n)
-    if n > 8192:
-        assert csr is None     # one LDS histogram per scene: small point sets only
-        return
+    csr = inverted_index(idx_d, n)        # (any n since round 5: 40 000 points = 5 windows of 8 192)
     order, sources = csr
     flat = idx.reshape(2, -1).long()
     assert order.dtype == torch.int32 and tuple(sources.shape) == (2, m * ns)
@@ -785,6 +782,72 @@ def test_csr_scatter_is_bitwise_reproducible_with_long_runs(hip_device, n, m, ns
     want.scatter_add_(2, idx3.view(2, 1, -1).expand(-1, c, -1).long(), contrib)
     err = (outs[0].cpu().double() - want).abs().max().item()
     assert err <= 2e-6 * want.abs().max().item(), err
+
+
+@pytest.mark.parametrize("n,e,b", [(40000, 131072, 2), (8193, 5000, 3), (20000, 70000, 1), (2049, 64, 1),
+                                   (300, 4000, 2)])
+def test_inverted_index_of_any_point_count_is_the_stable_sort(hip_device, n, e, b):
+    """nesie_inverted_index beyond 8 192 source points (windows of 8 192 per workgroup, each counting
+    the entries of the earlier windows first): (order, sources) = the STABLE sort of the entries by
+    source point, exactly -- with a few points in hundreds of entries and points without any."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    g = torch.Generator().manual_seed(n + e)
+    hot = torch.randint(0, 5, (b, e), generator=g) * (n // 5)
+    idx = torch.where(torch.rand(b, e, generator=g) < 0.3, hot, torch.randint(0, n, (b, e), generator=g)).int()
+    order, sources = hip.inverted_index(idx.view(b, e, 1).to(hip_device), n)
+    torch.cuda.synchronize()
+    for bi in range(b):
+        want = np.argsort(idx[bi].numpy(), kind='stable')
+        assert np.array_equal(order[bi].cpu().numpy(), want.astype(np.int32))
+        assert np.array_equal(sources[bi].cpu().numpy(), idx[bi].numpy()[want])
+
+
+def test_reference_shaped_backward_calls_are_bitwise_reproducible_by_default(oracle_kernels, hip_device):
+    """The drop-in API without any precomputed index (mmdet3d.ops call shapes): the backward of
+    grouping_operation, QueryAndGroup, gather_points and three_interpolate -- atomicAdd scatters in
+    group_points_cuda.cu:10-31, gather_points_cuda.cu:51-70, three_interpolate_cuda.cu:61-84 -- builds
+    the inverted index itself (HipKernels.DETERMINISTIC, the default): three runs give the same bits,
+    also at 40 000 source points and with indices that repeat hundreds of times; the atomic kernels
+    (set_deterministic(False)) agree to rounding."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    assert hip.DETERMINISTIC, 'the fixed-order backward is the default'
+    g = torch.Generator().manual_seed(5)
+    for (b, c, n, m, ns) in [(2, 16, 40000, 2048, 64), (2, 131, 2048, 1024, 32), (3, 9, 50, 7, 4)]:
+        pts = torch.randn(b, c, n, generator=g).to(hip_device)
+        xyz = torch.rand(b, n, 3, generator=g).to(hip_device)
+        # ball-query-like rows: low indices everywhere (the first nsample hits)
+        idx = torch.where(torch.rand(b, m, ns, generator=g) < 0.5, torch.randint(0, min(n, 8), (b, m, ns), generator=g),
+                          torch.randint(0, n, (b, m, ns), generator=g)).int().to(hip_device)
+        centres = xyz[:, :m].contiguous()
+        gi = torch.randint(0, max(n // 50, 2), (b, m), generator=g, dtype=torch.int32).to(hip_device)   # repeats
+        ti = torch.randint(0, n, (b, 3 * m + 1, 3), generator=g, dtype=torch.int32).to(hip_device)
+        w = torch.rand(b, 3 * m + 1, 3, generator=g).to(hip_device)
+        grouper = ops.QueryAndGroup(0.3, ns, use_xyz=True, normalize_xyz=True)
+        go = {k: torch.randn(*s_, generator=g).to(hip_device) for k, s_ in
+              dict(group=(b, c, m, ns), qg=(b, 3 + c, m, ns), gather=(b, c, m), interp=(b, c, 3 * m + 1)).items()}
+
+        def grads():
+            out = {}
+            for name, fn in (('group', lambda p: ops.grouping_operation(p, idx)),
+                             ('qg', lambda p: grouper(xyz, centres, p, idx=idx)),
+                             ('gather', lambda p: ops.gather_points(p, gi)),
+                             ('interp', lambda p: ops.three_interpolate(p, ti, w))):
+                p = pts.clone().requires_grad_(True)
+                fn(p).backward(go[name])
+                out[name] = p.grad.clone()
+            torch.cuda.synchronize()
+            return out
+        runs = [grads() for _ in range(3)]
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), (k, n)
+        prev = hip.set_deterministic(False)
+        try:
+            atomic = grads()
+        finally:
+            hip.set_deterministic(prev)
+        for k in atomic:
+            scale = runs[0][k].abs().max().item()
+            assert (atomic[k] - runs[0][k]).abs().max().item() <= 2e-5 * scale, (k, n)
 
 
 @pytest.mark.parametrize("n,m,c", [(1024, 512, 256), (512, 256, 256), (100, 7, 5)])

@@ -426,9 +426,9 @@ def test_rccl_all_reduce_runs_between_the_graph_replays_on_one_gpu():
     world_size = 1 ``nccl`` (= RCCL) process group, so dp.SegmentedAllReduce really launches both
     gradient all-reduces on the communication stream -- the head's segment between the g1a and g1b
     replays, the backbone's before g2 -- for 50 steps.  A one-rank sum divided by 1 is the identity,
-    so the loss trajectory must EQUAL the run without a group, step for step and bit for bit: both
-    children run in deterministic mode (NESIE_DETERMINISTIC=1: no unordered float sum in the
-    backward), so any difference would be the collective's doing -- a gradient segment reduced while
+    so the loss trajectory must EQUAL the run without a group, step for step and bit for bit: the
+    default backward has no unordered float sum (kernels.HipKernels.DETERMINISTIC), so any
+    difference would be the collective's doing -- a gradient segment reduced while
     it was still being written, an update that did not wait for the exchange (the reference's
     collective is NCCL through torch.distributed: train.py:132-139,
     nesie-votenet-scannet-train-010.py:143).  Children are fresh processes; nothing that touched the
@@ -441,7 +441,7 @@ def test_rccl_all_reduce_runs_between_the_graph_replays_on_one_gpu():
     base = {k: v for k, v in os.environ.items()
             if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'NESIE_DIST_BACKEND', 'NESIE_FORCE_PG')}
     base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    base['NESIE_DETERMINISTIC'] = '1'
+    base.pop('NESIE_DETERMINISTIC', None)              # the default mode, whatever the caller's shell says
     runs = {}
     for name, extra in (('plain', {}), ('rccl', dict(NESIE_FORCE_PG='1', MASTER_ADDR='127.0.0.1',
                                                      MASTER_PORT='29541'))):

@@ -147,11 +147,8 @@ def test_full_size_step_losses_and_gradients_match_the_cpu_oracle(oracle_kernels
     gmodel = copy.deepcopy(model).to(hip_device)
     with kernels.use_backend(oracle_kernels):
         cpu_l, cpu_g = _small.train_step_losses(model, pts, boxes, labels)
-    was = kernels.HipKernels.set_deterministic(True)     # fixed-order backward: the outcome is the code's, not the run's
-    try:
-        gpu_l, gpu_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
-    finally:
-        kernels.HipKernels.set_deterministic(was)
+    assert kernels.HipKernels.DETERMINISTIC      # fixed-order backward (the default): the outcome is the code's, not the run's
+    gpu_l, gpu_g = _small.train_step_losses(gmodel, pts.to(hip_device), boxes, labels)
     assert len(ref_l) == 8
     for k, v in ref_l.items():
         assert abs(float(gpu_l[k].sum()) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(gpu_l[k].sum()), v)
@@ -523,42 +520,43 @@ def test_saqe_graph_replay_at_sixteen_scenes_equals_eager_per_tensor_steps(hip_d
     assert gaps[0][0] < 1e-2, gaps[:6]
 
 
-@pytest.mark.parametrize('workload,batch', [('pretrain', 2), ('semi', 3)])
-def test_training_step_is_bitwise_reproducible_in_deterministic_mode(hip_device, workload, batch):
-    """Deterministic mode (kernels.HipKernels.set_deterministic): forward + backward of the same
-    full-size batch three times from the same weights, with the index chain ahead of the step as
-    bench.py's captured step has it -- every loss term and EVERY parameter gradient bit for bit
-    equal.  No unordered float sum is left in the backward: the scatter-adds run through inverted
-    indices with one owner wave per run (group_gather.hip), the blend backward stages its rows and
-    gathers them per seed (interpolate.hip), every partial-sum fold runs in slot order."""
+@pytest.mark.parametrize('workload,batch,ahead', [('pretrain', 2, True), ('pretrain', 2, False), ('semi', 3, True)])
+def test_training_step_is_bitwise_reproducible(hip_device, workload, batch, ahead):
+    """Forward + backward of the same full-size batch three times from the same weights, in the
+    DEFAULT mode -- every loss term and EVERY parameter gradient bit for bit equal.  ``ahead``:
+    with the index chain computed ahead of the step, as bench.py's captured step has it; without:
+    the reference-shaped call ``model.forward_train(points, ...)``, where every set-abstraction
+    module samples, groups and inverts its own indices.  No unordered float sum is left in the
+    backward: the scatter-adds run through inverted indices with one owner wave per run
+    (group_gather.hip), the blend backward stages its rows and gathers them per seed
+    (interpolate.hip), every partial-sum fold runs in slot order."""
     import bench
     hip = kernels.backend_for(torch.empty(1, device=hip_device))
-    prev = hip.set_deterministic(True)
-    try:
-        noise = _small.fixed_noise(batch, 256)
-        model, step, _ = bench.build_step(hip_device, batch, 77, 1e-3, 0.01, graph=False, workload=workload,
-                                          noise=noise)
-        inp = step.inputs
-        runs = []
-        for _ in range(3):
-            for p in model.parameters():
-                p.grad = None
-            if workload == 'pretrain':
+    assert hip.DETERMINISTIC
+    noise = _small.fixed_noise(batch, 256)
+    model, step, _ = bench.build_step(hip_device, batch, 77, 1e-3, 0.01, graph=False, workload=workload,
+                                      noise=noise)
+    inp = step.inputs
+    runs = []
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        if workload == 'pretrain':
+            pre = None
+            if ahead:
                 pre = dict(indices=model.backbone.sample_and_group_indices(inp['points']),
                            vote_targets=tuple(model.bbox_head.vote_targets_of(inp['points'], inp['gt'])))
-                losses = model.forward_train(inp['points'], None, inp['gt'], None, precomputed=pre)
-            else:
-                model.init_label_state(120, 1081, hip_device)
-                pre = dict(student=model.backbone.sample_and_group_indices(inp['points_s']),
-                           teacher=model.backbone.sample_and_group_indices(inp['points_t']))
-                losses = model.forward_train(inp['points_s'], inp['points_t'], inp['gt'], inp['use_label'],
-                                             inp['meta_s'], inp['meta_t'], inp['rows'], precomputed=pre)
-            model.parse_losses(losses).backward()
-            torch.cuda.synchronize()
-            runs.append(({k: v.detach().clone() for k, v in losses.items()},
-                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
-    finally:
-        hip.set_deterministic(prev)
+            losses = model.forward_train(inp['points'], None, inp['gt'], None, precomputed=pre)
+        else:
+            model.init_label_state(120, 1081, hip_device)
+            pre = dict(student=model.backbone.sample_and_group_indices(inp['points_s']),
+                       teacher=model.backbone.sample_and_group_indices(inp['points_t']))
+            losses = model.forward_train(inp['points_s'], inp['points_t'], inp['gt'], inp['use_label'],
+                                         inp['meta_s'], inp['meta_t'], inp['rows'], precomputed=pre)
+        model.parse_losses(losses).backward()
+        torch.cuda.synchronize()
+        runs.append(({k: v.detach().clone() for k, v in losses.items()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
     assert len(runs[0][1]) > 180
     for losses, grads in runs[1:]:
         differing = [k for k in runs[0][0] if not torch.equal(runs[0][0][k], losses[k])]
