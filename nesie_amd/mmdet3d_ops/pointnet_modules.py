@@ -295,7 +295,11 @@ class BasePointSAModule(nn.Module):
         with spatial_index_scope():   # FPS hands its sorted scene to the ball queries below
             new_xyz, indices = self._sample_points(points_xyz, None, None, None)
             group_idx = [g.ball_indices(points_xyz, new_xyz) for g in self.groupers]
-        group_csr = [inverted_index(i, points_xyz.shape[1]) for i in group_idx]
+        # ahead of the step only where a feature gradient is plausible AND the index is cheap: the
+        # 40 000-point input level carries input features (no gradient); a backward that does need an
+        # index over more points builds it itself (group_points.QueryGroupCat)
+        n = points_xyz.shape[1]
+        group_csr = [inverted_index(i, n) if n <= 8192 else None for i in group_idx]
         return dict(indices=indices, new_xyz=new_xyz, group_idx=group_idx, group_csr=group_csr)
 
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None, precomputed=None):
