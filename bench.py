@@ -93,6 +93,7 @@ class GemmTimer:
 
     def __init__(self, backend, method, flops):
         self.events, self.work, self.enabled = [], [], False
+        self.method = method
         inner = getattr(backend, method)
 
         def wrapped(*args, **kw):
@@ -111,10 +112,56 @@ class GemmTimer:
     def totals(self, big=True):
         """(launches, ms, flop, bytes) summed over the recorded launches of one size class."""
         n = ms = fl = by = 0.0
-        for (s, e), (f, b, pos) in zip(self.events, self.work):
+        for (s, e), w in zip(self.events, self.work):
+            f, b, pos = w[:3]
             if (pos >= self.BIG) == big:
                 n += 1; ms += s.elapsed_time(e); fl += f; by += b
         return n, ms, fl, by
+
+    def launches(self):
+        """-> [(shape signature, ms, flop, algorithmic bytes)] of every recorded launch."""
+        out = []
+        for (s, e), w in zip(self.events, self.work):
+            sig = w[3] if len(w) > 3 else ''
+            out.append((f'{self.method}{sig}', s.elapsed_time(e), w[0], w[1]))
+        return out
+
+
+def binding_roofline(timers, steps, mfma_peak_tflops, hbm_peak_gbs, list_below=0.5):
+    """price every launch of the family against the roofline that BINDS it -- HBM-bound
+    launches against HBM, GEMMs against the matrix cores: min_ms = max(flop / MFMA peak, algorithmic
+    bytes / HBM peak) per launch, frac_binding = sum(min_ms) / sum(ms).  Launches of one shape are
+    pooled; the shapes below ``list_below`` are the work queue (worst lost time first)."""
+    pool = {}
+    for t in timers:
+        for sig, ms, fl, by in t.launches():
+            e = pool.setdefault(sig, [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+    tot_ms = tot_min = 0.0
+    rows = []
+    for sig, (n, ms, fl, by) in pool.items():
+        t_mfma = fl / (mfma_peak_tflops * 1e12) * 1e3
+        t_hbm = by / (hbm_peak_gbs * 1e9) * 1e3
+        mn = max(t_mfma, t_hbm)
+        tot_ms += ms; tot_min += mn
+        rows.append(dict(launch=sig, per_step=n / steps, ms_per_step=ms / steps,
+                         bound='hbm' if t_hbm > t_mfma else 'mfma',
+                         frac_binding=mn / ms if ms else None,
+                         tflops=fl / (ms * 1e-3) / 1e12 if ms else None,
+                         algorithmic_gbs=by / (ms * 1e-3) / 1e9 if ms else None,
+                         lost_ms_per_step=(ms - mn) / steps))
+    rows.sort(key=lambda r: -r['lost_ms_per_step'])
+    return dict(frac_binding=tot_min / tot_ms if tot_ms else None,
+                min_ms_per_step=tot_min / steps, ms_per_step=tot_ms / steps,
+                hbm_bound_ms_per_step=sum(r['ms_per_step'] for r in rows if r['bound'] == 'hbm'),
+                mfma_bound_ms_per_step=sum(r['ms_per_step'] for r in rows if r['bound'] == 'mfma'),
+                peaks=dict(mfma_tflops=mfma_peak_tflops, hbm_gbs=hbm_peak_gbs),
+                definition='per launch min_ms = max(flop / MFMA peak, algorithmic bytes / HBM peak); '
+                           'frac_binding = sum(min_ms) / sum(HIP-event ms) over every launch of the family',
+                # the work queue: every shape of the family, most lost time first; `below_half` names the ones
+                # under half of their binding roofline
+                by_lost_time=rows[:24],
+                below_half=[r['launch'] for r in rows if r['frac_binding'] is not None and r['frac_binding'] < list_below])
 
 
 GATE_LOSS_TOL = 1e-4      # north_star: fp32 features / losses within 1e-4 of the CPU path
@@ -304,6 +351,9 @@ def transform_gt(boxes, meta, i):
     return semi.transform_boxes(boxes.unsqueeze(0).to(meta.trans.device), one)[0].cpu()
 
 
+_SIDE_STREAMS = {}
+
+
 def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', resident=0,
                noise=None):
     """-> (model, step, bucket).  step() = zero grads, forward, backward, gradient
@@ -402,7 +452,14 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     left = max(256 - 16 - 8 * ((batch + 7) // 8), 192)
     budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', str(left))) if on_gpu else 256}
 
+    head_dummy = None
+    if on_gpu and os.environ.get('NESIE_DIAG_HEAD_DUMMY'):   # diagnostic only: a long kernel in front of the step
+        n_ = int(os.environ['NESIE_DIAG_HEAD_DUMMY'])
+        head_dummy = (torch.randn(n_, n_, device=device), torch.empty(n_, n_, device=device))
+
     def phase1(pre=None):       # forward + the head's backward
+        if head_dummy is not None:
+            torch.mm(head_dummy[0], head_dummy[0], out=head_dummy[1])
         bucket.begin()
         if on_gpu and budget['cus'] != 256:
             with kernels.HipKernels.cu_budget(budget['cus']):
@@ -448,7 +505,13 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # side stream (it occupies one CU per scene) while this step trains.  Every step still
     # executes one full index chain and one full fwd+bwd+update; nothing is cached.
     pipelined = True
-    side = torch.cuda.Stream(device, priority=-1)  # few, long, latency-bound workgroups
+    # few, long, latency-bound workgroups.  ONE side stream per device and process: the runtime maps
+    # streams onto a handful of hardware queues round-robin, and the third stream a process creates can
+    # land on the main stream's queue -- the chain then runs IN LINE with the step (measured: the SAQE
+    # step at 16 scenes 70.5 ms instead of 35.3 as the third workload built in one process)
+    side = _SIDE_STREAMS.get(device)
+    if side is None:
+        side = _SIDE_STREAMS[device] = torch.cuda.Stream(device, priority=-1)
     main = torch.cuda.current_stream(device)
 
     from nesie_amd.votenet.backbone import (copy_tensors, index_tree_like,
@@ -633,11 +696,53 @@ def cpu_baseline(sample_batch, steps, warmup=2):
             step()
             times.append(time.perf_counter() - t0)
     dt = statistics.median(times)
+    avail = len(os.sched_getaffinity(0))
     return dict(value=sample_batch / dt, unit='scenes/s', cores=cores, kind='port',
+                cores_available=avail,
+                cores_note=(f'{cores} of the {avail} host cores visible to this process: capped at the GPU box\'s '
+                            'per-GPU CPU share (16) so that N ranks on one host do not over-subscribe it; '
+                            'NESIE_CPU_CORES overrides'),
                 step_seconds=dict(median=dt, min=min(times), max=max(times), mean=sum(times) / len(times)),
                 sample=f'median of {steps} timed training step(s) (after {warmup} warm-ups) of '
                        f'{sample_batch} scene(s) x {NUM_POINTS} pts, fwd+bwd+AdamW, oracle index ops + '
                        f'PyTorch-CPU dense ops on {cores} host threads, {dt:.2f} s/step')
+
+
+def other_workload(device, workload, batch, steps, warmup, gate=True):
+    """BASELINE configs[3] / [4] beside the headline: the student/teacher step of ``workload`` ('semi':
+    Nesie, 8 scenes per GPU, train-010.py:320-330; 'saqe': SAQE head, 16 scenes per GPU,
+    saqe-votenet-scannet-train-010.py) captured and replayed like the headline step -- ``steps`` timed
+    replays after ``warmup`` -- with its own parity-gate summary (one full-size 3-scene student/teacher
+    step on the CPU-oracle leg and the HIP leg).  -> dict for the JSON line."""
+    import gc
+    res = dict(workload=workload, scenes_per_gpu=batch, steps=steps, warmup=warmup)
+    if gate:
+        g = parity_gate(device, workload)
+        res['parity_gate'] = dict(passed=g['passed'], max_rel_diff=g['max_rel_diff'], worst_term=g['worst_term'],
+                                  terms=g['terms'], index_ops_bit_exact=g['index_ops']['bit_exact'],
+                                  pseudo_labels=g.get('pseudo_labels'),
+                                  flat_gradient_rel_l2=g['gradient']['flat_rel_l2_hip_vs_cpu'], sample=g['sample'])
+        if not g['passed']:
+            return res
+    cfg = nesie_votenet_scannet_cfg()
+    model, step, bucket = build_step(device, batch, 1000, cfg['optimizer']['lr'], cfg['optimizer']['weight_decay'],
+                                     graph=True, workload=workload)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res.update(value=batch * steps / dt, unit='student scenes/s', ms_per_step=dt / steps * 1e3,
+               loss_is_finite=bool(torch.isfinite(loss).item()),
+               graphs_per_step=getattr(step, 'graphs_per_step', None),
+               forward_cu_budget=(getattr(step, 'forward_cu_budget', None) or {'cus': 256})['cus'])
+    del model, step, bucket, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def spawn_ranks(n, argv, script=None):
@@ -716,6 +821,10 @@ def main():
     ap.add_argument('--loss-trace', type=int, default=0,
                     help='1: keep the total loss of every timed step (a device-side copy per step, no '
                          'synchronisation) and print it as `loss_trace` (tests)')
+    ap.add_argument('--other-workloads', type=int, default=1,
+                    help='1 (N = 1, pretrain runs only): after the headline, also replay BASELINE configs[3] (semi, 8 '
+                         'scenes) and configs[4] (saqe, 16 scenes) for a few steps each, with their parity gates, and '
+                         'report them as `other_workloads`; 0 to skip')
     ap.add_argument('--parity-gate', type=int, default=1,
                     help='0 to skip the CPU-vs-HIP check (index ops, loss dict, gradients) that '
                          'precedes the timing (N = 1 only)')
@@ -774,21 +883,24 @@ def main():
         nb, k, p = x.shape
         co = w.shape[1]
         out = nb * co * p * 4 if kw.get('y') is not None else 0
-        return 2.0 * nb * k * co * p, nb * k * p * 4 + out, nb * p
+        tag = ('T' if w.stride(2) != 1 else '') + ('+stats' if kw.get('stat_part') is not None else '') + \
+              ('+pool' if kw.get('pool_group') else '') + ('+rowbias' if kw.get('row_bias') is not None else '') + \
+              ('' if kw.get('y') is not None else '-nostore')
+        return 2.0 * nb * k * co * p, nb * k * p * 4 + out, nb * p, f'[{k}->{co}{tag}, {nb}x{p}]'
 
     def wgrad_flop(dy, x, dw, **kw):
         nb, co, p = dy.shape
-        return 2.0 * nb * co * x.shape[1] * p, nb * (co + x.shape[1]) * p * 4, nb * p
+        return 2.0 * nb * co * x.shape[1] * p, nb * (co + x.shape[1]) * p * 4, nb * p, f'[{co}x{x.shape[1]}, {nb}x{p}]'
 
     def dgrad_flop(dy, w, z, z_coef, da, **kw):   # + the raw output Z of the norm-backward reduction
         nb, k, p = dy.shape
         co = w.shape[1]
-        return 2.0 * nb * k * co * p, nb * (k + 2 * co) * p * 4, nb * p
+        return 2.0 * nb * k * co * p, nb * (k + 2 * co) * p * 4, nb * p, f'[{k}->{co}, {nb}x{p}]'
     def wgrad_bn_flop(da, z, z_coef, gamma, part, x, dz, dw, *a, **kw):
         # the weight gradient with the norm backward's apply pass inside: the SAME algorithmic FLOPs
         # (the per-element transform is not counted); reads dA, Z, X once, writes dZ once
         nb, co, p = da.shape
-        return 2.0 * nb * co * x.shape[1] * p, nb * (3 * co + x.shape[1]) * p * 4, nb * p
+        return 2.0 * nb * co * x.shape[1] * p, nb * (3 * co + x.shape[1]) * p * 4, nb * p, f'[{co}x{x.shape[1]}, {nb}x{p}]'
     def tail_flop(g, pooled, zstar, argmax, coef, gamma, w, z_prev, coef_prev, ns, *a, **kw):
         # backward of a pooled tail without its dense tensors (csrc/pool_tail.hip), ALL its launches as
         # one entry: the layer's input gradient + weight gradient, 2 x 2 nb c k p (what it issues is
@@ -796,7 +908,7 @@ def main():
         # reads the operand's raw form twice, writes dA once
         nb, k, p = z_prev.shape
         c = w.shape[0]
-        return 4.0 * nb * c * k * p, 3 * nb * k * p * 4, nb * p
+        return 4.0 * nb * c * k * p, 3 * nb * k * p * 4, nb * p, f'[{k}->{c}, {nb}x{p}]'
     gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
                    GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop),
                    GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop),
@@ -874,6 +986,8 @@ def main():
                        # graph + backbone segment after it; 0 without a process group)
                        'collectives_per_step': step.comm.collectives / max(1, step.comm.steps),
                        'hip_graph': bool(args.graph),
+                       # every scatter-add of the backward in an order fixed by the indices (no float atomics)
+                       'deterministic_backward': bool(kernels.HipKernels.DETERMINISTIC),
                        'graphs_per_step': getattr(step, 'graphs_per_step', None),
                        'index_chain_pipelined': bool(args.graph),
                        'forward_cu_budget': (getattr(step, 'forward_cu_budget', None) or {'cus': 256})['cus'],
@@ -921,6 +1035,7 @@ def main():
             n_all = n_l + n_w + n_wf + n_t + sn
             tf_all = fl_all / (ms_all * 1e-3) / 1e12
             tf = (fl_l + fl_w) / ((ms_l + ms_w) * 1e-3) / 1e12
+            binding = binding_roofline(gemm_timers, eager_steps, MFMA_F32_PEAK_TFLOPS, HBM_PEAK_GBS)
             # HBM bytes of the family as rocprofv3 counted them (separate --pmc FETCH_SIZE / WRITE_SIZE
             # passes of this command, gfx950 fetch correction applied): produced by tools/make_profiles.py
             # together with the sha256 of the library that ran; LOADED here, never measured inside this
@@ -955,6 +1070,8 @@ def main():
                           'and the 1-D per-seed / per-proposal chains -- fp32 MFMA (v_mfma_f32_16x16x4_f32)',
                 'bound': 'mfma', 'achieved': tf_all, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf_all / MFMA_F32_PEAK_TFLOPS,
+                # the same launches, each priced against the roofline that binds IT (HBM or MFMA)
+                'frac_binding': binding['frac_binding'], 'binding': binding,
                 'traffic': traffic, 'traffic_note': traffic_note,
                 'algorithmic_bytes_per_step': per_step(by_l + by_w + by_wf + by_t),   # launches over >= 32768 positions
                 'algorithmic_hbm_gbs': (by_l + by_w + by_wf + by_t) / ((ms_l + ms_w + ms_wf + ms_t) * 1e-3) / 1e9,
@@ -1030,6 +1147,14 @@ def main():
             out['parity_gate'] = gate
         if args.loss_trace:
             out['loss_trace'] = [float(t) for t in trace]
+        if args.other_workloads and world == 1 and args.workload == 'pretrain' and args.batch == 8 and args.graph:
+            # configs[3] / [4] in front of the driver: free the headline's model, graphs and pools first
+            import gc
+            step = model = bucket = loss = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['other_workloads'] = [other_workload(device, 'semi', 8, 5, 2, gate=bool(args.parity_gate)),
+                                      other_workload(device, 'saqe', 16, 5, 2, gate=bool(args.parity_gate))]
         if args.cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)
