@@ -191,6 +191,157 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
     if (tail && i < cend) dst[(size_t)i * n] += v[i];      // one lane per point in the whole launch
 }
 
+// The same scatter with the gradient rows IN LDS (round 5).  group_bwd_csr_kernel gathers
+// grad_out[channel][order[e]] from HBM: neighbouring lanes (sorted by SOURCE point) read columns
+// that lie anywhere in the (M, ns) row, 4 bytes per 64-byte line -- SA2's 137 MB gradient moved
+// ~2 GB and the launch took 135 us (six launches per step: 0.39 ms) -- and the wave that owns a
+// long run (a low-index point sits in a thousand balls: ball query keeps the FIRST nsample hits)
+// follows it alone through dozens of chunks, two dependent loads per trip.  Here a 1024-thread
+// workgroup owns CH whole channel rows of one scene and streams them into LDS once (dense 16-byte
+// loads); the run bounds of every point come from one pass over the sorted source list (LDS); then
+//   * a THREAD owns each point with a run of <= GR_LONG entries and adds its gathered values in
+//     ascending entry order -- the order of the reference's serial loop restated in the oracle
+//     (SURVEY appendix A.3): five instructions per entry where the segmented scan spent forty;
+//   * a WAVE owns each longer run: lane l adds entries l, l + 64, ... in ascending order, a fixed
+//     butterfly adds the 64 partials.
+// Every point is written once (a point without entries gets its zero here: no fill needed), in an
+// order fixed by the index alone: bitwise reproducible.
+constexpr int GR_BLOCK = 1024, GR_LONG = 64;
+
+template <int CH>
+__global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
+    int c, int n, int e_total, long long gstride, int ediv, const float *__restrict__ grad_out,
+    const float *__restrict__ weight, const int *__restrict__ order,
+    const int *__restrict__ src, float *__restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+  const int c0 = blockIdx.x * CH, bi = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncols = e_total / ediv;
+  const int ncols4 = (ncols + 3) & ~3;
+  float *rows = gr_lds;                                   // [CH][ncols4]
+  int *starts = (int *)(rows + (size_t)CH * ncols4);      // [n]
+  int *ends = starts + n;                                 // [n]
+  int *longs = ends + n;                                  // [n]: points with long runs; [n] = their count
+  const int cend = c - c0 < CH ? c - c0 : CH;
+  const float *gbase = grad_out + (size_t)bi * gstride + (size_t)c0 * ncols;
+  const int *sb = src + (size_t)bi * e_total;
+  const int *ob = order + (size_t)bi * e_total;
+  const float *wb = weight ? weight + (size_t)bi * e_total : nullptr;
+  for (int d = tid; d < n; d += GR_BLOCK) starts[d] = ends[d] = 0;
+  if (tid == 0) longs[n] = 0;
+  if ((((uintptr_t)gbase) & 15) == 0 && (ncols & 3) == 0) {     // rows are contiguous in the gradient
+    const float4 *g4 = (const float4 *)gbase;
+    float4 *r4 = (float4 *)rows;
+    for (int i = tid; i < cend * ncols / 4; i += GR_BLOCK) r4[i] = g4[i];
+  } else {
+    for (int i = tid; i < cend * ncols; i += GR_BLOCK) rows[(i / ncols) * ncols4 + i % ncols] = gbase[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < e_total; e += GR_BLOCK) {          // run bounds from the sorted source list
+    const int sv = sb[e];
+    const int pv = e > 0 ? sb[e - 1] : -1, nv = e + 1 < e_total ? sb[e + 1] : -1;
+    if (sv >= 0 && sv < n) {
+      if (sv != pv) starts[sv] = e;
+      if (sv != nv) ends[sv] = e + 1;
+    }
+  }
+  __syncthreads();
+  float *dst0 = grad_points + ((size_t)bi * c + c0) * n;
+  for (int d = tid; d < n; d += GR_BLOCK) {
+    const int st = starts[d], en = ends[d];
+    if (en - st > GR_LONG) {
+      longs[atomicAdd(&longs[n], 1)] = d;                  // (any order: every long run has one owner wave)
+      continue;
+    }
+    float acc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+    int j = st;
+    for (; j + 3 < en; j += 4) {                           // four index loads in flight, added in order
+      int col[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) col[u] = ob[j + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = wb ? wb[col[u]] : 1.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *g = rows + col[u] / ediv;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w[u]);
+      }
+    }
+    for (; j < en; ++j) {
+      const int col = ob[j];
+      const float w = wb ? wb[col] : 1.f;
+      const float *g = rows + col / ediv;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (i < cend) dst0[(size_t)i * n + d] = acc[i];
+  }
+  __syncthreads();
+  const int nlong = longs[n];
+  for (int li = wave; li < nlong; li += GR_BLOCK / 64) {
+    const int d = longs[li];
+    const int st = starts[d], en = ends[d];
+    float acc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+    for (int j = st + lane; j < en; j += 64) {
+      const int col = ob[j];
+      const float w = wb ? wb[col] : 1.f;
+      const float *g = rows + col / ediv;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        if (i < cend) dst0[(size_t)i * n + d] = acc[i];
+    }
+  }
+}
+
+// -> launched (true) or not applicable (false: the caller uses group_bwd_csr_kernel)
+static bool launch_group_bwd_csr_rows(int b, int c, int n, long long e_total, long long gstride, int ediv,
+                                      const float *grad_out, const float *weight, const int *order,
+                                      const int *src, float *grad_points, hipStream_t s) {
+  const char *sw = getenv("NESIE_CSR_ROWS");           // A/B switch, read per call (tests flip it)
+  const int on = sw ? atoi(sw) : 1;
+  const long long ncols = e_total / ediv;
+  constexpr long long LDS_MAX = 156 * 1024;
+  auto need = [&](int ch) { return ((long long)ch * ((ncols + 3) & ~3ll) + 3ll * n + 1) * 4; };
+  if (!on || need(1) > LDS_MAX || b > 65535 || e_total % ediv) return false;
+  // rows per workgroup: as many as fit, at most 8, and no more than leaves >= 256 workgroups
+  int ch = 8;
+  while (ch > 1 && (need(ch) > LDS_MAX || (long long)cdiv(c, ch) * b < 256)) ch >>= 1;
+  const size_t lds = (size_t)need(ch);
+  const dim3 grid(cdiv(c, ch), b);
+#define GRL(CH)                                                                                         \
+  do {                                                                                                  \
+    static bool attr = false;                                                                           \
+    if (!attr) {                                                                                        \
+      (void)hipFuncSetAttribute((const void *)group_bwd_csr_rows_kernel<CH>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);              \
+      attr = true;                                                                                      \
+    }                                                                                                   \
+    hipLaunchKernelGGL(group_bwd_csr_rows_kernel<CH>, grid, dim3(GR_BLOCK), lds, s, c, n, (int)e_total, \
+                       gstride, ediv, grad_out, weight, order, src, grad_points);                       \
+  } while (0)
+  if (ch == 8) GRL(8); else if (ch == 4) GRL(4); else if (ch == 2) GRL(2); else GRL(1);
+#undef GRL
+  return true;
+}
+
 // Inverted index of idx[b][0..e_total) over n source points, one workgroup per scene: LDS
 // histogram (integer ds_add), exclusive scan, then each column takes the next free slot of its
 // point's run (returning ds_add).  Built on the side stream with the ball query: 8 workgroups,
@@ -541,6 +692,9 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
   NESIE_REQUIRE(grad_out && order && sources && grad_features, W);
   if (e_total == 0) return NESIE_OK;
   NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  if (launch_group_bwd_csr_rows(b, c, n, e_total, (long long)(3 + c) * e_total, 1, grad_out + 3 * e_total, nullptr,
+                                order, sources, grad_features, (hipStream_t)stream))
+    return check_launch(W);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total,
                      (long long)(3 + c) * e_total, 1, grad_out + 3 * e_total,
@@ -560,6 +714,9 @@ extern "C" int nesie_group_points_backward_csr(int b, int c, int n, int npoints,
   if (b == 0 || n == 0 || c == 0 || e_total == 0) return NESIE_OK;
   NESIE_REQUIRE(grad_out && order && sources && grad_points, W);
   NESIE_REQUIRE(e_total < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  if (launch_group_bwd_csr_rows(b, c, n, e_total, (long long)c * e_total, 1, grad_out, nullptr, order, sources,
+                                grad_points, (hipStream_t)stream))
+    return check_launch(W);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total, (long long)c * e_total, 1,
                      grad_out, (const float *)nullptr, order, sources, grad_points);
@@ -609,6 +766,9 @@ extern "C" int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, cons
   if (b == 0 || n == 0) return NESIE_OK;
   NESIE_REQUIRE(grad_out && weight && order && sources && grad_points, W);
   NESIE_REQUIRE((long long)n * 3 < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
+  if (launch_group_bwd_csr_rows(b, c, m, (long long)n * 3, (long long)c * n, 3, grad_out, weight, order, sources,
+                                grad_points, (hipStream_t)stream))
+    return check_launch(W);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv((long long)n * 3, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, m, n * 3, (long long)c * n, 3,
                      grad_out, weight, order, sources, grad_points);

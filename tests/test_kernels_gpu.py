@@ -765,6 +765,20 @@ def test_csr_scatter_is_bitwise_reproducible_with_long_runs(hip_device, n, m, ns
     want.scatter_add_(2, idx.view(2, 1, -1).expand(-1, c, -1).long(), go[:, 3:].reshape(2, c, -1).double())
     err = (outs[0].cpu().double() - want).abs().max().item()
     assert err <= 2e-6 * want.abs().max().item(), err
+    # the form that gathers straight from HBM (NESIE_CSR_ROWS=0: rows beyond the LDS budget) adds the
+    # same terms in another fixed order: equal to rounding, and bitwise repeatable too
+    import os
+    os.environ['NESIE_CSR_ROWS'] = '0'
+    try:
+        two = []
+        for _ in range(2):
+            gf = torch.zeros(2, c, n, device=hip_device)
+            hip.query_and_group_backward_csr(go_d, (2, m, ns), order, sources, gf)
+            two.append(gf)
+        assert torch.equal(two[0], two[1])
+        assert (two[0] - outs[0]).abs().max().item() <= 2e-6 * want.abs().max().item()
+    finally:
+        del os.environ['NESIE_CSR_ROWS']
     # three weighted taps per column
     nq = m * ns // 3
     idx3 = idx.view(2, -1)[:, :nq * 3].reshape(2, nq, 3).contiguous()

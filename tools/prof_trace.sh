@@ -9,7 +9,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace --output-format c
 T=$(find $O/trace -name "*_kernel_trace.csv" | head -1)
 S=$(find $O/trace -name "*_kernel_stats.csv" | head -1)
 cp $S $O/kernel_stats.csv
-python3 $R/tools/timeline.py $T ${BACK:-9} --list > $O/timeline.txt 2>&1
+python3 $R/tools/timeline.py $T ${BACK:-0} --list > $O/timeline.txt 2>&1
 python3 $R/tools/profile_summary.py $S 20 > $O/per_step_summary.txt 2>&1
 head -c 400 $O/trace_bench.json; echo; head -30 $O/timeline.txt
 rm -rf $O/trace    # (the raw trace is hundreds of MB)

@@ -25,8 +25,23 @@ def main():
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     qkey = 'Queue_Id' if 'Queue_Id' in rows[0] else 'Stream_Id'
     marks = [i for i, r in enumerate(rows) if 'fps_pruned' in r['Kernel_Name']]
-    # a step = from one FPS launch to the next; take the window `back` from the end
-    lo, hi = marks[-back - 1], marks[-back]
+    # a step = from one FPS launch to the next; take the window `back` from the end -- or, with
+    # back = 0, the LAST window that looks like a graph-replayed step: two queues in it (the index
+    # chain on the side stream) and a full step's worth of layer-kernel launches on one of them
+    if back == 0:
+        best = None
+        for j in range(len(marks) - 1, 0, -1):
+            a, b = int(rows[marks[j - 1]]['Start_Timestamp']), int(rows[marks[j]]['Start_Timestamp'])
+            qs = collections.Counter(r[qkey] for r in rows[marks[j - 1]:marks[j]] if 'pw_fwd_kernel' in r['Kernel_Name'])
+            nq = len({r[qkey] for r in rows[marks[j - 1]:marks[j]]})
+            if nq >= 2 and qs and max(qs.values()) >= 60 and (b - a) < 40e6:
+                best = j
+                break
+        if best is None:
+            raise SystemExit('no window that looks like a replayed step')
+        lo, hi = marks[best - 1], marks[best]
+    else:
+        lo, hi = marks[-back - 1], marks[-back]
     t_lo, t_hi = int(rows[lo]['Start_Timestamp']), int(rows[hi]['Start_Timestamp'])
     per_q = collections.defaultdict(list)
     for r in rows:
