@@ -206,9 +206,11 @@ __global__ __launch_bounds__(GG_BLOCK) void group_bwd_csr_kernel(
 //     butterfly adds the 64 partials.
 // Every point is written once (a point without entries gets its zero here: no fill needed), in an
 // order fixed by the index alone: bitwise reproducible.
-constexpr int GR_BLOCK = 1024, GR_LONG = 64;
+constexpr int GR_BLOCK = 1024, GR_LPP = 4, GR_LONG = 64 * GR_LPP;
 
-template <int CH>
+// EDIV = taps per gradient column (1: grouping, 3: three_interpolate's weighted taps), compile-time:
+// a runtime division per entry was a third of the loop
+template <int CH, int EDIV>
 __global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
     int c, int n, int e_total, long long gstride, int ediv, const float *__restrict__ grad_out,
     const float *__restrict__ weight, const int *__restrict__ order,
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
   const int c0 = blockIdx.x * CH, bi = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncols = e_total / ediv;
+  const int ncols = e_total / EDIV;
   const int ncols4 = (ncols + 3) & ~3;
   float *rows = gr_lds;                                   // [CH][ncols4]
   int *starts = (int *)(rows + (size_t)CH * ncols4);      // [n]
@@ -233,55 +235,86 @@ __global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
   if ((((uintptr_t)gbase) & 15) == 0 && (ncols & 3) == 0) {     // rows are contiguous in the gradient
     const float4 *g4 = (const float4 *)gbase;
     float4 *r4 = (float4 *)rows;
-    for (int i = tid; i < cend * ncols / 4; i += GR_BLOCK) r4[i] = g4[i];
+    const int total4 = cend * ncols / 4;
+    int i = tid;
+    for (; i + 7 * GR_BLOCK < total4; i += 8 * GR_BLOCK) {      // eight 16-byte loads in flight per thread
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g4[i + u * GR_BLOCK];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r4[i + u * GR_BLOCK] = v[u];
+    }
+    for (; i < total4; i += GR_BLOCK) r4[i] = g4[i];
   } else {
     for (int i = tid; i < cend * ncols; i += GR_BLOCK) rows[(i / ncols) * ncols4 + i % ncols] = gbase[i];
   }
   __syncthreads();
-  for (int e = tid; e < e_total; e += GR_BLOCK) {          // run bounds from the sorted source list
-    const int sv = sb[e];
-    const int pv = e > 0 ? sb[e - 1] : -1, nv = e + 1 < e_total ? sb[e + 1] : -1;
-    if (sv >= 0 && sv < n) {
-      if (sv != pv) starts[sv] = e;
-      if (sv != nv) ends[sv] = e + 1;
+  {   // run bounds from the sorted source list: a thread owns four consecutive entries
+    for (int e0 = 4 * tid; e0 < e_total; e0 += 4 * GR_BLOCK) {
+      int sv[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int e = e0 - 1 + u;
+        sv[u] = (e >= 0 && e < e_total) ? sb[e] : -1;
+      }
+#pragma unroll
+      for (int u = 1; u < 5; ++u) {
+        const int e = e0 - 1 + u;
+        if (e < e_total && sv[u] >= 0 && sv[u] < n) {
+          if (sv[u] != sv[u - 1]) starts[sv[u]] = e;
+          if (sv[u] != sv[u + 1]) ends[sv[u]] = e + 1;
+        }
+      }
     }
   }
   __syncthreads();
   float *dst0 = grad_points + ((size_t)bi * c + c0) * n;
-  for (int d = tid; d < n; d += GR_BLOCK) {
-    const int st = starts[d], en = ends[d];
-    if (en - st > GR_LONG) {
-      longs[atomicAdd(&longs[n], 1)] = d;                  // (any order: every long run has one owner wave)
-      continue;
-    }
+  // GR_LPP lanes per point: lane l adds entries st + l, st + l + LPP, ... in ascending order (four index
+  // loads in flight), the LPP partials meet in a fixed butterfly
+  const int sub = tid % GR_LPP;
+  for (int d0 = 0; d0 < n; d0 += GR_BLOCK / GR_LPP) {
+    const int d = d0 + tid / GR_LPP;
+    const bool have = d < n;
+    const int st = have ? starts[d] : 0, en = have ? ends[d] : 0;
+    const bool is_long = en - st > GR_LONG;
+    if (is_long && sub == 0) longs[atomicAdd(&longs[n], 1)] = d;   // (any order: every long run has one owner wave)
     float acc[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) acc[i] = 0.f;
-    int j = st;
-    for (; j + 3 < en; j += 4) {                           // four index loads in flight, added in order
-      int col[4];
-      float w[4];
+    if (!is_long) {
+      int j = st + sub;
+      for (; j + 3 * GR_LPP < en; j += 4 * GR_LPP) {
+        int col[4];
+        float w[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) col[u] = ob[j + u];
+        for (int u = 0; u < 4; ++u) col[u] = ob[j + u * GR_LPP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) w[u] = wb ? wb[col[u]] : 1.f;
+        for (int u = 0; u < 4; ++u) w[u] = wb ? wb[col[u]] : 1.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float *g = rows + col[u] / ediv;
+        for (int u = 0; u < 4; ++u) {
+          const float *g = rows + col[u] / EDIV;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w[u]);
+          for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w[u]);
+        }
+      }
+      for (; j < en; j += GR_LPP) {
+        const int col = ob[j];
+        const float w = wb ? wb[col] : 1.f;
+        const float *g = rows + col / EDIV;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w);
       }
     }
-    for (; j < en; ++j) {
-      const int col = ob[j];
-      const float w = wb ? wb[col] : 1.f;
-      const float *g = rows + col / ediv;
 #pragma unroll
-      for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w);
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int off = GR_LPP / 2; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
     }
+    if (have && !is_long && sub == 0) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i)
-      if (i < cend) dst0[(size_t)i * n + d] = acc[i];
+      for (int i = 0; i < CH; ++i)
+        if (i < cend) dst0[(size_t)i * n + d] = acc[i];
+    }
   }
   __syncthreads();
   const int nlong = longs[n];
@@ -294,7 +327,7 @@ __global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
     for (int j = st + lane; j < en; j += 64) {
       const int col = ob[j];
       const float w = wb ? wb[col] : 1.f;
-      const float *g = rows + col / ediv;
+      const float *g = rows + col / EDIV;
 #pragma unroll
       for (int i = 0; i < CH; ++i) acc[i] += __fmul_rn(g[i * ncols4], w);
     }
@@ -320,24 +353,25 @@ static bool launch_group_bwd_csr_rows(int b, int c, int n, long long e_total, lo
   const long long ncols = e_total / ediv;
   constexpr long long LDS_MAX = 156 * 1024;
   auto need = [&](int ch) { return ((long long)ch * ((ncols + 3) & ~3ll) + 3ll * n + 1) * 4; };
-  if (!on || need(1) > LDS_MAX || b > 65535 || e_total % ediv) return false;
+  if (!on || need(1) > LDS_MAX || b > 65535 || e_total % ediv || (ediv != 1 && ediv != 3)) return false;
   // rows per workgroup: as many as fit, at most 8, and no more than leaves >= 256 workgroups
   int ch = 8;
   while (ch > 1 && (need(ch) > LDS_MAX || (long long)cdiv(c, ch) * b < 256)) ch >>= 1;
   const size_t lds = (size_t)need(ch);
   const dim3 grid(cdiv(c, ch), b);
-#define GRL(CH)                                                                                         \
+#define GRL(CH, ED)                                                                                     \
   do {                                                                                                  \
     static bool attr = false;                                                                           \
     if (!attr) {                                                                                        \
-      (void)hipFuncSetAttribute((const void *)group_bwd_csr_rows_kernel<CH>,                            \
+      (void)hipFuncSetAttribute((const void *)group_bwd_csr_rows_kernel<CH, ED>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);              \
       attr = true;                                                                                      \
     }                                                                                                   \
-    hipLaunchKernelGGL(group_bwd_csr_rows_kernel<CH>, grid, dim3(GR_BLOCK), lds, s, c, n, (int)e_total, \
+    hipLaunchKernelGGL((group_bwd_csr_rows_kernel<CH, ED>), grid, dim3(GR_BLOCK), lds, s, c, n, (int)e_total, \
                        gstride, ediv, grad_out, weight, order, src, grad_points);                       \
   } while (0)
-  if (ch == 8) GRL(8); else if (ch == 4) GRL(4); else if (ch == 2) GRL(2); else GRL(1);
+  if (ediv == 1) { if (ch == 8) GRL(8, 1); else if (ch == 4) GRL(4, 1); else if (ch == 2) GRL(2, 1); else GRL(1, 1); }
+  else { if (ch == 8) GRL(8, 3); else if (ch == 4) GRL(4, 3); else if (ch == 2) GRL(2, 3); else GRL(1, 3); }
 #undef GRL
   return true;
 }
