@@ -356,7 +356,7 @@ __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane) {
 constexpr int BL_SLOTS = 48;   // staging slots per 16-query group (= its taps: the worst case)
 
 template <int CPT, bool BNB, bool STAGED>
-__global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
+__global__ __launch_bounds__(256, 2) void blend_bwd_rows_kernel(
     int m, int n, int segs, int seg_len, int pitch, int seg_off,
     const float *__restrict__ dy /* (B, segs, C, per_seg) */, const int *__restrict__ idx,
     const float *__restrict__ weight, const float *__restrict__ rel,
@@ -382,43 +382,81 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
 #pragma unroll
   for (int e = 0; e < CPT; ++e) dx[e][0] = dx[e][1] = dx[e][2] = 0.f;
   const int run_end = run0 + BL_RUN < per_seg ? run0 + BL_RUN : per_seg;
-  for (int r0 = run0; r0 < run_end; r0 += TS_Q) {
-    __syncthreads();
+  // Round 5: the loads of tile t + 1 (C rows of dA [and of Z], the 64 queries' taps) are issued into
+  // REGISTERS at the top of tile t's compute phase and land while it runs; the top of the next
+  // iteration applies the norm backward and moves them into LDS.  (Round 4 loaded a tile in four
+  // batches of 16 rows BETWEEN two barriers: per tile four memory latencies with every wave of the
+  // workgroup waiting, then the compute phase with nothing in flight -- the ablation added up to the
+  // whole kernel: loads 186 us + taps 64 + row stores 78 + skeleton 125 of the side grid's 520.)
+  // The barriers wait for LDS only (`s_waitcnt lgkmcnt(0)`): __syncthreads() would also drain the
+  // prefetch.  2 workgroups per CU (66 KB of LDS each) = 2 waves per SIMD: 256 VGPRs per wave.
+  constexpr int NR = C / 4;                                  // rows per thread (row = 4 i + wave)
+  float traw[NR], zraw[BNB ? NR : 1];
+  int pj[3];
+  float pw[3], pr[3];
+  auto prefetch = [&](int r0) {
     if (threadIdx.x < TS_Q) {
       const int r = r0 + threadIdx.x;
       const int k = r / seg_len, g = r - k * seg_len;
       const size_t p = (size_t)bi * n + (size_t)(k * segs + sg) * seg_len + g;
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        int j = idx[p * 3 + t];
+        pj[t] = idx[p * 3 + t];
+        pw[t] = weight[p * 3 + t];
+        pr[t] = rel ? rel[p * 3 + t] : 0.f;
+      }
+    }
+    // wave-uniform base (scalar registers) + ONE per-lane byte offset: no per-row address registers
+    const unsigned voff = (unsigned)(((size_t)wv * per_seg + lane) * 4);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const float *sb_ = src + (size_t)(i * 4) * per_seg + r0;          // uniform
+      traw[i] = *(const float *)((const char *)sb_ + voff);
+    }
+  };
+  auto load_z = [&](int r0) {
+    const unsigned voff = (unsigned)(((size_t)wv * per_seg + lane) * 4);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const float *zb_ = zsrc + (size_t)(i * 4) * per_seg + r0;       // uniform
+      zraw[i] = *(const float *)((const char *)zb_ + voff);
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if (run0 < run_end) prefetch(run0);
+  for (int r0 = run0; r0 < run_end; r0 += TS_Q) {
+    // (Z is loaded here, one exposed latency per tile: with its 64 registers in flight beside dA's
+    // through the tap loop the kernel spills -- 60 registers, 523 us against 415 for the side grid)
+    if (BNB) load_z(r0);
+    lds_barrier();                                           // every wave is done with the previous tile
+    if (threadIdx.x < TS_Q) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int j = pj[t];
         sj[threadIdx.x][t] = j < 0 ? 0 : (j >= m ? m - 1 : j);
-        sw[threadIdx.x][t] = weight[p * 3 + t];
-        sr[threadIdx.x][t] = rel ? rel[p * 3 + t] : 0.f;
+        sw[threadIdx.x][t] = pw[t];
+        sr[threadIdx.x][t] = pr[t];
       }
     }
-    // dy tile: C rows x 64 queries, dense 256-byte row reads (lane = query);
-    // 16 independent loads in flight per wave before the first LDS store
 #pragma unroll
-    for (int rb = 0; rb < C / 4; rb += 16) {
-      float t16[16], z16[BNB ? 16 : 1];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        t16[u] = src[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
-        if (BNB) z16[u] = zsrc[(size_t)((rb + u) * 4 + wv) * per_seg + r0 + lane];
-      }
+    for (int i = 0; i < NR; ++i) {
+      float v = traw[i];
       if (BNB) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const float *cf = bnb + ((size_t)sg * C + (rb + u) * 4 + wvu) * 8;      // uniform
-          const float zz = z16[u];
-          const float gg = __builtin_fmaf(zz, cf[0], cf[1]) > 0.f ? t16[u] : 0.f;
-          t16[u] = __builtin_fmaf(cf[2], gg, __builtin_fmaf(cf[3] - zz, cf[4], cf[5]));
-        }
+        const float *cf = bnb + ((size_t)sg * C + i * 4 + wvu) * 8;      // uniform
+        const float zz = zraw[i];
+        const float gg = __builtin_fmaf(zz, cf[0], cf[1]) > 0.f ? v : 0.f;
+        v = __builtin_fmaf(cf[2], gg, __builtin_fmaf(cf[3] - zz, cf[4], cf[5]));
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) tile[((rb + u) * 4 + wv) * (TS_Q + 1) + lane] = t16[u];
+      tile[(i * 4 + wv) * (TS_Q + 1) + lane] = v;
     }
-    __syncthreads();
+    lds_barrier();
+    // (unconditional: past the run's last tile the last tile is read again -- a conditional prefetch
+    // keeps the old and the new register set alive across the join)
+    const int rn = r0 + TS_Q < run_end ? r0 + TS_Q : r0;
+    prefetch(rn);                                            // lands during the compute phase below
     const int q0 = wv * 16;
     // d_wx: sum_q dy * rel over this wave's 16 queries (lane = channel)
     if (d_wx_part) {
@@ -465,6 +503,7 @@ __global__ __launch_bounds__(256) void blend_bwd_rows_kernel(
         for (int e = 0; e < CPT; ++e) atomicAdd(dt + (size_t)cur * pitch + e * 64, acc[e]);
       }
     };
+#pragma unroll 1
     for (int i0 = 0; i0 < 48; i0 += 8) {
       // phase A: eight taps' products, all loads independent (they overlap in the LDS queue)
       int seeds[8];
