@@ -165,7 +165,8 @@ def binding_roofline(timers, steps, mfma_peak_tflops, hbm_peak_gbs, list_below=0
 
 
 GATE_LOSS_TOL = 1e-4      # north_star: fp32 features / losses within 1e-4 of the CPU path
-GATE_GRAD_TOL = 5e-3      # flat gradient, HIP leg vs CPU-oracle leg (both fp32), relative L2.  The
+GATE_GRAD_TOL = 4e-3      # flat gradient, HIP leg vs CPU-oracle leg (both fp32), relative L2 (measured 1.6e-3
+#                           supervised, 3.3e-3 Nesie student/teacher, 2.0e-3 SAQE; 5e-3 until round 4).  The
 #                           fp64-referenced bound (HIP no farther from float64 than the CPU path is)
 #                           lives in tests/test_parity_gpu.py; two fp32 legs sit 2e-3 .. 3.5e-3 from
 #                           float64 each at this size, on either side of it
