@@ -28,31 +28,46 @@ __global__ __launch_bounds__(64) void pw_stats_finalize_kernel(
     float eps, float *__restrict__ coef, const float *__restrict__ chan_bias) {
   const int ch = blockIdx.x, g = ch / cout, m = ch % cout;
   const float4 *pp = (const float4 *)part + ((size_t)g * nslots) * cout + m;
-  double n = 0.0, sm = 0.0;
-  for (int i = threadIdx.x; i < nslots; i += 64) {
-    const float4 q = pp[(size_t)i * cout];
-    if (q.x > 0.f) {
-      n += (double)q.x;
-      sm += (double)q.x * (double)q.y + (double)q.z;   // n_i * mean_i
-    }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    n += __shfl_xor(n, off, 64);
-    sm += __shfl_xor(sm, off, 64);
-  }
-  const double mean = n > 0.0 ? sm / n : 0.0;
-  double m2 = 0.0;
-  for (int i = threadIdx.x; i < nslots; i += 64) {
-    const float4 q = pp[(size_t)i * cout];
+  // ONE pass (round 5; two dependent passes before: the mean first, then the squares about it): a
+  // lane merges its slots pairwise with Chan's update -- four slot loads in flight -- and a fixed
+  // butterfly merges the 64 lanes' (n, mean, M2) triples, all in fp64
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  auto merge = [&](double nb_, double mb_, double m2b_) {
+    if (nb_ <= 0.0) return;
+    const double nn = n + nb_, d = mb_ - mean;
+    mean += d * (nb_ / nn);
+    m2 += m2b_ + d * d * (n * nb_ / nn);
+    n = nn;
+  };
+  auto slot = [&](const float4 q) {
     if (q.x > 0.f) {
       const double ni = q.x, mi = (double)q.y + (double)q.z / ni;
       const double m2i = (double)q.w - (double)q.z * (double)q.z / ni;
-      m2 += (m2i > 0.0 ? m2i : 0.0) + ni * (mi - mean) * (mi - mean);
+      merge(ni, mi, m2i > 0.0 ? m2i : 0.0);
     }
-  }
+  };
+  int i = threadIdx.x;
+  for (; i + 192 < nslots; i += 256) {
+    float4 q[4];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+    for (int u = 0; u < 4; ++u) q[u] = pp[(size_t)(i + 64 * u) * cout];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) slot(q[u]);
+  }
+  for (; i < nslots; i += 64) slot(pp[(size_t)i * cout]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double nb_ = __shfl_xor(n, off, 64), mb_ = __shfl_xor(mean, off, 64), m2b_ = __shfl_xor(m2, off, 64);
+    // (both lanes of a pair compute the same merged triple: a symmetric form, so that they agree bit for bit)
+    const double nn = n + nb_;
+    if (nn > 0.0) {
+      const double d = mb_ - mean;
+      const double mm = (n * mean + nb_ * mb_) / nn;
+      m2 = m2 + m2b_ + d * d * (n * nb_ / nn);
+      mean = mm;
+    }
+    n = nn;
+  }
   if (threadIdx.x != 0) return;
   const double var = n > 0.0 ? m2 / n : 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
@@ -154,7 +169,10 @@ extern "C" int nesie_pw_supported(int k, int cout, long long p) {
 // workgroups per weight group of a launch
 static int pw_groups(const PwGeom &g, int nb, int ng, long long p) {
   const long long tiles = (long long)(nb / ng) * cdiv(p, g.pt);
-  long long nwg = (long long)cu_count() * g.per_cu / (ng * g.nhalf);
+  // NESIE_PW_ROUNDS (A/B, default 1): R shorter rounds of workgroups instead of one -- a CU that is
+  // not available to this launch (a long-lived tenant of another stream) then delays 1/R of it
+  static const int rounds = [] { const char *e = getenv("NESIE_PW_ROUNDS"); return e ? atoi(e) : 1; }();
+  long long nwg = (long long)cu_count() * g.per_cu * (rounds > 0 ? rounds : 1) / (ng * g.nhalf);
   if (nwg < 1) nwg = 1;
   if (nwg > tiles) nwg = tiles;
   // several row blocks per tile: a grid that is a multiple of 8 * nhalf lets the row blocks of a

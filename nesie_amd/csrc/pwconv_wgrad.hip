@@ -296,7 +296,8 @@ static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw, bool bnb = 
   static const int per_cu_max = getenv("NESIE_WGRAD_PER_CU") ? atoi(getenv("NESIE_WGRAD_PER_CU")) : 2;
   // (the fused norm-backward variants need 146-150 VGPRs at 128 x 128: one workgroup per CU there)
   const int per_cu = (co <= 128 && cw <= (bnb ? 64 : 128) && per_cu_max >= 2) ? 2 : 1;
-  long long nwg = (long long)cu_count() * per_cu / ng;
+  static const int rounds = [] { const char *e = getenv("NESIE_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();   // A/B
+  long long nwg = (long long)cu_count() * per_cu * (rounds > 0 ? rounds : 1) / ng;
   const long long tiles = (long long)(nb / ng) * (p / 32);
   if (nwg > tiles) nwg = tiles;
   return nwg < 1 ? 1 : (int)nwg;

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 "$@" > $O/trace_bench.json 2> $O/trace.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-baseline 0 --other-workloads 0 "$@" > $O/trace_bench.json 2> $O/trace.err || exit 1
 T=$(find $O/trace -name "*_kernel_trace.csv" | head -1)
 S=$(find $O/trace -name "*_kernel_stats.csv" | head -1)
 cp $S $O/kernel_stats.csv
