@@ -250,6 +250,13 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
   float s = 0.f;
   if (i < total) {
     int r = wave;
+    for (; r + 15 * 16 < nparts; r += 16 * 16) {     // sixteen partials in flight (two trips at 512 partials)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      s += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+    }
     for (; r + 7 * 16 < nparts; r += 8 * 16) {
       float v[8];
 #pragma unroll
@@ -361,9 +368,19 @@ __global__ __launch_bounds__(64) void pw_bnb_coef_kernel(int channels, int nslot
                                                          float *__restrict__ dbeta) {
   const int c = blockIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < nslots; i += 64) {
-    s0 += (double)part[((size_t)c * nslots + i) * 2];
-    s1 += (double)part[((size_t)c * nslots + i) * 2 + 1];
+  const float2 *pc = (const float2 *)part + (size_t)c * nslots;
+  int i = threadIdx.x;
+  for (; i + 192 < nslots; i += 256) {           // four loads in flight, added in slot order
+    float2 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = pc[i + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s0 += (double)q[u].x; s1 += (double)q[u].y; }
+  }
+  for (; i < nslots; i += 64) {
+    const float2 q = pc[i];
+    s0 += (double)q.x;
+    s1 += (double)q.y;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
