@@ -280,6 +280,14 @@ int nesie_blend_conv_backward_staged(int b, int c, int m, int n, const float *dy
                                      const float *weight, const float *rel, float *d_table,
                                      float *d_wx, int segs, int seg_len, void *workspace,
                                      size_t workspace_bytes, void *stream);
+/* out[ch] = sum over the nb batch entries and p positions of x[n][ch][pos]; x (nb, c, p) with batch
+ * stride x_bstride >= c * p (a channel slice of a wider tensor is fine).  The bias gradient of a
+ * convolution without a norm behind it (autograd's grad.sum((0, 2)) for the nn.Conv1d outputs of
+ * reliable_conv_bbox_module.py:144-177, vote_module.py:75-79, side_pooling_module.py:55-78); one
+ * workgroup per channel, fixed summation order. */
+int nesie_channel_sum(int nb, int c, long long p, const float *x, long long x_bstride, float *out,
+                      void *stream);
+
 /* bnb[ch] = (scale, shift, a, mean, d1, e0, -, -) of a BatchNorm + ReLU backward from the partial
  * sums part [(channels) * nslots * 2] = (sum g, sum g zhat), the folded forward coefficients
  * z_coef [channels][4] and gamma; count = elements per channel; dgamma / dbeta written. */

@@ -713,6 +713,21 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_group_max_pool_backward_add", rows, ns, _ptr(grad_out),
                       _ptr(argmax), _ptr(grad_x), _stream(grad_x))
 
+    def channel_sum(self, x, out=None):
+        """x (NB, C, P) (batch stride free, each x[n] (C, P) contiguous) -> (C,) sums over batch and
+        positions in a fixed order (nesie_channel_sum): a conv bias's gradient."""
+        _f32(x)
+        nb, c, p = x.shape
+        assert x.is_cuda and x.stride(2) == 1 and x.stride(1) == p
+        if out is None:
+            out = torch.empty(c, dtype=torch.float32, device=x.device)
+        _check(out); _f32(out)
+        assert out.numel() == c
+        with torch.cuda.device(x.device):
+            _lib.call("nesie_channel_sum", nb, c, p, _ptr(x), x.stride(0) if nb > 1 else c * p, _ptr(out),
+                      _stream(x))
+        return out
+
     def lhs_nms_samecls(self, boxes, thr, keep):
         """boxes (B,K,8) f32, keep (B,K) uint8."""
         _check(boxes, keep); _f32(boxes)

@@ -297,7 +297,7 @@ def fused_mini_pointnets(nets, c0, c0_stats):
                                          grad_slots.reshaped(gamma1, -1), grad_slots.reshaped(beta1, -1),
                                          w4)  # w4 (S, F, H2)
     if b4:
-        out = out + b4[0].view(1, S, -1, 1)
+        out = fused_mlp.AddChannelBias.apply(out, b4[0].view(S, -1))
     return out
 
 

@@ -1237,3 +1237,20 @@ def test_sample_and_group_over_predicted_coordinates_matches_the_literal_chain(h
         assert b.abs().max().item() > 0
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item())
     assert torch.equal(got[2], again[2]) and torch.equal(got[3], again[3])
+
+
+@pytest.mark.parametrize("shape,slice_", [((8, 1536, 512), None), ((8, 20, 256), None), ((3, 7, 33), None),
+                                          ((8, 220, 256), (20, 218))])
+def test_channel_sum_matches_float64_and_repeats_bitwise(hip_device, shape, slice_):
+    """nesie_channel_sum (a conv bias's gradient, autograd's grad.sum((0, 2))): one workgroup per
+    channel in a fixed order -- float64 within rounding, bitwise equal on repeats, also on a channel
+    slice of a wider tensor (batch-strided view)."""
+    hip = kernels.backend_for(torch.empty(1, device=hip_device))
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(hip_device)
+    view = x if slice_ is None else x[:, slice_[0]:slice_[1]]
+    a, b = hip.channel_sum(view), hip.channel_sum(view)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    want = view.double().sum((0, 2))
+    assert (a.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
