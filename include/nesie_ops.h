@@ -638,6 +638,22 @@ int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
                    const float *x_coef, int x_relu, float *dw, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* Deferred reductions: nothing in a backward pass reads a weight gradient (its consumers are the
+ * optimiser and the gradient all-reduce), so the *_deferred forms run the product only and leave the
+ * fixed-order addition of the per-workgroup partials PENDING; nesie_pw_wgrad_flush_deferred(stream)
+ * then finishes every pending gradient in ONE launch (descriptor table in the kernel arguments;
+ * each element is summed exactly as by the immediate forms: bit-identical).  Until the flush the
+ * workspace of a deferred launch must stay untouched and dw holds no valid data.  A launch that
+ * runs as several column blocks reduces immediately.  nesie_pw_wgrad_pending(): how many wait;
+ * nesie_pw_wgrad_drop_deferred(): forget them (error paths).  Host-side queue, one per process. */
+int nesie_pw_wgrad_deferred(int nb, int ng, int co, int ci, long long p, const float *dy,
+                            long long dy_bstride, const float *x, long long x_bstride,
+                            const float *x_coef, int x_relu, float *dw, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int nesie_pw_wgrad_flush_deferred(void *stream);
+int nesie_pw_wgrad_pending(void);
+int nesie_pw_wgrad_drop_deferred(void);
+
 /* The same weight gradient fused with the BatchNorm + ReLU backward that PRODUCES its dY operand
  * (replaces nesie_bn_relu_backward_apply + nesie_pw_wgrad for a conv -> BatchNorm -> ReLU layer of
  * ConvModule, point_sa_module.py:277-289): da (nb, co, p) is the gradient of relu(bn(z)), z the raw
@@ -654,6 +670,14 @@ int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const float *dy,
  * Supported where one launch owns every column of dw (nesie_pw_wgrad_bn_supported). */
 int nesie_pw_wgrad_bn_supported(int co, int ci, long long p);
 int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
+                               const float *z, long long z_bstride, const float *z_coef,
+                               const float *gamma, const float *part, int nslots, const float *x,
+                               long long x_bstride, const float *x_coef, int x_relu, float *dz,
+                               float *dw, float *dgamma, float *dbeta, float *coef_ws,
+                               float *d_row_bias, int rb_group, void *workspace,
+                               size_t workspace_bytes, void *stream);
+/* ... with the weight gradient's reduction left pending (dz, dgamma, dbeta complete on return). */
+int nesie_pw_wgrad_bn_backward_deferred(int nb, int ng, int co, int ci, long long p, const float *da,
                                const float *z, long long z_bstride, const float *z_coef,
                                const float *gamma, const float *part, int nslots, const float *x,
                                long long x_bstride, const float *x_coef, int x_relu, float *dz,

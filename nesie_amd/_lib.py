@@ -107,7 +107,14 @@ SIGNATURES = {
                                   ctypes.c_size_t, _P],
     "nesie_pw_wgrad": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                        ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
+    "nesie_pw_wgrad_deferred": [_I, _I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                       ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_size_t, _P],
+    "nesie_pw_wgrad_flush_deferred": [_P],
+    "nesie_pw_wgrad_drop_deferred": [],
     "nesie_pw_wgrad_bn_backward": [_I, _I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P,
+                                   _P, _I, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P,
+                                   ctypes.c_size_t, _P],
+    "nesie_pw_wgrad_bn_backward_deferred": [_I, _I, _I, _I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P,
                                    _P, _I, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P,
                                    ctypes.c_size_t, _P],
     "nesie_pw_stats_finalize": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
@@ -170,6 +177,8 @@ def load():
     lib.nesie_pw_wgrad_bn_supported.restype = _I
     lib.nesie_pw_wgrad_workspace_bytes.argtypes = [_I, _I, _I, _I, ctypes.c_longlong]
     lib.nesie_pw_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.nesie_pw_wgrad_pending.argtypes = []
+    lib.nesie_pw_wgrad_pending.restype = _I
     lib.nesie_flat_adamw_workspace_bytes.argtypes = []
     lib.nesie_flat_adamw_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_pw_supported.argtypes = [_I, _I, ctypes.c_longlong]

@@ -297,6 +297,103 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_tiled_kernel(int co, int 
   dw[((size_t)g * co + rb * br + i / ci_b) * ci + cb * bc + i % ci_b] = s;
 }
 
+// ---- deferred reductions (round 5) ------------------------------------------------------------
+// The partials of a weight gradient are consumed by nobody but the optimiser (and the gradient
+// all-reduce): nothing in the backward pass reads dW.  So a launch may leave its reduction PENDING
+// (nesie_pw_wgrad_deferred / nesie_pw_wgrad_bn_backward_deferred: the workspace then has to stay
+// alive) and nesie_pw_wgrad_flush_deferred adds the partials of every pending gradient in ONE launch
+// -- a descriptor table in the kernel arguments, a workgroup finds its descriptor from the block
+// index -- with each element summed exactly as its own reduce kernel sums it (bit-identical).  39
+// reduce launches of 5 - 8 us per step become one or two.
+struct RDesc {
+  const float *part; float *dw;
+  int kind;                 // 0 plain (pw_wgrad_reduce_kernel), 1 tiled (pw_wgrad_reduce_tiled_kernel)
+  int nparts, total, ci, ld, col0, co, ng;
+  int br, bc, nblk;         // tiled: block extents and number of blocks
+};
+constexpr int RD_MAX = 40;
+struct RTable { int n; int start[RD_MAX + 1]; RDesc d[RD_MAX]; };
+
+__global__ __launch_bounds__(1024) void pw_wgrad_reduce_batch_kernel(const RTable t) {
+  __shared__ float sh[16][64];
+  int di = 0;
+  while (di + 1 < t.n && (int)blockIdx.x >= t.start[di + 1]) ++di;        // (uniform)
+  const RDesc &d = t.d[di];
+  const int local = blockIdx.x - t.start[di];
+  if (d.kind == 0) {
+    const int bpg = (d.total + 63) / 64;
+    const int bx = local % bpg, g = local / bpg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = bx * 64 + lane;
+    const float *src = d.part + (size_t)g * d.nparts * d.total;
+    const int total = d.total, nparts = d.nparts;
+    float s = 0.f;
+    if (i < total) {
+      int r = wave;
+      for (; r + 15 * 16 < nparts; r += 16 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        s += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+      }
+      for (; r + 7 * 16 < nparts; r += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (; r < nparts; r += 16) s += src[(size_t)r * total + i];
+    }
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < total) {
+      float tt = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tt += sh[w][lane];
+      d.dw[((size_t)g * d.co + i / d.ci) * d.ld + d.col0 + i % d.ci] = tt;
+    }
+  } else {
+    // one thread per element of a block, the partials in ascending order (four at a time)
+    const int per = (d.br * d.bc + 1023) / 1024;
+    const int q = local % per, blk = (local / per) % d.nblk, g = local / (per * d.nblk);
+    const int ncb = (d.ci + d.bc - 1) / d.bc;
+    const int rb = blk / ncb, cb = blk % ncb;
+    const int co_b = d.co - rb * d.br < d.br ? d.co - rb * d.br : d.br, ci_b = d.ci - cb * d.bc < d.bc ? d.ci - cb * d.bc : d.bc;
+    const int i = q * 1024 + threadIdx.x;
+    if (i >= co_b * ci_b) return;
+    const size_t bb = (size_t)d.br * d.bc;
+    const float *src = d.part + ((size_t)blk * d.ng + g) * d.nparts * bb + i;
+    float s = 0.f;
+    int r = 0;
+    for (; r + 3 < d.nparts; r += 4) {
+      const float v0 = src[(size_t)r * bb], v1 = src[(size_t)(r + 1) * bb], v2 = src[(size_t)(r + 2) * bb],
+                  v3 = src[(size_t)(r + 3) * bb];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < d.nparts; ++r) s += src[(size_t)r * bb];
+    d.dw[((size_t)g * d.co + rb * d.br + i / ci_b) * d.ci + cb * d.bc + i % ci_b] = s;
+  }
+}
+
+static RTable g_pending;      // host side: the reductions waiting for nesie_pw_wgrad_flush_deferred
+
+static void rd_push(const RDesc &d) {
+  const int blocks = d.kind == 0 ? ((d.total + 63) / 64) * d.ng : ((d.br * d.bc + 1023) / 1024) * d.nblk * d.ng;
+  const int n = g_pending.n;
+  g_pending.d[n] = d;
+  if (n == 0) g_pending.start[0] = 0;
+  g_pending.start[n + 1] = g_pending.start[n] + blocks;
+  g_pending.n = n + 1;
+}
+
+static int rd_flush(hipStream_t s) {
+  if (g_pending.n == 0) return NESIE_OK;
+  hipLaunchKernelGGL(pw_wgrad_reduce_batch_kernel, dim3(g_pending.start[g_pending.n]), dim3(1024), 0, s, g_pending);
+  g_pending.n = 0;
+  return check_launch("pw_wgrad_flush_deferred");
+}
+
 // workgroups per weight group: one per CU; TWO per CU where a block's tiles (<= 74 KB of LDS) and
 // registers (<= 128) allow it (NESIE_WGRAD_PER_CU=1: A/B switch)
 static int pw_wgrad_nwg(int nb, int ng, long long p, int co, int cw, bool bnb = false) {
@@ -403,7 +500,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
                            long long dy_bstride, const float *x, long long x_bstride,
                            const float *x_coef, int x_relu, float *dw, void *workspace,
                            size_t workspace_bytes, const float *bnz, const float *bnb, float *dz,
-                           float *d_rb, int rb_group, hipStream_t s) {
+                           float *d_rb, int rb_group, hipStream_t s, bool defer = false) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && ci >= 1 && p >= 0 && dw, W);
   if (nb == 0 || p == 0) {
     (void)hipMemsetAsync(dw, 0, (size_t)ng * co * ci * sizeof(float), s);
@@ -439,6 +536,14 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     } while (0)
     if (x_coef) LT(true); else LT(false);
 #undef LT
+    if (defer) {
+      if (g_pending.n == RD_MAX) { const int st = rd_flush(s); if (st) return st; }
+      RDesc d{};
+      d.part = partial; d.dw = dw; d.kind = 1; d.nparts = nwg; d.ci = ci; d.co = co; d.ng = ng;
+      d.br = TILED_B; d.bc = TILED_B; d.nblk = nrb * ncb;
+      rd_push(d);
+      return check_launch(W);
+    }
     hipLaunchKernelGGL(pw_wgrad_reduce_tiled_kernel, dim3(cdiv(TILED_B * TILED_B, 256), nrb * ncb, ng), dim3(256), 0, s,
                        co, ci, TILED_B, TILED_B, nwg, partial, dw);
     return check_launch(W);
@@ -480,6 +585,14 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     else if (co <= 128) L(8, 20, 2, 4);
     else L(16, 8, 4, 2);
     const int total = co * cw;
+    if (defer && block >= ci) {      // (column blocks share the workspace: only a whole-product launch may wait)
+      if (g_pending.n == RD_MAX) { const int st = rd_flush(s); if (st) return st; }
+      RDesc d{};
+      d.part = partial; d.dw = dw; d.kind = 0; d.nparts = nwg; d.total = total; d.ci = cw; d.ld = ci; d.col0 = c0;
+      d.co = co; d.ng = ng;
+      rd_push(d);
+      continue;
+    }
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(total, 64), ng), dim3(1024), 0, s, total, nwg,
                        partial, dw, cw, ci, c0, co);
   }
@@ -497,8 +610,47 @@ extern "C" int nesie_pw_wgrad(int nb, int ng, int co, int ci, long long p, const
                          workspace, workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
+// The same launch with its reduction left pending (see "deferred reductions"): dw is written by
+// nesie_pw_wgrad_flush_deferred; `workspace` must stay untouched until then.
+extern "C" int nesie_pw_wgrad_deferred(int nb, int ng, int co, int ci, long long p, const float *dy,
+                                       long long dy_bstride, const float *x, long long x_bstride,
+                                       const float *x_coef, int x_relu, float *dw, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+  return pw_wgrad_launch("pw_wgrad_deferred", nb, ng, co, ci, p, dy, dy_bstride, x, x_bstride, x_coef, x_relu, dw,
+                         workspace, workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, true);
+}
+
+extern "C" int nesie_pw_wgrad_flush_deferred(void *stream) { return rd_flush((hipStream_t)stream); }
+extern "C" int nesie_pw_wgrad_pending(void) { return g_pending.n; }
+extern "C" int nesie_pw_wgrad_drop_deferred(void) {      // (error paths: forget what is pending)
+  g_pending.n = 0;
+  return NESIE_OK;
+}
+
 extern "C" int nesie_pw_wgrad_bn_supported(int co, int ci, long long p) {
   return nesie_pw_wgrad_supported(co, ci, p) && pw_wgrad_block(co, ci) == ci ? 1 : 0;
+}
+
+static int pw_wgrad_bn_backward_impl(const char *W, bool defer, int nb, int ng, int co, int ci, long long p, const float *da,
+                                          const float *z, long long z_bstride, const float *z_coef,
+                                          const float *gamma, const float *part, int nslots,
+                                          const float *x, long long x_bstride, const float *x_coef,
+                                          int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
+                                          float *coef_ws, float *d_row_bias, int rb_group,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+  NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (nb == 0 || p == 0) {
+    if (dgamma) (void)hipMemsetAsync(dgamma, 0, (size_t)ng * co * sizeof(float), s);
+    if (dbeta) (void)hipMemsetAsync(dbeta, 0, (size_t)ng * co * sizeof(float), s);
+    return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
+                           workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, s, defer);
+  }
+  NESIE_REQUIRE(da && z && z_coef && part && dz && coef_ws && nb % ng == 0, W);
+  hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
+                     (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
+  return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
+                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s, defer);
 }
 
 extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
@@ -508,21 +660,24 @@ extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long l
                                           int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
                                           float *coef_ws, float *d_row_bias, int rb_group,
                                           void *workspace, size_t workspace_bytes, void *stream) {
-  const char *W = "pw_wgrad_bn_backward";
-  NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
-  hipStream_t s = (hipStream_t)stream;
-  if (nb == 0 || p == 0) {
-    if (dgamma) (void)hipMemsetAsync(dgamma, 0, (size_t)ng * co * sizeof(float), s);
-    if (dbeta) (void)hipMemsetAsync(dbeta, 0, (size_t)ng * co * sizeof(float), s);
-    return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                           workspace_bytes, nullptr, nullptr, nullptr, nullptr, 0, s);
-  }
-  NESIE_REQUIRE(da && z && z_coef && part && dz && coef_ws && nb % ng == 0, W);
-  hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
-                     (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
-  return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s);
+  return pw_wgrad_bn_backward_impl("pw_wgrad_bn_backward", false, nb, ng, co, ci, p, da, z, z_bstride, z_coef, gamma,
+                                   part, nslots, x, x_bstride, x_coef, x_relu, dz, dw, dgamma, dbeta, coef_ws,
+                                   d_row_bias, rb_group, workspace, workspace_bytes, stream);
 }
+
+// ... and with the weight gradient's reduction left pending (dz, dgamma, dbeta are complete on return)
+extern "C" int nesie_pw_wgrad_bn_backward_deferred(int nb, int ng, int co, int ci, long long p, const float *da,
+                                                   const float *z, long long z_bstride, const float *z_coef,
+                                                   const float *gamma, const float *part, int nslots,
+                                                   const float *x, long long x_bstride, const float *x_coef,
+                                                   int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
+                                                   float *coef_ws, float *d_row_bias, int rb_group,
+                                                   void *workspace, size_t workspace_bytes, void *stream) {
+  return pw_wgrad_bn_backward_impl("pw_wgrad_bn_backward_deferred", true, nb, ng, co, ci, p, da, z, z_bstride, z_coef,
+                                   gamma, part, nslots, x, x_bstride, x_coef, x_relu, dz, dw, dgamma, dbeta, coef_ws,
+                                   d_row_bias, rb_group, workspace, workspace_bytes, stream);
+}
+
 
 // The reduction coefficients of a BatchNorm + ReLU backward on their own (for a consumer of dZ
 // other than the weight gradient: nesie_blend_conv_backward_bn): bnb [channels][8], dgamma, dbeta.

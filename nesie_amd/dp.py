@@ -152,6 +152,13 @@ class FlatTrainState(FlatGradBucket):
         for p in self.params:
             p.grad = None
         grad_slots.begin(self)
+        # weight gradients written straight into their slots may leave their partial sums pending
+        # until collect() (kernels.HipKernels.begin_deferred_reductions)
+        self._deferral, self._collected = None, 0
+        if self.flat.is_cuda:
+            from .kernels import HipKernels
+            HipKernels.begin_deferred_reductions()
+            self._deferral = HipKernels
 
     def split_after(self, first_params):
         """-> (number of parameters, LAYOUT extent in elements) of the leading block
@@ -177,6 +184,25 @@ class FlatTrainState(FlatGradBucket):
     def collect(self, lo=0, hi=None):
         """Gather the gradients of parameters [lo, hi) (default: all) into the flat vector."""
         from . import grad_slots
+        if getattr(self, '_deferral', None) is not None:
+            # ONE launch finishes every weight gradient whose reduction was left pending (kernels.
+            # HipKernels.flush_deferred_reductions); the window closes with the last segment
+            n_seg = len(self.params[lo:hi])
+            self._collected = getattr(self, '_collected', 0) + n_seg
+            last = self._collected >= len(self.params)
+            done = self._deferral.flush_deferred_reductions(self.flat.device, close=last)
+            if last:
+                self._collected, self._deferral = 0, None
+            # each of them must arrive as the slot ITSELF: a gradient autograd combined with another
+            # one (a second use of the parameter outside the fused functions) was read before it was
+            # complete -- fail loudly (NESIE_DEFER_WGRAD=0 switches the deferral off)
+            spans = [(d.data_ptr(), d.data_ptr() + d.numel() * d.element_size()) for d in done]
+            if spans:
+                for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
+                    a = v.data_ptr()
+                    if p.grad is not None and p.grad.data_ptr() != a and any(s0 <= a < s1 for s0, s1 in spans):
+                        raise RuntimeError('a weight gradient with a deferred reduction was consumed before '
+                                           'FlatTrainState.collect() (parameter used twice?): set NESIE_DEFER_WGRAD=0')
         src, dst, missing = [], [], []
         for p, v in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:

@@ -786,10 +786,43 @@ class HipKernels(_BNPoolMixin):
         (wide layers over few positions: the 1-D chains)."""
         return bool(_lib.load().nesie_pw_wgrad_tiled(int(nb), int(ng), int(co), int(ci), int(p)))
 
-    def pw_wgrad(self, dy, x, dw, ng=1, x_coef=None, x_relu=True):
+    # ---- deferred weight-gradient reductions (nesie_pw_wgrad_deferred, include/nesie_ops.h) -----
+    # Between ``begin_deferred_reductions()`` and ``flush_deferred_reductions()`` a weight gradient
+    # whose destination is FINAL (a slot of the flat gradient vector: nothing reads it before the
+    # optimiser) leaves the addition of its partials pending; the flush runs them all in one launch.
+    # dp.FlatTrainState opens the window in begin() and flushes in collect().  NESIE_DEFER_WGRAD=0:
+    # every reduction runs with its own launch (A/B switch).
+    DEFER_WGRAD = os.environ.get('NESIE_DEFER_WGRAD', '1') != '0'
+    _deferred = None       # None: no window open; else the workspaces (and destinations) kept alive
+
+    @classmethod
+    def begin_deferred_reductions(cls):
+        if cls._deferred:      # a window left open by an aborted backward: its partials are stale
+            _lib.call("nesie_pw_wgrad_drop_deferred")
+        cls._deferred = [] if cls.DEFER_WGRAD else None
+
+    @classmethod
+    def flush_deferred_reductions(cls, device=None, close=False):
+        """Finish every pending weight gradient (one launch on the current stream); -> the
+        destinations that were written.  ``close``: end the window."""
+        held, done = cls._deferred, []
+        if held:
+            dev = device if device is not None else held[0][1].device
+            with torch.cuda.device(dev):
+                _lib.call("nesie_pw_wgrad_flush_deferred", torch.cuda.current_stream(dev).cuda_stream)
+            done = [dw for _, dw in held]
+            # (under a graph capture the workspaces live in the graph's pool; in eager mode the caching
+            # allocator hands a freed block to later launches of this stream only: both orders are safe)
+            cls._deferred = []
+        if close:
+            cls._deferred = None
+        return done
+
+    def pw_wgrad(self, dy, x, dw, ng=1, x_coef=None, x_relu=True, final=False):
         """dw (ng, co, ci) = sum over n % ng == g and positions of dy[n] (co, P) act(x[n])^T
         (nesie_pw_wgrad); dy (NB, co, P), x (NB, ci, P) batch-strided views allowed;
-        x_coef (ng*ci, 4) folded BatchNorm of x."""
+        x_coef (ng*ci, 4) folded BatchNorm of x.  ``final``: dw is read by nobody before the
+        deferred reductions are flushed (a slot of the flat gradient vector)."""
         _f32(dy, x, dw)
         nb, co, p = dy.shape
         ci = x.shape[1]
@@ -801,12 +834,15 @@ class HipKernels(_BNPoolMixin):
             assert tuple(x_coef.shape) == (ng * ci, 4)
         lib = _lib.load()
         need = lib.nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p)
+        defer = final and HipKernels._deferred is not None
         with torch.cuda.device(dy.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device)
-            _lib.call("nesie_pw_wgrad", nb, ng, co, ci, p, _ptr(dy),
+            _lib.call("nesie_pw_wgrad_deferred" if defer else "nesie_pw_wgrad", nb, ng, co, ci, p, _ptr(dy),
                       dy.stride(0) if nb > 1 else co * p, _ptr(x), x.stride(0) if nb > 1 else ci * p,
                       0 if x_coef is None else _ptr(x_coef), int(bool(x_relu)), _ptr(dw), _ptr(ws),
                       need, _stream(dy))
+            if defer:
+                HipKernels._deferred.append((ws, dw))
 
     def pw_bnb_coef(self, part, z_coef, gamma, count, dgamma, dbeta):
         """(channels, 8) reduction coefficients of a BatchNorm + ReLU backward from the partial sums
@@ -828,7 +864,7 @@ class HipKernels(_BNPoolMixin):
         return bool(_lib.load().nesie_pw_wgrad_bn_supported(int(co), int(ci), int(p)))
 
     def pw_wgrad_bn_backward(self, da, z, z_coef, gamma, part, x, dz, dw, dgamma, dbeta, ng=1,
-                             x_coef=None, x_relu=True, d_row_bias=None, group=0):
+                             x_coef=None, x_relu=True, d_row_bias=None, group=0, final=False):
         """The BatchNorm + ReLU backward's apply pass fused into the weight gradient it feeds
         (nesie_pw_wgrad_bn_backward): da (NB, co, P) gradient of relu(bn(z)), z raw conv output,
         z_coef (ng*co, 4), part (ng*co, slots, 2) from ``pw_dgrad_bn_reduce``; x (NB, ci, P) the
@@ -854,10 +890,14 @@ class HipKernels(_BNPoolMixin):
             assert tuple(x_coef.shape) == (ng * ci, 4)
         lib = _lib.load()
         need = lib.nesie_pw_wgrad_workspace_bytes(nb, ng, co, ci, p)
+        defer = final and HipKernels._deferred is not None
         with torch.cuda.device(da.device):
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=da.device)
             cws = torch.empty(ng * co, 8, dtype=torch.float32, device=da.device)
-            _lib.call("nesie_pw_wgrad_bn_backward", nb, ng, co, ci, p, _ptr(da), _ptr(z), co * p,
+            if defer:
+                HipKernels._deferred.append((ws, dw))
+            _lib.call("nesie_pw_wgrad_bn_backward_deferred" if defer else "nesie_pw_wgrad_bn_backward",
+                      nb, ng, co, ci, p, _ptr(da), _ptr(z), co * p,
                       _ptr(z_coef), 0 if gamma is None else _ptr(gamma), _ptr(part), part.shape[1],
                       _ptr(x), x.stride(0) if nb > 1 else ci * p, 0 if x_coef is None else _ptr(x_coef),
                       int(bool(x_relu)), _ptr(dz), _ptr(dw), _ptr(dgamma), _ptr(dbeta), _ptr(cws),

@@ -70,7 +70,9 @@ def _wgrad(backend, dy, x, x_coef, ng=1, slot=None):
     if backend.pw_wgrad_tiled(nb, ng, co, ci, p) or (
             backend.pw_wgrad_supported(co, ci, p) and (WIDE_WGRAD or (ci <= 320 if co <= 128 else ci <= 128))):
         dw = _dst(slot, dy, ng, co, ci)
-        backend.pw_wgrad(dy, x, dw, ng=ng, x_coef=x_coef, x_relu=True)
+        # (a slot of the flat gradient vector is read by nobody before the optimiser: its reduction
+        # may wait for the one batched launch at FlatTrainState.collect())
+        backend.pw_wgrad(dy, x, dw, ng=ng, x_coef=x_coef, x_relu=True, final=slot is not None)
         return dw
     if ng == 1 and ci <= 8 and backend.conv_wgrad_supported(co, ci):
         dw = _dst(slot, dy, co, ci)
@@ -130,7 +132,7 @@ def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_
     if FOLD_NORM_BWD and need_w and backend.pw_wgrad_bn_supported(co, ci, p):
         dw = _dst(s_w, da, ng, co, ci)
         backend.pw_wgrad_bn_backward(da, z, coef, gamma, part, src, da, dw, dgamma, dbeta, ng=ng,
-                                     x_coef=src_coef)
+                                     x_coef=src_coef, final=slots[0] is not None)
         return da, dw, dgamma, dbeta
     if FOLD_NORM_BWD and need_w and not need_dz and ng == 1 and ci <= 8 and backend.conv_wgrad_supported(co, ci):
         bnb = backend.pw_bnb_coef(part, coef, gamma, float(nb) * float(p), dgamma, dbeta)

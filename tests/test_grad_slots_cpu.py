@@ -203,3 +203,17 @@ def test_collect_overwrites_a_poisoned_slot_of_a_parameter_that_got_no_gradient(
         g = state.flat[o:o + p.numel()]
         reached = any(p is q for m in (pre, nets[0]) for q in m.parameters())
         assert torch.isfinite(g).all() and (reached or torch.all(g == 0))
+
+
+def test_deferred_reduction_window_is_a_no_op_without_a_gpu():
+    """FlatTrainState on CPU tensors never opens the deferred-reduction window of the HIP back end
+    (begin() / collect() leave kernels.HipKernels._deferred alone)."""
+    from nesie_amd.kernels import HipKernels
+    pre, nets, params = _toy()
+    state = dp.FlatTrainState(params)
+    before = HipKernels._deferred
+    state.begin()
+    assert HipKernels._deferred is before and state._deferral is None
+    nets[0](pre(torch.randn(2, 5))).sum().backward()
+    state.collect()
+    assert HipKernels._deferred is before

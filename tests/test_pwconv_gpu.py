@@ -813,3 +813,61 @@ def test_persistent_grids_sized_for_fewer_cus_give_the_same_layer():
 def _lib_cu_count():
     from nesie_amd import _lib
     return _lib.load().nesie_get_cu_count()
+
+
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones_bit_for_bit():
+    """nesie_pw_wgrad_deferred + nesie_pw_wgrad_flush_deferred: several weight gradients (whole-product
+    launches, a tiled split-K launch, a column-blocked one that must reduce at once) leave their
+    partials pending and ONE launch finishes them -- every element summed as its own reduce kernel sums
+    it: bitwise equal to the immediate form.  Outside a window ``final`` changes nothing."""
+    from nesie_amd.kernels import HipKernels
+    hip = _hip()
+    g = torch.Generator(device=_dev()).manual_seed(11)
+    shapes = [(4, 2, 128, 128, 256), (2, 1, 256, 128, 512), (8, 1, 256, 256, 1024), (6, 3, 128, 256, 256),
+              (2, 1, 256, 512, 128), (2, 1, 64, 64, 1024), (12, 6, 128, 166, 512),
+              (2, 1, 256, 256, 32768)]            # (the last one: two column blocks over many positions)
+    assert not hip.pw_wgrad_tiled(2, 1, 256, 256, 32768)
+    cases = []
+    for nb, ng, co, ci, p in shapes:
+        dy = torch.randn(nb, co, p, device=_dev(), generator=g)
+        x = torch.randn(nb, ci, p, device=_dev(), generator=g)
+        coef = torch.rand(ng * ci, 4, device=_dev(), generator=g) + 0.5
+        coef[:, 1] -= 1.0
+        want = torch.empty(ng, co, ci, device=_dev())
+        hip.pw_wgrad(dy, x, want, ng=ng, x_coef=coef, final=True)      # no window open: immediate
+        cases.append((dy, x, coef, ng, want))
+    assert _lib_pending() == 0
+    HipKernels.begin_deferred_reductions()
+    try:
+        got = []
+        for dy, x, coef, ng, want in cases:
+            dw = torch.full_like(want, float('nan'))
+            hip.pw_wgrad(dy, x, dw, ng=ng, x_coef=coef, final=True)
+            got.append(dw)
+        pending = _lib_pending()
+        assert 0 < pending < len(cases)          # (the column-blocked shape did not wait)
+        assert any(torch.isnan(d).any() for d in got)
+        done = HipKernels.flush_deferred_reductions(close=True)
+    finally:
+        HipKernels._deferred = None
+    torch.cuda.synchronize()
+    assert len(done) == len(cases) and _lib_pending() == 0     # (python keeps every workspace of the window alive)
+    for dw, (_, _, _, _, want) in zip(got, cases):
+        assert torch.equal(dw, want)
+    # more gradients than one table holds: the queue flushes itself and keeps going
+    HipKernels.begin_deferred_reductions()
+    try:
+        dy, x, coef, ng, want = cases[0]
+        outs = [torch.empty_like(want) for _ in range(45)]
+        for dw in outs:
+            hip.pw_wgrad(dy, x, dw, ng=ng, x_coef=coef, final=True)
+        HipKernels.flush_deferred_reductions(close=True)
+    finally:
+        HipKernels._deferred = None
+    torch.cuda.synchronize()
+    assert all(torch.equal(dw, want) for dw in outs)
+
+
+def _lib_pending():
+    from nesie_amd import _lib
+    return _lib.load().nesie_pw_wgrad_pending()
