@@ -132,13 +132,14 @@ int nesie_query_and_group_backward(int b, int c, int n, int npoints, int nsample
  * both; any n: n <= 2048 by a stable counting sort in one workgroup per scene, larger n in windows
  * of 8192 source points per workgroup).  Lanes own sorted entries, a segmented scan inside each wave sums the runs;
  * every run is summed by exactly ONE wave (the one that holds its first entry follows it through
- * the next chunks) and added into grad_features (zeroed by the caller) by one lane: no float
- * atomics.  Inside a run the columns are in ascending order (scratch[B, M*ns] holds the
+ * the next chunks) and written by one lane: no float atomics; grad_features is WRITTEN in full
+ * (round 5: a point without entries gets its zero here, the caller need not clear it).  Inside a run the columns are in ascending order (scratch[B, M*ns] holds the
  * arrival-order placement that the second pass ranks), so the sums are bitwise reproducible. */
 int nesie_inverted_index(int b, int n, long long e_total, const int *idx, int *order,
                          int *sources, int *scratch, void *stream);
 /* nesie_group_points_backward / nesie_gather_points_grad_wrapper (nsample = 1) through the same
- * index: grad_points (B,C,N, zeroed) += grad_out (B,C,npoints,nsample), every point's run summed by
+ * index: grad_points (B,C,N) = scatter of grad_out (B,C,npoints,nsample) (WRITTEN in full: the caller
+ * need not clear it), every point's run summed by
  * one wave in ascending column order (replaces the atomicAdd of group_points_cuda.cu:10-31 and
  * gather_points_cuda.cu:51-70 with a defined order). */
 int nesie_group_points_backward_csr(int b, int c, int n, int npoints, int nsample,
@@ -179,11 +180,12 @@ int nesie_query_and_group_backward_xyz(int b, int c, int n, int npoints, int nsa
                                        const float *d_centres, float *d_xyz, void *stream);
 
 /* three_interpolate_grad_wrapper through an inverted index of idx[B, n, 3] over the m known
- * points (nesie_inverted_index with e_total = 3n): grad_points[B, C, m] (zeroed) +=
- * weight * grad_out, one float atomic per (known point, wave) instead of three per target. */
+ * points (nesie_inverted_index with e_total = 3n): grad_points[B, C, m] = scatter of
+ * weight * grad_out, WRITTEN in full, no float atomics, fixed order; grad_out (B, C, n) with a free
+ * batch stride (a channel slice of a wider gradient: no copy). */
 int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
-                                     const float *weight, const int *order, const int *sources,
-                                     float *grad_points, void *stream);
+                                     long long grad_out_bstride, const float *weight, const int *order,
+                                     const int *sources, float *grad_points, void *stream);
 
 /* mmdet3d/ops/gather_points/src/gather_points.cpp:28-42  gather_points_wrapper
  * (b, c, n, npoints, points[B,C,N], idx[B,M], out[B,C,M]). */
@@ -280,13 +282,14 @@ int nesie_blend_conv_backward_staged(int b, int c, int m, int n, const float *dy
                                      const float *weight, const float *rel, float *d_table,
                                      float *d_wx, int segs, int seg_len, void *workspace,
                                      size_t workspace_bytes, void *stream);
-/* out[ch] = sum over the nb batch entries and p positions of x[n][ch][pos]; x (nb, c, p) with batch
- * stride x_bstride >= c * p (a channel slice of a wider tensor is fine).  The bias gradient of a
- * convolution without a norm behind it (autograd's grad.sum((0, 2)) for the nn.Conv1d outputs of
- * reliable_conv_bbox_module.py:144-177, vote_module.py:75-79, side_pooling_module.py:55-78); one
- * workgroup per channel, fixed summation order. */
-int nesie_channel_sum(int nb, int c, long long p, const float *x, long long x_bstride, float *out,
-                      void *stream);
+/* out[g * c + ch] = sum over the batch entries n = g (mod ng) and the p positions of x[n][ch][pos];
+ * x (nb, c, p) with batch stride x_bstride >= c * p (a channel slice of a wider tensor is fine).
+ * The bias gradient of a convolution without a norm behind it (autograd's grad.sum((0, 2)) for the
+ * nn.Conv1d outputs of reliable_conv_bbox_module.py:144-177, vote_module.py:75-79,
+ * side_pooling_module.py:55-78; ng = the S stacked nets of the quality head); one workgroup per
+ * (group, channel), fixed summation order. */
+int nesie_channel_sum(int nb, int ng, int c, long long p, const float *x, long long x_bstride,
+                      float *out, void *stream);
 
 /* bnb[ch] = (scale, shift, a, mean, d1, e0, -, -) of a BatchNorm + ReLU backward from the partial
  * sums part [(channels) * nslots * 2] = (sum g, sum g zhat), the folded forward coefficients

@@ -57,7 +57,7 @@ SIGNATURES = {
     "nesie_group_max_pool_backward": [ctypes.c_longlong, _I, _P, _P, _P, _P],
     "nesie_query_and_group_forward": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P],
     "nesie_query_and_group_backward": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "nesie_three_interpolate_grad_csr": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "nesie_three_interpolate_grad_csr": [_I, _I, _I, _I, _P, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_inverted_index": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nesie_group_points_backward_csr": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -66,7 +66,7 @@ SIGNATURES = {
     "nesie_vote_finish_backward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "nesie_query_and_group_backward_xyz": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P],
     "nesie_group_max_pool_backward_add": [ctypes.c_longlong, _I, _P, _P, _P, _P],
-    "nesie_channel_sum": [_I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P],
+    "nesie_channel_sum": [_I, _I, _I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P],
     "nesie_iou3d_forward": [_I, _P, _P, _P, _P, _P],
     "nesie_lhs_nms_samecls": [_I, _I, _P, _F, _P, _P],
     "nesie_bn_relu_maxpool_forward": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P,

@@ -344,6 +344,17 @@ __global__ __launch_bounds__(GR_BLOCK) void group_bwd_csr_rows_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) *(float4 *)(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  else for (long long j = i; j < n; ++j) p[j] = 0.f;
+}
+// (a kernel, not hipMemsetAsync: a memset node beside a kernel that adds into the same buffer lost its
+// ordering on later replays of a captured graph on this runtime)
+static void zero_fill(float *p, long long n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(zero_fill_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, p, n);
+}
+
 // -> launched (true) or not applicable (false: the caller uses group_bwd_csr_kernel)
 static bool launch_group_bwd_csr_rows(int b, int c, int n, long long e_total, long long gstride, int ediv,
                                       const float *grad_out, const float *weight, const int *order,
@@ -729,6 +740,7 @@ extern "C" int nesie_query_and_group_backward_csr(int b, int c, int n, int npoin
   if (launch_group_bwd_csr_rows(b, c, n, e_total, (long long)(3 + c) * e_total, 1, grad_out + 3 * e_total, nullptr,
                                 order, sources, grad_features, (hipStream_t)stream))
     return check_launch(W);
+  zero_fill(grad_features, (long long)b * c * n, (hipStream_t)stream);      // (the HBM-gather form ADDS)
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total,
                      (long long)(3 + c) * e_total, 1, grad_out + 3 * e_total,
@@ -751,6 +763,7 @@ extern "C" int nesie_group_points_backward_csr(int b, int c, int n, int npoints,
   if (launch_group_bwd_csr_rows(b, c, n, e_total, (long long)c * e_total, 1, grad_out, nullptr, order, sources,
                                 grad_points, (hipStream_t)stream))
     return check_launch(W);
+  zero_fill(grad_points, (long long)b * c * n, (hipStream_t)stream);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv(e_total, GG_BLOCK), cdiv(c, GG_CH), b),
                      dim3(GG_BLOCK), 0, (hipStream_t)stream, c, n, (int)e_total, (long long)c * e_total, 1,
                      grad_out, (const float *)nullptr, order, sources, grad_points);
@@ -792,19 +805,25 @@ extern "C" int nesie_inverted_index(int b, int n, long long e_total, const int *
 }
 
 extern "C" int nesie_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
-                                                const float *weight, const int *order,
-                                                const int *sources, float *grad_points,
+                                                long long grad_out_bstride, const float *weight,
+                                                const int *order, const int *sources, float *grad_points,
                                                 void *stream) {
   const char *W = "three_interpolate_grad_csr";
   NESIE_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 1, W);
-  if (b == 0 || n == 0) return NESIE_OK;
-  NESIE_REQUIRE(grad_out && weight && order && sources && grad_points, W);
+  if (b == 0) return NESIE_OK;
+  NESIE_REQUIRE(grad_points, W);
+  if (n == 0) {
+    zero_fill(grad_points, (long long)b * c * m, (hipStream_t)stream);
+    return check_launch(W);
+  }
+  NESIE_REQUIRE(grad_out && weight && order && sources && grad_out_bstride >= (long long)c * n, W);
   NESIE_REQUIRE((long long)n * 3 < (1ll << 31) && b <= 65535 && cdiv(c, GG_CH) <= 65535, W);
-  if (launch_group_bwd_csr_rows(b, c, m, (long long)n * 3, (long long)c * n, 3, grad_out, weight, order, sources,
+  if (launch_group_bwd_csr_rows(b, c, m, (long long)n * 3, grad_out_bstride, 3, grad_out, weight, order, sources,
                                 grad_points, (hipStream_t)stream))
     return check_launch(W);
+  zero_fill(grad_points, (long long)b * c * m, (hipStream_t)stream);
   hipLaunchKernelGGL(group_bwd_csr_kernel, dim3(cdiv((long long)n * 3, GG_BLOCK), cdiv(c, GG_CH), b),
-                     dim3(GG_BLOCK), 0, (hipStream_t)stream, c, m, n * 3, (long long)c * n, 3,
+                     dim3(GG_BLOCK), 0, (hipStream_t)stream, c, m, n * 3, grad_out_bstride, 3,
                      grad_out, weight, order, sources, grad_points);
   return check_launch(W);
 }

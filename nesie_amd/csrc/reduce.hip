@@ -10,11 +10,14 @@
 
 namespace nesie {
 
-__global__ __launch_bounds__(256) void channel_sum_kernel(int nb, int c, int p, long long bstride,
+__global__ __launch_bounds__(256) void channel_sum_kernel(int nb, int ng, int c, int p, long long bstride,
                                                           const float *__restrict__ x,
                                                           float *__restrict__ out) {
   __shared__ float part[4];
-  const int ch = blockIdx.x, tid = threadIdx.x;
+  const int ch = blockIdx.x % c, g = blockIdx.x / c, tid = threadIdx.x;
+  x += (size_t)g * bstride;                       // the group's batch entries: g, g + ng, ...
+  bstride *= ng;
+  nb /= ng;
   float s = 0.f;
   const int total = nb * p;                       // element e = (batch e / p, position e % p)
   int e = tid;
@@ -32,25 +35,25 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(int nb, int c, int p, 
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   if ((tid & 63) == 0) part[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0) out[ch] = (part[0] + part[1]) + (part[2] + part[3]);
+  if (tid == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 }  // namespace nesie
 
 using namespace nesie;
 
-extern "C" int nesie_channel_sum(int nb, int c, long long p, const float *x, long long x_bstride,
+extern "C" int nesie_channel_sum(int nb, int ng, int c, long long p, const float *x, long long x_bstride,
                                  float *out, void *stream) {
   const char *W = "channel_sum";
-  NESIE_REQUIRE(nb >= 0 && c >= 0 && p >= 0, W);
+  NESIE_REQUIRE(nb >= 0 && ng >= 1 && nb % ng == 0 && c >= 0 && p >= 0, W);
   if (c == 0) return NESIE_OK;
   NESIE_REQUIRE(out, W);
   if (nb == 0 || p == 0) {
-    (void)hipMemsetAsync(out, 0, (size_t)c * sizeof(float), (hipStream_t)stream);
+    (void)hipMemsetAsync(out, 0, (size_t)ng * c * sizeof(float), (hipStream_t)stream);
     return NESIE_OK;
   }
   NESIE_REQUIRE(x && (long long)nb * p < (1ll << 31) && p < (1ll << 31) && x_bstride >= (long long)c * p, W);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, nb, c, (int)p,
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(ng * c), dim3(256), 0, (hipStream_t)stream, nb, ng, c, (int)p,
                      x_bstride, x, out);
   return check_launch(W);
 }

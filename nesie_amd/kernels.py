@@ -245,17 +245,19 @@ class HipKernels(_BNPoolMixin):
                       _ptr(grad_features), _stream(grad_out))
 
     def three_interpolate_grad_csr(self, grad_out, weight, order, sources, grad_points):
-        """grad_points (B,C,m, zeroed) += weight * grad_out (B,C,n) through (order, sources) =
-        inverted_index(idx (B,n,3), m)."""
-        _check(grad_out, weight, order, sources, grad_points); _f32(grad_out, weight, grad_points)
+        """grad_points (B,C,m) = scatter of weight * grad_out (B,C,n) through (order, sources) =
+        inverted_index(idx (B,n,3), m); WRITTEN in full (no zero fill needed).  grad_out may be a
+        channel slice of a wider tensor (batch stride free, rows contiguous)."""
+        _check(weight, order, sources, grad_points); _f32(grad_out, weight, grad_points)
         _i32(order, sources)
         b, c, n = grad_out.shape
         m = grad_points.shape[2]
+        assert grad_out.is_cuda and grad_out.stride(2) == 1 and grad_out.stride(1) == n
         assert weight.numel() == b * n * 3 and tuple(order.shape) == (b, n * 3)
         with torch.cuda.device(grad_out.device):
             _lib.call("nesie_three_interpolate_grad_csr", b, c, n, m, _ptr(grad_out),
-                      _ptr(weight), _ptr(order), _ptr(sources), _ptr(grad_points),
-                      _stream(grad_out))
+                      grad_out.stride(0) if b > 1 else c * n, _ptr(weight), _ptr(order), _ptr(sources),
+                      _ptr(grad_points), _stream(grad_out))
 
     def inverted_index(self, idx, n):
         """idx (B, M, ns) int32 in [0, n) -> order, sources (B, M*ns) int32: the grouped columns
@@ -326,7 +328,8 @@ class HipKernels(_BNPoolMixin):
         return d_xyz
 
     def query_and_group_backward_csr(self, grad_out, idx_shape, order, offsets, grad_features):
-        """grad_features (B,C,N, zeroed) += channels 3.. of grad_out through (order, sources)."""
+        """grad_features (B,C,N) = scatter of channels 3.. of grad_out through (order, sources);
+        WRITTEN in full (no zero fill needed)."""
         _check(grad_out, order, offsets, grad_features); _f32(grad_out, grad_features)
         _i32(order, offsets)
         b, c, n = grad_features.shape
@@ -338,8 +341,9 @@ class HipKernels(_BNPoolMixin):
                       _ptr(order), _ptr(offsets), _ptr(grad_features), _stream(grad_out))
 
     def group_points_backward_csr(self, grad_out, order, sources, grad_points):
-        """grad_points (B,C,N, zeroed) += grad_out (B,C,M,ns) through (order, sources) =
-        inverted_index(idx (B,M,ns), N): no float atomics (nesie_group_points_backward_csr)."""
+        """grad_points (B,C,N) = scatter of grad_out (B,C,M,ns) through (order, sources) =
+        inverted_index(idx (B,M,ns), N): no float atomics, WRITTEN in full
+        (nesie_group_points_backward_csr)."""
         _check(grad_out, order, sources, grad_points); _f32(grad_out, grad_points); _i32(order, sources)
         b, c, n = grad_points.shape
         m, ns = grad_out.shape[2], grad_out.shape[3]
@@ -713,18 +717,19 @@ class HipKernels(_BNPoolMixin):
             _lib.call("nesie_group_max_pool_backward_add", rows, ns, _ptr(grad_out),
                       _ptr(argmax), _ptr(grad_x), _stream(grad_x))
 
-    def channel_sum(self, x, out=None):
-        """x (NB, C, P) (batch stride free, each x[n] (C, P) contiguous) -> (C,) sums over batch and
-        positions in a fixed order (nesie_channel_sum): a conv bias's gradient."""
+    def channel_sum(self, x, out=None, ng=1):
+        """x (NB, C, P) (batch stride free, each x[n] (C, P) contiguous) -> (ng * C,) sums over the
+        batch entries n = g (mod ng) and the positions, in a fixed order (nesie_channel_sum): a conv
+        bias's gradient (ng > 1: S stacked nets whose batch axis runs (scene, net))."""
         _f32(x)
         nb, c, p = x.shape
-        assert x.is_cuda and x.stride(2) == 1 and x.stride(1) == p
+        assert x.is_cuda and x.stride(2) == 1 and x.stride(1) == p and nb % ng == 0
         if out is None:
-            out = torch.empty(c, dtype=torch.float32, device=x.device)
+            out = torch.empty(ng * c, dtype=torch.float32, device=x.device)
         _check(out); _f32(out)
-        assert out.numel() == c
+        assert out.numel() == ng * c
         with torch.cuda.device(x.device):
-            _lib.call("nesie_channel_sum", nb, c, p, _ptr(x), x.stride(0) if nb > 1 else c * p, _ptr(out),
+            _lib.call("nesie_channel_sum", nb, ng, c, p, _ptr(x), x.stride(0) if nb > 1 else c * p, _ptr(out),
                       _stream(x))
         return out
 

@@ -733,10 +733,17 @@ class AddChannelBias(Function):
         B, S, F, K = ctx.dims
         db = None
         if ctx.needs_input_grad[1]:
-            gc = g.contiguous()
-            backend = backend_for(gc)
-            db = backend.channel_sum(gc.view(B, S * F, K)).view(S, F) if hasattr(backend, 'channel_sum') \
-                else gc.sum((0, 3))
+            backend = backend_for(g)
+            if hasattr(backend, 'channel_sum'):
+                # (scene, net) runs over the batch axis of a (B * S, F, K) view; a channel slice of a
+                # wider gradient (the cat in front of the score heads) keeps a uniform stride there
+                if g.stride(3) == 1 and g.stride(2) == K and g.stride(0) == S * g.stride(1):
+                    gv = g.as_strided((B * S, F, K), (g.stride(1), K, 1))
+                else:
+                    gv = g.contiguous().view(B * S, F, K)
+                db = backend.channel_sum(gv, ng=S).view(S, F)
+            else:
+                db = g.sum((0, 3))
         return g, db
 
 

@@ -25,15 +25,16 @@ class GatherPoints(Function):
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = grad_out.new_zeros((B, C, N))
         grad_out_data = grad_out.data.contiguous()
         backend = backend_for(grad_out_data)
         build = getattr(backend, 'scatter_index', None)
         csr = None if build is None else build(idx.view(B, npoint, 1), N)
         if csr is not None:     # fixed order whatever the indices repeat (gather_points_cuda.cu:51-70: atomicAdd)
+            grad_features = grad_out.new_empty((B, C, N))                    # (written in full)
             backend.group_points_backward_csr(grad_out_data.view(B, C, npoint, 1), csr[0], csr[1],
                                               grad_features.data)
         else:
+            grad_features = grad_out.new_zeros((B, C, N))
             backend.gather_points_grad_wrapper(B, C, N, npoint, grad_out_data, idx,
                                                grad_features.data)
         return grad_features, None

@@ -29,13 +29,15 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
-        grad_features = grad_out.new_zeros((B, C, N))
         grad_out_data = grad_out.data.contiguous()
         backend = backend_for(grad_out_data)
         csr = _scatter_index(backend, idx, N)
-        if csr is not None:     # fixed-order scatter (group_points_cuda.cu:10-31 adds with atomicAdd)
+        if csr is not None:     # fixed-order scatter (group_points_cuda.cu:10-31 adds with atomicAdd);
+            #                     it WRITES every point: no zero fill
+            grad_features = grad_out.new_empty((B, C, N))
             backend.group_points_backward_csr(grad_out_data, csr[0], csr[1], grad_features.data)
         else:
+            grad_features = grad_out.new_zeros((B, C, N))
             backend.group_points_backward(B, C, N, npoint, nsample, grad_out_data, idx,
                                           grad_features.data)
         return grad_features, None
@@ -89,10 +91,11 @@ class QueryGroupCat(Function):
         grad_out = grad_out.contiguous()
         backend = backend_for(grad_out)
         csr = ctx.saved_tensors[1:] if ctx.has_csr else _scatter_index(backend, idx, n)
-        grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
         if csr and hasattr(backend, 'query_and_group_backward_csr'):
+            grad_features = grad_out.new_empty(grad_out.shape[0], c, n)      # (written in full)
             backend.query_and_group_backward_csr(grad_out, idx.shape, csr[0], csr[1], grad_features)
         else:
+            grad_features = grad_out.new_zeros(grad_out.shape[0], c, n)
             backend.query_and_group_backward(grad_out, idx, grad_features)
         return None, None, grad_features, None, None, None
 
@@ -137,7 +140,7 @@ class SampleQueryGroupCat(Function):
         grad_out = grad_out.contiguous()
         d_feat = d_xyz = None
         if ctx.needs_input_grad[1]:
-            d_feat = grad_out.new_zeros(grad_out.shape[0], c, n)
+            d_feat = grad_out.new_empty(grad_out.shape[0], c, n)             # (written in full)
             backend.query_and_group_backward_csr(grad_out, idx.shape, order, sources, d_feat)
         if ctx.needs_input_grad[0]:
             d_xyz = backend.query_and_group_backward_xyz(

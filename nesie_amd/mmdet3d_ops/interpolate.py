@@ -54,15 +54,19 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         idx, weight, m, csr = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = grad_out.new_zeros((B, c, m))
-        grad_out_data = grad_out.data.contiguous()
-        backend = backend_for(grad_out_data)
+        backend = backend_for(grad_out)
         if csr is None and getattr(backend, 'scatter_index', None) is not None:
             csr = backend.scatter_index(idx, m)     # fixed-order scatter (three_interpolate_cuda.cu:61-84: atomicAdd)
         if csr is not None and hasattr(backend, 'three_interpolate_grad_csr'):
-            backend.three_interpolate_grad_csr(grad_out_data, weight, csr[0], csr[1],
-                                               grad_features.data)
+            # a channel slice of a wider gradient (the FP module's cat) goes in as it is: batch-strided
+            g = grad_out.data
+            if not (g.stride(2) == 1 and g.stride(1) == n):
+                g = g.contiguous()
+            grad_features = grad_out.new_empty((B, c, m))                    # (written in full)
+            backend.three_interpolate_grad_csr(g, weight, csr[0], csr[1], grad_features.data)
         else:
+            grad_features = grad_out.new_zeros((B, c, m))
+            grad_out_data = grad_out.data.contiguous()
             backend.three_interpolate_grad_wrapper(B, c, n, m, grad_out_data, idx, weight,
                                                    grad_features.data)
         return grad_features, None, None, None

@@ -1254,3 +1254,7 @@ def test_channel_sum_matches_float64_and_repeats_bitwise(hip_device, shape, slic
     assert torch.equal(a, b)
     want = view.double().sum((0, 2))
     assert (a.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    if view.shape[0] % 2 == 0:      # two weight groups: batch entries 0, 2, .. and 1, 3, ..
+        g2 = hip.channel_sum(view, ng=2)
+        want2 = torch.stack([view[0::2].double().sum((0, 2)), view[1::2].double().sum((0, 2))]).flatten()
+        assert (g2.double() - want2).abs().max().item() <= 1e-5 * max(1.0, want2.abs().max().item())
