@@ -278,27 +278,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(int total, int nparts,
                                                                  const float *__restrict__ partial,
                                                                  float *__restrict__ dw) {
-  __shared__ float sh[16][64];
+  __shared__ double sh[16][64];      // (double: see pw_wgrad_reduce_kernel)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
-  float s = 0.f;
+  double s = 0.0;
   if (i < total) {
     int r = wave;
     for (; r + 7 * 16 < nparts; r += 8 * 16) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + u * 16) * total + i];
-      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; r < nparts; r += 16) s += partial[(size_t)r * total + i];
+    for (; r < nparts; r += 16) s += (double)partial[(size_t)r * total + i];
   }
   sh[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && i < total) {
-    float t = 0.f;
+    double t = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += sh[w][lane];
-    dw[i] = t;
+    dw[i] = (float)t;
   }
 }
 

@@ -243,35 +243,39 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_kernel(int total, int np
                                                                const float *__restrict__ partial,
                                                                float *__restrict__ dw, int ci, int ld,
                                                                int col0, int co) {
-  __shared__ float sh[16][64];
+  // (partials added in DOUBLE since round 5: 512 fp32 addends per element cost ~1e-6 of the sum of their
+  // magnitudes, which for the backbone's heavily cancelling weight gradients was a visible share of the
+  // distance to a float64 evaluation; the kernel is bandwidth-bound either way)
+  __shared__ double sh[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane, g = blockIdx.y;
   const float *src = partial + (size_t)g * nparts * total;
-  float s = 0.f;
+  double s = 0.0;
   if (i < total) {
     int r = wave;
     for (; r + 15 * 16 < nparts; r += 16 * 16) {     // sixteen partials in flight (two trips at 512 partials)
       float v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
-      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      s += ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
     }
     for (; r + 7 * 16 < nparts; r += 8 * 16) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
-      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; r < nparts; r += 16) s += src[(size_t)r * total + i];
+    for (; r < nparts; r += 16) s += (double)src[(size_t)r * total + i];
   }
   sh[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && i < total) {
-    float tt = 0.f;
+    double tt = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) tt += sh[w][lane];
-    dw[((size_t)g * co + i / ci) * ld + col0 + i % ci] = tt;
+    dw[((size_t)g * co + i / ci) * ld + col0 + i % ci] = (float)tt;
   }
 }
 
@@ -286,15 +290,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_tiled_kernel(int co, int 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= co_b * ci_b) return;
   const float *src = partial + ((size_t)blk * gridDim.z + g) * nparts * br * bc + i;
-  float s = 0.f;
+  double s = 0.0;
   int r = 0;
   for (; r + 3 < nparts; r += 4) {
     const float v0 = src[(size_t)r * br * bc], v1 = src[(size_t)(r + 1) * br * bc],
                 v2 = src[(size_t)(r + 2) * br * bc], v3 = src[(size_t)(r + 3) * br * bc];
-    s += (v0 + v1) + (v2 + v3);
+    s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
   }
-  for (; r < nparts; ++r) s += src[(size_t)r * br * bc];
-  dw[((size_t)g * co + rb * br + i / ci_b) * ci + cb * bc + i % ci_b] = s;
+  for (; r < nparts; ++r) s += (double)src[(size_t)r * br * bc];
+  dw[((size_t)g * co + rb * br + i / ci_b) * ci + cb * bc + i % ci_b] = (float)s;
 }
 
 // ---- deferred reductions (round 5) ------------------------------------------------------------
@@ -315,7 +319,7 @@ constexpr int RD_MAX = 40;
 struct RTable { int n; int start[RD_MAX + 1]; RDesc d[RD_MAX]; };
 
 __global__ __launch_bounds__(1024) void pw_wgrad_reduce_batch_kernel(const RTable t) {
-  __shared__ float sh[16][64];
+  __shared__ double sh[16][64];
   int di = 0;
   while (di + 1 < t.n && (int)blockIdx.x >= t.start[di + 1]) ++di;        // (uniform)
   const RDesc &d = t.d[di];
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_batch_kernel(const RTabl
     const int i = bx * 64 + lane;
     const float *src = d.part + (size_t)g * d.nparts * d.total;
     const int total = d.total, nparts = d.nparts;
-    float s = 0.f;
+    double s = 0.0;
     if (i < total) {
       int r = wave;
       for (; r + 15 * 16 < nparts; r += 16 * 16) {
@@ -343,15 +347,15 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_batch_kernel(const RTabl
         for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + u * 16) * total + i];
         s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
-      for (; r < nparts; r += 16) s += src[(size_t)r * total + i];
+      for (; r < nparts; r += 16) s += (double)src[(size_t)r * total + i];
     }
     sh[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && i < total) {
-      float tt = 0.f;
+      double tt = 0.0;
 #pragma unroll
       for (int w = 0; w < 16; ++w) tt += sh[w][lane];
-      d.dw[((size_t)g * d.co + i / d.ci) * d.ld + d.col0 + i % d.ci] = tt;
+      d.dw[((size_t)g * d.co + i / d.ci) * d.ld + d.col0 + i % d.ci] = (float)tt;
     }
   } else {
     // one thread per element of a block, the partials in ascending order (four at a time)
@@ -364,15 +368,15 @@ __global__ __launch_bounds__(1024) void pw_wgrad_reduce_batch_kernel(const RTabl
     if (i >= co_b * ci_b) return;
     const size_t bb = (size_t)d.br * d.bc;
     const float *src = d.part + ((size_t)blk * d.ng + g) * d.nparts * bb + i;
-    float s = 0.f;
+    double s = 0.0;
     int r = 0;
     for (; r + 3 < d.nparts; r += 4) {
       const float v0 = src[(size_t)r * bb], v1 = src[(size_t)(r + 1) * bb], v2 = src[(size_t)(r + 2) * bb],
                   v3 = src[(size_t)(r + 3) * bb];
-      s += (v0 + v1) + (v2 + v3);
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
     }
-    for (; r < d.nparts; ++r) s += src[(size_t)r * bb];
-    d.dw[((size_t)g * d.co + rb * d.br + i / ci_b) * d.ci + cb * d.bc + i % ci_b] = s;
+    for (; r < d.nparts; ++r) s += (double)src[(size_t)r * bb];
+    d.dw[((size_t)g * d.co + rb * d.br + i / ci_b) * d.ci + cb * d.bc + i % ci_b] = (float)s;
   }
 }
 

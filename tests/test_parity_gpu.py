@@ -585,3 +585,55 @@ def test_training_step_is_bitwise_reproducible(hip_device, workload, batch, ahea
         assert not differing, differing
         differing = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], grads[n])]
         assert not differing, (len(differing), differing[:5])
+
+
+@pytest.mark.parametrize('kind,obj_bias', [('nesie', 1.7)])
+def test_full_size_student_teacher_gradient_is_no_farther_from_float64_than_the_cpu_leg(oracle_kernels, hip_device,
+                                                                                      kind, obj_bias):
+    """The float64 referee for BASELINE configs[3] at full size (3 scenes x 40 000 points, student +
+    EMA teacher, the whole configured model): three legs on the same weights, inputs, jitter, replayed
+    vote picks / grid taps AND the same pseudo labels and proposal <-> target assignments (the
+    CPU-oracle leg's: detached inputs of the student's loss, products of thresholded decisions)
+    -- float64 (tests/_fp64.py through tests/_semi.py), CPU oracle path (fp32),
+    HIP path.  Every loss term of the HIP leg within 1e-4 of the CPU leg's and of float64's (measured
+    <= 3e-6).  Flat student gradient, relative L2 from float64: MEASURED HIP 1.19e-2, CPU oracle path
+    7.7e-3 (the supervised step of the test above: 3.50e-3 / 3.44e-3) -- both errors sit in the
+    backbone's convolution weights (sums over 3 x 131 072 .. 3 x 8 192 positions at the end of the
+    longest backward chain) and move with the partition of those sums (NESIE_PW_ONE_PER_CU=1: 1.28e-2;
+    double-precision addition of the 512 per-workgroup partials: no change), i.e. accumulated fp32
+    rounding of the matrix-core accumulation chains, where the CPU leg's norm layers accumulate in double
+    (ATen's acc_type) and its GEMMs in 16-lane vector partials.  Bound: HIP <= 2 x CPU + 1e-4 and
+    < 1.5e-2 -- the honest statement is "1.5 x the CPU path's distance", not "no farther".  (The
+    two-fp32-leg comparison above allows 1.5e-2 with nothing replayed; bench.py's gate holds HIP vs CPU
+    to 4e-3, measured 3.3e-3.)"""
+    from tests import _semi
+    model = _semi_pair(kind, obj_bias=obj_bias, cls_bias=0.75, full=True)
+    # (the copies are made BEFORE any leg runs: the replay counters of the forced vote picks and grid
+    # taps travel with a deep copy)
+    gmodel = copy.deepcopy(model).to(hip_device)
+    model64 = _semi.as_double(model)
+    book = {}
+    cpu_l, cpu_g, cpu_p = _semi.semi_step(model, torch.device('cpu'), oracle_kernels, full=True, book=book)
+    assert 0 < int(cpu_p['valid'].sum()) < cpu_p['valid'].numel()
+    ref_l, ref_g, _ = _semi.semi_step(model64, torch.device('cpu'), _fp64.Fp64Kernels(), full=True,
+                                      dtype=torch.float64, book=book)
+    gpu_l, gpu_g, gpu_p = _semi.semi_step(gmodel, hip_device, full=True, book=book)
+    assert torch.equal(gpu_p['valid'], cpu_p['valid'])            # (its own decisions, before the replay)
+    for k in ref_l:
+        print(f'  {k:28s} float64 {float(ref_l[k].sum()):.7f}  HIP {float(gpu_l[k].sum()):.7f}  CPU {float(cpu_l[k].sum()):.7f}')
+    for k in ref_l:
+        a, b, c = float(ref_l[k].sum()), float(gpu_l[k].sum()), float(cpu_l[k].sum())
+        assert abs(b - c) <= 1e-4 * max(1.0, abs(c)), (k, b, c)
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (k, a, b)
+    names = sorted(ref_g)
+    assert set(gpu_g) == set(names) == set(cpu_g)
+    ref = _flat(ref_g, names)
+    e_gpu = float((_flat(gpu_g, names) - ref).norm() / ref.norm())
+    e_cpu = float((_flat(cpu_g, names) - ref).norm() / ref.norm())
+    print(f'{kind} full size vs float64: flat gradient rel. L2  HIP {e_gpu:.3e}  CPU oracle path {e_cpu:.3e}')
+    contrib = sorted(((float((gpu_g[n].double().cpu() - ref_g[n].double()).pow(2).sum()),
+                       float((cpu_g[n].double() - ref_g[n].double()).pow(2).sum()), n) for n in names), reverse=True)
+    tot = float(ref.pow(2).sum())
+    for eg, ec, n in contrib[:8]:
+        print(f'    {n:60s} share of the squared error: HIP {eg / tot:.2e}  CPU {ec / tot:.2e}')
+    assert e_gpu <= 2.0 * e_cpu + 1e-4 and e_gpu < 1.5e-2, (e_gpu, e_cpu)
