@@ -717,6 +717,34 @@ def mini_pointnets_fused_supported(backend, c0, c0_part, G):
 # load, this layer's statistics from the accumulators), and in the backward one input-gradient
 # launch with the norm reduction, one weight-gradient launch and one norm apply pass.
 
+class SplitXyzFeat(Function):
+    """w (S, H, 3 + C) -- the stacked first-conv weights of S MiniPointNets, whose input is
+    cat[rel_xyz (3), blended features (C)] (side_pooling_module.py:226-243, 346-349) -> (w_xyz (S, H, 3)
+    contiguous, w_feat (S * H, C) as a strided VIEW).  Two plain slices cost autograd two zero-filled
+    (S, H, 3 + C) tensors, two slice copies and an addition on the way back; here the two gradients
+    are written side by side with ONE concatenation, straight into the weight's slot of the flat
+    gradient vector when there is one."""
+
+    @staticmethod
+    def forward(ctx, w):
+        S, H, K = w.shape
+        ctx.dims = (S, H, K)
+        ctx.slot = grad_slots.take(w) if ctx.needs_input_grad[0] else None
+        return w[:, :, :3].contiguous(), w[:, :, 3:].reshape(S * H, K - 3)
+
+    @staticmethod
+    def backward(ctx, d_xyz, d_feat):
+        S, H, K = ctx.dims
+        like = d_xyz if d_xyz is not None else d_feat
+        if d_xyz is None:
+            d_xyz = like.new_zeros(S, H, 3)
+        if d_feat is None:
+            d_feat = like.new_zeros(S * H, K - 3)
+        out = ctx.slot.view(S, H, K) if ctx.slot is not None else like.new_empty(S, H, K)
+        torch.cat([d_xyz.view(S, H, 3), d_feat.view(S, H, K - 3)], dim=2, out=out)
+        return out
+
+
 class AddChannelBias(Function):
     """x (B, S, F, K) + bias (S, F) broadcast over batch and positions (the conv bias a max-pool
     commutes with, added after pooling: side_pooling_module.py:357, 361-368).  The backward hands the

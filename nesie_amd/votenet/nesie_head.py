@@ -640,10 +640,6 @@ class NesieHead(nn.Module):
         gt = gt_bboxes_3d if isinstance(gt_bboxes_3d, GTBatch) else \
             GTBatch.collate(gt_bboxes_3d, gt_labels_3d, device)
         T = gt.boxes.shape[1]
-        col = torch.arange(T, device=device).unsqueeze(0)
-        is_col = col < gt.count.unsqueeze(1)
-        centres = torch.cat([gt.boxes[..., :2],
-                             (gt.boxes[..., 2] + gt.boxes[..., 5] * 0.5).unsqueeze(-1)], -1)
         vote_targets, vote_target_masks = vote_targets if vote_targets is not None \
             else self.vote_targets_of(pts, gt)
 
@@ -661,6 +657,10 @@ class NesieHead(nn.Module):
             return (vote_targets, vote_target_masks, tg['center_targets'], tg['bbox_targets'],
                     tg['mask_targets'], gt.valid, tg['obj_targets'], tg['obj_weights'],
                     tg['box_weights'], tg['valid_weights'], tg['assignment'])
+        col = torch.arange(T, device=device).unsqueeze(0)
+        is_col = col < gt.count.unsqueeze(1)
+        centres = torch.cat([gt.boxes[..., :2],
+                             (gt.boxes[..., 2] + gt.boxes[..., 5] * 0.5).unsqueeze(-1)], -1)
         d = aggregated_points.unsqueeze(2) - centres.unsqueeze(1)
         d = (d * d).sum(-1)  # (B,K,T) squared L2
         d = torch.where(is_col.unsqueeze(1), d, torch.full_like(d, float('inf')))

@@ -565,7 +565,8 @@ class SidePooling(nn.Module):
         from ..mmdet3d_ops import fused_mlp
         w = fused_mlp.stack_groups([[net.first_conv[0].weight.flatten(1) for net in nets]])[0]   # (S, H, 3+C)
         H = w.shape[1]
-        table = torch.matmul(origin_features, w[:, :, 3:].reshape(segs * H, -1).t())  # (B,N,S*H)
+        w_xyz, w_feat = fused_mlp.SplitXyzFeat.apply(w)       # (S, H, 3) contiguous, (S*H, C) view
+        table = torch.matmul(origin_features, w_feat.t())     # (B,N,S*H)
         bns = [net.first_conv[1] for net in nets]
         if with_norm and _stackable_bn(bns) and H % 64 == 0 and H <= 256 and (K * G) % 64 == 0 \
                 and origin_features.dtype == torch.float32:
@@ -573,7 +574,7 @@ class SidePooling(nn.Module):
             from ..mmdet3d_ops import norm as _norm
             rm = torch.cat([l.running_mean for l in bns])
             rv = torch.cat([l.running_var for l in bns])
-            out = blend_conv_bn(table, w[:, :, :3], torch.cat([l.weight for l in bns]),
+            out = blend_conv_bn(table, w_xyz, torch.cat([l.weight for l in bns]),
                                 torch.cat([l.bias for l in bns]), idx, weight, rel, rm, rv,
                                 bns[0].momentum, bns[0].eps, segs, G)
             with torch.no_grad():
@@ -583,9 +584,9 @@ class SidePooling(nn.Module):
                     _norm.count_batch(l.num_batches_tracked)
             return out.view(B, segs, H, K, G), True, None
         if defer:   # evaluated by its consumer (BlendMiniHeadFn, or materialize() for any other)
-            return DeferredBlendConv(table, w[:, :, :3], idx, weight, rel, segs, G, K), False, None
+            return DeferredBlendConv(table, w_xyz, idx, weight, rel, segs, G, K), False, None
         # (B, S, H, K*G) and the (sum, sum^2) partials of it for the first norm layer
-        out, stats = blend_conv(table, w[:, :, :3], idx, weight, rel, segs, G, True)
+        out, stats = blend_conv(table, w_xyz, idx, weight, rel, segs, G, True)
         return out.view(B, segs, H, K, G), False, (stats if stats.numel() else None)
 
     def grid_features(self, origin_xyz, origin_features, whole_grid, center, segs=1):
