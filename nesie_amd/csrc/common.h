@@ -11,6 +11,8 @@ namespace nesie {
 void set_error(const char *fmt, ...);
 int distance_form();   // 0 (default), 1, 2: see sqdist_form
 int cu_count();        // CUs the persistent grids are sized for (nesie_set_cu_count; 256)
+// 1: a persistent launch over an operand of this size walks its tiles last-to-first (nesie_lib.hip)
+int walk_dir(long long operand_bytes);
 
 inline int check_launch(const char *what) {
   hipError_t e = hipGetLastError();

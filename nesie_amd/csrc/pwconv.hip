@@ -250,6 +250,8 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   a.stamps = nullptr;
   static const int w_stage = [] { const char *e = getenv("NESIE_PW_WSTAGE"); return e ? atoi(e) : 1; }();
   a.w_stage = w_stage;
+  static const int rev_fwd = [] { const char *e = getenv("NESIE_PW_REV_FWD"); return e ? atoi(e) : 3; }();   // A/B: bit 0 forward products, bit 1 input gradients
+  a.rev = ((bn_z ? rev_fwd & 2 : rev_fwd & 1) != 0) ? walk_dir((long long)nb * k * p * 4) : 0;     // (a big operand is read last tile first: nesie_lib.hip)
 #ifdef PW_STAMP
   a.stamps = g_pw_stamps;
 #endif

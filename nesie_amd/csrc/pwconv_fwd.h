@@ -153,6 +153,7 @@ struct PwFwd {
   int xcd_map;         // the nhalf workgroups of a tile stream sit on ONE XCD (grid % (8 nhalf) == 0)
   const float2 *sp_ent; int sp_ns_shift, sp_groups;   // PW_SPARSE*: entries, log2(ns), groups per batch element
   int w_stage;         // 1: row-major weights come in through LDS (NESIE_PW_WSTAGE=0: lane loads, A/B switch)
+  int rev;             // 1: the tile stream runs from the LAST tile of the group to the first (big operands: nesie_lib.hip)
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -345,6 +346,10 @@ void pw_fwd_kernel(const PwFwd a) {
     c.t += nwg; c.q += dq; c.r += dr;
     if (c.r >= tpb) { c.r -= tpb; ++c.q; }
   };
+  // (batch, tile) a cursor stands for: as it counts, or mirrored (a.rev)
+  const int nq = a.nb / a.ng;
+  auto QQ = [&](const Cursor &c) { return a.rev ? nq - 1 - c.q : c.q; };
+  auto RR = [&](const Cursor &c) { return a.rev ? tpb - 1 - c.r : c.r; };
   f32x4 stg[NX];
   // loads of slot i of sub-tile c (kh compile-time) into its staging registers; `live` false:
   // the sub-tile does not exist, read the first words of the tensor instead
@@ -352,14 +357,14 @@ void pw_fwd_kernel(const PwFwd a) {
     constexpr int i = decltype(ic)::value, kh = decltype(khc)::value;
     if constexpr (SPC > 0 && kh * KT + slot_row(i) < SPC) {
       // wave-uniform: first entry of the tile's first group, row kh KT + slot_row(i)
-      const float2 *eb = a.sp_ent + ((size_t)(g + a.ng * c.q) * a.sp_groups + (size_t)(((long long)c.r * PT) >> a.sp_ns_shift)) * SPC
+      const float2 *eb = a.sp_ent + ((size_t)(g + a.ng * QQ(c)) * a.sp_groups + (size_t)(((long long)RR(c) * PT) >> a.sp_ns_shift)) * SPC
                          + (kh * KT + slot_row(i));
       const float2 e = *(const float2 *)((const char *)(live ? eb : a.sp_ent) + (live ? sp_voff : 0u));
       stg[i][0] = e.x;
       stg[i][1] = e.y;
       return;
     }
-    const float *xb = a.x + (size_t)(g + a.ng * c.q) * a.x_bs + (size_t)c.r * PT + (long long)(kh * KT - SPC) * p;
+    const float *xb = a.x + (size_t)(g + a.ng * QQ(c)) * a.x_bs + (size_t)RR(c) * PT + (long long)(kh * KT - SPC) * p;
     if constexpr (kh < KH - 1) {
       const float *xs = live ? xb + (size_t)slot_row(i) * p : a.x;   // wave-uniform
       stg[i] = load16_saddr(live ? voff0 : 0u, xs);
@@ -679,8 +684,8 @@ void pw_fwd_kernel(const PwFwd a) {
       for (int e = 0; e < 4; ++e) acc[rw][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   for (; cur.t < ntiles; ++iter) {
-    const int n = g + a.ng * cur.q;
-    const long long p0 = (long long)cur.r * PT;
+    const int n = g + a.ng * QQ(cur);
+    const long long p0 = (long long)RR(cur) * PT;
     static_for<0, KH>([&](auto khc) {
       constexpr int kh = decltype(khc)::value;
       STAMP(0)

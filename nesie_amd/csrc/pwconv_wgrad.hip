@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     int nb, int ng, int co_all, int ci_all, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
     float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
-    const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group) {
+    const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group, int rev) {
   const int row0 = blockIdx.y * CO16 * 16, col0 = blockIdx.z * CI16 * 16;   // (0, 0) unless tiled
   const int co = co_all - row0 < CO16 * 16 ? co_all - row0 : CO16 * 16;     // this block's extent
   const int ci = ci_all - col0 < CI16 * 16 ? ci_all - col0 : CI16 * 16;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   auto load_tile = [&](int t) {
     pend_ok = t < ntiles;
     t = t < ntiles ? t : ntiles - 1;
+    t = rev ? ntiles - 1 - t : t;          // (big operands: last tile first, see nesie_lib.hip)
     const int n = g + ng * (t / tpb);
     const long long p0 = (long long)(t % tpb) * PT;
     pend = (size_t)n * dy_bs + p0;
@@ -521,6 +522,9 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
   NESIE_REQUIRE((long long)(co > ci ? co : ci) * p < (1ll << 30), W);
   NESIE_REQUIRE((long long)(nb / ng) * (p / 32) < (1ll << 30), W);     // (32-bit tile cursor)
   const float lo0 = x_relu ? 0.f : -__builtin_inff();
+  // dY is the tensor a launch has just written: a big one is read last tile first (nesie_lib.hip)
+  static const int rev_on = [] { const char *e = getenv("NESIE_PW_REV_WGRAD"); return e ? atoi(e) : 1; }();   // A/B
+  const int rev = rev_on ? walk_dir((long long)nb * co * p * 4) : 0;
   if (tiled_mode) {
     const int nwg = pw_wgrad_tiled_nwg(nb, ng, co, ci, p);
     const int nrb = cdiv(co, TILED_B), ncb = cdiv(ci, TILED_B);
@@ -536,7 +540,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       }                                                                                                \
       hipLaunchKernelGGL(kern, dim3(nwg * ng, nrb, ncb), dim3(512), lds, s, nb, ng, co, ci, p, dy, dy_bstride, x, \
                          x_bstride, x_coef, ci, lo0, partial, nwg, (const float *)nullptr, (const float *)nullptr, \
-                         (float *)nullptr, (float *)nullptr, 0);                                        \
+                         (float *)nullptr, (float *)nullptr, 0, rev);                                   \
     } while (0)
     if (x_coef) LT(true); else LT(false);
 #undef LT
@@ -570,7 +574,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       attr = true;                                                                               \
     }                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,           \
-                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group); \
+                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev); \
   } while (0)
 #define L(CO16, CI16, WM, WN)                                                                    \
   do {                                                                                           \
