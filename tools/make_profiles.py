@@ -28,10 +28,12 @@ def last_json(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
     P = R + f'gpurun_out/prof_{tag}/'
     out = R + f'profiles/{tag}_'
     sha = open(P + 'lib.sha256').read().strip()
+    bench_args = open(P + 'bench_args.txt').read().strip() if os.path.exists(P + 'bench_args.txt') else ''
+    extra = (' ' + bench_args) if bench_args else ''
     open(out + 'bench_kernel_stats.csv', 'w').write(open(P + 'kernel_stats.csv').read())
     b, clean = last_json(P + 'trace_bench.json'), last_json(P + 'clean_bench.json')
     json.dump(clean, open(out + 'bench_line.json', 'w'), indent=1)
@@ -48,11 +50,11 @@ def main():
     small = sum(int(r['Calls']) for r in rows if float(r['AverageNs']) < 12000) / STEPS
     small_ms = sum(float(r['TotalDurationNs']) for r in rows if float(r['AverageNs']) < 12000) / STEPS / 1e6
     hdr = [
-        f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --cpu-baseline 0   (1x MI355X, {tag}, tools/prof_round.sh; libnesie_hip.so sha256 {sha[:16]}..)",
+        f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --cpu-baseline 0 --other-workloads 0{extra}   (1x MI355X, {tag}, tools/prof_round.sh; libnesie_hip.so sha256 {sha[:16]}..)",
         f"bench line under the profiler: value={b['value']:.1f} scenes/s  ms_per_step={b['ms_per_step']:.2f}; without it (profiles/{tag}_bench_line.json): {clean['value']:.1f} scenes/s, {clean['ms_per_step']:.2f} ms",
         "The process runs 20 training steps in all (2 eager warm-up steps before capture, 3 warm-up, 10 timed, 5 un-captured for the HIP-event",
         "timings of the roofline entries) plus the parity gate's one B=2 step on each leg; per-step = total / 20.  FPS, ball query, inverted indices, FP taps and",
-        f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms of kernel time, mostly one CU per scene: overlapped, at a measured cost of 0.65 - 0.75 ms to the step, DESIGN.md section 9 item 6).",
+        f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms of kernel time, mostly one CU per scene: overlapped, at a measured cost of 0.65 - 0.75 ms to the step, HISTORY.md, round-4 list item 6).",
         f"GEMM time: nesie::pw_fwd_kernel + pw_wgrad_kernel (+ conv_wgrad, mlp_stream) = {native:.2f} ms vs rocBLAS {rb:.2f} ms -> {100 * native / (native + rb):.0f} % of the GEMM time is in nesie:: kernels.",
         f"Launches per step (both streams): {calls:.0f}; kernel families averaging under 12 us: {small:.0f} launches, {small_ms:.2f} ms; everything that is neither nesie:: nor rocBLAS "
         f"(ATen elementwise / reduce / cat / copies / fills): {aten:.2f} ms = {100 * aten / allt:.1f} % of the summed kernel time.",
@@ -60,7 +62,7 @@ def main():
     open(out + 'bench_per_step_summary.txt', 'w').write(
         run('tools/profile_summary.py', f'profiles/{tag}_bench_kernel_stats.csv', str(STEPS), *hdr))
     open(out + 'timeline.txt', 'w').write(
-        "tools/timeline.py on the kernel trace of the same run (one replayed step; under the profiler both streams are serialised into one queue)\n"
+        "tools/timeline.py on the kernel trace of the same run: the last window between two SA1 sampling launches that holds a graph-replayed step (two queues: main stream and the pipelined index chain)\n"
         + open(P + 'timeline.txt').read())
     # ---- matrix-pipe utilisation
     mf = P + 'mfma_counters.csv'
@@ -72,7 +74,7 @@ def main():
         if 'pw_fwd_kernel' in name or 'pw_wgrad_kernel' in name:
             act += val
     util = busy / (act / 8 * 256 * 4) if act else 0.0
-    head = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline 0 --graph 0 --parity-gate 0   ({tag}; tools/prof_round.sh)\n"
+    head = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline 0 --other-workloads 0 --graph 0 --parity-gate 0{extra}   ({tag}; tools/prof_round.sh)\n"
             "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) (tools/mfma_util.py)\n"
             f"time-weighted over every pw_fwd_kernel / pw_wgrad_kernel launch (1-D chains included): {100 * util:.1f} % of the matrix-pipe cycles\n\n")
     open(out + 'mfma_util.txt', 'w').write(head + run('tools/mfma_util.py', mf))
@@ -111,7 +113,7 @@ def main():
                'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of bench.py --steps 2 --warmup 1 --graph 0 --parity-gate 0; '
                          'FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md)'},
               open(out + 'pmc_hbm_traffic.json', 'w'), indent=1)
-    head = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline 0 --graph 0 --parity-gate 0   ({tag}; tools/prof_round.sh)\n"
+    head = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline 0 --other-workloads 0 --graph 0 --parity-gate 0{extra}   ({tag}; tools/prof_round.sh)\n"
             f"libnesie_hip.so sha256 {sha}\n"
             "Counter_Value is in KB per dispatch, averaged over the dispatches of a (kernel, grid) (tools/pmc_summary.py).  gfx950 correction\n"
             "(MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request, so dense streaming reads are DOUBLED in the corr. column;\n"
