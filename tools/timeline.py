@@ -77,6 +77,11 @@ def main():
           f'(median {sorted(gaps)[len(gaps) // 2] / 1e3:.1f} us, > 5 us: {sum(g > 5000 for g in gaps)}), '
           f'span {span / 1e6:.3f} ms')
     print(f'kernels under 12 us: {small_n} launches, {small_t / 1e6:.3f} ms')
+    cls = collections.defaultdict(lambda: [0, 0.0])
+    for n, (c, d, g) in fam.items():
+        k = 'nesie::' if n.startswith('nesie::') else 'rocBLAS' if n.startswith('Cijk') else 'ATen / runtime copy / fill'
+        cls[k][0] += c; cls[k][1] += d
+    print('by class (main stream): ' + '; '.join(f'{k}: {c} launches, {d / 1e6:.3f} ms' for k, (c, d) in cls.items()))
     print('\nby kernel (main stream): launches | busy ms | gap-before ms | name')
     for n, (c, d, g) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:70]:
         print(f'{c:5d} {d / 1e6:8.3f} {g / 1e6:8.3f}  {n}')
