@@ -1049,12 +1049,17 @@ def main():
             # run, and dropped (null) when the library loaded now is not the one that was profiled
             traffic, traffic_note = None, None
             lib_sha = _lib.library_sha256()
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles'))
-                           if f.endswith('_pmc_hbm_traffic.json'))
-            if not (args.workload == 'pretrain' and args.batch == 8):
-                traffic_note = 'PMC traffic was collected for the pretrain workload at B = 8 only'
+            # a set is for one workload: tools/make_profiles.py records the extra bench arguments it ran with
+            want = {'pretrain': '', 'semi': '--workload semi', 'saqe': '--workload saqe'}[args.workload]
+            cands = []
+            for f in sorted(os.listdir(os.path.join(ROOT, 'profiles'))):
+                if f.endswith('_pmc_hbm_traffic.json'):
+                    if json.load(open(os.path.join(ROOT, 'profiles', f))).get('bench_args', '') == want:
+                        cands.append(f)
+            if args.batch != 8:
+                traffic_note = 'PMC traffic was collected at B = 8 only'
             elif not cands:
-                traffic_note = 'no profiles/*_pmc_hbm_traffic.json'
+                traffic_note = f'no profiles/*_pmc_hbm_traffic.json for the {args.workload} workload'
             else:
                 t = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
                 if t.get('lib_sha256') != lib_sha:

@@ -105,7 +105,7 @@ def main():
         alg_w = 8 * 128 * 131072 * 4 + 2 * 8 * 128 * (131072 // 32) * 5       # Y + (max, min) x (value, position)
         worst = {'kernel': name, 'grid': grid, 'write_bytes': w / n * 1024, 'fetch_corrected_bytes': 2 * f / n * 1024,
                  'algorithmic_write_bytes': alg_w, 'write_over_algorithmic': w / n * 1024 / alg_w}
-    json.dump({'lib_sha256': sha, 'family_bytes_per_step': family_bytes,
+    json.dump({'lib_sha256': sha, 'bench_args': bench_args, 'family_bytes_per_step': family_bytes,
                'fetch_corrected_bytes_per_step': fam_f * 1024 / PMC_STEPS,
                'write_bytes_per_step': fam_w * 1024 / PMC_STEPS,
                'largest_launch': {'kernel': big[0][0], 'grid': big[0][1], 'fetch_corrected_bytes': bf, 'write_bytes': bw},
