@@ -707,6 +707,46 @@ int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p, const 
                                    long long x_bstride, const float *w, const float *in_coef,
                                    int in_relu, float *y, float *stat_partial, void *stream);
 
+/* ---- round 5: the first shared-MLP layer of PointSAModule over a 4-channel input WITHOUT its
+ * output tensor.  Reference: the first ConvModule (Conv2d(4, 64, 1) + BatchNorm2d + ReLU) of SA1's
+ * `self.mlps[0]` (point_sa_module.py:277-289, pointnet2_sa_ssg.py:62-79), its output's three
+ * consumers in the forward / backward of the SECOND ConvModule, and autograd's conv2d / batch_norm
+ * backward for the first.  Z0 = W0 . X4 (X4 = the grouped coordinates + height, (nb, 4, p), 17 MB at
+ * 8 x 131 072 positions; Z0 would be 268 MB) is rebuilt from X4 with one fixed fma chain wherever
+ * it is an operand, and the first layer's weight gradient follows from reductions:
+ *  - nesie_mlp_layer_forward_stream with y == NULL leaves only the statistics of Z0;
+ *  - nesie_pw_layer_forward_k4: the second layer, y = W . relu(in_coef . Z0) (cout = 64; w0 (64, 4)
+ *    row-major; in_coef [64][4] the first layer's folded norm), with statistics like
+ *    nesie_pw_layer_forward;
+ *  - nesie_pw_wgrad_bn_backward_k4: nesie_pw_wgrad_bn_backward of the second layer (64 x 64) with
+ *    its X operand rebuilt (x_coef = in_coef above); defer != 0 leaves the reduction pending;
+ *  - nesie_pw_dgrad_bn_reduce_k4: nesie_pw_dgrad_bn_reduce of the second layer whose OUTPUT (the
+ *    gradient of the first activation) is not stored: bn_part as there, and
+ *    g_part[(m * nslots + slot)][4] = sum over the slot's positions of gg[m] X4[j], j = 0 .. 3
+ *    (nslots = nesie_pw_stat_slots(nb, 1, k, 64, p));
+ *  - nesie_k4_first_layer_wgrad: dW0[m][j] = a G[m][j] + e0 Sx[j] + d1 (mu Sx[j] - sum_k W0[m][k] M[k][j])
+ *    with (.., a, mu, d1, e0, ..) = bnb[m][2..5] of nesie_pw_bnb_coef over that bn_part, G the slot
+ *    sums of g_part, Sx / M the first and second moments of X4 (computed here, in double).
+ * All of it requires no gradient for X4 (the backbone's grouped input coordinates). */
+int nesie_pw_layer_forward_k4(int nb, int cout, long long p, const float *x4, long long x4_bstride,
+                              const float *w0, const float *w, int w_rstride, int w_cstride,
+                              const float *in_coef, float *y, long long y_bstride, float *stat_part,
+                              void *stream);
+int nesie_pw_dgrad_bn_reduce_k4(int nb, int k, long long p, const float *x, long long x_bstride,
+                                const float *w, int w_rstride, int w_cstride, const float *x4,
+                                long long x4_bstride, const float *w0, const float *bn_coef,
+                                float *bn_part, float *g_part, void *stream);
+int nesie_pw_wgrad_bn_backward_k4(int nb, long long p, const float *da, const float *z,
+                                  long long z_bstride, const float *z_coef, const float *gamma,
+                                  const float *part, int nslots, const float *x4,
+                                  long long x4_bstride, const float *w0, const float *x_coef,
+                                  float *dz, float *dw, float *dgamma, float *dbeta, float *coef_ws,
+                                  void *workspace, size_t workspace_bytes, int defer, void *stream);
+size_t nesie_k4_first_layer_wgrad_workspace_bytes(void);
+int nesie_k4_first_layer_wgrad(int nb, long long p, const float *x4, long long x4_bstride,
+                               const float *w0, const float *bnb, const float *g_part, int nslots,
+                               float *dw, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Weight gradient of a 1x1 conv on the matrix cores: dw[cout][cin] = sum over scenes and
  * positions of dy[b][m][p] * act(x[b][k][p]); dy (B, cout, p), x[b] (cin, p) at x + b*x_bstride,
  * act as in nesie_mlp_layer_forward_stream (x_coef NULL = identity).  Reference: the conv2d backward

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void mlp_stream_kernel(
         const int mu = i * 32 + (r & 3) + 8 * (r >> 2);       // uniform part of the row
         const float v = acc[r];
         float *row = yb + (size_t)mu * p + n0;                // uniform
-        if (mu + 4 * half < cout && in_range) row[st_off] = v;
+        if (y && mu + 4 * half < cout && in_range) row[st_off] = v;      // (y null: statistics only)
         qrow[i][r] += v * v;      // out-of-range columns are exact zeros
       }
     }
@@ -533,6 +533,112 @@ __global__ __launch_bounds__(256) void mlp_stream_kernel(
   }
 }
 
+
+// ---- SA1's first layer without its output tensor: the weight gradient from reductions -----------
+// With Z0 = W0 . X4 rebuilt wherever it is needed (pwconv_fwd.h, PW_K4IN / PW_K4Z) the gradient of
+// the first activation is never stored either: dZ0 = a g + e0 + (mu - Z0) d1 per channel (the norm
+// backward's coefficients, pw_bnb_coef), so
+//   dW0[c][j] = sum_pos dZ0[c] X4[j] = a G[c][j] + e0 Sx[j] + d1 (mu Sx[j] - sum_k W0[c][k] M[k][j])
+// with G[c][j] = sum g[c] X4[j] (left per slot by the input-gradient launch), Sx[j] = sum X4[j] and
+// M = X4 X4^T (4 x 4) -- the moments of the INPUT, 20 sums over 17 MB.  Everything is added in
+// double in a fixed order.
+constexpr int K4_MOM_WGS = 256;
+
+__global__ __launch_bounds__(256) void k4_moments_kernel(int nb, long long p, long long x_bstride,
+                                                         const float *__restrict__ x4, double *__restrict__ part) {
+  const long long chunks = (long long)nb * (p / 4);
+  double s[4], m[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[j][k] = 0.0;
+  }
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (long long)K4_MOM_WGS * 256) {
+    const long long n = c / (p / 4), q = c % (p / 4);
+    const float *xb = x4 + (size_t)n * x_bstride + 4 * q;
+    float v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = *(const float4 *)(xb + (size_t)j * p);
+      v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+    }
+    float fs[4], fm[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fs[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+#pragma unroll
+      for (int k = j; k < 4; ++k)
+        fm[j][k] = __builtin_fmaf(v[j][3], v[k][3], __builtin_fmaf(v[j][2], v[k][2], __builtin_fmaf(v[j][1], v[k][1], v[j][0] * v[k][0])));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] += (double)fs[j];
+#pragma unroll
+      for (int k = j; k < 4; ++k) m[j][k] += (double)fm[j][k];
+    }
+  }
+  __shared__ double red[4][20];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double all[20];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    all[j] = s[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) all[4 + 4 * j + k] = k >= j ? m[j][k] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 20; ++u) {
+    double t = all[u];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) red[wave][u] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 20) {
+    const int u = threadIdx.x;
+    part[(size_t)blockIdx.x * 20 + u] = (red[0][u] + red[1][u]) + (red[2][u] + red[3][u]);
+  }
+}
+
+// one 64-lane workgroup per channel
+__global__ __launch_bounds__(64) void k4_wgrad_finish_kernel(int nslots, const double *__restrict__ mom_part,
+                                                             const float *__restrict__ g_part,
+                                                             const float *__restrict__ bnb,
+                                                             const float *__restrict__ w0, float *__restrict__ dw) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  __shared__ double mom[20];
+  for (int u = 0; u < 20; ++u) {
+    double t = 0.0;
+    for (int i = lane; i < K4_MOM_WGS; i += 64) t += mom_part[(size_t)i * 20 + u];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) mom[u] = t;
+  }
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+  const float4 *gp = (const float4 *)g_part + (size_t)c * nslots;
+  for (int i = lane; i < nslots; i += 64) {
+    const float4 q = gp[i];
+    g[0] += (double)q.x; g[1] += (double)q.y; g[2] += (double)q.z; g[3] += (double)q.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g[j] += __shfl_xor(g[j], off, 64);
+  __syncthreads();
+  if (lane < 4) {
+    const int j = lane;
+    const double a = bnb[c * 8 + 2], mu = bnb[c * 8 + 3], d1 = bnb[c * 8 + 4], e0 = bnb[c * 8 + 5];
+    double zx = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      const double mkj = k <= j ? mom[4 + 4 * k + j] : mom[4 + 4 * j + k];   // (upper triangle stored)
+      zx += (double)w0[c * 4 + k] * mkj;
+    }
+    const double gj = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
+    dw[c * 4 + j] = (float)(a * gj + e0 * mom[j] + d1 * (mu * mom[j] - zx));
+  }
+}
+
 static int stream_cols(int b, long long p) {
   // ~2048 workgroups of whole 128-column groups
   long long per = (p * b + 2047) / 2048;
@@ -555,7 +661,7 @@ extern "C" int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long lon
   const char *W = "mlp_layer_forward_stream";
   NESIE_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && p >= 0, W);
   if (b == 0 || p == 0) return NESIE_OK;
-  NESIE_REQUIRE(x && w && y && x_bstride >= (long long)cin * p && b <= 65535, W);
+  NESIE_REQUIRE(x && w && (y || stat_partial) && x_bstride >= (long long)cin * p && b <= 65535, W);
   NESIE_REQUIRE(p < (1ll << 28), W);
   if (cin > 64 || cout > 128) {
     set_error("%s: %d -> %d (built for Cin <= 64, Cout <= 128)", W, cin, cout);
@@ -576,5 +682,26 @@ extern "C" int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long lon
     return NESIE_ERR_UNSUPPORTED;
   }
 #undef L
+  return check_launch(W);
+}
+
+extern "C" size_t nesie_k4_first_layer_wgrad_workspace_bytes(void) { return (size_t)nesie::K4_MOM_WGS * 20 * sizeof(double); }
+
+// dW0 (64, 4) of SA1's first layer from the reductions alone (see k4_moments_kernel): x4 (nb, 4, p)
+// the layer's input, bnb [64][8] the norm backward's coefficients (nesie_pw_bnb_coef over the
+// bn_part of nesie_pw_dgrad_bn_reduce_k4), g_part [64][nslots][4] of the same launch.
+extern "C" int nesie_k4_first_layer_wgrad(int nb, long long p, const float *x4, long long x4_bstride,
+                                          const float *w0, const float *bnb, const float *g_part,
+                                          int nslots, float *dw, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+  const char *W = "k4_first_layer_wgrad";
+  NESIE_REQUIRE(nb >= 1 && p >= 4 && p % 4 == 0 && nslots >= 1 && x4 && w0 && bnb && g_part && dw && workspace, W);
+  NESIE_REQUIRE(x4_bstride >= 4 * p && (x4_bstride & 3) == 0 && ((uintptr_t)x4 & 15) == 0 && ((uintptr_t)g_part & 15) == 0, W);
+  NESIE_REQUIRE(workspace_bytes >= nesie_k4_first_layer_wgrad_workspace_bytes() && ((uintptr_t)workspace & 7) == 0, W);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nesie::k4_moments_kernel, dim3(nesie::K4_MOM_WGS), dim3(256), 0, s, nb, p, x4_bstride, x4,
+                     (double *)workspace);
+  hipLaunchKernelGGL(nesie::k4_wgrad_finish_kernel, dim3(64), dim3(64), 0, s, nslots, (const double *)workspace,
+                     g_part, bnb, w0, dw);
   return check_launch(W);
 }

@@ -413,7 +413,8 @@ extern "C" int nesie_pool_tail_dgrad(int nb, int k, int c, long long p, int ns, 
   a.nhalf = 1;
   a.xcd_map = 0;
   a.w_stage = 0;       // (96-row sub-tiles: lane loads)
-  a.rev = 0;           // (its operand is the forward pass's: nothing of it is cached either way)
+  a.rev = 0;
+  a.k4_w = nullptr; a.k4_gpart = nullptr;           // (its operand is the forward pass's: nothing of it is cached either way)
   a.sp_ent = (const float2 *)ent; a.sp_ns_shift = pt_ns_shift(ns); a.sp_groups = (int)(p / ns);
   const int st = pw_launch_sparse_6_2_4_1_1(a, a.nwg_g, g.lds, (hipStream_t)stream);
   if (st != NESIE_OK) return st;

@@ -206,7 +206,8 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
                            int pool_min, float *pool_max_out, float *pool_min_out,
                            uint8_t *arg_max_out, uint8_t *arg_min_out, const float *bn_z,
                            long long bnz_bstride, const float *bn_coef, float *bn_part,
-                           void *stream) {
+                           void *stream, const float *k4_w = nullptr, int k4_in = 0,
+                           float *k4_gpart = nullptr) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && k >= 1 && cout >= 1 && p >= 0, W);
   if (nb == 0 || p == 0) return NESIE_OK;
   NESIE_REQUIRE(nb % ng == 0 && x && w, W);
@@ -227,8 +228,17 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   }
   if (bias) epi |= PW_BIAS;
   if (bn_z) {
-    NESIE_REQUIRE(y && bn_coef && bn_part && ((uintptr_t)bn_z & 15) == 0 && (bnz_bstride & 3) == 0, W);
+    NESIE_REQUIRE((y || k4_gpart) && bn_coef && bn_part && ((uintptr_t)bn_z & 15) == 0 && (bnz_bstride & 3) == 0, W);
     epi |= PW_BNRED;
+  }
+  if (k4_in) {      // the operand is rebuilt from the four rows of x (pwconv_fwd.h, PW_K4IN)
+    NESIE_REQUIRE(k4_w && in_coef && k == 64 && ng == 1 && x_bstride >= 4 * p && ((uintptr_t)k4_w & 15) == 0, W);
+    epi |= PW_K4IN;
+  }
+  if (k4_gpart) {   // Z of the reduction is rebuilt from the four rows of bn_z (PW_K4Z)
+    NESIE_REQUIRE(k4_w && bn_z && !y && cout == 64 && ng == 1 && bnz_bstride >= 4 * p && ((uintptr_t)k4_w & 15) == 0 &&
+                  ((uintptr_t)k4_gpart & 15) == 0, W);
+    epi |= PW_K4Z;
   }
   if (pool_group) {
     NESIE_REQUIRE(pool_group == 16 || pool_group == 32, W);
@@ -248,10 +258,11 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   a.pool_max = pool_max_out; a.pool_min = pool_min_out; a.arg_max = arg_max_out; a.arg_min = arg_min_out;
   a.bn_z = bn_z; a.bnz_bs = bnz_bstride; a.bn_coef = bn_coef; a.bn_part = bn_part;
   a.stamps = nullptr;
+  a.k4_w = k4_w; a.k4_gpart = k4_gpart;
   static const int w_stage = [] { const char *e = getenv("NESIE_PW_WSTAGE"); return e ? atoi(e) : 1; }();
   a.w_stage = w_stage;
   static const int rev_fwd = [] { const char *e = getenv("NESIE_PW_REV_FWD"); return e ? atoi(e) : 3; }();   // A/B: bit 0 forward products, bit 1 input gradients
-  a.rev = ((bn_z ? rev_fwd & 2 : rev_fwd & 1) != 0) ? walk_dir((long long)nb * k * p * 4) : 0;     // (a big operand is read last tile first: nesie_lib.hip)
+  a.rev = ((bn_z ? rev_fwd & 2 : rev_fwd & 1) != 0) ? walk_dir((long long)nb * (k4_in ? 4 : k) * p * 4) : 0;     // (a big operand is read last tile first: nesie_lib.hip)
 #ifdef PW_STAMP
   a.stamps = g_pw_stamps;
 #endif
@@ -313,6 +324,36 @@ extern "C" int nesie_pw_dgrad_bn_reduce(int nb, int ng, int k, int cout, long lo
   return pw_forward_impl(W, nb, ng, k, cout, p, x, x_bstride, w, w_gstride, w_rstride, w_cstride,
                          nullptr, 0, nullptr, 0, nullptr, y, y_bstride, nullptr, 0, 0, nullptr,
                          nullptr, nullptr, nullptr, bn_z, bnz_bstride, bn_coef, bn_part, stream);
+}
+
+// SA1's second layer over the REBUILT output of its first: the operand rows are relu(bn(W0 . X4)),
+// formed in the staging from the four rows of x4 (nb, 4, p) -- the 64-row tensor is never written
+// or read.  w0 (64, 4) row-major; in_coef [64][4] the folded norm of the first layer.
+extern "C" int nesie_pw_layer_forward_k4(int nb, int cout, long long p, const float *x4,
+                                         long long x4_bstride, const float *w0, const float *w,
+                                         int w_rstride, int w_cstride, const float *in_coef,
+                                         float *y, long long y_bstride, float *stat_part,
+                                         void *stream) {
+  return pw_forward_impl("pw_layer_forward_k4", nb, 1, 64, cout, p, x4, x4_bstride, w, 0, w_rstride,
+                         w_cstride, in_coef, 1, nullptr, 0, nullptr, y, y_bstride, stat_part, 0, 0,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, stream, w0, 1);
+}
+
+// ... and the input gradient of that second layer, of which only the REDUCTIONS are wanted: the
+// gradient g = dA0 [bn(Z0) > 0] is never stored.  Per channel and slot it leaves sum(g),
+// sum(g zhat) (bn_part, as nesie_pw_dgrad_bn_reduce) and sum(g X4[j]), j = 0 .. 3 (g_part
+// [64][slots][4]): with the moments of X4 they determine the first layer's weight gradient
+// (nesie_k4_first_layer_wgrad).
+extern "C" int nesie_pw_dgrad_bn_reduce_k4(int nb, int k, long long p, const float *x,
+                                           long long x_bstride, const float *w, int w_rstride,
+                                           int w_cstride, const float *x4, long long x4_bstride,
+                                           const float *w0, const float *bn_coef, float *bn_part,
+                                           float *g_part, void *stream) {
+  const char *W = "pw_dgrad_bn_reduce_k4";
+  NESIE_REQUIRE(x4 && w0 && bn_coef && bn_part && g_part, W);
+  return pw_forward_impl(W, nb, 1, k, 64, p, x, x_bstride, w, 0, w_rstride, w_cstride, nullptr, 0,
+                         nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, nullptr,
+                         nullptr, x4, x4_bstride, bn_coef, bn_part, stream, w0, 0, g_part);
 }
 
 extern "C" int nesie_pw_stats_finalize(int channels, int cout, int nslots, const float *stat_part,

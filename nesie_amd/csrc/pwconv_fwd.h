@@ -136,7 +136,18 @@ enum : int {
   // operand (x, in_coef) supplies rows SPC .. K - 1; K = KH * KT exactly.
   PW_SPARSE128 = 256,
   PW_SPARSE256 = 512,
+  // A 64-row tensor that is the raw output of a 4 -> 64 convolution, Z0 = W0 . X4 (SA1's first
+  // layer), is not read but REBUILT from the 4 rows of X4 (k4_dot below: the same four roundings
+  // everywhere, so that the forward's ReLU and the backward's masks agree):
+  PW_K4IN = 1024,   // ... as the operand: x = X4 (nb, 4, p), k = 64, in_coef = the folded norm of Z0
+  PW_K4Z = 2048,    // ... as the Z of PW_BNRED: bn_z = X4; additionally leaves sum(g . X4[j]), j = 0 .. 3, per
+                    // channel and slot (k4_gpart) -- with them the FIRST layer's weight gradient needs no pass over g
 };
+
+// Z0[m] at one position from the four input rows: ((w0 x0 + w1 x1) + w2 x2) + w3 x3 as an fma chain
+__device__ __forceinline__ float k4_dot(const float4 w, float x0, float x1, float x2, float x3) {
+  return __builtin_fmaf(w.w, x3, __builtin_fmaf(w.z, x2, __builtin_fmaf(w.y, x1, w.x * x0)));
+}
 
 struct PwFwd {
   const float *x; long long x_bs; long long p; int nb, k;
@@ -154,6 +165,8 @@ struct PwFwd {
   const float2 *sp_ent; int sp_ns_shift, sp_groups;   // PW_SPARSE*: entries, log2(ns), groups per batch element
   int w_stage;         // 1: row-major weights come in through LDS (NESIE_PW_WSTAGE=0: lane loads, A/B switch)
   int rev;             // 1: the tile stream runs from the LAST tile of the group to the first (big operands: nesie_lib.hip)
+  const float *k4_w;   // PW_K4IN / PW_K4Z: W0 (64, 4) row-major
+  float *k4_gpart;     // PW_K4Z: [ng * cout][nslots][4]
   long long *stamps;   // development only (PW_STAMP builds): per-phase s_memtime of workgroup 0
 };
 #ifdef PW_STAMP
@@ -330,6 +343,13 @@ void pw_fwd_kernel(const PwFwd a) {
         cof[kh][i] = *(const float2 *)(a.in_coef + ((size_t)g * (k - SPC) + row) * 4);
       }
   }
+  // PW_K4IN: W0 rows of this thread's four operand rows; the slot index doubles as the X4 row it fetches
+  float4 k4w[(EPI & PW_K4IN) ? NX : 1];
+  if constexpr ((EPI & PW_K4IN) != 0) {
+    static_assert(KH == 1 && KT == 64 && NX == 4 && EVEN && SPC == 0, "PW_K4IN: one 64-row sub-tile, four slots");
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k4w[i] = *(const float4 *)(a.k4_w + (size_t)(slot_row(i) + srow) * 4);
+  }
   // built rows: entry of (group of this lane's 16-byte chunk, row srow) relative to the tile's first
   // group and the slot's first row; and the chunk's first position inside its group
   const unsigned sp_voff = SPC > 0 ? (unsigned)(((((4 * scol) >> a.sp_ns_shift) * SPC) + srow) * 8) : 0u;
@@ -364,6 +384,12 @@ void pw_fwd_kernel(const PwFwd a) {
       stg[i][1] = e.y;
       return;
     }
+    if constexpr ((EPI & PW_K4IN) != 0) {
+      // slot i = row i of X4 at this thread's 16-byte column (every operand row of the column needs all four)
+      const float *x4 = a.x + (size_t)(g + a.ng * QQ(c)) * a.x_bs + (size_t)RR(c) * PT + (size_t)i * p;   // wave-uniform
+      stg[i] = load16_saddr(live ? (unsigned)(scol * 16) : 0u, live ? x4 : a.x);
+      return;
+    }
     const float *xb = a.x + (size_t)(g + a.ng * QQ(c)) * a.x_bs + (size_t)RR(c) * PT + (long long)(kh * KT - SPC) * p;
     if constexpr (kh < KH - 1) {
       const float *xs = live ? xb + (size_t)slot_row(i) * p : a.x;   // wave-uniform
@@ -373,9 +399,19 @@ void pw_fwd_kernel(const PwFwd a) {
     }
   };
   // previous layer's BatchNorm + ReLU in registers, then into LDS buffer `buf` (0 / 1)
+  f32x4 k4x[(EPI & PW_K4IN) ? 4 : 1];      // PW_K4IN: the four rows of X4 of the sub-tile being written
   auto write_slot = [&](auto ic, auto khc, int buf) {
     constexpr int i = decltype(ic)::value;
     f32x4 q = stg[i];
+    if constexpr ((EPI & PW_K4IN) != 0) {
+      // (slot 0 is written first and re-loaded right behind its write: keep all four rows)
+      if constexpr (i == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k4x[j] = stg[j];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = k4_dot(k4w[i], k4x[0][e], k4x[1][e], k4x[2][e], k4x[3][e]);
+    }
     if constexpr (SPC > 0 && decltype(khc)::value * KT + slot_row(i) < SPC) {
       const int at = __float_as_int(q[1]) - sp_pos0;
       const float v = q[0];
@@ -422,7 +458,12 @@ void pw_fwd_kernel(const PwFwd a) {
 
   // PW_BNRED: the raw output Z of the layer whose activation gradient this launch produces, at
   // this lane's output elements (loaded ahead of the MFMAs of the tile's last sub-tile), and the sums
-  f32x4 zv[(EPI & PW_BNRED) ? RW : 1][4];
+  constexpr bool K4Z = (EPI & PW_K4Z) != 0;
+  static_assert(!K4Z || ((EPI & PW_BNRED) && !RAGGED), "PW_K4Z rides on PW_BNRED");
+  f32x4 zv[((EPI & PW_BNRED) && !K4Z) ? RW : 1][4];
+  f32x4 xz[K4Z ? 4 : 1][4];                // PW_K4Z: X4 rows at this lane's output positions
+  float4 k4zw[K4Z ? RW : 1];               // ... and W0 rows of its channels
+  float gx[K4Z ? RW : 1][4];               // ... sums of g . X4[j]
   float r0[RW], r1[RW];
   float4 zc[RW];
 #pragma unroll
@@ -432,11 +473,23 @@ void pw_fwd_kernel(const PwFwd a) {
     if (EPI & PW_BNRED) {
       const int m = c0 + (wr * RW + rw) * 16 + l16;
       if (!RAGGED || m < cout) zc[rw] = *(const float4 *)(a.bn_coef + ((size_t)g * cout + m) * 4);
+      if constexpr (K4Z) {
+        k4zw[rw] = *(const float4 *)(a.k4_w + (size_t)m * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gx[rw][j] = 0.f;
+      }
     }
   }
   auto row_ok = [&](int rw) { return !RAGGED || c0 + (wr * RW + rw) * 16 + l16 < cout; };
   auto load_z = [&](int n, long long p0) {
     const float *zt = a.bn_z + (size_t)n * a.bnz_bs + p0;   // wave-uniform
+    if constexpr (K4Z) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xz[j][r] = load16_saddr((unsigned)(q0 * 4) + 4u * RS * r, zt + (size_t)j * p);
+      return;
+    }
 #pragma unroll
     for (int rw = 0; rw < RW; ++rw) {
 #pragma unroll
@@ -495,10 +548,16 @@ void pw_fwd_kernel(const PwFwd a) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float z = zv[rw][r][e];
+            float z;
+            if constexpr (K4Z) z = k4_dot(k4zw[rw], xz[0][r][e], xz[1][r][e], xz[2][r][e], xz[3][r][e]);
+            else z = zv[rw][r][e];
             const float gg = __builtin_fmaf(z, zc[rw].x, zc[rw].y) > 0.f ? acc[rw][e][r] : 0.f;
             r0[rw] += gg;
             r1[rw] += gg * ((z - zc[rw].z) * zc[rw].w);
+            if constexpr (K4Z) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) gx[rw][j] = __builtin_fmaf(gg, xz[j][r][e], gx[rw][j]);
+            }
           }
       }
       if (EPI & PW_STATS) {
@@ -622,8 +681,13 @@ void pw_fwd_kernel(const PwFwd a) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(cof[kh][i].x), "+v"(cof[kh][i].y));
   }
+  if constexpr ((EPI & PW_K4IN) != 0) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(k4w[i].x), "+v"(k4w[i].y), "+v"(k4w[i].z), "+v"(k4w[i].w));
+  }
 #pragma unroll
   for (int rw = 0; rw < RW; ++rw) {
+    if constexpr (K4Z) asm volatile("" : "+v"(k4zw[rw].x), "+v"(k4zw[rw].y), "+v"(k4zw[rw].z), "+v"(k4zw[rw].w));
     if (EPI & PW_BNRED) asm volatile("" : "+v"(zc[rw].x), "+v"(zc[rw].y), "+v"(zc[rw].z), "+v"(zc[rw].w));
     if (EPI & PW_BIAS) asm volatile("" : "+v"(cbias[rw]));
   }
@@ -734,6 +798,18 @@ void pw_fwd_kernel(const PwFwd a) {
       t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
       if (quad == 0 && m < cout)
         *(float2 *)(a.bn_part + (((size_t)g * cout + m) * a.nslots + slot) * 2) = make_float2(t0, t1);
+      if constexpr (K4Z) {
+        float4 t;
+        float *tv = &t.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = gx[rw][j];
+          u += __shfl_xor(u, 16, 64);
+          u += __shfl_xor(u, 32, 64);
+          tv[j] = u;
+        }
+        if (quad == 0 && m < cout) *(float4 *)(a.k4_gpart + (((size_t)g * cout + m) * a.nslots + slot) * 4) = t;
+      }
     }
   }
   if (EPI & PW_STATS) {
@@ -801,6 +877,15 @@ static int pw_launch_epi(const PwFwd &a, int epi, int pg, int grid, size_t lds, 
   set_error("dev build");
   return NESIE_ERR_UNSUPPORTED;
 #else
+  // SA1's rebuilt first activation (one geometry: 64 -> 64 with four waves)
+  if (epi & (PW_K4IN | PW_K4Z)) {
+    if constexpr (KT16 == 4 && KH == 1 && WR == 4 && WC == 1 && RW == 1) {
+      if (epi == (PW_K4IN | PW_AFFINE | PW_STORE | PW_STATS)) GOW(PW_K4IN | PW_AFFINE | PW_STORE | PW_STATS, 16);
+      if (epi == (PW_K4Z | PW_BNRED)) GOW(PW_K4Z | PW_BNRED, 16);
+    }
+    set_error("pw_layer_forward: the rebuilt 4 -> 64 operand is built for 64 -> 64 layers only (0x%x)", epi);
+    return NESIE_ERR_UNSUPPORTED;
+  }
   const int aff = epi & PW_AFFINE;
   const int base = epi & ~PW_AFFINE;
   // the prologue / epilogue combinations the step uses

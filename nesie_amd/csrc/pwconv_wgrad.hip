@@ -39,12 +39,16 @@ namespace nesie {
 // block with its own runs of positions and its own partials -- for layers whose co x ci is large
 // and whose position count is small (the 1-D chains: 256 x 512 over 8 x 1024 positions), where one
 // whole-product workgroup per 32 positions wrote 128 KB of partial per 32 positions.
-template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB>
+// K4 (one build: 64 x 64 with AFF and BNB): the 64 rows of X are the raw output of a 4 -> 64
+// convolution, Z0 = W0 . X4, and are REBUILT from the four rows of x (nb, 4, p) on the operand load
+// (k4_dot, pwconv_fwd.h: the same roundings as the forward's) -- SA1's first activation is never stored.
+template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB, bool K4 = false>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     int nb, int ng, int co_all, int ci_all, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
     float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
-    const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group, int rev) {
+    const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group, int rev,
+    const float *__restrict__ k4_w) {
   const int row0 = blockIdx.y * CO16 * 16, col0 = blockIdx.z * CI16 * 16;   // (0, 0) unless tiled
   const int co = co_all - row0 < CO16 * 16 ? co_all - row0 : CO16 * 16;     // this block's extent
   const int ci = ci_all - col0 < CI16 * 16 ? ci_all - col0 : CI16 * 16;
@@ -65,6 +69,10 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   const int wm = wave / WN, wn = wave % WN;
   const int g = blockIdx.x % ng, rank = blockIdx.x / ng;
 
+  static_assert(!K4 || (AFF && NX - DYSLOTS == 1 && CI16 == 4 && EVEN), "K4: one slot of X rows");
+  float4 k4w = make_float4(0.f, 0.f, 0.f, 0.f);      // K4: W0 row of this thread's X row
+  unsigned k4off = 0;                                  // ... and its 16-byte column
+  f32x4 k4x[K4 ? 3 : 1];                               // ... rows 1 .. 3 of X4 (row 0 sits in the slot's own register)
   unsigned goff[NX], lw[NX];
   bool okslot[NX];
   float sc[AFF ? NX : 1], bi[AFF ? NX : 1];
@@ -79,6 +87,13 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
     okslot[i] = ok;
     goff[i] = ok ? (unsigned)(((size_t)r * p + cp * 4) * 4) : 0u;
     lw[i] = (unsigned)((row * PITCH + cp * 4) * 4);
+    if constexpr (K4) {
+      if (!isdy) {
+        k4w = *(const float4 *)(k4_w + (size_t)r * 4);
+        k4off = (unsigned)(cp * 16);
+        asm volatile("" : "+v"(k4w.x), "+v"(k4w.y), "+v"(k4w.z), "+v"(k4w.w));
+      }
+    }
     if (AFF) {
       const float s0 = (ok && !isdy) ? x_coef[((size_t)g * coef_gs + r) * 4] : 0.f;
       const float b0 = (ok && !isdy) ? x_coef[((size_t)g * coef_gs + r) * 4 + 1] : 0.f;
@@ -129,6 +144,16 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       // selection sees a hoisted 64-bit register pair and drops the scalar-base addressing form)
       unsigned o = goff[i];
       asm volatile("" : "+v"(o));
+      if constexpr (K4) {
+        if (i >= DYSLOTS) {
+          unsigned o4 = k4off;
+          asm volatile("" : "+v"(o4));
+          stg[i] = load16_saddr(o4, xb);
+#pragma unroll
+          for (int j = 1; j < 4; ++j) k4x[j - 1] = load16_saddr(o4, xb + (size_t)j * p);
+          continue;
+        }
+      }
       stg[i] = load16_saddr(o, i < DYSLOTS ? dyb : xb);
       if constexpr (BNB) {
         if (i < DYSLOTS) stz[i] = load16_saddr(o, bnz + pend);
@@ -161,6 +186,12 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
               if (rb_group == 64) atomicAdd(dst, tsum); else *dst = tsum;
             }
           }
+        }
+      }
+      if constexpr (K4) {
+        if (i >= DYSLOTS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = k4_dot(k4w, q[e], k4x[0][e], k4x[1][e], k4x[2][e]);
         }
       }
       if (AFF && i >= DYSLOTS) {
@@ -505,8 +536,12 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
                            long long dy_bstride, const float *x, long long x_bstride,
                            const float *x_coef, int x_relu, float *dw, void *workspace,
                            size_t workspace_bytes, const float *bnz, const float *bnb, float *dz,
-                           float *d_rb, int rb_group, hipStream_t s, bool defer = false) {
+                           float *d_rb, int rb_group, hipStream_t s, bool defer = false,
+                           const float *k4_w = nullptr) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && ci >= 1 && p >= 0 && dw, W);
+  // (k4_w: x is X4 (nb, 4, p) and the 64 operand rows are rebuilt from it -- one build)
+  NESIE_REQUIRE(!k4_w || (co == 64 && ci == 64 && ng == 1 && bnb && x_coef && !d_rb && x_bstride >= 4 * p &&
+                          ((uintptr_t)k4_w & 15) == 0), W);
   if (nb == 0 || p == 0) {
     (void)hipMemsetAsync(dw, 0, (size_t)ng * co * ci * sizeof(float), s);
     return NESIE_OK;
@@ -540,7 +575,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       }                                                                                                \
       hipLaunchKernelGGL(kern, dim3(nwg * ng, nrb, ncb), dim3(512), lds, s, nb, ng, co, ci, p, dy, dy_bstride, x, \
                          x_bstride, x_coef, ci, lo0, partial, nwg, (const float *)nullptr, (const float *)nullptr, \
-                         (float *)nullptr, (float *)nullptr, 0, rev);                                   \
+                         (float *)nullptr, (float *)nullptr, 0, rev, (const float *)nullptr);           \
     } while (0)
     if (x_coef) LT(true); else LT(false);
 #undef LT
@@ -574,7 +609,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       attr = true;                                                                               \
     }                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,           \
-                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev); \
+                       dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, \
+                       (const float *)nullptr);                                                  \
   } while (0)
 #define L(CO16, CI16, WM, WN)                                                                    \
   do {                                                                                           \
@@ -585,7 +621,17 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     const int cw = ci - c0 < block ? ci - c0 : block;   // workspace is free again when the next one starts
     const float *xc = x + (size_t)c0 * p;
     const float *cc = x_coef ? x_coef + (size_t)c0 * 4 : nullptr;
-    if (co <= 64 && cw <= 64) L(4, 4, 2, 4);
+    if (k4_w) {
+      const size_t lds = (size_t)2 * (4 + 4) * 16 * 36 * sizeof(float);
+      auto kern = pw_wgrad_kernel<4, 4, 2, 4, true, true, true>;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy, dy_bstride, xc, x_bstride, cc,
+                         ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, k4_w);
+    } else if (co <= 64 && cw <= 64) L(4, 4, 2, 4);
     else if (co <= 128 && cw <= 64) L(8, 4, 4, 2);
     else if (co <= 128 && cw <= 128) L(8, 8, 2, 4);
     else if (co <= 128 && cw <= 192) L(8, 12, 2, 4);
@@ -645,7 +691,8 @@ static int pw_wgrad_bn_backward_impl(const char *W, bool defer, int nb, int ng, 
                                           const float *x, long long x_bstride, const float *x_coef,
                                           int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
                                           float *coef_ws, float *d_row_bias, int rb_group,
-                                          void *workspace, size_t workspace_bytes, void *stream) {
+                                          void *workspace, size_t workspace_bytes, void *stream,
+                                          const float *k4_w = nullptr) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
   hipStream_t s = (hipStream_t)stream;
   if (nb == 0 || p == 0) {
@@ -658,7 +705,7 @@ static int pw_wgrad_bn_backward_impl(const char *W, bool defer, int nb, int ng, 
   hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
                      (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
   return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s, defer);
+                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s, defer, k4_w);
 }
 
 extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
@@ -686,6 +733,21 @@ extern "C" int nesie_pw_wgrad_bn_backward_deferred(int nb, int ng, int co, int c
                                    d_row_bias, rb_group, workspace, workspace_bytes, stream);
 }
 
+
+// ... of SA1's second layer (64 x 64), whose X is the REBUILT output of the first: x4 (nb, 4, p),
+// w0 (64, 4), x_coef the first layer's folded norm.  defer != 0: the reduction stays pending.
+extern "C" int nesie_pw_wgrad_bn_backward_k4(int nb, long long p, const float *da, const float *z,
+                                             long long z_bstride, const float *z_coef, const float *gamma,
+                                             const float *part, int nslots, const float *x4,
+                                             long long x4_bstride, const float *w0, const float *x_coef,
+                                             float *dz, float *dw, float *dgamma, float *dbeta, float *coef_ws,
+                                             void *workspace, size_t workspace_bytes, int defer, void *stream) {
+  const char *W = "pw_wgrad_bn_backward_k4";
+  NESIE_REQUIRE(nb >= 1 && p >= 32 && x4 && w0 && x_coef, W);
+  return pw_wgrad_bn_backward_impl(W, defer != 0, nb, 1, 64, 64, p, da, z, z_bstride, z_coef, gamma, part, nslots, x4,
+                                   x4_bstride, x_coef, 1, dz, dw, dgamma, dbeta, coef_ws, nullptr, 0, workspace,
+                                   workspace_bytes, stream, w0);
+}
 
 // The reduction coefficients of a BatchNorm + ReLU backward on their own (for a consumer of dZ
 // other than the weight gradient: nesie_blend_conv_backward_bn): bnb [channels][8], dgamma, dbeta.

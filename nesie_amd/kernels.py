@@ -425,17 +425,23 @@ class HipKernels(_BNPoolMixin):
         """y[b] = W . act(x[b]) on the matrix cores, streaming form (Cin <= 64, Cout <= 128):
         x (B,Cin,P), w (Cout,Cin), y (B,Cout,P); stat_partial (parts, Cout, 2) receives the
         per-workgroup (sum, sum of squares) of y, parts = mlp_stream_parts(B, P)."""
-        _check(x, w, y); _f32(x, w, y)
+        _check(x, w); _f32(x, w)
         b, cin, p = x.shape
         cout = w.shape[0]
-        assert tuple(w.shape) == (cout, cin) and tuple(y.shape) == (b, cout, p)
+        assert tuple(w.shape) == (cout, cin)
+        if y is not None:       # (None: only the statistics of y are wanted)
+            _check(y); _f32(y)
+            assert tuple(y.shape) == (b, cout, p)
+        else:
+            assert stat_partial is not None
         if stat_partial is not None:
             _check(stat_partial); _f32(stat_partial)
             assert tuple(stat_partial.shape) == (self.mlp_stream_parts(b, p), cout, 2)
         with torch.cuda.device(x.device):
             _lib.call("nesie_mlp_layer_forward_stream", b, cin, cout, p, _ptr(x), cin * p,
                       _ptr(w), 0 if in_coef is None else _ptr(in_coef), int(bool(in_relu)),
-                      _ptr(y), 0 if stat_partial is None else _ptr(stat_partial), _stream(x))
+                      0 if y is None else _ptr(y), 0 if stat_partial is None else _ptr(stat_partial),
+                      _stream(x))
 
     @staticmethod
     def mlp_stream_parts(b, p):
@@ -989,6 +995,86 @@ class HipKernels(_BNPoolMixin):
                       y.stride(0) if (y is not None and nb > 1) else cout * p, opt(stat_part),
                       int(pool_group),
                       int(bool(pool_min)), opt(pmax), opt(pmin), opt(amax), opt(amin), _stream(x))
+
+    # ---- SA1's first layer without its output tensor (include/nesie_ops.h, "round 5: the first
+    # shared-MLP layer ... WITHOUT its output tensor")
+    @staticmethod
+    def _k4_check(x4, w0):
+        _f32(x4, w0); _check(w0)
+        nb, c, p = x4.shape
+        assert x4.is_cuda and c == 4 and x4.stride(2) == 1 and x4.stride(1) == p and tuple(w0.shape) == (64, 4)
+        return nb, p
+
+    def k4_supported(self, c0, c1, c2, p):
+        """SA1's shape: 4 -> 64 -> 64 over whole 64-position tiles."""
+        return c0 == 4 and c1 == 64 and c2 == 64 and p % 64 == 0 and self.pw_supported(64, 64, p) \
+            and self.pw_wgrad_bn_supported(64, 64, p)
+
+    def pw_layer_forward_k4(self, x4, w0, w, in_coef, y, stat_part):
+        """y[n] = W . relu(bn(W0 . x4[n])) with the inner 64-row tensor rebuilt in the staging
+        (nesie_pw_layer_forward_k4): x4 (NB, 4, P), w0 (64, 4), w (Cout = 64, 64) any strided view,
+        in_coef (64, 4) the first layer's folded norm, y (NB, 64, P), stat_part as pw_layer_forward."""
+        nb, p = self._k4_check(x4, w0)
+        _f32(w, y); _check(in_coef, y, stat_part); _f32(in_coef, stat_part)
+        cout = w.shape[0]
+        assert tuple(w.shape) == (cout, 64) and tuple(y.shape) == (nb, cout, p) and tuple(in_coef.shape) == (64, 4)
+        assert tuple(stat_part.shape) == (1, self.pw_stat_slots(nb, 1, 64, cout, p), cout, 4)
+        with torch.cuda.device(x4.device):
+            _lib.call("nesie_pw_layer_forward_k4", nb, cout, p, _ptr(x4), x4.stride(0) if nb > 1 else 4 * p,
+                      _ptr(w0), _ptr(w), w.stride(0), w.stride(1), _ptr(in_coef), _ptr(y), cout * p,
+                      _ptr(stat_part), _stream(x4))
+
+    def pw_dgrad_bn_reduce_k4(self, dy, w, x4, w0, z_coef):
+        """The reductions of ``pw_dgrad_bn_reduce`` for a layer whose input was relu(bn(W0 . x4)),
+        WITHOUT the input gradient itself (nesie_pw_dgrad_bn_reduce_k4): dy (NB, K, P), w the
+        transposed weight view (64, K) -> (part (64, slots, 2), g_part (64, slots, 4))."""
+        nb, p = self._k4_check(x4, w0)
+        _f32(dy, w); _check(z_coef); _f32(z_coef)
+        k = dy.shape[1]
+        assert tuple(dy.shape) == (nb, k, p) and dy.is_cuda and dy.stride(2) == 1 and dy.stride(1) == p
+        assert tuple(w.shape) == (64, k) and tuple(z_coef.shape) == (64, 4)
+        slots = self.pw_stat_slots(nb, 1, k, 64, p)
+        part = torch.empty(64, slots, 2, dtype=torch.float32, device=dy.device)
+        g_part = torch.empty(64, slots, 4, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.call("nesie_pw_dgrad_bn_reduce_k4", nb, k, p, _ptr(dy), dy.stride(0) if nb > 1 else k * p,
+                      _ptr(w), w.stride(0), w.stride(1), _ptr(x4), x4.stride(0) if nb > 1 else 4 * p,
+                      _ptr(w0), _ptr(z_coef), _ptr(part), _ptr(g_part), _stream(dy))
+        return part, g_part
+
+    def pw_wgrad_bn_backward_k4(self, da, z, z_coef, gamma, part, x4, w0, x_coef, dw, dgamma, dbeta,
+                                final=False):
+        """``pw_wgrad_bn_backward`` of a 64 x 64 layer whose X operand is relu(bn(W0 . x4)), rebuilt on
+        the load (nesie_pw_wgrad_bn_backward_k4); dz is written over da."""
+        nb, p = self._k4_check(x4, w0)
+        _f32(da, z, dw, dgamma, dbeta); _check(da, z, z_coef, part, x_coef, dw); _f32(z_coef, part, x_coef)
+        assert tuple(da.shape) == (nb, 64, p) == tuple(z.shape) and dw.numel() == 64 * 64
+        assert tuple(z_coef.shape) == (64, 4) == tuple(x_coef.shape) and part.shape[0] == 64 and part.shape[2] == 2
+        if gamma is not None:
+            _check(gamma); _f32(gamma)
+        need = _lib.load().nesie_pw_wgrad_workspace_bytes(nb, 1, 64, 64, p)
+        defer = final and HipKernels._deferred is not None
+        with torch.cuda.device(da.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=da.device)
+            cws = torch.empty(64, 8, dtype=torch.float32, device=da.device)
+            if defer:
+                HipKernels._deferred.append((ws, dw))
+            _lib.call("nesie_pw_wgrad_bn_backward_k4", nb, p, _ptr(da), _ptr(z), 64 * p, _ptr(z_coef),
+                      0 if gamma is None else _ptr(gamma), _ptr(part), part.shape[1], _ptr(x4),
+                      x4.stride(0) if nb > 1 else 4 * p, _ptr(w0), _ptr(x_coef), _ptr(da), _ptr(dw),
+                      _ptr(dgamma), _ptr(dbeta), _ptr(cws), _ptr(ws), need, int(defer), _stream(da))
+
+    def k4_first_layer_wgrad(self, x4, w0, bnb, g_part, dw):
+        """dW0 (64, 4) from the reductions (nesie_k4_first_layer_wgrad): bnb (64, 8) from
+        ``pw_bnb_coef`` over the part of ``pw_dgrad_bn_reduce_k4``, g_part (64, slots, 4) of the same."""
+        nb, p = self._k4_check(x4, w0)
+        _check(bnb, g_part, dw); _f32(bnb, g_part, dw)
+        assert tuple(bnb.shape) == (64, 8) and g_part.shape[0] == 64 and g_part.shape[2] == 4 and dw.numel() == 256
+        need = _lib.load().nesie_k4_first_layer_wgrad_workspace_bytes()
+        with torch.cuda.device(x4.device):
+            ws = torch.empty(need // 8, dtype=torch.float64, device=x4.device)
+            _lib.call("nesie_k4_first_layer_wgrad", nb, p, _ptr(x4), x4.stride(0) if nb > 1 else 4 * p, _ptr(w0),
+                      _ptr(bnb), _ptr(g_part), g_part.shape[1], _ptr(dw), _ptr(ws), need, _stream(x4))
 
     def pw_dgrad_bn_reduce(self, dy, w, z, z_coef, da, ng=1):
         """da[n] = W[n % ng] . dy[n] (w = the transposed weight view (ng, Cin, Cout)) plus the

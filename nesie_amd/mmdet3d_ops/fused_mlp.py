@@ -147,6 +147,11 @@ def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_
     return dz, dw, dgamma, dbeta
 
 
+# SA1's first activation (4 -> 64 over 10^6 positions, 268 MB) is rebuilt from the 17 MB input wherever
+# it is an operand instead of being stored (include/nesie_ops.h, round 5).  0 = store it (A/B switch).
+SA1_K4 = _os.environ.get('NESIE_SA1_K4', '1') != '0'
+
+
 class SAStackFn(Function):
     """x (B, C0, M, ns) -> max_ns relu(bn_L(conv_L(... relu(bn_1(conv_1(x)))))) (B, C_L, M).
     ``fixed_lead`` = number of leading input channels that are inputs of the step (grouped
@@ -165,6 +170,12 @@ class SAStackFn(Function):
         coef = None
         pool_group = 16 if ns == 16 else 32
         pool_out = None
+        need = ctx.needs_input_grad
+        k4_ok = getattr(backend, 'k4_supported', None)
+        ctx.k4 = bool(SA1_K4 and L >= 3 and k4_ok is not None and not need[0]
+                      and (all(need[3:9]) or not any(need))
+                      and k4_ok(c0, params[0].shape[0], params[3].shape[0], P))
+        w0c = params[0].reshape(params[0].shape[0], c0) if ctx.k4 else None
         for l in range(L):
             w, gamma, beta = params[3 * l:3 * l + 3]
             rm, rv, momentum, eps = bufs[l]
@@ -173,9 +184,14 @@ class SAStackFn(Function):
             src = x3 if l == 0 else ys[-1]
             last = l == L - 1
             tail = bool(last and l > 0 and POOL_TAIL and backend.pool_tail_supported(cin, cout, P, ns))
-            y = None if tail else x.new_empty(B, cout, P)     # (tail: the raw output is never written)
+            # (tail: the raw output is never written; k4: nor is the first layer's)
+            y = None if (tail or (ctx.k4 and l == 0)) else x.new_empty(B, cout, P)
             new_coef = x.new_empty(cout, 4)
-            if l == 0 and cin <= 8 and not last:
+            if ctx.k4 and l == 1:
+                part = x.new_empty(1, backend.pw_stat_slots(B, 1, cin, cout, P), cout, 4)
+                backend.pw_layer_forward_k4(x3, w0c, w2[0], coef, y, part)
+                backend.pw_stats_finalize(part, gamma, beta, rm, rv, momentum, eps, new_coef)
+            elif l == 0 and cin <= 8 and not last:
                 part = x.new_empty(backend.mlp_stream_parts(B, P), cout, 2)
                 backend.mlp_stream_forward(src, w2[0].contiguous(), y, part)
                 backend.mlp_stat_finalize(part, B * P, gamma, beta, rm, rv, momentum, eps, new_coef)
@@ -251,6 +267,25 @@ class SAStackFn(Function):
             src = x3 if l == 0 else ys[l - 1]
             src_coef = None if l == 0 else coefs[l - 1]
             need_w = ctx.needs_input_grad[3 + 3 * l]
+            if ctx.k4 and l == 1:
+                # second layer over the rebuilt first activation: its fused norm backward + weight
+                # gradient, then ONLY the reductions of its input gradient -- they determine the
+                # first layer's norm backward and weight gradient (nesie_k4_first_layer_wgrad)
+                assert pending is not None
+                w0 = params[0]
+                w0c = w0.reshape(w0.shape[0], c0)
+                dgamma, dbeta = _dst(slots[4], g, cout), _dst(slots[5], g, cout)
+                dw = _dst(slots[3], g, 1, cout, cin)
+                backend.pw_wgrad_bn_backward_k4(pending[0], ys[1], coefs[1], params[4], pending[1], x3, w0c,
+                                                coefs[0], dw, dgamma, dbeta, final=slots[3] is not None)
+                grads[3], grads[4], grads[5] = dw.view_as(w), dgamma, dbeta
+                part, g_part = backend.pw_dgrad_bn_reduce_k4(pending[0], w2.t(), x3, w0c, coefs[0])
+                dgamma0, dbeta0 = _dst(slots[1], g, cin), _dst(slots[2], g, cin)
+                bnb = backend.pw_bnb_coef(part, coefs[0], params[1], float(B) * float(P), dgamma0, dbeta0)
+                dw0 = _dst(slots[0], g, cin, c0)
+                backend.k4_first_layer_wgrad(x3, w0c, bnb, g_part, dw0)
+                grads[0], grads[1], grads[2] = dw0.view_as(w0), dgamma0, dbeta0
+                break
             if pending is not None:     # norm backward of this layer, with its weight gradient
                 dy, dw, dgamma, dbeta = _norm_backward_wgrad(
                     backend, pending[0], ys[l], params[3 * l + 1], coefs[l], pending[1], src, src_coef,

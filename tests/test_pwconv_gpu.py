@@ -408,6 +408,97 @@ def _sa_module(c_in, mlp, ns):
                          normalize_xyz=True).to(_dev())
 
 
+def test_sa1_rebuilt_first_activation_matches_the_stored_form_and_the_module_path():
+    """Round 5: 4 -> 64 -> 64 -> 128 with the first layer's output never stored (fused_mlp.SA1_K4):
+    same output, running statistics and all nine parameter gradients as the stored form and as the
+    module-by-module path; bitwise equal on a repeat."""
+    from nesie_amd.mmdet3d_ops import fused_mlp
+    sa = _sa_module(1, [64, 64, 128], 64)
+    with torch.no_grad():
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(-1.0, 1.5)
+                m.bias.normal_(0, 0.3)
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    xyz = torch.rand(3, 2048, 3, device=_dev(), generator=g)
+    feats = torch.rand(3, 1, 2048, device=_dev(), generator=g) * 2.5      # (a height: not centred)
+    seen = []
+
+    def run(enabled, k4):
+        fused_mlp.ENABLED, fused_mlp.SA1_K4 = enabled, k4
+        for p_ in sa.parameters():
+            p_.grad = None
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.zero_(); m.running_var.fill_(1.0)
+        _, out, _ = sa(xyz, feats)
+        seen.append(out.grad_fn)
+        (out * torch.linspace(-1, 1, out.numel(), device=_dev()).view_as(out)).sum().backward()
+        stats = [m.running_var.clone() for m in sa.modules() if isinstance(m, torch.nn.BatchNorm2d)] \
+            + [m.running_mean.clone() for m in sa.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        return out.detach(), [p_.grad.clone() for p_ in sa.parameters()], stats
+
+    keep = fused_mlp.SA1_K4
+    try:
+        module = run(False, False)
+        stored = run(True, False)
+        rebuilt = run(True, True)
+        again = run(True, True)
+    finally:
+        fused_mlp.ENABLED, fused_mlp.SA1_K4 = True, keep
+    assert torch.equal(rebuilt[0], again[0]) and all(torch.equal(a, b) for a, b in zip(rebuilt[1], again[1]))
+    for want in (stored, module):
+        torch.testing.assert_close(rebuilt[0], want[0], rtol=1e-4, atol=1e-4)
+        for a, b in zip(rebuilt[1], want[1]):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(b.abs().max().item(), 1e-3))
+        for a, b in zip(rebuilt[2], want[2]):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_k4_first_layer_weight_gradient_from_reductions_against_float64():
+    """nesie_pw_dgrad_bn_reduce_k4 + nesie_pw_bnb_coef + nesie_k4_first_layer_wgrad against the
+    float64 chain  dA0 = W1^T dZ1,  dZ0 = bn_relu_backward(dA0, Z0),  dW0 = dZ0 X4^T  at SA1's
+    positions-per-scene with a biased fourth input row."""
+    hip = _hip()
+    g = torch.Generator(device=_dev()).manual_seed(11)
+    nb, p = 2, 8192
+    x4 = torch.randn(nb, 4, p, device=_dev(), generator=g)
+    x4[:, 3] = x4[:, 3].abs() + 1.0
+    w0 = torch.randn(64, 4, device=_dev(), generator=g) * 0.5
+    w1 = torch.randn(64, 64, device=_dev(), generator=g) * 0.2
+    dz1 = torch.randn(nb, 64, p, device=_dev(), generator=g)
+    gamma = torch.randn(64, device=_dev(), generator=g)
+    beta = torch.randn(64, device=_dev(), generator=g) * 0.3
+    # Z0 as the kernels rebuild it (one fma chain), then everything else in float64
+    z0 = torch.addcmul(torch.addcmul(torch.addcmul(w0[:, 0].view(1, -1, 1) * x4[:, 0:1], w0[:, 1].view(1, -1, 1), x4[:, 1:2]),
+                                     w0[:, 2].view(1, -1, 1), x4[:, 2:3]), w0[:, 3].view(1, -1, 1), x4[:, 3:4])
+    zd = z0.double()
+    mean, invstd = zd.mean((0, 2)), (zd.var((0, 2), unbiased=False) + 1e-5).rsqrt()
+    scale = gamma.double() * invstd
+    zcoef = torch.stack([scale, beta.double() - mean * scale, mean, invstd], -1).float().contiguous()
+    zc = zcoef.double()
+    da0 = torch.matmul(w1.double().t(), dz1.double())
+    act = zd * zc[:, 0].view(1, -1, 1) + zc[:, 1].view(1, -1, 1)
+    gg = torch.where(act > 0, da0, torch.zeros_like(da0))
+    zhat = (zd - zc[:, 2].view(1, -1, 1)) * zc[:, 3].view(1, -1, 1)
+    n = nb * p
+    s0, s1 = gg.sum((0, 2)), (gg * zhat).sum((0, 2))
+    dz0 = (gamma.double() * zc[:, 3]).view(1, -1, 1) * (gg - (s0 / n).view(1, -1, 1) - zhat * (s1 / n).view(1, -1, 1))
+    want = torch.bmm(dz0, x4.double().transpose(1, 2)).sum(0)
+    # knife-edge positions (|act| tiny) may fall on the other side in fp32: exclude none, allow for them
+    part, g_part = hip.pw_dgrad_bn_reduce_k4(dz1, w1.t(), x4, w0, zcoef)
+    dgamma, dbeta = torch.empty(64, device=_dev()), torch.empty(64, device=_dev())
+    bnb = hip.pw_bnb_coef(part, zcoef, gamma, float(n), dgamma, dbeta)
+    dw0 = torch.empty(64, 4, device=_dev())
+    hip.k4_first_layer_wgrad(x4, w0, bnb, g_part, dw0)
+    torch.cuda.synchronize()
+    assert (dw0.double() - want).abs().max().item() < 2e-4 * want.abs().max().item()
+    torch.testing.assert_close(dbeta.double(), s0, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dgamma.double(), s1, rtol=1e-4, atol=1e-3)
+    gx = torch.einsum('ncp,njp->cj', gg, x4.double())
+    torch.testing.assert_close(g_part.double().sum(1), gx, rtol=1e-4, atol=1e-3 * gx.abs().max().item())
+
+
 @pytest.mark.parametrize('c_in,mlp,ns', [(1, [64, 64, 128], 64), (128, [128, 128, 256], 32),
                                          (256, [128, 128, 256], 16)])
 def test_fused_sa_stack_matches_the_module_by_module_path(c_in, mlp, ns):
