@@ -714,7 +714,11 @@ int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p, const 
  * backward for the first.  Z0 = W0 . X4 (X4 = the grouped coordinates + height, (nb, 4, p), 17 MB at
  * 8 x 131 072 positions; Z0 would be 268 MB) is rebuilt from X4 with one fixed fma chain wherever
  * it is an operand, and the first layer's weight gradient follows from reductions:
- *  - nesie_mlp_layer_forward_stream with y == NULL leaves only the statistics of Z0;
+ *  - nesie_k4_moments: the first and second moments of X4 (20 sums, per-workgroup partials in
+ *    double, nesie_k4_moments_bytes() bytes); nesie_k4_stat_finalize: the first layer's BatchNorm
+ *    statistics from them -- mean(Z0[c]) = W0[c] . mean(X4), var(Z0[c]) = W0[c]^T Cov(X4) W0[c] --
+ *    as coef [64][4] = (scale, bias, mean, invstd) + the running statistics (no pass over Z0;
+ *    nesie_mlp_layer_forward_stream with y == NULL is the direct form of the same statistics);
  *  - nesie_pw_layer_forward_k4: the second layer, y = W . relu(in_coef . Z0) (cout = 64; w0 (64, 4)
  *    row-major; in_coef [64][4] the first layer's folded norm), with statistics like
  *    nesie_pw_layer_forward;
@@ -726,7 +730,7 @@ int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long long p, const 
  *    (nslots = nesie_pw_stat_slots(nb, 1, k, 64, p));
  *  - nesie_k4_first_layer_wgrad: dW0[m][j] = a G[m][j] + e0 Sx[j] + d1 (mu Sx[j] - sum_k W0[m][k] M[k][j])
  *    with (.., a, mu, d1, e0, ..) = bnb[m][2..5] of nesie_pw_bnb_coef over that bn_part, G the slot
- *    sums of g_part, Sx / M the first and second moments of X4 (computed here, in double).
+ *    sums of g_part, Sx / M the first and second moments of X4 (mom_part of nesie_k4_moments).
  * All of it requires no gradient for X4 (the backbone's grouped input coordinates). */
 int nesie_pw_layer_forward_k4(int nb, int cout, long long p, const float *x4, long long x4_bstride,
                               const float *w0, const float *w, int w_rstride, int w_cstride,
@@ -742,10 +746,14 @@ int nesie_pw_wgrad_bn_backward_k4(int nb, long long p, const float *da, const fl
                                   long long x4_bstride, const float *w0, const float *x_coef,
                                   float *dz, float *dw, float *dgamma, float *dbeta, float *coef_ws,
                                   void *workspace, size_t workspace_bytes, int defer, void *stream);
-size_t nesie_k4_first_layer_wgrad_workspace_bytes(void);
-int nesie_k4_first_layer_wgrad(int nb, long long p, const float *x4, long long x4_bstride,
-                               const float *w0, const float *bnb, const float *g_part, int nslots,
-                               float *dw, void *workspace, size_t workspace_bytes, void *stream);
+size_t nesie_k4_moments_bytes(void);
+int nesie_k4_moments(int nb, long long p, const float *x4, long long x4_bstride, void *mom_part,
+                     void *stream);
+int nesie_k4_stat_finalize(double count, const void *mom_part, const float *w0, const float *gamma,
+                           const float *beta, float *running_mean, float *running_var, float momentum,
+                           float eps, float *coef, void *stream);
+int nesie_k4_first_layer_wgrad(const void *mom_part, const float *w0, const float *bnb,
+                               const float *g_part, int nslots, float *dw, void *stream);
 
 /* Weight gradient of a 1x1 conv on the matrix cores: dw[cout][cin] = sum over scenes and
  * positions of dy[b][m][p] * act(x[b][k][p]); dy (B, cout, p), x[b] (cin, p) at x + b*x_bstride,

@@ -601,42 +601,103 @@ __global__ __launch_bounds__(256) void k4_moments_kernel(int nb, long long p, lo
   }
 }
 
-// one 64-lane workgroup per channel
-__global__ __launch_bounds__(64) void k4_wgrad_finish_kernel(int nslots, const double *__restrict__ mom_part,
-                                                             const float *__restrict__ g_part,
-                                                             const float *__restrict__ bnb,
-                                                             const float *__restrict__ w0, float *__restrict__ dw) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  __shared__ double mom[20];
+// one 256-thread workgroup per channel: thread t folds moment partial t, wave 0 the channel's slots
+__global__ __launch_bounds__(256) void k4_wgrad_finish_kernel(int nslots, const double *__restrict__ mom_part,
+                                                              const float *__restrict__ g_part,
+                                                              const float *__restrict__ bnb,
+                                                              const float *__restrict__ w0, float *__restrict__ dw) {
+  static_assert(K4_MOM_WGS == 256, "one partial per thread");
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double red[4][20];
+  __shared__ double gs[4];
+  double m[20];
+#pragma unroll
+  for (int u = 0; u < 20; ++u) m[u] = mom_part[(size_t)tid * 20 + u];
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+  if (wave == 0) {
+    const float4 *gp = (const float4 *)g_part + (size_t)c * nslots;
+    for (int i = lane; i < nslots; i += 64) {
+      const float4 q = gp[i];
+      g[0] += (double)q.x; g[1] += (double)q.y; g[2] += (double)q.z; g[3] += (double)q.w;
+    }
+  }
+#pragma unroll
   for (int u = 0; u < 20; ++u) {
-    double t = 0.0;
-    for (int i = lane; i < K4_MOM_WGS; i += 64) t += mom_part[(size_t)i * 20 + u];
+    double t = m[u];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    if (lane == 0) mom[u] = t;
+    if (lane == 0) red[wave][u] = t;
   }
-  double g[4] = {0.0, 0.0, 0.0, 0.0};
-  const float4 *gp = (const float4 *)g_part + (size_t)c * nslots;
-  for (int i = lane; i < nslots; i += 64) {
-    const float4 q = gp[i];
-    g[0] += (double)q.x; g[1] += (double)q.y; g[2] += (double)q.z; g[3] += (double)q.w;
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double t = g[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (lane == 0) gs[j] = t;
+    }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) g[j] += __shfl_xor(g[j], off, 64);
   __syncthreads();
-  if (lane < 4) {
-    const int j = lane;
+  if (tid < 4) {
+    const int j = tid;
+    auto mom = [&](int u) { return (red[0][u] + red[1][u]) + (red[2][u] + red[3][u]); };
     const double a = bnb[c * 8 + 2], mu = bnb[c * 8 + 3], d1 = bnb[c * 8 + 4], e0 = bnb[c * 8 + 5];
     double zx = 0.0;
     for (int k = 0; k < 4; ++k) {
-      const double mkj = k <= j ? mom[4 + 4 * k + j] : mom[4 + 4 * j + k];   // (upper triangle stored)
+      const double mkj = k <= j ? mom(4 + 4 * k + j) : mom(4 + 4 * j + k);   // (upper triangle stored)
       zx += (double)w0[c * 4 + k] * mkj;
     }
-    const double gj = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
-    dw[c * 4 + j] = (float)(a * gj + e0 * mom[j] + d1 * (mu * mom[j] - zx));
+    const double sx = mom(j);
+    dw[c * 4 + j] = (float)(a * gs[j] + e0 * sx + d1 * (mu * sx - zx));
   }
+}
+
+// The first layer's BatchNorm statistics from the same moments: mean(Z0[c]) = W0[c] . mean(X4),
+// var(Z0[c]) = W0[c]^T Cov(X4) W0[c] (the covariance formed first, in double) -- no pass over Z0.
+__global__ __launch_bounds__(256) void k4_stat_finalize_kernel(double n, const double *__restrict__ mom_part,
+                                                               const float *__restrict__ w0,
+                                                               const float *gamma, const float *beta,
+                                                               float *running_mean, float *running_var,
+                                                               float momentum, float eps, float *__restrict__ coef) {
+  static_assert(K4_MOM_WGS == 256, "one partial per thread");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double red[4][20];
+  double m[20];
+#pragma unroll
+  for (int u = 0; u < 20; ++u) m[u] = mom_part[(size_t)tid * 20 + u];
+#pragma unroll
+  for (int u = 0; u < 20; ++u) {
+    double t = m[u];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) red[wave][u] = t;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int c = tid;
+  auto mom = [&](int u) { return (red[0][u] + red[1][u]) + (red[2][u] + red[3][u]); };
+  double mu[4], cov[4][4];
+  for (int j = 0; j < 4; ++j) mu[j] = mom(j) / n;
+  for (int j = 0; j < 4; ++j)
+    for (int k = j; k < 4; ++k) cov[j][k] = cov[k][j] = mom(4 + 4 * j + k) / n - mu[j] * mu[k];
+  double mean = 0.0, var = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    const double wj = (double)w0[c * 4 + j];
+    mean += wj * mu[j];
+    for (int k = 0; k < 4; ++k) var += wj * (double)w0[c * 4 + k] * cov[j][k];
+  }
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  if (running_mean) {
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+  const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  coef[c * 4 + 0] = (float)(g * invstd);
+  coef[c * 4 + 1] = (float)(bt - mean * g * invstd);
+  coef[c * 4 + 2] = (float)mean;
+  coef[c * 4 + 3] = (float)invstd;
 }
 
 static int stream_cols(int b, long long p) {
@@ -685,23 +746,42 @@ extern "C" int nesie_mlp_layer_forward_stream(int b, int cin, int cout, long lon
   return check_launch(W);
 }
 
-extern "C" size_t nesie_k4_first_layer_wgrad_workspace_bytes(void) { return (size_t)nesie::K4_MOM_WGS * 20 * sizeof(double); }
+extern "C" size_t nesie_k4_moments_bytes(void) { return (size_t)nesie::K4_MOM_WGS * 20 * sizeof(double); }
 
-// dW0 (64, 4) of SA1's first layer from the reductions alone (see k4_moments_kernel): x4 (nb, 4, p)
-// the layer's input, bnb [64][8] the norm backward's coefficients (nesie_pw_bnb_coef over the
-// bn_part of nesie_pw_dgrad_bn_reduce_k4), g_part [64][nslots][4] of the same launch.
-extern "C" int nesie_k4_first_layer_wgrad(int nb, long long p, const float *x4, long long x4_bstride,
-                                          const float *w0, const float *bnb, const float *g_part,
-                                          int nslots, float *dw, void *workspace, size_t workspace_bytes,
-                                          void *stream) {
+// First and second moments of x4 (nb, 4, p) as per-workgroup partial sums in double:
+// mom_part [256][20] = (sum X4[j], j = 0 .. 3; sum X4[j] X4[k], k >= j at 4 + 4 j + k).
+extern "C" int nesie_k4_moments(int nb, long long p, const float *x4, long long x4_bstride, void *mom_part,
+                                void *stream) {
+  const char *W = "k4_moments";
+  NESIE_REQUIRE(nb >= 1 && p >= 4 && p % 4 == 0 && x4 && mom_part, W);
+  NESIE_REQUIRE(x4_bstride >= 4 * p && (x4_bstride & 3) == 0 && ((uintptr_t)x4 & 15) == 0 && ((uintptr_t)mom_part & 7) == 0, W);
+  hipLaunchKernelGGL(nesie::k4_moments_kernel, dim3(nesie::K4_MOM_WGS), dim3(256), 0, (hipStream_t)stream, nb, p,
+                     x4_bstride, x4, (double *)mom_part);
+  return check_launch(W);
+}
+
+// coef [64][4] = (scale, bias, mean, invstd) of BatchNorm(W0 . X4) in training mode from the moments
+// of X4 (count = nb * p), running statistics updated like torch.nn.BatchNorm2d.
+extern "C" int nesie_k4_stat_finalize(double count, const void *mom_part, const float *w0, const float *gamma,
+                                      const float *beta, float *running_mean, float *running_var,
+                                      float momentum, float eps, float *coef, void *stream) {
+  const char *W = "k4_stat_finalize";
+  NESIE_REQUIRE(count >= 1.0 && mom_part && w0 && coef, W);
+  NESIE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), W);
+  hipLaunchKernelGGL(nesie::k4_stat_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, count,
+                     (const double *)mom_part, w0, gamma, beta, running_mean, running_var, momentum, eps, coef);
+  return check_launch(W);
+}
+
+// dW0 (64, 4) of SA1's first layer from the reductions alone (see k4_moments_kernel): mom_part the
+// moments of the layer's input (nesie_k4_moments), bnb [64][8] the norm backward's coefficients
+// (nesie_pw_bnb_coef over the bn_part of nesie_pw_dgrad_bn_reduce_k4), g_part [64][nslots][4] of
+// the same launch.
+extern "C" int nesie_k4_first_layer_wgrad(const void *mom_part, const float *w0, const float *bnb,
+                                          const float *g_part, int nslots, float *dw, void *stream) {
   const char *W = "k4_first_layer_wgrad";
-  NESIE_REQUIRE(nb >= 1 && p >= 4 && p % 4 == 0 && nslots >= 1 && x4 && w0 && bnb && g_part && dw && workspace, W);
-  NESIE_REQUIRE(x4_bstride >= 4 * p && (x4_bstride & 3) == 0 && ((uintptr_t)x4 & 15) == 0 && ((uintptr_t)g_part & 15) == 0, W);
-  NESIE_REQUIRE(workspace_bytes >= nesie_k4_first_layer_wgrad_workspace_bytes() && ((uintptr_t)workspace & 7) == 0, W);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(nesie::k4_moments_kernel, dim3(nesie::K4_MOM_WGS), dim3(256), 0, s, nb, p, x4_bstride, x4,
-                     (double *)workspace);
-  hipLaunchKernelGGL(nesie::k4_wgrad_finish_kernel, dim3(64), dim3(64), 0, s, nslots, (const double *)workspace,
-                     g_part, bnb, w0, dw);
+  NESIE_REQUIRE(nslots >= 1 && mom_part && w0 && bnb && g_part && dw && ((uintptr_t)g_part & 15) == 0, W);
+  hipLaunchKernelGGL(nesie::k4_wgrad_finish_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, nslots,
+                     (const double *)mom_part, g_part, bnb, w0, dw);
   return check_launch(W);
 }

@@ -273,7 +273,7 @@ static int pw_forward_impl(const char *W, int nb, int ng, int k, int cout, long 
   const int grid = a.nwg_g * ng * g.nhalf;
   static const bool xcd_on = !(getenv("NESIE_PW_XCD") && atoi(getenv("NESIE_PW_XCD")) == 0);   // A/B switch
   a.xcd_map = (xcd_on && g.nhalf > 1 && grid % (8 * g.nhalf) == 0) ? 1 : 0;
-  const size_t lds = pw_lds_bytes(g);
+  const size_t lds = pw_lds_bytes(g) + (k4_gpart ? 2048 : 0);    // (PW_K4Z: + the tile's X4, two halves)
   hipStream_t s = (hipStream_t)stream;
   int st = NESIE_ERR_UNSUPPORTED;
 #define G(KT16, KH, WR, WC, RW)                                                          \

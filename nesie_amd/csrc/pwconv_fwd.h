@@ -217,6 +217,7 @@ void pw_fwd_kernel(const PwFwd a) {
   constexpr int ROWSTEP = NT / CPR;                      // rows between two slots of a thread
   constexpr int CROWS = WR * RW * 16;                    // output rows per workgroup
   constexpr int SPC = (EPI & PW_SPARSE128) ? 128 : (EPI & PW_SPARSE256) ? 256 : 0;   // built operand rows
+  constexpr bool K4Z = (EPI & PW_K4Z) != 0;
   static_assert(SPC % ROWSTEP == 0 && (SPC == 0 || (NCH == NX * NT && SPC < KH * KT)), "sparse rows");
   static_assert(NT % CPR == 0 && (PG == 16 || PG == 32), "tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -371,10 +372,18 @@ void pw_fwd_kernel(const PwFwd a) {
   auto QQ = [&](const Cursor &c) { return a.rev ? nq - 1 - c.q : c.q; };
   auto RR = [&](const Cursor &c) { return a.rev ? tpb - 1 - c.r : c.r; };
   f32x4 stg[NX];
+  // PW_K4Z: one more staging register -- this thread's 16 bytes of the tile's X4 rows (row (tid / 16) % 4)
+  f32x4 stx = {0.f, 0.f, 0.f, 0.f};
+  const unsigned k4z_goff = (unsigned)((((size_t)((tid >> 4) & 3)) * p + (tid & 15) * 4) * 4);
+  const unsigned k4z_lw = lds_addr(lds) + (unsigned)(2 * TILE * 4) + (unsigned)(((((tid >> 4) & 3) * 64) + (tid & 15) * 4) * 4);
   // loads of slot i of sub-tile c (kh compile-time) into its staging registers; `live` false:
   // the sub-tile does not exist, read the first words of the tensor instead
   auto load_slot = [&](auto ic, auto khc, const Cursor &c, bool live) {
     constexpr int i = decltype(ic)::value, kh = decltype(khc)::value;
+    if constexpr (K4Z && i == 0) {
+      const float *x4 = a.bn_z + (size_t)(g + a.ng * QQ(c)) * a.bnz_bs + (size_t)RR(c) * PT;   // wave-uniform
+      stx = load16_saddr(live ? k4z_goff : 0u, live ? x4 : a.bn_z);
+    }
     if constexpr (SPC > 0 && kh * KT + slot_row(i) < SPC) {
       // wave-uniform: first entry of the tile's first group, row kh KT + slot_row(i)
       const float2 *eb = a.sp_ent + ((size_t)(g + a.ng * QQ(c)) * a.sp_groups + (size_t)(((long long)RR(c) * PT) >> a.sp_ns_shift)) * SPC
@@ -399,18 +408,18 @@ void pw_fwd_kernel(const PwFwd a) {
     }
   };
   // previous layer's BatchNorm + ReLU in registers, then into LDS buffer `buf` (0 / 1)
-  f32x4 k4x[(EPI & PW_K4IN) ? 4 : 1];      // PW_K4IN: the four rows of X4 of the sub-tile being written
   auto write_slot = [&](auto ic, auto khc, int buf) {
     constexpr int i = decltype(ic)::value;
     f32x4 q = stg[i];
     if constexpr ((EPI & PW_K4IN) != 0) {
-      // (slot 0 is written first and re-loaded right behind its write: keep all four rows)
-      if constexpr (i == 0) {
+      // (every slot needs all four rows: the four writes of a sub-tile run together, in front of its re-loads)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k4x[j] = stg[j];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) q[e] = k4_dot(k4w[i], k4x[0][e], k4x[1][e], k4x[2][e], k4x[3][e]);
+      for (int e = 0; e < 4; ++e) q[e] = k4_dot(k4w[i], stg[0][e], stg[1][e], stg[2][e], stg[3][e]);
+    }
+    if constexpr (K4Z) {
+      // X4 of the tile whose operand this is -> its 1 KB next to the operand buffer (all 256 threads
+      // write; rows repeat four times with the same words)
+      if constexpr (i == 0) lds_write_b128<0>(k4z_lw + (unsigned)(buf * 1024), stx);
     }
     if constexpr (SPC > 0 && decltype(khc)::value * KT + slot_row(i) < SPC) {
       const int at = __float_as_int(q[1]) - sp_pos0;
@@ -458,10 +467,8 @@ void pw_fwd_kernel(const PwFwd a) {
 
   // PW_BNRED: the raw output Z of the layer whose activation gradient this launch produces, at
   // this lane's output elements (loaded ahead of the MFMAs of the tile's last sub-tile), and the sums
-  constexpr bool K4Z = (EPI & PW_K4Z) != 0;
-  static_assert(!K4Z || ((EPI & PW_BNRED) && !RAGGED), "PW_K4Z rides on PW_BNRED");
+  static_assert(!K4Z || ((EPI & PW_BNRED) && !RAGGED && WC == 1), "PW_K4Z rides on PW_BNRED");
   f32x4 zv[((EPI & PW_BNRED) && !K4Z) ? RW : 1][4];
-  f32x4 xz[K4Z ? 4 : 1][4];                // PW_K4Z: X4 rows at this lane's output positions
   float4 k4zw[K4Z ? RW : 1];               // ... and W0 rows of its channels
   float gx[K4Z ? RW : 1][4];               // ... sums of g . X4[j]
   float r0[RW], r1[RW];
@@ -483,13 +490,7 @@ void pw_fwd_kernel(const PwFwd a) {
   auto row_ok = [&](int rw) { return !RAGGED || c0 + (wr * RW + rw) * 16 + l16 < cout; };
   auto load_z = [&](int n, long long p0) {
     const float *zt = a.bn_z + (size_t)n * a.bnz_bs + p0;   // wave-uniform
-    if constexpr (K4Z) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xz[j][r] = load16_saddr((unsigned)(q0 * 4) + 4u * RS * r, zt + (size_t)j * p);
-      return;
-    }
+    if constexpr (K4Z) return;      // (X4 of the tile lies in LDS: staged with the operand)
 #pragma unroll
     for (int rw = 0; rw < RW; ++rw) {
 #pragma unroll
@@ -522,6 +523,7 @@ void pw_fwd_kernel(const PwFwd a) {
 
   // accumulators: acc[rw][e][r] = Y[row set rw][position q0 + RS r + e]
   f32x4 acc[RW][4];
+  int k4z_buf = 0;                         // PW_K4Z: the LDS half that holds the current tile's X4
   auto epilogue = [&](int n, long long p0) {
     float *ytile = a.y + (size_t)n * a.y_bs + p0;        // wave-uniform
     static_for<0, RW>([&](auto rwc) {
@@ -543,21 +545,45 @@ void pw_fwd_kernel(const PwFwd a) {
           });
         }
       }
-      if (EPI & PW_BNRED) {
+      if constexpr (K4Z) {
+        // X4 at this lane's positions 16 r + 4 quad + e from the tile's LDS copy, one r ahead
+        f32x4 xr[2][4];
+        const unsigned xa = lds_addr(lds) + (unsigned)(2 * TILE * 4) + (unsigned)(k4z_buf * 1024) + (unsigned)(16 * quad);
+        static_for<0, 4>([&](auto jc) { xr[0][decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 256>(xa); });
+        static_for<0, 4>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if constexpr (r < 3) {
+            static_for<0, 4>([&](auto jc) {
+              xr[(r + 1) & 1][decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 256 + (r + 1) * 64>(xa);
+            });
+            lgkm_wait<4>();
+          } else {
+            lgkm_wait<0>();
+          }
+          // (the reads are asm: pin their destinations BEHIND the wait, or the uses are scheduled in front of it)
+          asm volatile("" : "+v"(xr[r & 1][0]), "+v"(xr[r & 1][1]), "+v"(xr[r & 1][2]), "+v"(xr[r & 1][3]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = xr[r & 1][0][e], x1 = xr[r & 1][1][e], x2 = xr[r & 1][2][e], x3 = xr[r & 1][3][e];
+            const float z = k4_dot(k4zw[rw], x0, x1, x2, x3);
+            const float gg = __builtin_fmaf(z, zc[rw].x, zc[rw].y) > 0.f ? acc[rw][e][r] : 0.f;
+            r0[rw] += gg;
+            r1[rw] += gg * ((z - zc[rw].z) * zc[rw].w);
+            gx[rw][0] = __builtin_fmaf(gg, x0, gx[rw][0]);
+            gx[rw][1] = __builtin_fmaf(gg, x1, gx[rw][1]);
+            gx[rw][2] = __builtin_fmaf(gg, x2, gx[rw][2]);
+            gx[rw][3] = __builtin_fmaf(gg, x3, gx[rw][3]);
+          }
+        });
+      } else if (EPI & PW_BNRED) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float z;
-            if constexpr (K4Z) z = k4_dot(k4zw[rw], xz[0][r][e], xz[1][r][e], xz[2][r][e], xz[3][r][e]);
-            else z = zv[rw][r][e];
+            const float z = zv[rw][r][e];
             const float gg = __builtin_fmaf(z, zc[rw].x, zc[rw].y) > 0.f ? acc[rw][e][r] : 0.f;
             r0[rw] += gg;
             r1[rw] += gg * ((z - zc[rw].z) * zc[rw].w);
-            if constexpr (K4Z) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) gx[rw][j] = __builtin_fmaf(gg, xz[j][r][e], gx[rw][j]);
-            }
           }
       }
       if (EPI & PW_STATS) {
@@ -772,12 +798,20 @@ void pw_fwd_kernel(const PwFwd a) {
         if constexpr (kk >= S0 && (kk - S0) % 2 == 0 && (kk - S0) / 2 < NX) {
           constexpr int i = (kk - S0) / 2;
           // the sub-tile after this one has kh + 1 (mod KH), the one after that kh + 2 (mod KH)
-          write_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 1) % KH>{}, buf ^ 1);
-          load_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 2) % KH>{}, ld, have2);
+          if constexpr ((EPI & PW_K4IN) != 0) {
+            if constexpr (i == 0) {
+              static_for<0, NX>([&](auto jc) { write_slot(jc, std::integral_constant<int, 0>{}, buf ^ 1); });
+              static_for<0, NX>([&](auto jc) { load_slot(jc, std::integral_constant<int, 0>{}, ld, have2); });
+            }
+          } else {
+            write_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 1) % KH>{}, buf ^ 1);
+            load_slot(std::integral_constant<int, i>{}, std::integral_constant<int, (kh + 2) % KH>{}, ld, have2);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       });
       STAMP(2)
+      if constexpr (K4Z) k4z_buf = buf;
       if (kh == KH - 1) epilogue(n, p0);
       STAMP(3)
       cur = nxt;

@@ -1064,17 +1064,35 @@ class HipKernels(_BNPoolMixin):
                       x4.stride(0) if nb > 1 else 4 * p, _ptr(w0), _ptr(x_coef), _ptr(da), _ptr(dw),
                       _ptr(dgamma), _ptr(dbeta), _ptr(cws), _ptr(ws), need, int(defer), _stream(da))
 
-    def k4_first_layer_wgrad(self, x4, w0, bnb, g_part, dw):
-        """dW0 (64, 4) from the reductions (nesie_k4_first_layer_wgrad): bnb (64, 8) from
-        ``pw_bnb_coef`` over the part of ``pw_dgrad_bn_reduce_k4``, g_part (64, slots, 4) of the same."""
-        nb, p = self._k4_check(x4, w0)
-        _check(bnb, g_part, dw); _f32(bnb, g_part, dw)
-        assert tuple(bnb.shape) == (64, 8) and g_part.shape[0] == 64 and g_part.shape[2] == 4 and dw.numel() == 256
-        need = _lib.load().nesie_k4_first_layer_wgrad_workspace_bytes()
+    def k4_moments(self, x4):
+        """-> (256, 20) float64 per-workgroup partial sums of X4[j] and X4[j] X4[k] (nesie_k4_moments)."""
+        _f32(x4)
+        nb, c, p = x4.shape
+        assert x4.is_cuda and c == 4 and x4.stride(2) == 1 and x4.stride(1) == p
+        need = _lib.load().nesie_k4_moments_bytes()
         with torch.cuda.device(x4.device):
-            ws = torch.empty(need // 8, dtype=torch.float64, device=x4.device)
-            _lib.call("nesie_k4_first_layer_wgrad", nb, p, _ptr(x4), x4.stride(0) if nb > 1 else 4 * p, _ptr(w0),
-                      _ptr(bnb), _ptr(g_part), g_part.shape[1], _ptr(dw), _ptr(ws), need, _stream(x4))
+            mom = torch.empty(need // 160, 20, dtype=torch.float64, device=x4.device)
+            _lib.call("nesie_k4_moments", nb, p, _ptr(x4), x4.stride(0) if nb > 1 else 4 * p, _ptr(mom), _stream(x4))
+        return mom
+
+    def k4_stat_finalize(self, mom, w0, gamma, beta, running_mean, running_var, momentum, eps, count, coef):
+        """Training-mode BatchNorm coefficients of W0 . X4 from the moments of X4 (nesie_k4_stat_finalize)."""
+        _check(mom, w0, coef); _f32(w0, coef)
+        assert mom.dtype == torch.float64 and tuple(w0.shape) == (64, 4) and tuple(coef.shape) == (64, 4)
+        opt = lambda t: 0 if t is None else _ptr(t)  # noqa: E731
+        with torch.cuda.device(mom.device):
+            _lib.call("nesie_k4_stat_finalize", float(count), _ptr(mom), _ptr(w0), opt(gamma), opt(beta),
+                      opt(running_mean), opt(running_var), float(momentum), float(eps), _ptr(coef), _stream(mom))
+
+    def k4_first_layer_wgrad(self, mom, w0, bnb, g_part, dw):
+        """dW0 (64, 4) from the reductions (nesie_k4_first_layer_wgrad): mom from ``k4_moments``, bnb (64, 8)
+        from ``pw_bnb_coef`` over the part of ``pw_dgrad_bn_reduce_k4``, g_part (64, slots, 4) of the same."""
+        _check(mom, w0, bnb, g_part, dw); _f32(w0, bnb, g_part, dw)
+        assert mom.dtype == torch.float64 and tuple(w0.shape) == (64, 4)
+        assert tuple(bnb.shape) == (64, 8) and g_part.shape[0] == 64 and g_part.shape[2] == 4 and dw.numel() == 256
+        with torch.cuda.device(mom.device):
+            _lib.call("nesie_k4_first_layer_wgrad", _ptr(mom), _ptr(w0), _ptr(bnb), _ptr(g_part), g_part.shape[1],
+                      _ptr(dw), _stream(mom))
 
     def pw_dgrad_bn_reduce(self, dy, w, z, z_coef, da, ng=1):
         """da[n] = W[n % ng] . dy[n] (w = the transposed weight view (ng, Cin, Cout)) plus the

@@ -191,6 +191,9 @@ class SAStackFn(Function):
                 part = x.new_empty(1, backend.pw_stat_slots(B, 1, cin, cout, P), cout, 4)
                 backend.pw_layer_forward_k4(x3, w0c, w2[0], coef, y, part)
                 backend.pw_stats_finalize(part, gamma, beta, rm, rv, momentum, eps, new_coef)
+            elif ctx.k4 and l == 0:
+                k4_mom = backend.k4_moments(x3)
+                backend.k4_stat_finalize(k4_mom, w0c, gamma, beta, rm, rv, momentum, eps, float(B) * float(P), new_coef)
             elif l == 0 and cin <= 8 and not last:
                 part = x.new_empty(backend.mlp_stream_parts(B, P), cout, 2)
                 backend.mlp_stream_forward(src, w2[0].contiguous(), y, part)
@@ -220,7 +223,7 @@ class SAStackFn(Function):
         ctx.L, ctx.ns, ctx.fixed_lead = L, ns, int(fixed_lead)
         # gradient slots of (weight, gamma, beta) per layer -- only when a backward will follow
         ctx.slots = [grad_slots.take(t) if ctx.needs_input_grad[3 + j] else None for j, t in enumerate(params)]
-        ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *params)
+        ctx.save_for_backward(x3, pooled, argmax, *ys, *coefs, *params, *([k4_mom] if ctx.k4 else []))
         ctx.mark_non_differentiable(argmax)
         return pooled
 
@@ -230,7 +233,7 @@ class SAStackFn(Function):
         sv = ctx.saved_tensors
         x3, pooled, argmax = sv[:3]
         ys, coefs = sv[3:3 + L], sv[3 + L:3 + 2 * L]
-        params = sv[3 + 2 * L:]
+        params = sv[3 + 2 * L:3 + 5 * L]
         backend = backend_for(g)
         B, c0, P = x3.shape
         M = P // ns
@@ -283,7 +286,7 @@ class SAStackFn(Function):
                 dgamma0, dbeta0 = _dst(slots[1], g, cin), _dst(slots[2], g, cin)
                 bnb = backend.pw_bnb_coef(part, coefs[0], params[1], float(B) * float(P), dgamma0, dbeta0)
                 dw0 = _dst(slots[0], g, cin, c0)
-                backend.k4_first_layer_wgrad(x3, w0c, bnb, g_part, dw0)
+                backend.k4_first_layer_wgrad(sv[3 + 5 * L], w0c, bnb, g_part, dw0)
                 grads[0], grads[1], grads[2] = dw0.view_as(w0), dgamma0, dbeta0
                 break
             if pending is not None:     # norm backward of this layer, with its weight gradient

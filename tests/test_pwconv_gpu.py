@@ -455,6 +455,30 @@ def test_sa1_rebuilt_first_activation_matches_the_stored_form_and_the_module_pat
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_k4_statistics_from_input_moments_against_float64():
+    """nesie_k4_moments + nesie_k4_stat_finalize: BatchNorm coefficients and running statistics of
+    W0 . X4 without forming it, against float64 statistics of the product."""
+    hip = _hip()
+    g = torch.Generator(device=_dev()).manual_seed(3)
+    nb, p = 3, 4096
+    x4 = torch.randn(nb, 4, p, device=_dev(), generator=g)
+    x4[:, 3] = x4[:, 3].abs() * 0.7 + 1.3
+    w0 = torch.randn(64, 4, device=_dev(), generator=g)
+    gamma = torch.randn(64, device=_dev(), generator=g)
+    beta = torch.randn(64, device=_dev(), generator=g)
+    rm, rv = torch.zeros(64, device=_dev()), torch.ones(64, device=_dev())
+    coef = torch.empty(64, 4, device=_dev())
+    hip.k4_stat_finalize(hip.k4_moments(x4), w0, gamma, beta, rm, rv, 0.1, 1e-5, float(nb * p), coef)
+    z = torch.einsum('cj,njp->ncp', w0.double(), x4.double())
+    mean, var = z.mean((0, 2)), z.var((0, 2), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    want = torch.stack([gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd, mean, invstd], -1)
+    torch.testing.assert_close(coef.double(), want, rtol=2e-5, atol=2e-5)
+    n = nb * p
+    torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * n / (n - 1), rtol=1e-5, atol=1e-6)
+
+
 def test_k4_first_layer_weight_gradient_from_reductions_against_float64():
     """nesie_pw_dgrad_bn_reduce_k4 + nesie_pw_bnb_coef + nesie_k4_first_layer_wgrad against the
     float64 chain  dA0 = W1^T dZ1,  dZ0 = bn_relu_backward(dA0, Z0),  dW0 = dZ0 X4^T  at SA1's
@@ -490,7 +514,7 @@ def test_k4_first_layer_weight_gradient_from_reductions_against_float64():
     dgamma, dbeta = torch.empty(64, device=_dev()), torch.empty(64, device=_dev())
     bnb = hip.pw_bnb_coef(part, zcoef, gamma, float(n), dgamma, dbeta)
     dw0 = torch.empty(64, 4, device=_dev())
-    hip.k4_first_layer_wgrad(x4, w0, bnb, g_part, dw0)
+    hip.k4_first_layer_wgrad(hip.k4_moments(x4), w0, bnb, g_part, dw0)
     torch.cuda.synchronize()
     assert (dw0.double() - want).abs().max().item() < 2e-4 * want.abs().max().item()
     torch.testing.assert_close(dbeta.double(), s0, rtol=1e-4, atol=1e-3)
