@@ -91,9 +91,15 @@ class GemmTimer:
 
     BIG = 32768
 
-    def __init__(self, backend, method, flops):
+    def __init__(self, backend, method, flops, also=()):
+        """``also`` = [(method, flops)]: more entry points counted in the same class (the forms of
+        this one for SA1's rebuilt first activation)."""
         self.events, self.work, self.enabled = [], [], False
         self.method = method
+        for name, fl in ((method, flops),) + tuple(also):
+            self._wrap(backend, name, fl)
+
+    def _wrap(self, backend, method, flops):
         inner = getattr(backend, method)
 
         def wrapped(*args, **kw):
@@ -105,7 +111,7 @@ class GemmTimer:
             r = inner(*args, **kw)
             e.record()
             self.events.append((s, e))
-            self.work.append(flops(*args, **kw))
+            self.work.append(tuple(flops(*args, **kw)) + (method,))
             return r
         setattr(backend, method, wrapped)
 
@@ -122,8 +128,7 @@ class GemmTimer:
         """-> [(shape signature, ms, flop, algorithmic bytes)] of every recorded launch."""
         out = []
         for (s, e), w in zip(self.events, self.work):
-            sig = w[3] if len(w) > 3 else ''
-            out.append((f'{self.method}{sig}', s.elapsed_time(e), w[0], w[1]))
+            out.append((f'{w[4]}{w[3]}', s.elapsed_time(e), w[0], w[1]))
         return out
 
 
@@ -916,9 +921,25 @@ def main():
         nb, k, p = z_prev.shape
         c = w.shape[0]
         return 4.0 * nb * c * k * p, 3 * nb * k * p * 4, nb * p, f'[{k}->{c}, {nb}x{p}]'
-    gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop), GemmTimer(hip, 'pw_wgrad', wgrad_flop),
-                   GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop),
-                   GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop),
+    # ... and their forms over SA1's rebuilt first activation (Z0 = W0 . X4 is never stored): the same
+    # products, the 64-row operand replaced by the 4 rows of X4 in the byte count; the rebuild's own
+    # 2 * 4 * 64 flop per position are overhead, not counted
+    def fwd_k4_flop(x4, w0, w, in_coef, y, stat_part):
+        nb, _, p = x4.shape
+        co = w.shape[0]
+        return 2.0 * nb * 64 * co * p, nb * (4 + co) * p * 4, nb * p, f'[4=>64->{co}+stats, {nb}x{p}]'
+
+    def dgrad_k4_flop(dy, w, x4, w0, z_coef):
+        nb, k, p = dy.shape
+        return 2.0 * nb * k * 64 * p, nb * (k + 4) * p * 4, nb * p, f'[{k}->64-nostore, {nb}x{p}]'
+
+    def wgrad_bn_k4_flop(da, z, z_coef, gamma, part, x4, *a, **kw):
+        nb, co, p = da.shape
+        return 2.0 * nb * co * 64 * p, nb * (3 * co + 4) * p * 4, nb * p, f'[{co}x64<=4, {nb}x{p}]'
+    gemm_timers = (GemmTimer(hip, 'pw_layer_forward', fwd_flop, also=[('pw_layer_forward_k4', fwd_k4_flop)]),
+                   GemmTimer(hip, 'pw_wgrad', wgrad_flop),
+                   GemmTimer(hip, 'pw_dgrad_bn_reduce', dgrad_flop, also=[('pw_dgrad_bn_reduce_k4', dgrad_k4_flop)]),
+                   GemmTimer(hip, 'pw_wgrad_bn_backward', wgrad_bn_flop, also=[('pw_wgrad_bn_backward_k4', wgrad_bn_k4_flop)]),
                    GemmTimer(hip, 'pool_tail_backward', tail_flop))
     bn_apply_timer = KernelTimer(hip, 'bn_relu_backward_apply', lambda dy, *_: dy.numel() == mid)
     timers = (fps_timer, pool_fwd_timer, pool_bwd_timer, bn_fwd_timer, bn_bwd_timer, bn_apply_timer) + gemm_timers
@@ -1071,7 +1092,7 @@ def main():
                                # the family's largest launch by bytes, counted / algorithmic
                                'largest_launch_over_algorithmic': (
                                    (t['largest_launch']['fetch_corrected_bytes'] + t['largest_launch']['write_bytes'])
-                                   / max(b_ for tm in (gemm_timers[0], gemm_timers[2]) for (_, b_, _) in tm.work)),
+                                   / max(b_ for tm in (gemm_timers[0], gemm_timers[2]) for (_, b_, *_r) in tm.work)),
                                'worst_launch': t.get('worst_launch'),
                                'source': 'profiles/' + cands[-1], 'lib_sha256': lib_sha, 'measured_in_run': False}
             out['roofline'] = {

@@ -546,25 +546,19 @@ void pw_fwd_kernel(const PwFwd a) {
         }
       }
       if constexpr (K4Z) {
-        // X4 at this lane's positions 16 r + 4 quad + e from the tile's LDS copy, one r ahead
-        f32x4 xr[2][4];
+        // X4 at this lane's positions 16 r + 4 quad + e from the tile's LDS copy (one register set:
+        // a second one, read a step ahead, spilled -- the SIMD's other waves cover the LDS latency)
+        f32x4 xr[4];
         const unsigned xa = lds_addr(lds) + (unsigned)(2 * TILE * 4) + (unsigned)(k4z_buf * 1024) + (unsigned)(16 * quad);
-        static_for<0, 4>([&](auto jc) { xr[0][decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 256>(xa); });
         static_for<0, 4>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
-          if constexpr (r < 3) {
-            static_for<0, 4>([&](auto jc) {
-              xr[(r + 1) & 1][decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 256 + (r + 1) * 64>(xa);
-            });
-            lgkm_wait<4>();
-          } else {
-            lgkm_wait<0>();
-          }
+          static_for<0, 4>([&](auto jc) { xr[decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 256 + r * 64>(xa); });
+          lgkm_wait<0>();
           // (the reads are asm: pin their destinations BEHIND the wait, or the uses are scheduled in front of it)
-          asm volatile("" : "+v"(xr[r & 1][0]), "+v"(xr[r & 1][1]), "+v"(xr[r & 1][2]), "+v"(xr[r & 1][3]));
+          asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x0 = xr[r & 1][0][e], x1 = xr[r & 1][1][e], x2 = xr[r & 1][2][e], x3 = xr[r & 1][3][e];
+            const float x0 = xr[0][e], x1 = xr[1][e], x2 = xr[2][e], x3 = xr[3][e];
             const float z = k4_dot(k4zw[rw], x0, x1, x2, x3);
             const float gg = __builtin_fmaf(z, zc[rw].x, zc[rw].y) > 0.f ? acc[rw][e][r] : 0.f;
             r0[rw] += gg;
@@ -574,6 +568,8 @@ void pw_fwd_kernel(const PwFwd a) {
             gx[rw][2] = __builtin_fmaf(gg, x2, gx[rw][2]);
             gx[rw][3] = __builtin_fmaf(gg, x3, gx[rw][3]);
           }
+          // (... and keep the next reads behind these uses)
+          asm volatile("" :: "v"(xr[0]), "v"(xr[1]), "v"(xr[2]), "v"(xr[3]));
         });
       } else if (EPI & PW_BNRED) {
 #pragma unroll
