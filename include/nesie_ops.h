@@ -746,6 +746,19 @@ int nesie_pw_wgrad_bn_backward_k4(int nb, long long p, const float *da, const fl
                                   long long x4_bstride, const float *w0, const float *x_coef,
                                   float *dz, float *dw, float *dgamma, float *dbeta, float *coef_ws,
                                   void *workspace, size_t workspace_bytes, int defer, void *stream);
+/* nesie_pw_wgrad_bn_backward_k4 and nesie_pw_dgrad_bn_reduce_k4 as ONE launch: the dZ tile that the
+ * weight gradient forms in LDS is also multiplied by w^T (w (64, 64) row-major, the layer's weight) and
+ * only the reductions of that product leave the kernel -- in_part [64][slots][2], in_gpart
+ * [64][slots][4], slots = nesie_pw_wgrad_bn_backward_k4_slots(nb, p); dZ itself is written nowhere
+ * (da is left untouched). */
+int nesie_pw_wgrad_bn_backward_k4_slots(int nb, long long p);
+int nesie_pw_wgrad_bn_backward_k4_fused(int nb, long long p, const float *da, const float *z,
+                                        long long z_bstride, const float *z_coef, const float *gamma,
+                                        const float *part, int nslots, const float *x4,
+                                        long long x4_bstride, const float *w0, const float *x_coef,
+                                        const float *w, float *dw, float *dgamma, float *dbeta,
+                                        float *coef_ws, float *in_part, float *in_gpart,
+                                        void *workspace, size_t workspace_bytes, int defer, void *stream);
 size_t nesie_k4_moments_bytes(void);
 int nesie_k4_moments(int nb, long long p, const float *x4, long long x4_bstride, void *mom_part,
                      void *stream);

@@ -123,6 +123,9 @@ SIGNATURES = {
                                     ctypes.c_longlong, _P, _P, _P, _P, _P],
     "nesie_pw_wgrad_bn_backward_k4": [_I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P,
                                       ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _I, _P],
+    "nesie_pw_wgrad_bn_backward_k4_fused": [_I, ctypes.c_longlong, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _P,
+                                            ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                            ctypes.c_size_t, _I, _P],
     "nesie_k4_moments": [_I, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P],
     "nesie_k4_stat_finalize": [ctypes.c_double, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P],
     "nesie_k4_first_layer_wgrad": [_P, _P, _P, _P, _I, _P, _P],
@@ -188,6 +191,8 @@ def load():
     lib.nesie_pw_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.nesie_k4_moments_bytes.argtypes = []
     lib.nesie_k4_moments_bytes.restype = ctypes.c_size_t
+    lib.nesie_pw_wgrad_bn_backward_k4_slots.argtypes = [_I, ctypes.c_longlong]
+    lib.nesie_pw_wgrad_bn_backward_k4_slots.restype = _I
     lib.nesie_pw_wgrad_pending.argtypes = []
     lib.nesie_pw_wgrad_pending.restype = _I
     lib.nesie_flat_adamw_workspace_bytes.argtypes = []

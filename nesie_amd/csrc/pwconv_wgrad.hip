@@ -42,13 +42,18 @@ namespace nesie {
 // K4 (one build: 64 x 64 with AFF and BNB): the 64 rows of X are the raw output of a 4 -> 64
 // convolution, Z0 = W0 . X4, and are REBUILT from the four rows of x (nb, 4, p) on the operand load
 // (k4_dot, pwconv_fwd.h: the same roundings as the forward's) -- SA1's first activation is never stored.
-template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB, bool K4 = false>
-__global__ __launch_bounds__(512) void pw_wgrad_kernel(
+// FDG (with K4): the layer's INPUT gradient is formed from the same dZ tile in the same launch,
+// dA0 = W^T dZ (16 more MFMAs per wave and tile), and only its reductions leave the kernel -- sum(g),
+// sum(g zhat), sum(g X4[j]) with g = dA0 [bn(Z0) > 0] per channel and slot (what
+// nesie_pw_dgrad_bn_reduce_k4 leaves): dZ is then needed by nobody and is NOT written.
+template <int CO16, int CI16, int WM, int WN, bool AFF, bool BNB, bool K4 = false, bool FDG = false>
+__global__ __launch_bounds__(512, FDG ? 4 : 1) void pw_wgrad_kernel(      // (FDG: two workgroups per CU = 128 VGPRs)
     int nb, int ng, int co_all, int ci_all, long long p, const float *__restrict__ dy, long long dy_bs,
     const float *__restrict__ x, long long x_bs, const float *__restrict__ x_coef, int coef_gs,
     float x_lo, float *__restrict__ partial, int nwg_g, const float *__restrict__ bnz,
     const float *__restrict__ bnb, float *dz, float *__restrict__ d_rb, int rb_group, int rev,
-    const float *__restrict__ k4_w) {
+    const float *__restrict__ k4_w, const float *__restrict__ fdg_w = nullptr, float *__restrict__ fdg_part = nullptr,
+    float *__restrict__ fdg_gpart = nullptr) {
   const int row0 = blockIdx.y * CO16 * 16, col0 = blockIdx.z * CI16 * 16;   // (0, 0) unless tiled
   const int co = co_all - row0 < CO16 * 16 ? co_all - row0 : CO16 * 16;     // this block's extent
   const int ci = ci_all - col0 < CI16 * 16 ? ci_all - col0 : CI16 * 16;
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   constexpr int DYSLOTS = CO16 * 16 * CPR / NT;          // slots that hold dY rows (CO16 % 4 == 0)
   static_assert(WM * WN == 8 && CO16 % WM == 0 && CI16 % WN == 0 && (CO16 * 16 * CPR) % NT == 0, "tiling");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int TILE = ROWS * PITCH;
+  constexpr int TILE = ROWS * PITCH + (FDG ? 4 * PITCH : 0);     // (FDG: + the tile's four X4 rows)
+  static_assert(!FDG || (K4 && BNB && CO16 == 4 && CI16 == 4), "FDG: the 64 x 64 layer over a rebuilt operand");
   const int tid = threadIdx.x, lane = tid & 63, quad = lane >> 4, l16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   static_assert(!K4 || (AFF && NX - DYSLOTS == 1 && CI16 == 4 && EVEN), "K4: one slot of X rows");
   float4 k4w = make_float4(0.f, 0.f, 0.f, 0.f);      // K4: W0 row of this thread's X row
   unsigned k4off = 0;                                  // ... and its 16-byte column
+  bool k4row0 = false;                                 // ... which is row 0's (FDG: it stores the X4 rows)
   f32x4 k4x[K4 ? 3 : 1];                               // ... rows 1 .. 3 of X4 (row 0 sits in the slot's own register)
   unsigned goff[NX], lw[NX];
   bool okslot[NX];
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       if (!isdy) {
         k4w = *(const float4 *)(k4_w + (size_t)r * 4);
         k4off = (unsigned)(cp * 16);
+        k4row0 = r == 0;
         asm volatile("" : "+v"(k4w.x), "+v"(k4w.y), "+v"(k4w.z), "+v"(k4w.w));
       }
     }
@@ -172,7 +180,9 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
             const float gg = __builtin_fmaf(zz, zsc[i], zbi[i]) > 0.f ? q[e] : 0.f;
             q[e] = __builtin_fmaf(za[i], gg, __builtin_fmaf(zmu[i] - zz, zd1[i], ze0[i]));
           }
-          if (pend_ok && okslot[i]) *(f32x4 *)((char *)(dz + pend) + goff[i]) = q;
+          if constexpr (!FDG) {
+            if (pend_ok && okslot[i]) *(f32x4 *)((char *)(dz + pend) + goff[i]) = q;
+          }
           if (d_rb) {      // (wave-uniform)
             float tsum = (q[0] + q[1]) + (q[2] + q[3]);
             tsum += __shfl_xor(tsum, 1, 64);
@@ -190,6 +200,16 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       }
       if constexpr (K4) {
         if (i >= DYSLOTS) {
+          if constexpr (FDG) {
+            // the thread of X row 0 also leaves the four X4 rows of its 16-byte column behind the tile
+            if (k4row0) {
+              float *xt = buf + ROWS * PITCH + (k4off >> 2);
+              *(f32x4 *)(xt) = q;
+              *(f32x4 *)(xt + PITCH) = k4x[0];
+              *(f32x4 *)(xt + 2 * PITCH) = k4x[1];
+              *(f32x4 *)(xt + 3 * PITCH) = k4x[2];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) q[e] = k4_dot(k4w, q[e], k4x[0][e], k4x[1][e], k4x[2][e]);
         }
@@ -208,6 +228,22 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // FDG: wave = (16-channel block cb of the input gradient, 16-position half ph of the tile); a lane
+  // owns channel 16 cb + l16 at positions 16 ph + 4 quad .. + 3
+  const int cb = wave & 3, ph = wave >> 2;
+  float fw[FDG ? 16 : 1];                  // W[m = 4 kk + quad][c]: the B operand, for the whole launch
+  float4 fw0 = make_float4(0.f, 0.f, 0.f, 0.f), fco = fw0;   // W0 row and (scale, shift, mean, invstd) of the channel
+  float fr0 = 0.f, fr1 = 0.f, fgx[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FDG) {
+    const int c = 16 * cb + l16;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) fw[kk] = fdg_w[(size_t)(4 * kk + quad) * 64 + c];
+    fw0 = *(const float4 *)(k4_w + (size_t)c * 4);
+    fco = *(const float4 *)(x_coef + (size_t)c * 4);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) asm volatile("" : "+v"(fw[kk]));
+    asm volatile("" : "+v"(fw0.x), "+v"(fw0.y), "+v"(fw0.z), "+v"(fw0.w), "+v"(fco.x), "+v"(fco.y), "+v"(fco.z), "+v"(fco.w));
+  }
 
   float *b0 = lds, *b1 = lds + TILE;
   int t = rank;
@@ -249,10 +285,46 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (FDG) {
+      // dA0[pos][c] = sum_m dZ[m][pos] W[m][c] over the tile in b0: A = dZ^T straight from the LDS rows
+      f32x4 da = {0.f, 0.f, 0.f, 0.f};
+      const float *az = b0 + quad * PITCH + 16 * ph + l16;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        da = __builtin_amdgcn_mfma_f32_16x16x4f32(az[kk * 4 * PITCH], fw[kk], da, 0, 0, 0);
+      const float *xt = b0 + ROWS * PITCH + 16 * ph + 4 * quad;
+      const f32x4 x0 = *(const f32x4 *)xt, x1 = *(const f32x4 *)(xt + PITCH), x2 = *(const f32x4 *)(xt + 2 * PITCH),
+                  x3 = *(const f32x4 *)(xt + 3 * PITCH);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = k4_dot(fw0, x0[r], x1[r], x2[r], x3[r]);
+        const float gg = __builtin_fmaf(z, fco.x, fco.y) > 0.f ? da[r] : 0.f;
+        fr0 += gg;
+        fr1 += gg * ((z - fco.z) * fco.w);
+        fgx[0] = __builtin_fmaf(gg, x0[r], fgx[0]);
+        fgx[1] = __builtin_fmaf(gg, x1[r], fgx[1]);
+        fgx[2] = __builtin_fmaf(gg, x2[r], fgx[2]);
+        fgx[3] = __builtin_fmaf(gg, x3[r], fgx[3]);
+      }
+    }
     write_tile(b1);          // tile t + 1 (after the last tile: a copy of it that nobody reads)
     __builtin_amdgcn_sched_barrier(0);
     load_tile(t + 2 * nwg_g);
     float *const tb = b0; b0 = b1; b1 = tb;
+  }
+  if constexpr (FDG) {
+    // per channel: the four quads of this wave, then one slot per (workgroup, position half)
+    float v[6] = {fr0, fr1, fgx[0], fgx[1], fgx[2], fgx[3]};
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      v[u] += __shfl_xor(v[u], 16, 64);
+      v[u] += __shfl_xor(v[u], 32, 64);
+    }
+    if (quad == 0) {
+      const int c = 16 * cb + l16, slot = 2 * rank + ph, nslots = 2 * nwg_g;
+      *(float2 *)(fdg_part + ((size_t)c * nslots + slot) * 2) = make_float2(v[0], v[1]);
+      *(float4 *)(fdg_gpart + ((size_t)c * nslots + slot) * 4) = make_float4(v[2], v[3], v[4], v[5]);
+    }
   }
   // partial[(g * nwg + rank)][co][ci]: lane (quad, l16) holds rows 4 quad + r, column l16
   // (tiled: [block][g * nwg + rank][co][ci] with each block's own co x ci, stride the full block)
@@ -537,7 +609,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
                            const float *x_coef, int x_relu, float *dw, void *workspace,
                            size_t workspace_bytes, const float *bnz, const float *bnb, float *dz,
                            float *d_rb, int rb_group, hipStream_t s, bool defer = false,
-                           const float *k4_w = nullptr) {
+                           const float *k4_w = nullptr, const float *fdg_w = nullptr, float *fdg_part = nullptr,
+                           float *fdg_gpart = nullptr) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && ci >= 1 && p >= 0 && dw, W);
   // (k4_w: x is X4 (nb, 4, p) and the 64 operand rows are rebuilt from it -- one build)
   NESIE_REQUIRE(!k4_w || (co == 64 && ci == 64 && ng == 1 && bnb && x_coef && !d_rb && x_bstride >= 4 * p &&
@@ -575,7 +648,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
       }                                                                                                \
       hipLaunchKernelGGL(kern, dim3(nwg * ng, nrb, ncb), dim3(512), lds, s, nb, ng, co, ci, p, dy, dy_bstride, x, \
                          x_bstride, x_coef, ci, lo0, partial, nwg, (const float *)nullptr, (const float *)nullptr, \
-                         (float *)nullptr, (float *)nullptr, 0, rev, (const float *)nullptr);           \
+                         (float *)nullptr, (float *)nullptr, 0, rev, (const float *)nullptr,            \
+                         (const float *)nullptr, (float *)nullptr, (float *)nullptr);                   \
     } while (0)
     if (x_coef) LT(true); else LT(false);
 #undef LT
@@ -610,7 +684,7 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     }                                                                                            \
     hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy,           \
                        dy_bstride, xc, x_bstride, cc, ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, \
-                       (const float *)nullptr);                                                  \
+                       (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr); \
   } while (0)
 #define L(CO16, CI16, WM, WN)                                                                    \
   do {                                                                                           \
@@ -621,7 +695,18 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
     const int cw = ci - c0 < block ? ci - c0 : block;   // workspace is free again when the next one starts
     const float *xc = x + (size_t)c0 * p;
     const float *cc = x_coef ? x_coef + (size_t)c0 * 4 : nullptr;
-    if (k4_w) {
+    if (k4_w && fdg_w) {     // ... with the input gradient's reductions in the same launch (dz is not written)
+      NESIE_REQUIRE(fdg_part && fdg_gpart && ((uintptr_t)fdg_gpart & 15) == 0 && ((uintptr_t)fdg_part & 7) == 0, W);
+      const size_t lds = (size_t)2 * ((4 + 4) * 16 * 36 + 4 * 36) * sizeof(float);
+      auto kern = pw_wgrad_kernel<4, 4, 2, 4, true, true, true, true>;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy, dy_bstride, xc, x_bstride, cc,
+                         ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, k4_w, fdg_w, fdg_part, fdg_gpart);
+    } else if (k4_w) {
       const size_t lds = (size_t)2 * (4 + 4) * 16 * 36 * sizeof(float);
       auto kern = pw_wgrad_kernel<4, 4, 2, 4, true, true, true>;
       static bool attr = false;
@@ -630,7 +715,8 @@ static int pw_wgrad_launch(const char *W, int nb, int ng, int co, int ci, long l
         attr = true;
       }
       hipLaunchKernelGGL(kern, dim3(nwg * ng), dim3(512), lds, s, nb, ng, co, cw, p, dy, dy_bstride, xc, x_bstride, cc,
-                         ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, k4_w);
+                         ci, lo, partial, nwg, bnz, bnb, dz, d_rb, rb_group, rev, k4_w, (const float *)nullptr,
+                         (float *)nullptr, (float *)nullptr);
     } else if (co <= 64 && cw <= 64) L(4, 4, 2, 4);
     else if (co <= 128 && cw <= 64) L(8, 4, 4, 2);
     else if (co <= 128 && cw <= 128) L(8, 8, 2, 4);
@@ -692,7 +778,8 @@ static int pw_wgrad_bn_backward_impl(const char *W, bool defer, int nb, int ng, 
                                           int x_relu, float *dz, float *dw, float *dgamma, float *dbeta,
                                           float *coef_ws, float *d_row_bias, int rb_group,
                                           void *workspace, size_t workspace_bytes, void *stream,
-                                          const float *k4_w = nullptr) {
+                                          const float *k4_w = nullptr, const float *fdg_w = nullptr,
+                                          float *fdg_part = nullptr, float *fdg_gpart = nullptr) {
   NESIE_REQUIRE(nb >= 0 && ng >= 1 && co >= 1 && nslots >= 1, W);
   hipStream_t s = (hipStream_t)stream;
   if (nb == 0 || p == 0) {
@@ -705,7 +792,7 @@ static int pw_wgrad_bn_backward_impl(const char *W, bool defer, int nb, int ng, 
   hipLaunchKernelGGL(pw_bnb_coef_kernel, dim3(ng * co), dim3(64), 0, s, ng * co, nslots,
                      (double)(nb / ng) * (double)p, part, z_coef, gamma, coef_ws, dgamma, dbeta);
   return pw_wgrad_launch(W, nb, ng, co, ci, p, da, z_bstride, x, x_bstride, x_coef, x_relu, dw, workspace,
-                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s, defer, k4_w);
+                         workspace_bytes, z, coef_ws, dz, d_row_bias, rb_group, s, defer, k4_w, fdg_w, fdg_part, fdg_gpart);
 }
 
 extern "C" int nesie_pw_wgrad_bn_backward(int nb, int ng, int co, int ci, long long p, const float *da,
@@ -747,6 +834,28 @@ extern "C" int nesie_pw_wgrad_bn_backward_k4(int nb, long long p, const float *d
   return pw_wgrad_bn_backward_impl(W, defer != 0, nb, 1, 64, 64, p, da, z, z_bstride, z_coef, gamma, part, nslots, x4,
                                    x4_bstride, x_coef, 1, dz, dw, dgamma, dbeta, coef_ws, nullptr, 0, workspace,
                                    workspace_bytes, stream, w0);
+}
+
+// ... and with the reductions of the layer's INPUT gradient from the same launch (pw_wgrad_kernel,
+// FDG): w (64, 64) row-major the layer's weight; in_part [64][slots][2], in_gpart [64][slots][4] as
+// nesie_pw_dgrad_bn_reduce_k4 leaves them, slots = nesie_pw_wgrad_bn_backward_k4_slots(nb, p).  The
+// layer's dZ is consumed inside the launch and NOT written: da is left as it was.
+extern "C" int nesie_pw_wgrad_bn_backward_k4_slots(int nb, long long p) {
+  return 2 * pw_wgrad_nwg(nb, 1, p, 64, 64, true);
+}
+extern "C" int nesie_pw_wgrad_bn_backward_k4_fused(int nb, long long p, const float *da, const float *z,
+                                                   long long z_bstride, const float *z_coef, const float *gamma,
+                                                   const float *part, int nslots, const float *x4,
+                                                   long long x4_bstride, const float *w0, const float *x_coef,
+                                                   const float *w, float *dw, float *dgamma, float *dbeta,
+                                                   float *coef_ws, float *in_part, float *in_gpart,
+                                                   void *workspace, size_t workspace_bytes, int defer,
+                                                   void *stream) {
+  const char *W = "pw_wgrad_bn_backward_k4_fused";
+  NESIE_REQUIRE(nb >= 1 && p >= 32 && x4 && w0 && x_coef && w && in_part && in_gpart, W);
+  return pw_wgrad_bn_backward_impl(W, defer != 0, nb, 1, 64, 64, p, da, z, z_bstride, z_coef, gamma, part, nslots, x4,
+                                   x4_bstride, x_coef, 1, const_cast<float *>(da), dw, dgamma, dbeta, coef_ws, nullptr, 0,
+                                   workspace, workspace_bytes, stream, w0, w, in_part, in_gpart);
 }
 
 // The reduction coefficients of a BatchNorm + ReLU backward on their own (for a consumer of dZ

@@ -1064,6 +1064,35 @@ class HipKernels(_BNPoolMixin):
                       x4.stride(0) if nb > 1 else 4 * p, _ptr(w0), _ptr(x_coef), _ptr(da), _ptr(dw),
                       _ptr(dgamma), _ptr(dbeta), _ptr(cws), _ptr(ws), need, int(defer), _stream(da))
 
+    def pw_wgrad_bn_backward_k4_fused(self, da, z, z_coef, gamma, part, x4, w0, x_coef, w, dw, dgamma, dbeta,
+                                      final=False):
+        """``pw_wgrad_bn_backward_k4`` + ``pw_dgrad_bn_reduce_k4`` as one launch
+        (nesie_pw_wgrad_bn_backward_k4_fused): w (64, 64) the layer's weight; da is NOT overwritten (dz is
+        consumed inside the launch).  -> (in_part (64, slots, 2), in_gpart (64, slots, 4))."""
+        nb, p = self._k4_check(x4, w0)
+        _f32(da, z, dw, dgamma, dbeta, w); _check(da, z, z_coef, part, x_coef, dw, w); _f32(z_coef, part, x_coef)
+        assert tuple(da.shape) == (nb, 64, p) == tuple(z.shape) and dw.numel() == 64 * 64 and tuple(w.shape) == (64, 64)
+        assert tuple(z_coef.shape) == (64, 4) == tuple(x_coef.shape) and part.shape[0] == 64 and part.shape[2] == 2
+        if gamma is not None:
+            _check(gamma); _f32(gamma)
+        lib = _lib.load()
+        need = lib.nesie_pw_wgrad_workspace_bytes(nb, 1, 64, 64, p)
+        slots = lib.nesie_pw_wgrad_bn_backward_k4_slots(nb, p)
+        defer = final and HipKernels._deferred is not None
+        with torch.cuda.device(da.device):
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=da.device)
+            cws = torch.empty(64, 8, dtype=torch.float32, device=da.device)
+            in_part = torch.empty(64, slots, 2, dtype=torch.float32, device=da.device)
+            in_gpart = torch.empty(64, slots, 4, dtype=torch.float32, device=da.device)
+            if defer:
+                HipKernels._deferred.append((ws, dw))
+            _lib.call("nesie_pw_wgrad_bn_backward_k4_fused", nb, p, _ptr(da), _ptr(z), 64 * p, _ptr(z_coef),
+                      0 if gamma is None else _ptr(gamma), _ptr(part), part.shape[1], _ptr(x4),
+                      x4.stride(0) if nb > 1 else 4 * p, _ptr(w0), _ptr(x_coef), _ptr(w), _ptr(dw),
+                      _ptr(dgamma), _ptr(dbeta), _ptr(cws), _ptr(in_part), _ptr(in_gpart), _ptr(ws), need,
+                      int(defer), _stream(da))
+        return in_part, in_gpart
+
     def k4_moments(self, x4):
         """-> (256, 20) float64 per-workgroup partial sums of X4[j] and X4[j] X4[k] (nesie_k4_moments)."""
         _f32(x4)

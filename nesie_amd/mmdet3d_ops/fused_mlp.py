@@ -150,6 +150,7 @@ def _norm_backward_wgrad(backend, da, z, gamma, coef, part, src, src_coef, need_
 # SA1's first activation (4 -> 64 over 10^6 positions, 268 MB) is rebuilt from the 17 MB input wherever
 # it is an operand instead of being stored (include/nesie_ops.h, round 5).  0 = store it (A/B switch).
 SA1_K4 = _os.environ.get('NESIE_SA1_K4', '1') != '0'
+SA1_K4_FUSED = _os.environ.get('NESIE_SA1_K4_FUSED', '1') != '0'     # (A/B: 0 = two launches with dZ in between)
 
 
 class SAStackFn(Function):
@@ -279,10 +280,15 @@ class SAStackFn(Function):
                 w0c = w0.reshape(w0.shape[0], c0)
                 dgamma, dbeta = _dst(slots[4], g, cout), _dst(slots[5], g, cout)
                 dw = _dst(slots[3], g, 1, cout, cin)
-                backend.pw_wgrad_bn_backward_k4(pending[0], ys[1], coefs[1], params[4], pending[1], x3, w0c,
-                                                coefs[0], dw, dgamma, dbeta, final=slots[3] is not None)
+                if SA1_K4_FUSED:     # ... both as one launch: the layer's dZ never leaves the chip
+                    part, g_part = backend.pw_wgrad_bn_backward_k4_fused(
+                        pending[0], ys[1], coefs[1], params[4], pending[1], x3, w0c, coefs[0], w2, dw, dgamma, dbeta,
+                        final=slots[3] is not None)
+                else:
+                    backend.pw_wgrad_bn_backward_k4(pending[0], ys[1], coefs[1], params[4], pending[1], x3, w0c,
+                                                    coefs[0], dw, dgamma, dbeta, final=slots[3] is not None)
+                    part, g_part = backend.pw_dgrad_bn_reduce_k4(pending[0], w2.t(), x3, w0c, coefs[0])
                 grads[3], grads[4], grads[5] = dw.view_as(w), dgamma, dbeta
-                part, g_part = backend.pw_dgrad_bn_reduce_k4(pending[0], w2.t(), x3, w0c, coefs[0])
                 dgamma0, dbeta0 = _dst(slots[1], g, cin), _dst(slots[2], g, cin)
                 bnb = backend.pw_bnb_coef(part, coefs[0], params[1], float(B) * float(P), dgamma0, dbeta0)
                 dw0 = _dst(slots[0], g, cin, c0)

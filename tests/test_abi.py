@@ -41,7 +41,7 @@ def test_binding_covers_every_compute_entry_point():
                             "nesie_fps_workspace_bytes", "nesie_fps_leaves_index",
                             "nesie_bn_workspace_bytes",
                             "nesie_pw_supported", "nesie_pw_stat_slots", "nesie_pw_wgrad_supported", "nesie_pw_wgrad_tiled", "nesie_pool_tail_supported",
-                            "nesie_pw_wgrad_workspace_bytes", "nesie_pw_wgrad_pending", "nesie_k4_moments_bytes", "nesie_pw_wgrad_bn_supported", "nesie_blend_conv_runs", "nesie_blend_conv_backward_workspace_bytes",
+                            "nesie_pw_wgrad_workspace_bytes", "nesie_pw_wgrad_pending", "nesie_k4_moments_bytes", "nesie_pw_wgrad_bn_backward_k4_slots", "nesie_pw_wgrad_bn_supported", "nesie_blend_conv_runs", "nesie_blend_conv_backward_workspace_bytes",
                             "nesie_conv_wgrad_workspace_bytes", "nesie_mlp_stream_partials",
                             "nesie_blend_conv_bn_workspace_bytes",
                             "nesie_flat_adamw_workspace_bytes")]

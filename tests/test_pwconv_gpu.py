@@ -455,6 +455,55 @@ def test_sa1_rebuilt_first_activation_matches_the_stored_form_and_the_module_pat
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_k4_fused_weight_gradient_and_input_gradient_reductions_match_the_two_launches():
+    """nesie_pw_wgrad_bn_backward_k4_fused against nesie_pw_wgrad_bn_backward_k4 followed by
+    nesie_pw_dgrad_bn_reduce_k4: the same weight gradient bit for bit, dgamma / dbeta bit for bit, the
+    input gradient's reductions equal to rounding (other slots), and da left untouched."""
+    hip = _hip()
+    g = torch.Generator(device=_dev()).manual_seed(21)
+    nb, p = 3, 16384
+    x4 = torch.randn(nb, 4, p, device=_dev(), generator=g) * 0.5
+    x4[:, 3] = x4[:, 3].abs() + 0.5
+    w0 = torch.randn(64, 4, device=_dev(), generator=g) * 0.5
+    w1 = torch.randn(64, 64, device=_dev(), generator=g) * 0.2
+    da = torch.randn(nb, 64, p, device=_dev(), generator=g)
+    z1 = torch.randn(nb, 64, p, device=_dev(), generator=g)
+    gamma1 = torch.rand(64, device=_dev(), generator=g) + 0.5
+
+    def coef_of(z, gamma, beta):
+        zd = z.double()
+        mean, invstd = zd.mean((0, 2)), (zd.var((0, 2), unbiased=False) + 1e-5).rsqrt()
+        scale = gamma.double() * invstd
+        return torch.stack([scale, beta.double() - mean * scale, mean, invstd], -1).float().contiguous()
+    z0 = torch.einsum('cj,njp->ncp', w0, x4)
+    coef0 = coef_of(z0, torch.rand(64, device=_dev(), generator=g) + 0.5, torch.randn(64, device=_dev(), generator=g) * 0.3)
+    coef1 = coef_of(z1, gamma1, torch.randn(64, device=_dev(), generator=g) * 0.3)
+    zc = coef1.double()
+    gg = torch.where(torch.addcmul(coef1[:, 1].view(1, -1, 1), z1, coef1[:, 0].view(1, -1, 1)) > 0, da, torch.zeros_like(da)).double()
+    zhat = (z1.double() - zc[:, 2].view(1, -1, 1)) * zc[:, 3].view(1, -1, 1)
+    part1 = torch.stack([gg.sum((0, 2)), (gg * zhat).sum((0, 2))], -1).view(64, 1, 2).float().contiguous()
+
+    def two():
+        d = da.clone()
+        dw, dg, db = (torch.empty(64, 64, device=_dev()), torch.empty(64, device=_dev()), torch.empty(64, device=_dev()))
+        hip.pw_wgrad_bn_backward_k4(d, z1, coef1, gamma1, part1, x4, w0, coef0, dw, dg, db)
+        part, gpart = hip.pw_dgrad_bn_reduce_k4(d, w1.t(), x4, w0, coef0)
+        return dw, dg, db, part.double().sum(1), gpart.double().sum(1)
+
+    def one():
+        d = da.clone()
+        dw, dg, db = (torch.empty(64, 64, device=_dev()), torch.empty(64, device=_dev()), torch.empty(64, device=_dev()))
+        part, gpart = hip.pw_wgrad_bn_backward_k4_fused(d, z1, coef1, gamma1, part1, x4, w0, coef0, w1, dw, dg, db)
+        assert torch.equal(d, da)
+        return dw, dg, db, part.double().sum(1), gpart.double().sum(1)
+    a, b, b2 = two(), one(), one()
+    for u, v in zip(b, b2):
+        assert torch.equal(u, v)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for u, v in zip(a[3:], b[3:]):
+        torch.testing.assert_close(v, u, rtol=1e-4, atol=1e-4 * u.abs().max().item())
+
+
 def test_k4_statistics_from_input_moments_against_float64():
     """nesie_k4_moments + nesie_k4_stat_finalize: BatchNorm coefficients and running statistics of
     W0 . X4 without forming it, against float64 statistics of the product."""
