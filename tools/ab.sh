@@ -6,7 +6,7 @@ O=$R/gpurun_out/ab_$NAME
 mkdir -p $O
 for i in $(seq 1 $RUNS); do
   (cd $R/build_ab/$NAME && python bench.py --steps 30 --warmup 5 --cpu-baseline 0 --parity-gate 0 "$@" > $O/base_$i.json 2> $O/base_$i.err) || exit 1
-  (cd $R && python bench.py --steps 30 --warmup 5 --cpu-baseline 0 --parity-gate 0 "$@" > $O/new_$i.json 2> $O/new_$i.err) || exit 1
+  (cd $R && python bench.py --steps 30 --warmup 5 --cpu-baseline 0 --parity-gate 0 --other-workloads 0 "$@" > $O/new_$i.json 2> $O/new_$i.err) || exit 1
 done
 python - <<PY
 import json, glob
