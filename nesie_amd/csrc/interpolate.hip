@@ -137,6 +137,136 @@ __global__ __launch_bounds__(NN_BLOCK) void grid_taps_kernel(
   }
 }
 
+// ---- the same, with the seed list of every WAVE pruned first (round 5) --------------------------
+// The 64 grid points of a wave belong to one or two proposals: they lie in a ball (C, R).  With d3 =
+// the distance from C to its third-nearest seed, every grid point u of the wave has its three nearest
+// seeds within d3 + R (the three seeds nearest to C are that close to u), so a seed farther than
+// d3 + 2 R from C is farther than d3 + R from every u of the wave and can be in no top-3 -- not even
+// as a tie.  The wave keeps the seeds inside that radius (a margin of 1e-5 relative + 1e-6 covers the
+// rounding of the pruning distances, which are NOT the compared ones), compacted IN INDEX ORDER
+// with their indices, and runs the exact scan of grid_taps_kernel over them: same compares in the
+// same order on the survivors, bit-identical taps.  At 1 024 seeds in a room a proposal's wave keeps
+// 70 - 700 of them.
+constexpr int GTP_PER = 16;                  // seeds per lane: m <= 64 * GTP_PER
+constexpr int GTP_CAP = 64 * GTP_PER;
+
+template <int FORM>
+__global__ __launch_bounds__(NN_BLOCK) void grid_taps_pruned_kernel(
+    int kprop, int gp, int m, const float *__restrict__ centre, const float *__restrict__ size,
+    const float *__restrict__ heading, const float *__restrict__ mult,
+    const float *__restrict__ plane, const float *__restrict__ known, int *__restrict__ idx,
+    float *__restrict__ weight, float *__restrict__ rel) {
+  extern __shared__ float4 cand_all[];       // [waves][GTP_CAP]: (x, y, z, index bits)
+  const int bi = blockIdx.y;
+  const int n = kprop * gp;
+  const int q = blockIdx.x * NN_BLOCK + threadIdx.x;
+  const bool live = q < n;
+  const int qq = live ? q : n - 1;
+  const int k = qq / gp, g = qq - k * gp;
+  const float *c3 = centre + ((size_t)bi * kprop + k) * 3;
+  const float *s3 = size + ((size_t)bi * kprop + k) * 3;
+  const float cx = c3[0], cy = c3[1], cz = c3[2];
+  float l[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float f = __fmul_rn(mult[g * 3 + d], s3[d]) / 2.f;
+    l[d] = __fadd_rn(f, __fmul_rn(f, plane[g * 3 + d]));
+  }
+  const float h = heading[(size_t)bi * kprop + k];
+  const float ch = cosf(h), sh = sinf(h);
+  const float ux = __fadd_rn(__fadd_rn(__fmul_rn(l[0], ch), __fmul_rn(l[1], sh)), cx);
+  const float uy = __fadd_rn(__fadd_rn(__fmul_rn(l[0], -sh), __fmul_rn(l[1], ch)), cy);
+  const float uz = __fadd_rn(l[2], cz);
+  known += (size_t)bi * m * 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 *cand = cand_all + (size_t)wave * GTP_CAP;
+  // the wave's ball
+  float mx = ux, my = uy, mz = uz;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx += __shfl_xor(mx, off, 64); my += __shfl_xor(my, off, 64); mz += __shfl_xor(mz, off, 64);
+  }
+  mx *= 1.f / 64.f; my *= 1.f / 64.f; mz *= 1.f / 64.f;
+  float rad = sqrtf((ux - mx) * (ux - mx) + (uy - my) * (uy - my) + (uz - mz) * (uz - mz));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) rad = fmaxf(rad, __shfl_xor(rad, off, 64));
+  // distances from the ball's centre to the seeds r * 64 + lane
+  float sx[GTP_PER], sy[GTP_PER], sz[GTP_PER], dc[GTP_PER];
+#pragma unroll
+  for (int r = 0; r < GTP_PER; ++r) {
+    const int i = r * 64 + lane;
+    const int ii = i < m ? i : m - 1;
+    sx[r] = known[ii * 3 + 0]; sy[r] = known[ii * 3 + 1]; sz[r] = known[ii * 3 + 2];
+    const float dx = sx[r] - mx, dy = sy[r] - my, dz = sz[r] - mz;
+    dc[r] = i < m ? sqrtf(dx * dx + dy * dy + dz * dz) : INFINITY;
+  }
+  // d3: the third smallest of them (three rounds of "smallest (distance, index) above the previous one")
+  float pd = -1.f;
+  int pi = -1;
+#pragma unroll 1
+  for (int round = 0; round < 3; ++round) {
+    float bd = INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < GTP_PER; ++r) {
+      const int i = r * 64 + lane;
+      const bool above = dc[r] > pd || (dc[r] == pd && i > pi);
+      const bool better = above && (dc[r] < bd || (dc[r] == bd && i < bidx));
+      bd = better ? dc[r] : bd;
+      bidx = better ? i : bidx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od = __shfl_xor(bd, off, 64);
+      const int oi = __shfl_xor(bidx, off, 64);
+      const bool take = od < bd || (od == bd && oi < bidx);
+      bd = take ? od : bd;
+      bidx = take ? oi : bidx;
+    }
+    pd = bd; pi = bidx;
+  }
+  const float reach = pd + 2.f * rad;
+  const float thr = reach * (1.f + 1e-5f) + 1e-6f;           // (inf when m < 3: nothing is pruned)
+  // survivors in index order
+  int cnt = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < GTP_PER; ++r) {
+    const int i = r * 64 + lane;
+    const bool keep = i < m && !(dc[r] > thr);
+    const unsigned long long mask = __ballot(keep);
+    if (keep) cand[cnt + __popcll(mask & below)] = make_float4(sx[r], sy[r], sz[r], __int_as_float(i));
+    cnt += __popcll(mask);
+  }
+  __syncthreads();
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+#pragma unroll 4
+  for (int i = 0; i < cnt; ++i) {
+    const float4 kp = cand[i];
+    const float d = sqdist_form<FORM>(ux - kp.x, uy - kp.y, uz - kp.z);
+    if (d < b3) {
+      const int kidx = __float_as_int(kp.w);
+      if (d < b1) {
+        b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kidx;
+      } else if (d < b2) {
+        b3 = b2; i3 = i2; b2 = d; i2 = kidx;
+      } else {
+        b3 = d; i3 = kidx;
+      }
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)bi * n + q) * 3;
+    const float w1 = 1.f / __fadd_rn(sqrtf(b1), 1e-8f), w2 = 1.f / __fadd_rn(sqrtf(b2), 1e-8f),
+                w3 = 1.f / __fadd_rn(sqrtf(b3), 1e-8f);
+    const float ws = __fadd_rn(__fadd_rn(w1, w2), w3);
+    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    weight[o] = w1 / ws; weight[o + 1] = w2 / ws; weight[o + 2] = w3 / ws;
+    rel[o] = ux - cx; rel[o + 1] = uy - cy; rel[o + 2] = uz - cz;
+  }
+}
+
 constexpr int TI_BLOCK = 256;
 constexpr int TI_CH = 8;
 
@@ -1051,6 +1181,30 @@ extern "C" int nesie_grid_taps(int b, int kprop, int gp, int m, const float *cen
   hipLaunchKernelGGL(grid_taps_kernel<FORM>, dim3(cdiv((long long)kprop * gp, NN_BLOCK), b),     \
                      dim3(NN_BLOCK), 0, (hipStream_t)stream, kprop, gp, m, centre, size, heading, \
                      mult, plane, known, idx, weight, rel)
+  // OFF by default: on the random-init proposals of the benchmark step (median box edge 2.9 m) 56 % of the
+  // seeds survive and the launch pair takes 0.37 ms against 0.22 (HISTORY.md, round 5); boxes of trained
+  // size (~1 m) would keep 70 - 200 seeds.  NESIE_GRID_TAPS_PRUNE=1 selects it; results are bit-identical.
+  static const bool prune = getenv("NESIE_GRID_TAPS_PRUNE") && atoi(getenv("NESIE_GRID_TAPS_PRUNE")) != 0;
+  if (prune && m <= GTP_CAP) {      // every wave scans only the seeds that can matter to it (bit-identical taps)
+    const size_t lds = (size_t)(NN_BLOCK / 64) * GTP_CAP * sizeof(float4);
+#define GTP(FORM)                                                                               \
+    do {                                                                                        \
+      auto kern = grid_taps_pruned_kernel<FORM>;                                                \
+      static bool attr = false;                                                                 \
+      if (!attr) {                                                                              \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        attr = true;                                                                            \
+      }                                                                                         \
+      hipLaunchKernelGGL(kern, dim3(cdiv((long long)kprop * gp, NN_BLOCK), b), dim3(NN_BLOCK), lds, \
+                         (hipStream_t)stream, kprop, gp, m, centre, size, heading, mult, plane, known, \
+                         idx, weight, rel);                                                     \
+    } while (0)
+    if (distance_form() == 1) GTP(1);
+    else if (distance_form() == 2) GTP(2);
+    else GTP(0);
+#undef GTP
+    return check_launch(W);
+  }
   if (distance_form() == 1) GT(1);      // (mmcv.ops.three_nn is an nvcc build as well)
   else if (distance_form() == 2) GT(2);
   else GT(0);
