@@ -463,6 +463,23 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # 224 at 16 (240: 36.17, 224: 35.64, 208: 36.07 ms))
     left = max(256 - 16 - 8 * ((batch + 7) // 8), 192)
     budget = {'cus': int(os.environ.get('NESIE_FWD_CUS', str(left))) if on_gpu else 256}
+    # ... and the LATE part of the forward pass -- from the detection head on -- is sized for 16 CUs more:
+    # the next batch's 40 000-point sampling launch is over by then, the shorter levels' sampling and the
+    # index kernels behind it still run (the whole chip for the head: 12.10 ms; 248 from the head on:
+    # 11.85; 232 throughout: 11.92 -- same box, alternating; from SA4 or the first FP level on: no better).
+    # Supervised step only (the student / teacher steps run two forwards under one chain): 0 = off
+    late_default = min(left + 16, 248) if (workload == 'pretrain' and left < 248) else 0
+    late_cus = int(os.environ.get('NESIE_FWD_CUS_LATE', str(late_default))) if on_gpu else 0
+    if late_cus and budget['cus'] != 256:
+        late_mod = model
+        for part in os.environ.get('NESIE_FWD_LATE_AT', 'bbox_head').split('.'):
+            late_mod = getattr(late_mod, part)
+
+        def _late(mod, args):
+            if budget['cus'] != 256 and kernels._lib.load().nesie_get_cu_count() == budget['cus']:   # (only inside the budgeted forward)
+                kernels._lib.call('nesie_set_cu_count', late_cus)
+        late_mod.register_forward_pre_hook(_late)
+    budget['late'] = late_cus
 
     head_dummy = None
     if on_gpu and os.environ.get('NESIE_DIAG_HEAD_DUMMY'):   # diagnostic only: a long kernel in front of the step
@@ -1019,6 +1036,7 @@ def main():
                        'graphs_per_step': getattr(step, 'graphs_per_step', None),
                        'index_chain_pipelined': bool(args.graph),
                        'forward_cu_budget': (getattr(step, 'forward_cu_budget', None) or {'cus': 256})['cus'],
+                       'forward_cu_budget_from_the_head_on': (getattr(step, 'forward_cu_budget', None) or {}).get('late') or None,
                        'grad_allreduce_bytes': bucket.nbytes(),
                        'grad_allreduce': 'two segments on a communication stream: head gradients '
                                          'during the backbone backward graph, backbone gradients after it',
@@ -1114,7 +1132,8 @@ def main():
                 'family_ms_per_step': per_step(ms_all),
                 'grids': ('timed alone, persistent grids sized for all 256 CUs; inside the replayed step the FORWARD '
                           f'launches are sized for {budget_in_step} CUs (the next batch\'s sampling kernels hold one '
-                          'CU per XCD meanwhile)' if budget_in_step != 256 else 'sized for all 256 CUs'),
+                          'CU per XCD meanwhile)' + (f', {fwd_budget.get("late")} from the detection head on' if fwd_budget.get('late') else '')
+                          if budget_in_step != 256 else 'sized for all 256 CUs'),
                 'avg_launch_ms': ms_all / n_all,
                 'algorithmic_flops_per_launch': fl_all / n_all,
                 # sub-entry: the launches over >= 32768 positions WITHOUT the fused norm-backward ones
