@@ -467,7 +467,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # the next batch's 40 000-point sampling launch is over by then, the shorter levels' sampling and the
     # index kernels behind it still run (the whole chip for the head: 12.10 ms; 248 from the head on:
     # 11.85; 232 throughout: 11.92 -- same box, alternating; from SA4 or the first FP level on: no better).
-    # (A budget for the head's BACKWARD -- 248 / 240 -- costs 0.12 / 0.2 ms: the chain is over by then.)
+    # (A budget for the head's BACKWARD -- 248 / 240 -- costs 0.12 / 0.2 ms: the chain is over by then.  A third
+    # stage of 240 from SA3 / SA4 / the first FP level on: + 0.15 / + 0.15 / 0.0 ms.)
     # Supervised step only (the student / teacher steps run two forwards under one chain): 0 = off
     late_default = min(left + 16, 248) if (workload == 'pretrain' and left < 248) else 0
     late_cus = int(os.environ.get('NESIE_FWD_CUS_LATE', str(late_default))) if on_gpu else 0
