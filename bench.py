@@ -428,6 +428,8 @@ def build_step(device, batch, seed, lr, wd, graph=False, workload='pretrain', re
     # all-reduce, the clip and AdamW each see ONE tensor
     groups = model.stacked_parameter_groups() if hasattr(model, 'stacked_parameter_groups') else None
     bucket = dp.FlatTrainState(model.parameters(), stack_groups=groups)
+    if workload in ('semi', 'saqe') and os.environ.get('NESIE_FLAT_EMA', '1') != '0':
+        model.teacher.use_flat(bucket)      # the teacher's weights as one vector too (EMATeacher.use_flat)
     if on_gpu:
         # clip (max_norm 10) + AdamW as two launches over the flat vectors (dp.FlatAdamW)
         opt = dp.FlatAdamW(bucket.flat_param, lr=lr, weight_decay=wd, max_norm=10)

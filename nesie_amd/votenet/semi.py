@@ -183,6 +183,44 @@ class EMATeacher:
     def emas(self):
         return self._bind()[1]
 
+    def use_flat(self, state):
+        """The EMA copies as views of ONE flat vector laid out like ``state.flat_param``
+        (``dp.FlatTrainState``: the parameters are views of it already): ``update`` is then two
+        element-wise launches over the vector and ``swap`` three copies of it, element for element
+        the per-tensor arithmetic (round 5: 38 multi-tensor launches + 6 multi-tensor copies per
+        step otherwise).  A no-op unless every tracked parameter lives in the state."""
+        params, emas = self._bind()
+        offs = {id(q): o for q, o in zip(state.params, state.offsets)}
+        if len(params) != len(state.params) or any(id(q) not in offs for q in params):
+            return False
+        flat_p = state.flat_param.data
+        flat_e = torch.zeros_like(flat_p)
+        with torch.no_grad():
+            for (name, buf_name), q, e in zip(self.names, params, emas):
+                o = offs[id(q)]
+                v = flat_e[o:o + q.numel()].view_as(q)
+                v.copy_(e)
+                self.model._buffers[buf_name] = v
+        ends = (0, len(params) - 1)
+        self._flat = (state, flat_p, flat_e, torch.empty_like(flat_p), [(i, offs[id(params[i])]) for i in ends])
+        self._bound = None
+        return True
+
+    def _flat_ok(self):
+        """The flat pair while it still IS the storage of parameters and EMA copies (a ``.to()`` /
+        ``load_state_dict(assign=True)`` replaces tensors: the per-tensor path takes over again)."""
+        f = getattr(self, '_flat', None)
+        if f is None:
+            return None
+        _, flat_p, flat_e, _, ends = f
+        params, emas = self._bind()
+        es = flat_p.element_size()
+        for i, o in ends:
+            if params[i].data_ptr() != flat_p.data_ptr() + o * es or emas[i].data_ptr() != flat_e.data_ptr() + o * es:
+                self._flat = None
+                return None
+        return f
+
     def resync(self):
         """EMA copies <- current parameters (e.g. after loading pre-trained weights)."""
         params, emas = self._bind()
@@ -193,14 +231,25 @@ class EMATeacher:
         if curr_step % self.interval != 0:
             return
         m = min(self.momentum, (1 + curr_step) / (self.warm_up + curr_step))
-        params, emas = self._bind()
+        f = self._flat_ok()
         with torch.no_grad():
+            if f is not None:
+                f[2].mul_(1 - m).add_(f[1], alpha=m)
+                return
+            params, emas = self._bind()
             torch._foreach_mul_(emas, 1 - m)
             torch._foreach_add_(emas, [p.data for p in params], alpha=m)
 
     def swap(self):
         """Parameters <-> EMA copies, as three multi-tensor copies through a scratch list kept
         between calls (one clone launch per parameter otherwise: ~440 tiny copies per step)."""
+        f = self._flat_ok()
+        if f is not None:
+            with torch.no_grad():
+                f[3].copy_(f[1])
+                f[1].copy_(f[2])
+                f[2].copy_(f[3])
+            return
         params, emas = self._bind()
         with torch.no_grad():
             data = [p.data for p in params]

@@ -217,3 +217,37 @@ def test_deferred_reduction_window_is_a_no_op_without_a_gpu():
     nets[0](pre(torch.randn(2, 5))).sum().backward()
     state.collect()
     assert HipKernels._deferred is before
+
+
+def test_flat_ema_teacher_equals_the_per_tensor_teacher_bit_for_bit():
+    """EMATeacher.use_flat (round 5): update and swap over ONE flat vector give the per-tensor
+    arithmetic element for element; a replaced buffer drops back to the per-tensor path."""
+    from nesie_amd import dp
+    from nesie_amd.votenet.semi import EMATeacher
+
+    def mk():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    a, b = mk(), mk()
+    ta, tb = EMATeacher(a, momentum=0.01), EMATeacher(b, momentum=0.01)
+    dp.FlatTrainState(a.parameters())
+    sb = dp.FlatTrainState(b.parameters())
+    assert tb.use_flat(sb) and tb._flat_ok() is not None
+    for step in range(1, 6):
+        for m_ in (a, b):
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(step)
+                for p in m_.parameters():
+                    p.data.add_(torch.randn(p.shape, generator=g) * 0.1)
+        ta.update(step); tb.update(step)
+        ta.swap(); tb.swap()
+        assert all(torch.equal(x, y) for x, y in zip(a.parameters(), b.parameters()))
+        ta.swap(); tb.swap()
+        assert all(torch.equal(x, y) for x, y in zip(ta.emas, tb.emas))
+        assert all(torch.equal(x, y) for x, y in zip(a.parameters(), b.parameters()))
+    assert tb._flat_ok() is not None
+    b._buffers[tb.names[0][1]] = b._buffers[tb.names[0][1]].clone()      # e.g. a state-dict load with assign
+    assert tb._flat_ok() is None
+    ta.update(7); tb.update(7)
+    assert all(torch.equal(x, y) for x, y in zip(ta.emas, tb.emas))
+

@@ -8,7 +8,7 @@ from nesie_amd.votenet import nesie_votenet_scannet_cfg
 
 dev = torch.device('cuda:0')
 cfg = nesie_votenet_scannet_cfg()['optimizer']
-model, step, bucket = bench.build_step(dev, 8, 1000, cfg['lr'], cfg['weight_decay'], graph=False)
+model, step, bucket = bench.build_step(dev, 8, 1000, cfg['lr'], cfg['weight_decay'], graph=False, workload=(sys.argv[1] if len(sys.argv) > 1 else 'pretrain'))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
