@@ -54,7 +54,7 @@ def main():
         f"bench line under the profiler: value={b['value']:.1f} scenes/s  ms_per_step={b['ms_per_step']:.2f}; without it (profiles/{tag}_bench_line.json): {clean['value']:.1f} scenes/s, {clean['ms_per_step']:.2f} ms",
         "The process runs 20 training steps in all (2 eager warm-up steps before capture, 3 warm-up, 10 timed, 5 un-captured for the HIP-event",
         "timings of the roofline entries) plus the parity gate's one B=2 step on each leg; per-step = total / 20.  FPS, ball query, inverted indices, FP taps and",
-        f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms of kernel time, mostly one CU per scene: overlapped, at a measured cost of 0.65 - 0.75 ms to the step, HISTORY.md, round-4 list item 6).",
+        f"the vote targets run on a side stream under the previous step (fps_pruned + fps_reg + ball_query + inverted_index + three_nn = {side:.1f} ms of kernel time, mostly one CU per scene: overlapped, at a measured cost of 0.30 ms of interference + 0.17 ms for the forward's reduced CU budget, DESIGN.md section 0 item 6).",
         f"GEMM time: nesie::pw_fwd_kernel + pw_wgrad_kernel (+ conv_wgrad, mlp_stream) = {native:.2f} ms vs rocBLAS {rb:.2f} ms -> {100 * native / (native + rb):.0f} % of the GEMM time is in nesie:: kernels.",
         f"Launches per step (both streams): {calls:.0f}; kernel families averaging under 12 us: {small:.0f} launches, {small_ms:.2f} ms; everything that is neither nesie:: nor rocBLAS "
         f"(ATen elementwise / reduce / cat / copies / fills): {aten:.2f} ms = {100 * aten / allt:.1f} % of the summed kernel time.",
