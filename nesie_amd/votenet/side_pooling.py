@@ -29,6 +29,34 @@ def rot_gpu(t):
                         torch.stack([z, z, o], -1)], -2)
 
 
+class _TableProduct(torch.autograd.Function):
+    """table (B, N, S*H) = features (B, N, C) . W^T (W (S*H, C)): the blend's per-seed products (the
+    first conv of the MiniPointNets evaluated over the N seeds, BlendConv).  What autograd would run for
+    it, except the weight gradient dW = dTable^T . features: a (S*H) x C product over B*N = 8 192 rows,
+    which the BLAS library serves with ONE 32 x 32-tile kernel at S*H = C = 256 (64 workgroups on 256 CUs:
+    67 us for 1 GFLOP) -- here it is a batched product over the B scenes + a sum over them (B times the
+    workgroups) whenever S*H * C is small."""
+
+    @staticmethod
+    def forward(ctx, features, w):
+        ctx.save_for_backward(features, w)
+        return torch.matmul(features, w.t())
+
+    @staticmethod
+    def backward(ctx, d_table):
+        features, w = ctx.saved_tensors
+        d_feat = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_feat = torch.matmul(d_table, w)
+        if ctx.needs_input_grad[1]:
+            B, N, SH = d_table.shape
+            if B > 1 and SH * w.shape[1] <= 256 * 256:
+                d_w = torch.bmm(d_table.transpose(1, 2), features).sum(0)
+            else:
+                d_w = torch.mm(d_table.reshape(B * N, SH).t(), features.reshape(B * N, -1))
+        return d_feat, d_w
+
+
 class DeferredBlendConv:
     """The raw first-conv outputs of S MiniPointNets, (B, S, H, K, G), NOT evaluated yet: the
     operands of ``mmdet3d_ops.BlendConv`` (side_pooling_module.py:226-243, 346-349 through the 3-NN
@@ -566,7 +594,7 @@ class SidePooling(nn.Module):
         w = fused_mlp.stack_groups([[net.first_conv[0].weight.flatten(1) for net in nets]])[0]   # (S, H, 3+C)
         H = w.shape[1]
         w_xyz, w_feat = fused_mlp.SplitXyzFeat.apply(w)       # (S, H, 3) contiguous, (S*H, C) view
-        table = torch.matmul(origin_features, w_feat.t())     # (B,N,S*H)
+        table = _TableProduct.apply(origin_features, w_feat)  # (B,N,S*H)
         bns = [net.first_conv[1] for net in nets]
         if with_norm and _stackable_bn(bns) and H % 64 == 0 and H <= 256 and (K * G) % 64 == 0 \
                 and origin_features.dtype == torch.float32:
